@@ -1,0 +1,433 @@
+#!/usr/bin/env python3
+"""
+Generates the golden fixtures in this directory by IMPORTING the unmodified reference
+(lorenlugosch/end-to-end-SLU) from a path given on the command line (default /root/reference).
+
+Runs only in the authoring container: the reference never travels to the GPU box, only the
+small data fixtures written here do.  No reference source is copied: this script calls the
+reference's public classes/functions (models.SincLayer, models.PretrainedModel, models.Model,
+models.Downsample, data.read_config, training.Trainer) on seeded inputs and stores
+inputs + outputs.
+
+    python tests/golden/make_goldens.py [/root/reference]
+
+Fixtures:
+  g1_sinc_filters.npz   SincLayer filterbank for default and perturbed float64 parameters, + grads
+  g2_frontend.npz       x(2,8000) through sinc0 / pool0+act0 / conv1+act1 / conv2+act2
+  g3_gru_*.npz          nn.GRU cases (I,H,T,B): weights, x, output, grads for loss=(out*g).sum()
+  g4_downsample.npz     Downsample none/avg/max on odd T; dropout mask seeds + checksums
+  g5_tiny_model.npz     reduced-size Model: full state_dict, x, y, eval & train-mode loss/acc/logits
+                        and every parameter gradient (train mode: dropout masks by seed)
+  g5_tiny_asr.npz       reduced-size PretrainedModel.forward (ASR losses) + grads
+  g6_full_model.npz     no_unfreezing.cfg architecture, seed 1234, x=randn(16,16000): state_dict
+                        SHA-256 per tensor (weights are re-drawn, not stored), eval logits/loss/acc,
+                        train-mode loss + grad digests, one Trainer.train step (post-Adam digests,
+                        log.csv row)
+  g8_config.json        for all 29 reference cfgs: cfg text (input) and vars(read_config(cfg))
+                        or the exception the reference raises (output)
+"""
+import hashlib
+import io
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+for m in ("torchaudio", "soundfile", "textgrid"):          # not installed; only dataset code uses them
+    sys.modules.setdefault(m, types.ModuleType(m))
+
+import models as ref_models                                  # noqa: E402
+import data as ref_data                                      # noqa: E402
+import training as ref_training                              # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def npd(t):
+    return t.detach().cpu().numpy()
+
+
+def digest(t):
+    """Small, order-sensitive fingerprint of a float tensor: L2 norm, sum, first 8 values."""
+    f = t.detach().double().flatten()
+    return np.concatenate([[f.norm().item(), f.sum().item()], f[:8].numpy(),
+                           np.zeros(max(0, 8 - f.numel()))]).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------
+def g1():
+    lay = ref_models.SincLayer(80, 401, 16000, stride=80, padding=200)
+    x = torch.zeros(1, 1, 800)
+    out = {}
+
+    def filters_of(layer):
+        # SincLayer has no filter accessor; recover the bank exactly by convolving unit impulses:
+        # conv1d(delta_k) at an output position reads filters[:, j] — instead use stride 1 probe.
+        probe = ref_models.SincLayer(80, 401, 16000, stride=1, padding=0)
+        probe.filt_b1.data.copy_(layer.filt_b1.data)
+        probe.filt_band.data.copy_(layer.filt_band.data)
+        eye = torch.zeros(401, 1, 401)
+        for k in range(401):
+            eye[k, 0, k] = 1.0
+        return probe(eye)[:, :, 0].t().contiguous(), probe   # (80,401)
+
+    f0, _ = filters_of(lay)
+    out["b1_default"] = npd(lay.filt_b1)
+    out["band_default"] = npd(lay.filt_band)
+    out["filters_default"] = npd(f0)
+    g = torch.Generator().manual_seed(7)
+    lay2 = ref_models.SincLayer(80, 401, 16000, stride=80, padding=200)
+    lay2.filt_b1.data.mul_(1 + 0.3 * torch.randn(80, generator=g, dtype=torch.float64))
+    lay2.filt_band.data.mul_(1 + 0.3 * torch.randn(80, generator=g, dtype=torch.float64))
+    lay2.filt_b1.data[3] *= -1                                # exercise abs()
+    lay2.filt_band.data[5] *= -1
+    f1, probe = filters_of(lay2)
+    out["b1_perturbed"] = npd(lay2.filt_b1)
+    out["band_perturbed"] = npd(lay2.filt_band)
+    out["filters_perturbed"] = npd(f1)
+    # gradient of sum(filters * G) wrt the two float64 parameters (through the reference autograd)
+    G = torch.randn(80, 401, generator=g)
+    eye = torch.zeros(401, 1, 401)
+    for k in range(401):
+        eye[k, 0, k] = 1.0
+    filt = probe(eye)[:, :, 0].t()
+    (filt * G).sum().backward()
+    out["G"] = npd(G)
+    out["grad_b1_perturbed"] = npd(probe.filt_b1.grad)
+    out["grad_band_perturbed"] = npd(probe.filt_band.grad)
+    # small-shape bank (used by the tiny model): N_filt=8, Filt_dim=41
+    probe3 = ref_models.SincLayer(8, 41, 16000, stride=1, padding=0)
+    eye3 = torch.zeros(41, 1, 41)
+    for k in range(41):
+        eye3[k, 0, k] = 1.0
+    out["b1_small"] = npd(probe3.filt_b1)
+    out["band_small"] = npd(probe3.filt_band)
+    out["filters_small"] = npd(probe3(eye3)[:, :, 0].t())
+    np.savez_compressed(os.path.join(OUT, "g1_sinc_filters.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------------
+class Cfg:
+    pass
+
+
+def base_cfg(**kw):
+    c = Cfg()
+    c.use_sincnet = True
+    c.fs = 16000
+    c.cnn_N_filt = [80, 60, 60]
+    c.cnn_len_filt = [401, 5, 5]
+    c.cnn_stride = [80, 1, 1]
+    c.cnn_max_pool_len = [2, 1, 1]
+    c.cnn_act = ["leaky_relu"] * 3
+    c.cnn_drop = [0.0, 0.0, 0.0]
+    c.phone_rnn_num_hidden = [128, 128]
+    c.phone_downsample_len = [2, 2]
+    c.phone_downsample_type = ["avg", "avg"]
+    c.phone_rnn_drop = [0.5, 0.5]
+    c.phone_rnn_bidirectional = True
+    c.word_rnn_num_hidden = [128, 128]
+    c.word_downsample_len = [2, 2]
+    c.word_downsample_type = ["avg", "avg"]
+    c.word_rnn_drop = [0.5, 0.5]
+    c.word_rnn_bidirectional = True
+    c.vocabulary_size = 10000
+    c.intent_rnn_num_hidden = [128]
+    c.intent_downsample_len = [1]
+    c.intent_downsample_type = ["none"]
+    c.intent_rnn_drop = [0.5]
+    c.intent_rnn_bidirectional = True
+    c.pretraining_type = 0
+    c.unfreezing_type = 0
+    c.starting_unfreezing_index = 1
+    c.num_phonemes = 42
+    c.values_per_slot = [6, 14, 4]
+    c.Sy_intent = {"action": {str(i): i for i in range(6)},
+                   "object": {str(i): i for i in range(14)},
+                   "location": {str(i): i for i in range(4)}}
+    c.seq2seq = False
+    c.folder = "."
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def g2():
+    torch.manual_seed(1234)
+    cfg = base_cfg()
+    pm = ref_models.PretrainedModel(cfg)
+    pm.eval()
+    x = 0.1 * torch.randn(2, 8000)
+    out = {"x": npd(x)}
+    for k in ("phoneme_layers.5.weight", "phoneme_layers.5.bias",
+              "phoneme_layers.9.weight", "phoneme_layers.9.bias",
+              "phoneme_layers.0.filt_b1", "phoneme_layers.0.filt_band"):
+        out[k] = npd(pm.state_dict()[k])
+    h = x.unsqueeze(1)
+    for i, layer in enumerate(pm.phoneme_layers):
+        h = layer(h)
+        if layer.name in ("sinc0", "dropout0", "dropout1", "dropout2"):
+            out["after_" + layer.name] = npd(h)
+        if layer.name == "dropout2":
+            break
+    np.savez_compressed(os.path.join(OUT, "g2_frontend.npz"), **out)
+
+
+def g3():
+    for (I, H, T, B, bi) in [(60, 128, 100, 4, True), (256, 128, 50, 4, True), (8, 16, 7, 3, True),
+                             (12, 32, 9, 5, False)]:
+        torch.manual_seed(100 + I + H + T)
+        gru = torch.nn.GRU(input_size=I, hidden_size=H, batch_first=True, bidirectional=bi)
+        x = torch.randn(B, T, I, requires_grad=True)
+        out, _ = gru(x)
+        g = torch.randn_like(out)
+        (out * g).sum().backward()
+        d = {"x": npd(x), "out": npd(out), "g": npd(g), "dx": npd(x.grad)}
+        for k, v in gru.named_parameters():
+            d[k] = npd(v)
+            d["grad_" + k] = npd(v.grad)
+        np.savez_compressed(os.path.join(OUT, "g3_gru_I%d_H%d_T%d_B%d_%s.npz" % (I, H, T, B, "bi" if bi else "uni")), **d)
+
+
+def g4():
+    out = {}
+    g = torch.Generator().manual_seed(4)
+    for T in (25, 75, 6, 1):
+        x = torch.randn(3, T, 10, generator=g)
+        out["x_T%d" % T] = npd(x)
+        for method in ("none", "avg", "max"):
+            for factor in (1, 2, 3):
+                y = ref_models.Downsample(method=method, factor=factor, axis=1)(x)
+                out["y_T%d_%s_%d" % (T, method, factor)] = npd(y)
+    # dropout: nn.Dropout(0.5) in train mode under a seed; store output of ones -> mask*2
+    for seed in (11, 12):
+        torch.manual_seed(seed)
+        d = torch.nn.Dropout(0.5)
+        y = d(torch.ones(4, 9, 16))
+        out["dropout_seed%d" % seed] = npd(y)
+    np.savez_compressed(os.path.join(OUT, "g4_downsample.npz"), **out)
+
+
+def tiny_cfg(**kw):
+    c = base_cfg(cnn_N_filt=[8, 6, 6], cnn_len_filt=[41, 5, 3], cnn_stride=[10, 1, 1],
+                 cnn_max_pool_len=[2, 1, 1],
+                 phone_rnn_num_hidden=[16, 16], word_rnn_num_hidden=[16, 16],
+                 intent_rnn_num_hidden=[16], vocabulary_size=50, num_phonemes=11,
+                 values_per_slot=[3, 4, 2])
+    c.Sy_intent = {"action": {str(i): i for i in range(3)},
+                   "object": {str(i): i for i in range(4)},
+                   "location": {str(i): i for i in range(2)}}
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def run_model_case(model, x, y, train, seed):
+    model.zero_grad()
+    if train:
+        model.train()
+        torch.manual_seed(seed)
+    else:
+        model.eval()
+    loss, acc = model(x, y)
+    loss.backward()
+    d = {"loss": npd(loss), "acc": npd(acc)}
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            d["grad." + k] = npd(p.grad)
+    return d
+
+
+def g5():
+    torch.manual_seed(55)
+    cfg = tiny_cfg()
+    model = ref_models.Model(cfg)
+    x = 0.1 * torch.randn(3, 1000)
+    y = torch.stack([torch.randint(0, n, (3,)) for n in cfg.values_per_slot], dim=1)
+    out = {"x": npd(x), "y": npd(y)}
+    for k, v in model.state_dict().items():
+        out["sd." + k] = npd(v)
+    model.eval()
+    logits, pred = model.predict_intents(x)
+    out["eval.logits"] = npd(logits)
+    out["eval.pred"] = npd(pred)
+    feats = model.pretrained_model.compute_features(x)
+    out["eval.features"] = npd(feats)
+    for k, v in run_model_case(model, x, y, train=False, seed=0).items():
+        out["eval." + k] = v
+    for k, v in run_model_case(model, x, y, train=True, seed=77).items():
+        out["train77." + k] = v
+    np.savez_compressed(os.path.join(OUT, "g5_tiny_model.npz"), **out)
+
+    # ASR heads (PretrainedModel.forward), pretraining_type 2 and 1
+    torch.manual_seed(56)
+    cfg = tiny_cfg(pretraining_type=2)
+    pm = ref_models.PretrainedModel(cfg)
+    x = 0.1 * torch.randn(3, 1000)
+    st = None
+    pm.eval()
+    ph, wd = pm.compute_posteriors(x)
+    Tp, Tw = ph.shape[1], wd.shape[1]
+    yp = torch.randint(0, cfg.num_phonemes, (3, Tp))
+    yw = torch.randint(0, cfg.vocabulary_size, (3, Tw))
+    yp[0, -2:] = -1
+    yw[1, -1] = -1
+    out = {"x": npd(x), "y_phoneme": npd(yp), "y_word": npd(yw),
+           "posteriors.phoneme": npd(ph), "posteriors.word": npd(wd)}
+    for k, v in pm.state_dict().items():
+        out["sd." + k] = npd(v)
+    for ptype in (2, 1):
+        pm.pretraining_type = ptype
+        pm.zero_grad()
+        pl, wl, pa, wa = pm(x, yp, yw)
+        loss = pl + wl if ptype == 2 else pl
+        loss.backward()
+        tag = "pt%d." % ptype
+        out[tag + "phoneme_loss"], out[tag + "word_loss"] = npd(pl), npd(wl)
+        out[tag + "phoneme_acc"], out[tag + "word_acc"] = npd(pa), npd(wa)
+        for k, p in pm.named_parameters():
+            if p.grad is not None:
+                out[tag + "grad." + k] = npd(p.grad)
+    np.savez_compressed(os.path.join(OUT, "g5_tiny_asr.npz"), **out)
+
+
+CFG_NO_UNFREEZING = "no_unfreezing.cfg"
+
+
+def g6():
+    """BASELINE.json configs[0]: experiments/no_unfreezing.cfg on the CPU reference path,
+    16 synthetic 1 s waveforms, one forward+backward (+Adam) step."""
+    work = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    try:
+        os.chdir(work)
+        os.mkdir("experiments")
+        shutil.copy(os.path.join(REF, "experiments", CFG_NO_UNFREEZING), "experiments/")
+        cfg = ref_data.read_config("experiments/" + CFG_NO_UNFREEZING)
+        cfg.values_per_slot = [6, 14, 4]
+        cfg.Sy_intent = base_cfg().Sy_intent
+        cfg.num_phonemes = 42
+        # synthetic pre-training checkpoint (the published .pth files are absent): seed 4321
+        torch.manual_seed(4321)
+        pre = ref_models.PretrainedModel(cfg)
+        torch.save(pre.state_dict(), os.path.join(cfg.folder, "pretraining", "model_state.pth"))
+        pre_sha = {k: sha(v) for k, v in pre.state_dict().items()}
+        torch.manual_seed(cfg.seed)
+        model = ref_models.Model(cfg)
+        out = {}
+        meta = {"pretrain_seed": 4321, "model_seed": cfg.seed,
+                "pretrained_sha256": pre_sha,
+                "model_sha256": {k: sha(v) for k, v in model.state_dict().items()},
+                "dtypes": {k: str(v.dtype) for k, v in model.state_dict().items()},
+                "shapes": {k: list(v.shape) for k, v in model.state_dict().items()}}
+        g = torch.Generator().manual_seed(1234)
+        x = 0.1 * torch.randn(16, 16000, generator=g)
+        y = torch.stack([torch.randint(0, n, (16,), generator=g) for n in cfg.values_per_slot], dim=1)
+        out["x_sha256"] = np.frombuffer(bytes.fromhex(sha(x)), dtype=np.uint8)
+        out["y"] = npd(y)
+        model.eval()
+        logits, pred = model.predict_intents(x)
+        out["eval.logits"] = npd(logits)
+        out["eval.pred"] = npd(pred)
+        out["eval.features_digest"] = digest(model.pretrained_model.compute_features(x))
+        loss, acc = model(x, y)
+        out["eval.loss"], out["eval.acc"] = npd(loss), npd(acc)
+        # train-mode forward/backward, dropout seeded
+        model.train()
+        model.zero_grad()
+        torch.manual_seed(999)
+        loss, acc = model(x, y)
+        loss.backward()
+        out["train999.loss"], out["train999.acc"] = npd(loss), npd(acc)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out["train999.graddigest." + k] = digest(p.grad)
+        # everything unfrozen: same batch, same dropout seed
+        for p in model.parameters():
+            p.requires_grad = True
+        model.zero_grad()
+        torch.manual_seed(999)
+        loss, acc = model(x, y)
+        loss.backward()
+        out["unfrozen999.loss"] = npd(loss)
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                out["unfrozen999.graddigest." + k] = digest(p.grad)
+        model.freeze_all_layers()
+        model.zero_grad()
+        # one Trainer.train step over a one-batch "dataset"
+        class DS:
+            loader = [(x, y)]
+        trainer = ref_training.Trainer(model=model, config=cfg)
+        buf = io.StringIO()
+        stdout = sys.stdout
+        sys.stdout = buf
+        torch.manual_seed(2024)
+        try:
+            tr_acc, tr_loss = trainer.train(DS())
+        finally:
+            sys.stdout = stdout
+        meta["print_frozen"] = [l for l in buf.getvalue().splitlines() if ": " in l and "intent" not in l]
+        out["trainer.acc"], out["trainer.loss"] = np.float64(tr_acc), np.float64(tr_loss)
+        for k, v in model.state_dict().items():
+            if k.startswith("intent_layers"):
+                out["trainer.postadam_digest." + k] = digest(v)
+        with open(os.path.join(cfg.folder, "training", "log.csv")) as f:
+            meta["log_csv"] = f.read()
+        out["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "g6_full_model.npz"), **out)
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work)
+
+
+def g8():
+    work = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    res = {}
+    try:
+        os.chdir(work)
+        os.mkdir("experiments")
+        for name in sorted(os.listdir(os.path.join(REF, "experiments"))):
+            if not name.endswith(".cfg"):
+                continue
+            with open(os.path.join(REF, "experiments", name)) as f:
+                text = f.read()
+            shutil.copy(os.path.join(REF, "experiments", name), "experiments/")
+            entry = {"text": text}
+            buf = io.StringIO()
+            stdout = sys.stdout
+            sys.stdout = buf
+            try:
+                cfg = ref_data.read_config("experiments/" + name)
+                entry["expected"] = {k: v for k, v in vars(cfg).items()}
+            except Exception as e:                              # noqa: BLE001
+                entry["error_type"] = type(e).__name__
+                entry["error"] = str(e)
+            finally:
+                sys.stdout = stdout
+            entry["stdout"] = buf.getvalue()
+            res[name] = entry
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work)
+    with open(os.path.join(OUT, "g8_config.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    g1(); g2(); g3(); g4(); g5(); g6(); g8()
+    for fn in sorted(os.listdir(OUT)):
+        print("%9d  %s" % (os.path.getsize(os.path.join(OUT, fn)), fn))
