@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libslu_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${SLU_EXTRA_FLAGS:-}"
+OBJS=()
+for f in slu_api slu_sinc slu_wconv slu_gemm slu_gru slu_pool; do
+  if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/slu_common.h" -nt "$OUT/$f.o" ] \
+     || [ "$HERE/../../include/slu_hip.h" -nt "$OUT/$f.o" ]; then
+    echo "[build] $f.hip"
+    "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OUT/$f.o"
+  fi
+  OBJS+=("$OUT/$f.o")
+done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$OUT/libslu_hip.so"
+echo "[build] $OUT/libslu_hip.so"

@@ -1,0 +1,375 @@
+// Persistent GRU recurrence for gfx950 (reference: torch.nn.GRU at models.py:232, :262, :686;
+// h0 = 0, gate order [r; z; n], one layer, optional reverse direction; RNNSelect models.py:138-149).
+//
+// The recurrence is independent per sequence, so the grid is (16-sequence tile) x (direction): one
+// workgroup of H/16 waves runs the whole time loop with no inter-workgroup communication.
+//   * Wave w owns hidden units [16w, 16w+16).  Its slice of W_hh (3 gates x 16 units x H) stays
+//     RESIDENT IN VGPRs for all T steps as the MFMA B operand (3H/4 = 96 registers for H = 128).
+//   * Per step: G = h_{t-1} (16 x H) * W_hh^T via v_mfma_f32_16x16x4_f32 (exact fp32), three
+//     independent accumulator chains (r, z, n) per wave so the 40-cycle MFMA dependency latency is
+//     covered; h_{t-1} is read from LDS (row stride H+2 floats: conflict-free ds_read_b64).
+//   * The MFMA C layout gives each lane the r, z, n pre-activations of the SAME (sequence, unit)
+//     for 4 sequences, so sigmoid/tanh/hadamard/blend are fused in registers and h_{t-1} for the
+//     blend never leaves the lane.  h_t goes to LDS (next step's A operand, double buffered ->
+//     one barrier per step) and to HBM.
+//   * x-side pre-activations gx = x W_ih^T + b_ih come from slu_gemm_f32 and are prefetched one
+//     step ahead.
+// The backward kernel mirrors this with W_hh consumed transposed (dh_{t-1} += dG W_hh).
+#include "slu_common.h"
+
+namespace slu {
+
+#ifdef SLU_GRU_ACCURATE_MATH
+__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_tanh(float x) { return tanhf(x); }
+#else
+// v_exp_f32 / v_rcp_f32 (1 ulp each): absolute error of the gate values < 3e-7.
+__device__ __forceinline__ float act_sigmoid(float x) {
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
+  return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float act_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);   // exp(2x)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+#endif
+
+struct GruFwdParams {
+  const float* gx;        // (T, B, D*3H)
+  const float* w_hh[2];   // (3H, H) per direction
+  const float* b_hh[2];   // (3H)
+  float* out;             // (T, B, D*H)
+  float* reserve;         // [D][T][NBT][NW][5][64][4] or null
+  int T, B, D;
+};
+
+template <int H>
+__global__ void __launch_bounds__(H * 4)
+gru_seq_fwd_kernel(const GruFwdParams p) {
+  constexpr int NW = H / 16;      // waves
+  constexpr int KQ = H / 4;       // k range per lane group
+  constexpr int LD = H + 2;       // LDS row stride (floats)
+  __shared__ __attribute__((aligned(16))) float hbuf[2][16 * LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kg = lane >> 4;
+  const int btile = blockIdx.x, dir = blockIdx.y;
+  const int NBT = gridDim.x;
+  const int b0 = btile * 16;
+  const int j = w * 16 + i;       // hidden unit of this lane's outputs
+  const int T = p.T, B = p.B, D = p.D;
+
+  // resident W_hh slice: B[k = kg*KQ + kk][j] = W_hh[gate*H + j][kg*KQ + kk]
+  float wr[KQ], wz[KQ], wn[KQ];
+  {
+    const float* __restrict__ W = p.w_hh[dir];
+    const float* pr = W + ((size_t)(0 * H + j)) * H + kg * KQ;
+    const float* pz = W + ((size_t)(1 * H + j)) * H + kg * KQ;
+    const float* pn = W + ((size_t)(2 * H + j)) * H + kg * KQ;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) { wr[k] = pr[k]; wz[k] = pz[k]; wn[k] = pn[k]; }
+  }
+  const float bhr = p.b_hh[dir][j], bhz = p.b_hh[dir][H + j], bhn = p.b_hh[dir][2 * H + j];
+
+  for (int x = tid; x < 2 * 16 * LD; x += H * 4) (&hbuf[0][0])[x] = 0.0f;   // h0 = 0
+  float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+  bool rowok[4];
+  size_t grow[4];   // gx / out row offsets exclude t
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * kg + r;
+    rowok[r] = b < B;
+    grow[r] = (size_t)(rowok[r] ? b : 0);
+  }
+  const size_t gx_ts = (size_t)B * D * 3 * H;      // stride of t in gx
+  const size_t out_ts = (size_t)B * D * H;
+  const float* __restrict__ gxd = p.gx + (size_t)dir * 3 * H + j;
+  float* __restrict__ outd = p.out + (size_t)dir * H + j;
+
+  float gr[4], gz[4], gn[4];
+  {
+    const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* g = gxd + (size_t)t0 * gx_ts + grow[r] * D * 3 * H;
+      gr[r] = rowok[r] ? g[0] : 0.f;
+      gz[r] = rowok[r] ? g[H] : 0.f;
+      gn[r] = rowok[r] ? g[2 * H] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int cur = s & 1;
+    // prefetch next step's x-side pre-activations
+    float ngr[4], ngz[4], ngn[4];
+    if (s + 1 < T) {
+      const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* g = gxd + (size_t)tn * gx_ts + grow[r] * D * 3 * H;
+        ngr[r] = rowok[r] ? g[0] : 0.f;
+        ngz[r] = rowok[r] ? g[H] : 0.f;
+        ngn[r] = rowok[r] ? g[2 * H] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ngr[r] = 0.f; ngz[r] = 0.f; ngn[r] = 0.f; }
+    }
+
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ hrow = &hbuf[cur][i * LD + kg * KQ];
+#pragma unroll
+    for (int v = 0; v < KQ / 2; ++v) {
+      const float2 a = *reinterpret_cast<const float2*>(hrow + 2 * v);
+      ar = mfma16(a.x, wr[2 * v], ar);
+      az = mfma16(a.x, wz[2 * v], az);
+      an = mfma16(a.x, wn[2 * v], an);
+      ar = mfma16(a.y, wr[2 * v + 1], ar);
+      az = mfma16(a.y, wz[2 * v + 1], az);
+      an = mfma16(a.y, wn[2 * v + 1], an);
+    }
+
+    float rr[4], zz[4], nn[4], qq[4], hn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      rr[r] = act_sigmoid(gr[r] + (ar[r] + bhr));
+      zz[r] = act_sigmoid(gz[r] + (az[r] + bhz));
+      qq[r] = an[r] + bhn;
+      nn[r] = act_tanh(gn[r] + rr[r] * qq[r]);
+      hn[r] = (1.0f - zz[r]) * nn[r] + zz[r] * hprev[r];
+    }
+    float* __restrict__ hnext = &hbuf[cur ^ 1][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      hnext[(4 * kg + r) * LD + j] = hn[r];
+      if (rowok[r]) outd[(size_t)t * out_ts + grow[r] * D * H] = hn[r];
+    }
+    if (p.reserve) {
+      float4* __restrict__ rs = reinterpret_cast<float4*>(
+          p.reserve + ((((size_t)dir * T + t) * NBT + btile) * NW + w) * (5 * 256)) + lane;
+      rs[0 * 64] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+      rs[1 * 64] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+      rs[2 * 64] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+      rs[3 * 64] = make_float4(qq[0], qq[1], qq[2], qq[3]);
+      rs[4 * 64] = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { hprev[r] = hn[r]; gr[r] = ngr[r]; gz[r] = ngz[r]; gn[r] = ngn[r]; }
+    __syncthreads();
+  }
+}
+
+struct GruBwdParams {
+  const float* d_out;     // (T, B, D*H)
+  const float* reserve;
+  const float* w_hh[2];
+  float* d_gx;            // (T, B, D*3H)
+  float* d_q;             // (T, B, D*H)
+  float* d_bias_part;     // [NBT][D][4H] or null: sums over t and the tile's sequences of d_gx | d_q
+  int T, B, D;
+};
+
+template <int H>
+__global__ void __launch_bounds__(H * 4)
+gru_seq_bwd_kernel(const GruBwdParams p) {
+  constexpr int NW = H / 16;
+  constexpr int KQ = H / 4;
+  constexpr int LDB = 3 * H + 2;
+  __shared__ __attribute__((aligned(16))) float gbuf[2][16 * LDB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kg = lane >> 4;
+  const int btile = blockIdx.x, dir = blockIdx.y;
+  const int NBT = gridDim.x;
+  const int b0 = btile * 16;
+  const int j = w * 16 + i;
+  const int T = p.T, B = p.B, D = p.D;
+
+  // resident transposed slice: B[k = g][n = j] = W_hh[gate*H + kg*KQ + kk][j]
+  float wr[KQ], wz[KQ], wn[KQ];
+  {
+    const float* __restrict__ W = p.w_hh[dir];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      wr[k] = W[((size_t)(0 * H + kg * KQ + k)) * H + j];
+      wz[k] = W[((size_t)(1 * H + kg * KQ + k)) * H + j];
+      wn[k] = W[((size_t)(2 * H + kg * KQ + k)) * H + j];
+    }
+  }
+  bool rowok[4];
+  size_t grow[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * kg + r;
+    rowok[r] = b < B;
+    grow[r] = (size_t)(rowok[r] ? b : 0);
+  }
+  const size_t out_ts = (size_t)B * D * H;
+  const size_t gx_ts = (size_t)B * D * 3 * H;
+  const float* __restrict__ dod = p.d_out + (size_t)dir * H + j;
+  float* __restrict__ dgxd = p.d_gx + (size_t)dir * 3 * H + j;
+  float* __restrict__ dqd = p.d_q + (size_t)dir * H + j;
+
+  float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
+  float sbr = 0.f, sbz = 0.f, sbn = 0.f, sbq = 0.f;
+
+  // step s of the backward pass visits the time index the forward pass visited LAST first
+  auto tindex = [&](int s) { return dir ? s : T - 1 - s; };
+  auto rsv = [&](int t) {
+    return reinterpret_cast<const float4*>(
+               p.reserve + ((((size_t)dir * T + t) * NBT + btile) * NW + w) * (5 * 256)) + lane;
+  };
+
+  float4 c_r, c_z, c_n, c_q, c_h;
+  float c_do[4];
+  {
+    const int t = tindex(0);
+    const float4* rs = rsv(t);
+    c_r = rs[0]; c_z = rs[64]; c_n = rs[128]; c_q = rs[192]; c_h = rs[256];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c_do[r] = rowok[r] ? dod[(size_t)t * out_ts + grow[r] * D * H] : 0.f;
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const int t = tindex(s);
+    const int cur = s & 1;
+    float4 n_r = c_r, n_z = c_z, n_n = c_n, n_q = c_q, n_h = c_h;
+    float n_do[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s + 1 < T) {
+      const int tn = tindex(s + 1);
+      const float4* rs = rsv(tn);
+      n_r = rs[0]; n_z = rs[64]; n_n = rs[128]; n_q = rs[192]; n_h = rs[256];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) n_do[r] = rowok[r] ? dod[(size_t)tn * out_ts + grow[r] * D * H] : 0.f;
+    }
+
+    const float rr[4] = {c_r.x, c_r.y, c_r.z, c_r.w};
+    const float zz[4] = {c_z.x, c_z.y, c_z.z, c_z.w};
+    const float nn[4] = {c_n.x, c_n.y, c_n.z, c_n.w};
+    const float qq[4] = {c_q.x, c_q.y, c_q.z, c_q.w};
+    const float hp[4] = {c_h.x, c_h.y, c_h.z, c_h.w};
+    float ddirect[4];
+    float* __restrict__ gcur = &gbuf[cur][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float dh = dcarry[r] + c_do[r];
+      const float dn = dh * (1.0f - zz[r]);
+      const float dz = dh * (hp[r] - nn[r]);
+      ddirect[r] = dh * zz[r];
+      const float dn_pre = dn * (1.0f - nn[r] * nn[r]);
+      const float dz_pre = dz * zz[r] * (1.0f - zz[r]);
+      const float dq = dn_pre * rr[r];
+      const float dr_pre = (dn_pre * qq[r]) * rr[r] * (1.0f - rr[r]);
+      const int brow = 4 * kg + r;
+      gcur[brow * LDB + 0 * H + j] = dr_pre;
+      gcur[brow * LDB + 1 * H + j] = dz_pre;
+      gcur[brow * LDB + 2 * H + j] = dq;
+      if (rowok[r]) {
+        float* g = dgxd + (size_t)t * gx_ts + grow[r] * D * 3 * H;
+        g[0] = dr_pre; g[H] = dz_pre; g[2 * H] = dn_pre;
+        dqd[(size_t)t * out_ts + grow[r] * D * H] = dq;
+        sbr += dr_pre; sbz += dz_pre; sbn += dn_pre; sbq += dq;
+      }
+    }
+    __syncthreads();
+
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ grow_l = &gbuf[cur][i * LDB + kg * KQ];
+#pragma unroll
+    for (int v = 0; v < KQ / 2; ++v) {
+      const float2 a0 = *reinterpret_cast<const float2*>(grow_l + 0 * H + 2 * v);
+      const float2 a1 = *reinterpret_cast<const float2*>(grow_l + 1 * H + 2 * v);
+      const float2 a2 = *reinterpret_cast<const float2*>(grow_l + 2 * H + 2 * v);
+      ar = mfma16(a0.x, wr[2 * v], ar);
+      az = mfma16(a1.x, wz[2 * v], az);
+      an = mfma16(a2.x, wn[2 * v], an);
+      ar = mfma16(a0.y, wr[2 * v + 1], ar);
+      az = mfma16(a1.y, wz[2 * v + 1], az);
+      an = mfma16(a2.y, wn[2 * v + 1], an);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dcarry[r] = ddirect[r] + ((ar[r] + az[r]) + an[r]);
+
+    c_r = n_r; c_z = n_z; c_n = n_n; c_q = n_q; c_h = n_h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c_do[r] = n_do[r];
+    // gbuf[cur] is rewritten two steps from now; the barrier of the next step orders that.
+  }
+
+  if (p.d_bias_part) {
+    // sum the 4 lane groups (same unit j, different sequences)
+    sbr += __shfl_xor(sbr, 16); sbr += __shfl_xor(sbr, 32);
+    sbz += __shfl_xor(sbz, 16); sbz += __shfl_xor(sbz, 32);
+    sbn += __shfl_xor(sbn, 16); sbn += __shfl_xor(sbn, 32);
+    sbq += __shfl_xor(sbq, 16); sbq += __shfl_xor(sbq, 32);
+    if (kg == 0) {
+      float* o = p.d_bias_part + ((size_t)btile * D + dir) * 4 * H;
+      o[j] = sbr; o[H + j] = sbz; o[2 * H + j] = sbn; o[3 * H + j] = sbq;
+    }
+  }
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t D) {
+  const int64_t nbt = cdiv(B, 16);
+  return (size_t)(D * T * nbt * (H / 16) * 5 * 256) * sizeof(float);
+}
+
+static int gru_check(const char* who, int64_t T, int64_t B, int64_t H, int64_t D) {
+  SLU_REQUIRE(T > 0 && B > 0, "%s: non-positive T or B", who);
+  SLU_REQUIRE(D == 1 || D == 2, "%s: D must be 1 or 2", who);
+  if (!(H == 16 || H == 32 || H == 64 || H == 128))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: hidden size %lld not instantiated (16, 32, 64, 128)", who, (long long)H);
+  SLU_REQUIRE(cdiv(B, 16) <= 65535, "%s: B too large", who);
+  return SLU_OK;
+}
+
+extern "C" int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
+                               const float* b_hh_fwd, const float* b_hh_rev, float* out,
+                               float* reserve, int64_t T, int64_t B, int64_t H, int64_t D,
+                               void* stream) {
+  SLU_REQUIRE(gx && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd: null pointer");
+  SLU_REQUIRE(D == 1 || (w_hh_rev && b_hh_rev), "slu_gru_seq_fwd: reverse weights missing");
+  int rc = gru_check("slu_gru_seq_fwd", T, B, H, D);
+  if (rc) return rc;
+  GruFwdParams p;
+  p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
+  p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 16: hipLaunchKernelGGL(gru_seq_fwd_kernel<16>, grid, dim3(64), 0, st, p); break;
+    case 32: hipLaunchKernelGGL(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, p); break;
+    case 64: hipLaunchKernelGGL(gru_seq_fwd_kernel<64>, grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(gru_seq_fwd_kernel<128>, grid, dim3(512), 0, st, p); break;
+  }
+  SLU_CHECK_LAUNCH("gru_seq_fwd_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_fwd,
+                               const float* w_hh_rev, float* d_gx, float* d_q, float* d_bias_part,
+                               int64_t T, int64_t B, int64_t H, int64_t D, void* stream) {
+  SLU_REQUIRE(d_out && reserve && w_hh_fwd && d_gx && d_q, "slu_gru_seq_bwd: null pointer");
+  SLU_REQUIRE(D == 1 || w_hh_rev, "slu_gru_seq_bwd: reverse weights missing");
+  int rc = gru_check("slu_gru_seq_bwd", T, B, H, D);
+  if (rc) return rc;
+  GruBwdParams p;
+  p.d_out = d_out; p.reserve = reserve; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev;
+  p.d_gx = d_gx; p.d_q = d_q; p.d_bias_part = d_bias_part; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 16: hipLaunchKernelGGL(gru_seq_bwd_kernel<16>, grid, dim3(64), 0, st, p); break;
+    case 32: hipLaunchKernelGGL(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, p); break;
+    case 64: hipLaunchKernelGGL(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, p); break;
+  }
+  SLU_CHECK_LAUNCH("gru_seq_bwd_kernel");
+  return SLU_OK;
+}

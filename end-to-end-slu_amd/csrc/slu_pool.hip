@@ -1,0 +1,150 @@
+// Fused Dropout + Downsample for time-major GRU outputs (reference: nn.Dropout models.py:246,276,700
+// followed by Downsample models.py:26-46: "none" = strided slice, "avg"/"max" = pool1d with
+// ceil_mode=True, where a partial last window uses only the frames that exist).
+//
+// Pure HBM-bound elementwise work: one thread per output element, channel index fastest so that
+// every wave access is a contiguous 256-byte row segment.
+#include "slu_common.h"
+
+namespace slu {
+
+// Philox4x32-10 (Salmon et al.), counter = (element index / 4, offset), key = seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+  uint32_t c[4] = {(uint32_t)(idx >> 2), (uint32_t)(idx >> 34), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+  const uint32_t x = c[idx & 3];
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+struct PoolParams {
+  const float* mask; long long m_st, m_sb;
+  float p, scale;
+  unsigned long long seed, offset;
+  int method, factor;
+  int T, B, C, T_out;
+};
+
+// keep-factor (0 or 1/(1-p)) of element (t,b,c)
+__device__ __forceinline__ float keep_scale(const PoolParams& q, int t, int b, int c) {
+  if (q.p <= 0.0f) return 1.0f;
+  if (q.mask) return q.mask[(long long)t * q.m_st + (long long)b * q.m_sb + c] * q.scale;
+  const uint64_t idx = ((uint64_t)t * q.B + b) * q.C + c;
+  return philox_uniform(q.seed, q.offset, idx) < (1.0f - q.p) ? q.scale : 0.0f;
+}
+
+__global__ void __launch_bounds__(256)
+dropout_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const PoolParams q) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)q.T_out * q.B * q.C;
+  if (idx >= total) return;
+  const int c = (int)(idx % q.C);
+  const long long tb = idx / q.C;
+  const int b = (int)(tb % q.B);
+  const int to = (int)(tb / q.B);
+  const int t0 = to * q.factor;
+  const long long row = (long long)q.B * q.C;
+  if (q.method == 0) {
+    y[idx] = x[(long long)t0 * row + (long long)b * q.C + c] * keep_scale(q, t0, b, c);
+    return;
+  }
+  const int t1 = min(q.T, t0 + q.factor);
+  float acc = (q.method == 1) ? 0.0f : -INFINITY;
+  for (int t = t0; t < t1; ++t) {
+    const float v = x[(long long)t * row + (long long)b * q.C + c] * keep_scale(q, t, b, c);
+    acc = (q.method == 1) ? acc + v : fmaxf(acc, v);
+  }
+  y[idx] = (q.method == 1) ? acc / (float)(t1 - t0) : acc;
+}
+
+__global__ void __launch_bounds__(256)
+dropout_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                        float* __restrict__ dx, const PoolParams q) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)q.T * q.B * q.C;
+  if (idx >= total) return;
+  const int c = (int)(idx % q.C);
+  const long long tb = idx / q.C;
+  const int b = (int)(tb % q.B);
+  const int t = (int)(tb / q.B);
+  const int to = t / q.factor;
+  const int t0 = to * q.factor;
+  const long long row = (long long)q.B * q.C;
+  const float g = dy[(long long)to * row + (long long)b * q.C + c];
+  const float ks = keep_scale(q, t, b, c);
+  float out;
+  if (q.method == 0) {
+    out = (t == t0) ? g * ks : 0.0f;
+  } else if (q.method == 1) {
+    const int t1 = min(q.T, t0 + q.factor);
+    out = g * ks / (float)(t1 - t0);
+  } else {
+    const int t1 = min(q.T, t0 + q.factor);
+    int arg = t0;
+    float best = -INFINITY;
+    for (int tt = t0; tt < t1; ++tt) {
+      const float v = x[(long long)tt * row + (long long)b * q.C + c] * keep_scale(q, tt, b, c);
+      if (v > best) { best = v; arg = tt; }
+    }
+    out = (arg == t) ? g * ks : 0.0f;
+  }
+  dx[idx] = out;
+}
+
+static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t m_st, int64_t m_sb,
+                     float p, uint64_t seed, uint64_t offset, int method, int64_t factor, int64_t T,
+                     int64_t B, int64_t C) {
+  SLU_REQUIRE(T > 0 && B > 0 && C > 0 && factor > 0, "%s: non-positive size", who);
+  SLU_REQUIRE(method >= 0 && method <= 2, "%s: downsampling method must be 0 (none), 1 (avg) or 2 (max)", who);
+  SLU_REQUIRE(p >= 0.0f && p < 1.0f, "%s: dropout p must be in [0,1)", who);
+  q.mask = mask; q.m_st = m_st; q.m_sb = m_sb; q.p = p; q.scale = 1.0f / (1.0f - p);
+  q.seed = seed; q.offset = offset; q.method = method; q.factor = (int)factor;
+  q.T = (int)T; q.B = (int)B; q.C = (int)C; q.T_out = (int)cdiv(T, factor);
+  return SLU_OK;
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb,
+                                    float p, uint64_t seed, uint64_t offset, int method,
+                                    int64_t factor, float* y, int64_t T, int64_t B, int64_t C,
+                                    void* stream) {
+  SLU_REQUIRE(x && y, "slu_dropout_pool_fwd: null pointer");
+  PoolParams q;
+  int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, p, seed, offset, method, factor, T, B, C);
+  if (rc) return rc;
+  const long long total = (long long)q.T_out * B * C;
+  hipLaunchKernelGGL(dropout_pool_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, q);
+  SLU_CHECK_LAUNCH("dropout_pool_fwd_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y,
+                                    const float* mask, int64_t m_st, int64_t m_sb, float p,
+                                    uint64_t seed, uint64_t offset, int method, int64_t factor,
+                                    float* dx, int64_t T, int64_t B, int64_t C, void* stream) {
+  SLU_REQUIRE(dy && dx, "slu_dropout_pool_bwd: null pointer");
+  SLU_REQUIRE(method != 2 || x, "slu_dropout_pool_bwd: x is required for max pooling");
+  (void)y;
+  PoolParams q;
+  int rc = pool_fill(q, "slu_dropout_pool_bwd", mask, m_st, m_sb, p, seed, offset, method, factor, T, B, C);
+  if (rc) return rc;
+  const long long total = (long long)T * B * C;
+  hipLaunchKernelGGL(dropout_pool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dy, x, dx, q);
+  SLU_CHECK_LAUNCH("dropout_pool_bwd_kernel");
+  return SLU_OK;
+}

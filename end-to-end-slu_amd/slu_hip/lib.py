@@ -1,0 +1,85 @@
+"""ctypes binding of libslu_hip.so (C ABI declared in include/slu_hip.h).
+
+The library is built in-tree by csrc/build.sh (hipcc --offload-arch=gfx950).  There is no CPU or
+PyTorch fallback: if the shared object is missing, or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libslu_hip.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_f64 = ctypes.c_double
+c_u64 = ctypes.c_uint64
+c_sz = ctypes.c_size_t
+vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/slu_hip.h one to one
+SIGNATURES = {
+    "slu_version": (c_int, []),
+    "slu_last_error": (ctypes.c_char_p, []),
+    "slu_device_check": (c_int, []),
+    "slu_device_arch": (ctypes.c_char_p, []),
+    "slu_sinc_filters_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_f64, vp]),
+    "slu_sinc_filters_bwd": (c_int, [vp, vp, vp, vp, vp, c_i64, c_i64, c_f64, vp]),
+    "slu_wconv_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "slu_wconv_fwd": (c_int, [vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int,
+                              c_int, c_f32, c_i64, c_i64, vp, c_sz, vp]),
+    "slu_wconv_bwd_act": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_i64, c_int, c_int, c_f32, c_i64,
+                                  c_i64, vp]),
+    "slu_wconv_bwd_data": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, vp, c_sz, vp]),
+    "slu_wconv_bwd_weight_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "slu_wconv_bwd_weight": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, vp,
+                                     c_sz, vp]),
+    "slu_gemm_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "slu_gemm_f32": (c_int, [vp, c_i64, c_i64, vp, c_i64, c_i64, vp, c_i64, c_i64, vp, c_i64, c_i64,
+                             c_i64, c_int, vp, c_sz, vp]),
+    "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
+    "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
+    "slu_gru_seq_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
+    "slu_gru_seq_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
+    "slu_dropout_pool_fwd": (c_int, [vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, c_int, c_i64, vp,
+                                     c_i64, c_i64, c_i64, vp]),
+    "slu_dropout_pool_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, c_int,
+                                     c_i64, vp, c_i64, c_i64, c_i64, vp]),
+}
+
+_lib = None
+
+
+class SluHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libslu_hip.so (once).  Raises SluHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SluHipError(
+            "libslu_hip.so not found at %s — build it with end-to-end-slu_amd/csrc/build.sh "
+            "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the ABI and this table disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.slu_version() != 1:
+        raise SluHipError("libslu_hip.so ABI version %d, expected 1" % lib.slu_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().slu_last_error().decode("utf-8", "replace")
+        raise SluHipError("%s failed (status %d): %s" % (what or "libslu_hip call", rc, msg))
+
+
+def require_gfx950():
+    lib = load()
+    check(lib.slu_device_check(), "slu_device_check")

@@ -1,0 +1,343 @@
+"""Tensor-level wrappers over the C ABI (include/slu_hip.h) and the autograd Functions built on them.
+
+Layouts used between kernels (the host mirror in models.py converts at the module boundary):
+  waveform (B, T); CNN activations channels-last (B, L, C); everything from the last CNN layer
+  on is TIME-MAJOR (T, B, C), which is also the memory order ATen's batch_first GRU uses.
+
+torch is plumbing here: it owns the device buffers, the stream and the autograd tape.  All
+arithmetic of the hot path happens in libslu_hip.so; there is no fallback path.
+"""
+import torch
+
+from . import lib as _lib
+
+METHODS = {"none": 0, "avg": 1, "max": 2}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError("%s must be a float32 CUDA tensor (got %s on %s)" % (what, t.dtype, t.device))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------
+# functional wrappers (no autograd)
+# ------------------------------------------------------------------------------------------------
+
+def sinc_filters(b1, band, filt_dim, fs):
+    L = _lib.load()
+    n = b1.numel()
+    out = torch.empty(n, filt_dim, dtype=torch.float32, device=b1.device)
+    _lib.check(L.slu_sinc_filters_fwd(b1.data_ptr(), band.data_ptr(), out.data_ptr(), n, filt_dim,
+                                      float(fs), _stream()), "slu_sinc_filters_fwd")
+    return out
+
+
+def sinc_filters_bwd(b1, band, d_filters, filt_dim, fs):
+    L = _lib.load()
+    n = b1.numel()
+    d_filters = _f32c(d_filters, "d_filters")
+    db1 = torch.empty_like(b1)
+    dband = torch.empty_like(band)
+    _lib.check(L.slu_sinc_filters_bwd(b1.data_ptr(), band.data_ptr(), d_filters.data_ptr(),
+                                      db1.data_ptr(), dband.data_ptr(), n, filt_dim, float(fs),
+                                      _stream()), "slu_sinc_filters_bwd")
+    return db1, dband
+
+
+def conv_out_len(l_in, k_t, stride):
+    return (l_in + 2 * (k_t // 2) - k_t) // stride + 1
+
+
+def wconv_fwd(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, want_route):
+    """x: contiguous (B, l_in, c_in) [or (B, T) with c_in = 1]; weight (c_out, c_in, k_t)."""
+    L = _lib.load()
+    x = _f32c(x, "x")
+    weight = _f32c(weight, "weight")
+    c_out, _, k_t = weight.shape
+    l_conv = conv_out_len(l_in, k_t, stride)
+    l_out = -(-l_conv // pool)
+    if time_major:
+        out = torch.empty(l_out, B, c_out, dtype=torch.float32, device=x.device)
+        sb, sl = c_out, B * c_out
+    else:
+        out = torch.empty(B, l_out, c_out, dtype=torch.float32, device=x.device)
+        sb, sl = l_out * c_out, c_out
+    route = torch.empty(B, l_out, c_out, dtype=torch.uint8, device=x.device) if want_route else None
+    wsb = L.slu_wconv_workspace_bytes(c_out, c_in, k_t)
+    ws = _workspace(wsb, x.device)
+    _lib.check(L.slu_wconv_fwd(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(),
+                               _ptr(route), B, l_in, c_in, c_out, k_t, stride, int(do_abs), pool,
+                               float(slope), sb, sl, ws.data_ptr(), wsb, _stream()), "slu_wconv_fwd")
+    return out, route, l_conv
+
+
+def wconv_bwd_act(dy, y, route, B, l_conv, c_out, do_abs, pool, slope, time_major):
+    L = _lib.load()
+    dy = _f32c(dy, "dy")
+    l_out = -(-l_conv // pool)
+    sb, sl = (c_out, B * c_out) if time_major else (l_out * c_out, c_out)
+    d_conv = torch.empty(B, l_conv, c_out, dtype=torch.float32, device=dy.device)
+    _lib.check(L.slu_wconv_bwd_act(dy.data_ptr(), y.data_ptr(), _ptr(route), d_conv.data_ptr(), B,
+                                   l_conv, c_out, int(do_abs), pool, float(slope), sb, sl,
+                                   _stream()), "slu_wconv_bwd_act")
+    return d_conv
+
+
+def wconv_bwd_data(d_conv, weight, B, l_in):
+    L = _lib.load()
+    c_out, c_in, k_t = weight.shape
+    d_in = torch.empty(B, l_in, c_in, dtype=torch.float32, device=d_conv.device)
+    wsb = L.slu_wconv_workspace_bytes(c_out, c_in, k_t)
+    ws = _workspace(wsb, d_conv.device)
+    _lib.check(L.slu_wconv_bwd_data(d_conv.data_ptr(), weight.data_ptr(), d_in.data_ptr(), B, l_in,
+                                    c_in, c_out, k_t, ws.data_ptr(), wsb, _stream()),
+               "slu_wconv_bwd_data")
+    return d_in
+
+
+def wconv_bwd_weight(d_conv, x, B, l_in, c_in, c_out, k_t, stride, want_bias):
+    L = _lib.load()
+    dW = torch.empty(c_out, c_in, k_t, dtype=torch.float32, device=x.device)
+    db = torch.empty(c_out, dtype=torch.float32, device=x.device) if want_bias else None
+    wsb = L.slu_wconv_bwd_weight_workspace_bytes(B, l_in, c_in, c_out, k_t, stride)
+    ws = _workspace(wsb, x.device)
+    _lib.check(L.slu_wconv_bwd_weight(d_conv.data_ptr(), x.data_ptr(), dW.data_ptr(), _ptr(db), B,
+                                      l_in, c_in, c_out, k_t, stride, ws.data_ptr(), wsb, _stream()),
+               "slu_wconv_bwd_weight")
+    return dW, db
+
+
+def gemm(a, b, bias=None, out=None, accumulate=False):
+    """out(M,N) = [out] + a(M,K) @ b(K,N) + bias(N); a, b, out are 2-D views with ANY strides."""
+    L = _lib.load()
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2, (a.shape, b.shape)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    wsb = L.slu_gemm_workspace_bytes(M, N, K)
+    ws = _workspace(wsb, a.device) if wsb else None
+    _lib.check(L.slu_gemm_f32(a.data_ptr(), a.stride(0), a.stride(1), b.data_ptr(), b.stride(0),
+                              b.stride(1), out.data_ptr(), out.stride(0), out.stride(1), _ptr(bias),
+                              M, N, K, int(accumulate), _ptr(ws), wsb, _stream()), "slu_gemm_f32")
+    return out
+
+
+def colsum(x2d, out=None, accumulate=False):
+    L = _lib.load()
+    M, N = x2d.shape
+    assert x2d.stride(1) == 1
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    _lib.check(L.slu_colsum_f32(x2d.data_ptr(), x2d.stride(0), out.data_ptr(), M, N, int(accumulate),
+                                _stream()), "slu_colsum_f32")
+    return out
+
+
+def gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, want_reserve):
+    L = _lib.load()
+    out = torch.empty(T, B, D * H, dtype=torch.float32, device=gx.device)
+    reserve = None
+    if want_reserve:
+        reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=gx.device)
+    _lib.check(L.slu_gru_seq_fwd(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(),
+                                 _ptr(b_hh_r), out.data_ptr(), _ptr(reserve), T, B, H, D, _stream()),
+               "slu_gru_seq_fwd")
+    return out, reserve
+
+
+def gru_seq_bwd(d_out, reserve, w_hh_f, w_hh_r, T, B, H, D):
+    L = _lib.load()
+    d_out = _f32c(d_out, "d_out")
+    dev = d_out.device
+    d_gx = torch.empty(T, B, D * 3 * H, dtype=torch.float32, device=dev)
+    d_q = torch.empty(T, B, D * H, dtype=torch.float32, device=dev)
+    nbt = -(-B // 16)
+    d_bias_part = torch.empty(nbt, D, 4 * H, dtype=torch.float32, device=dev)
+    _lib.check(L.slu_gru_seq_bwd(d_out.data_ptr(), reserve.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r),
+                                 d_gx.data_ptr(), d_q.data_ptr(), d_bias_part.data_ptr(), T, B, H, D,
+                                 _stream()), "slu_gru_seq_bwd")
+    return d_gx, d_q, d_bias_part
+
+
+def _mask_args(mask, T, B, C):
+    """mask: None or a float32 {0,1} tensor of logical shape (T,B,C) with unit channel stride."""
+    if mask is None:
+        return 0, 0, 0
+    assert mask.dtype == torch.float32 and tuple(mask.shape) == (T, B, C) and mask.stride(2) == 1
+    return mask.data_ptr(), mask.stride(0), mask.stride(1)
+
+
+def dropout_pool_fwd(x, mask, p, seed, offset, method, factor):
+    L = _lib.load()
+    T, B, C = x.shape
+    T_out = -(-T // factor)
+    y = torch.empty(T_out, B, C, dtype=torch.float32, device=x.device)
+    mp, mst, msb = _mask_args(mask, T, B, C)
+    _lib.check(L.slu_dropout_pool_fwd(x.data_ptr(), mp, mst, msb, float(p), int(seed), int(offset),
+                                      METHODS[method], factor, y.data_ptr(), T, B, C, _stream()),
+               "slu_dropout_pool_fwd")
+    return y
+
+
+def dropout_pool_bwd(dy, x, mask, p, seed, offset, method, factor):
+    L = _lib.load()
+    T, B, C = x.shape
+    dy = _f32c(dy, "dy")
+    dx = torch.empty(T, B, C, dtype=torch.float32, device=x.device)
+    mp, mst, msb = _mask_args(mask, T, B, C)
+    _lib.check(L.slu_dropout_pool_bwd(dy.data_ptr(), x.data_ptr(), 0, mp, mst, msb, float(p), int(seed),
+                                      int(offset), METHODS[method], factor, dx.data_ptr(), T, B, C,
+                                      _stream()), "slu_dropout_pool_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions (one per fused stage of the encoder)
+# ------------------------------------------------------------------------------------------------
+
+class SincBlockFn(torch.autograd.Function):
+    """SincLayer -> Abs -> MaxPool1d(ceil) -> LeakyReLU  (models.py:77-110, :163-168, :205, :211).
+    x (B,T) -> (B, L_out, N_filt) channels-last, or (L_out, B, N_filt) when time_major."""
+
+    @staticmethod
+    def forward(ctx, x, b1, band, filt_dim, fs, stride, pool, slope, time_major):
+        B, T = x.shape
+        filters = sinc_filters(b1, band, filt_dim, fs)
+        need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        out, route, l_conv = wconv_fwd(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, True,
+                                       pool, slope, time_major, need)
+        ctx.cfg = (B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv)
+        if need:
+            ctx.save_for_backward(x, b1, band, out, route)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv = ctx.cfg
+        x, b1, band, out, route = ctx.saved_tensors
+        n = b1.numel()
+        d_conv = wconv_bwd_act(dy, out, route, B, l_conv, n, True, pool, slope, time_major)
+        dW, _ = wconv_bwd_weight(d_conv, x, B, T, 1, n, filt_dim, stride, False)
+        db1, dband = sinc_filters_bwd(b1, band, dW.view(n, filt_dim), filt_dim, fs)
+        return None, db1, dband, None, None, None, None, None, None
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """Conv1d -> [Abs] -> MaxPool1d(ceil) -> LeakyReLU/ReLU  (models.py:190/200, :205, :211-213).
+    x channels-last (B, L, Cin) -> (B, L_out, Cout) or time-major (L_out, B, Cout)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, do_abs, pool, slope, time_major):
+        B, l_in, c_in = x.shape
+        x = x.contiguous()
+        need_route = (pool != 1 or do_abs) and any(ctx.needs_input_grad[:3])
+        out, route, l_conv = wconv_fwd(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope,
+                                       time_major, need_route)
+        ctx.cfg = (B, l_in, c_in, stride, do_abs, pool, slope, time_major, l_conv)
+        ctx.save_for_backward(x, weight, out, route)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, l_in, c_in, stride, do_abs, pool, slope, time_major, l_conv = ctx.cfg
+        x, weight, out, route = ctx.saved_tensors
+        c_out, _, k_t = weight.shape
+        d_conv = wconv_bwd_act(dy, out, route, B, l_conv, c_out, do_abs, pool, slope, time_major)
+        dx = dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dW, db = wconv_bwd_weight(d_conv, x, B, l_in, c_in, c_out, k_t, stride, ctx.has_bias)
+        if ctx.needs_input_grad[0]:
+            if stride != 1:
+                raise NotImplementedError("data gradient of a strided Conv1d layer is not implemented "
+                                          "(only the first CNN layer of the reference is strided)")
+            dx = wconv_bwd_data(d_conv, weight, B, l_in)
+        return dx, dW, db, None, None, None, None, None
+
+
+class GRULayerFn(torch.autograd.Function):
+    """nn.GRU (1 layer, h0 = 0) -> RNNSelect -> Dropout -> Downsample  (models.py:232-253).
+    x time-major (T, B, I) -> (T_out, B, D*H)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r,
+                p, mask, seed, offset, method, factor):
+        x = x.contiguous()
+        T, B, I = x.shape
+        H = w_hh_f.shape[1]
+        D = 1 if w_ih_r is None else 2
+        x2 = x.view(T * B, I)
+        gx = torch.empty(T * B, D * 3 * H, dtype=torch.float32, device=x.device)
+        gemm(x2, w_ih_f.t(), b_ih_f, out=gx[:, :3 * H])
+        if D == 2:
+            gemm(x2, w_ih_r.t(), b_ih_r, out=gx[:, 3 * H:])
+        params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+        need = any(ctx.needs_input_grad[:9])
+        raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
+        if p == 0.0 and (factor == 1):
+            y = raw
+        else:
+            y = dropout_pool_fwd(raw, mask, p, seed, offset, method, factor)
+        if need:
+            ctx.save_for_backward(x, raw, reserve, mask, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+            ctx.cfg = (T, B, I, H, D, p, seed, offset, method, factor)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        T, B, I, H, D, p, seed, offset, method, factor = ctx.cfg
+        x, raw, reserve, mask, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
+        if p == 0.0 and factor == 1:
+            d_raw = dy
+        else:
+            d_raw = dropout_pool_bwd(dy, raw, mask, p, seed, offset, method, factor)
+        d_gx, d_q, dbp = gru_seq_bwd(d_raw, reserve, w_hh_f, w_hh_r, T, B, H, D)
+        dbp = dbp.sum(0)                                   # (D, 4H): [d_gx sums (3H) | d_q sums (H)]
+        x2 = x.view(T * B, I)
+        g2 = d_gx.view(T * B, D * 3 * H)
+        q2 = d_q.view(T * B, D * H)
+        r2 = raw.view(T * B, D * H)
+        ng = ctx.needs_input_grad
+        grads = [None] * 15
+        w_ih = (w_ih_f, w_ih_r)
+        for d in range(D):
+            base = 1 + 4 * d                               # positions of (w_ih, w_hh, b_ih, b_hh)
+            gd = g2[:, d * 3 * H:(d + 1) * 3 * H]
+            if ng[base]:                                   # dW_ih = d_gx^T x
+                grads[base] = gemm(gd.t(), x2)
+            if ng[base + 1]:                               # dW_hh = dG_h^T h_{t-1}
+                dW = torch.zeros(3 * H, H, dtype=torch.float32, device=x.device)
+                if T > 1:
+                    n = (T - 1) * B
+                    if d == 0:     # h_{t-1} = raw[t-1]: gradient rows t >= 1 against raw rows t-1
+                        ga, qa, hp = gd[B:], q2[B:, :H], r2[:n, :H]
+                    else:          # reverse scan: h_prev(t) = raw[t+1]
+                        ga, qa, hp = gd[:n], q2[:n, H:], r2[B:, H:]
+                    gemm(ga[:, :2 * H].t(), hp, out=dW[:2 * H])
+                    gemm(qa.t(), hp, out=dW[2 * H:])
+                grads[base + 1] = dW
+            if ng[base + 2]:
+                grads[base + 2] = dbp[d, :3 * H].clone()
+            if ng[base + 3]:
+                grads[base + 3] = torch.cat([dbp[d, :2 * H], dbp[d, 3 * H:]])
+        if ng[0]:
+            dx = gemm(g2[:, :3 * H], w_ih_f)
+            if D == 2:
+                gemm(g2[:, 3 * H:], w_ih_r, out=dx, accumulate=True)
+            grads[0] = dx.view(T, B, I)
+        return tuple(grads)

@@ -1,0 +1,156 @@
+/*
+ * slu_hip.h — C ABI of libslu_hip.so: hand-written HIP kernels (gfx950 / CDNA4, MI355X) for the
+ * SincNet-conv + stacked-biGRU speech-encoder hot path of lorenlugosch/end-to-end-SLU.
+ *
+ * The reference has no FFI of its own: its "kernel launches" are the PyTorch operator call
+ * sites in models.py (F.conv1d :108, nn.Conv1d :190/:200, nn.MaxPool1d :205, nn.LeakyReLU :211,
+ * nn.GRU :232/:262/:686, nn.Dropout :246/:276/:700, F.avg_pool1d/max_pool1d :44/:46).  Each entry
+ * point below names the call site(s) it replaces.  A maintainer of the reference binds them with
+ * ctypes exactly as end-to-end-slu_amd/slu_hip/lib.py does (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative slu_status; slu_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - all data pointers are DEVICE pointers to caller-owned buffers (16-byte aligned, as
+ *     torch's allocator guarantees); nothing is retained after the call returns;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, no
+ *     entry point synchronises the device, allocates or frees (safe under hipGraph capture);
+ *   - scratch memory is supplied by the caller: query with the matching *_workspace_bytes;
+ *   - sizes are int64_t, strides are in ELEMENTS;
+ *   - activation layouts: waveform (B,T); CNN activations channels-last (B,L,C) or, through the
+ *     output strides, time-major (L,B,C); RNN activations TIME-MAJOR (T,B,C).  The host mirror
+ *     presents them to callers in the reference's (B,C,L)/(B,T,C) shapes as strided views.
+ */
+#ifndef SLU_HIP_H
+#define SLU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  SLU_OK = 0,
+  SLU_ERR_INVALID_ARG = -1,   /* bad size / null pointer / unsupported combination        */
+  SLU_ERR_UNSUPPORTED = -2,   /* shape outside what the gfx950 kernels are instantiated for */
+  SLU_ERR_HIP = -3,           /* a HIP runtime call failed (message has hipGetErrorString)  */
+  SLU_ERR_WORKSPACE = -4,     /* workspace too small                                         */
+  SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
+} slu_status;
+
+#define SLU_ABI_VERSION 1
+
+/* -------- library ------------------------------------------------------------------------- */
+int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
+const char* slu_last_error(void);         /* thread-local, never NULL                          */
+int slu_device_check(void);               /* 0 iff the current HIP device is gfx950            */
+const char* slu_device_arch(void);        /* gcnArchName of the current device ("" on failure) */
+
+/* -------- Sinc filterbank: models.py:79-106 (SincLayer.forward up to the conv), :7-24 ------- */
+/* filters[n_filt][filt_dim] (float32) from the two float64 parameters, filt_dim odd.            */
+int slu_sinc_filters_fwd(const double* filt_b1, const double* filt_band, float* filters,
+                         int64_t n_filt, int64_t filt_dim, double fs, void* stream);
+/* d(filt_b1), d(filt_band) (float64, what torch autograd leaves in .grad of the f64 params)
+ * from d(filters).                                                                               */
+int slu_sinc_filters_bwd(const double* filt_b1, const double* filt_band, const float* d_filters,
+                         double* d_filt_b1, double* d_filt_band,
+                         int64_t n_filt, int64_t filt_dim, double fs, void* stream);
+
+/* -------- windowed convolution block --------------------------------------------------------
+ * One fused launch for [conv -> (+bias) -> (abs) -> MaxPool1d(pool, ceil_mode) -> LeakyReLU(slope)]
+ * i.e. models.py:108 + :163-168 + :205 + :211 for the Sinc layer (c_in = 1, weights = the
+ * filterbank, do_abs = 1, pool = 2) and models.py:200 + :205 + :211 for the dense Conv1d layers.
+ *   in      (B, l_in, c_in) channels-last, contiguous (the waveform is l_in = T, c_in = 1)
+ *   weight  (c_out, c_in, k_t) — torch Conv1d layout; padding = k_t / 2 (models.py:186,200)
+ *   bias    (c_out) or NULL
+ *   out     element (b, l, c) at out[b*out_sb + l*out_sl + c]; l_out = ceil(l_conv / pool),
+ *           l_conv = (l_in + 2*(k_t/2) - k_t) / stride_t + 1
+ *   route   NULL or uint8 (B, l_out, c_out) contiguous: bit0 = index of the max inside the pool
+ *           window, bit1 = conv value was negative before abs (needed by slu_wconv_bwd_act)
+ *   slope   LeakyReLU negative slope (0.2), 0.0 for ReLU, 1.0 for "no activation"
+ * pool must be 1 or 2, c_out <= 128.                                                            */
+size_t slu_wconv_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t);
+int slu_wconv_fwd(const float* in, const float* weight, const float* bias, float* out,
+                  uint8_t* route, int64_t B, int64_t l_in, int64_t c_in, int64_t c_out,
+                  int64_t k_t, int64_t stride_t, int do_abs, int pool, float slope,
+                  int64_t out_sb, int64_t out_sl, void* workspace, size_t workspace_bytes,
+                  void* stream);
+/* d(conv output) (B, l_conv, c_out) contiguous from d(out): undoes activation, pooling, abs.
+ *   dy / y  element (b,l,c) at [b*sb + l*sl + c] (same strides for both); route as written by fwd
+ *           (may be NULL when pool == 1 and do_abs == 0).                                        */
+int slu_wconv_bwd_act(const float* dy, const float* y, const uint8_t* route, float* d_conv,
+                      int64_t B, int64_t l_conv, int64_t c_out, int do_abs, int pool, float slope,
+                      int64_t sb, int64_t sl, void* stream);
+/* d(in) (B, l_in, c_in) from d_conv; stride_t must be 1 (the only strided layer of the
+ * reference architecture is the first one, whose input needs no gradient).                      */
+int slu_wconv_bwd_data(const float* d_conv, const float* weight, float* d_in,
+                       int64_t B, int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* d(weight) (c_out, c_in, k_t) and d(bias) (c_out; may be NULL) from d_conv and the layer input. */
+size_t slu_wconv_bwd_weight_workspace_bytes(int64_t B, int64_t l_in, int64_t c_in, int64_t c_out,
+                                            int64_t k_t, int64_t stride_t);
+int slu_wconv_bwd_weight(const float* d_conv, const float* in, float* d_weight, float* d_bias,
+                         int64_t B, int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t,
+                         int64_t stride_t, void* workspace, size_t workspace_bytes, void* stream);
+
+/* -------- fp32 MFMA GEMM (GRU input projections and their gradients; nn.GRU's x @ W_ih^T) ----
+ * C(m,n) = [C(m,n) if accumulate] + sum_k A(m,k) * B(k,n) + (bias_n ? bias_n[n] : 0)
+ * with A(m,k) = A[m*a_rs + k*a_cs], B(k,n) = B[k*b_rs + n*b_cs], C(m,n) = C[m*c_rs + n*c_cs].
+ * Exact fp32 (v_mfma_f32_16x16x4_f32), split-K through the workspace when M*N is small.          */
+size_t slu_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int64_t b_rs,
+                 int64_t b_cs, float* C, int64_t c_rs, int64_t c_cs, const float* bias_n,
+                 int64_t M, int64_t N, int64_t K, int accumulate, void* workspace,
+                 size_t workspace_bytes, void* stream);
+/* out[n] = [out[n] if accumulate] + sum_m X[m*x_rs + n]   (bias gradients)                       */
+int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,
+                   int accumulate, void* stream);
+
+/* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
+ *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)
+ *   w_hh[d] (3H, H), b_hh[d] (3H): weight_hh_l0 / bias_hh_l0 (d = 0) and *_reverse (d = 1)
+ *   out     (T, B, D*H): hidden state of direction d at time t in columns [d*H, (d+1)*H);
+ *           direction 1 scans t = T-1 .. 0 (bidirectional GRU output, RNNSelect models.py:138-149)
+ *   reserve NULL (inference / frozen layer) or slu_gru_reserve_bytes(): per step r, z, n,
+ *           W_hn h + b_hn and h_{t-1}, in the lane order of the backward kernel
+ * One persistent workgroup per (direction, 16-sequence tile) runs the whole time loop with its
+ * slice of W_hh resident in VGPRs; H must be a multiple of 16, H <= 128; D is 1 or 2.            */
+size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t D);
+int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
+                    const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
+                    int64_t T, int64_t B, int64_t H, int64_t D, void* stream);
+/* Back-propagation through time.
+ *   d_out   (T, B, D*H)  gradient w.r.t. `out`
+ *   d_gx    (T, B, D*3H) gradient w.r.t. gx (= w.r.t. the pre-activations incl. b_ih)
+ *   d_q     (T, B, D*H)  gradient w.r.t. (W_hn h_{t-1} + b_hn); together with the r,z columns of
+ *           d_gx it is the gradient w.r.t. W_hh h_{t-1} + b_hh, from which the caller forms
+ *           d(W_hh) with slu_gemm_f32 against the time-shifted `out`.
+ *   d_bias_part NULL or (ceil(B/16), D, 4H): per 16-sequence tile, the sums over t and the tile's
+ *           sequences of [d_gx (3H) | d_q (H)]; summing over the first axis gives
+ *           d(b_ih) = [0:3H) and d(b_hh) = [0:2H) ++ [3H:4H).  (No atomics: deterministic.)       */
+int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_fwd,
+                    const float* w_hh_rev, float* d_gx, float* d_q, float* d_bias_part,
+                    int64_t T, int64_t B, int64_t H, int64_t D, void* stream);
+
+/* -------- Dropout + Downsample: nn.Dropout (models.py:246,276,700) + Downsample (:26-46) -------
+ *   x (T,B,C) time-major -> y (T_out,B,C); method 0 "none" (x[::factor]), 1 "avg", 2 "max" with
+ *   ceil_mode (partial last window uses the frames that exist); T_out = ceil(T / factor).
+ *   Dropout keep-mask, applied BEFORE pooling, scaled by 1/(1-p):
+ *     mask != NULL : float {0,1} values, element (t,b,c) at mask[t*m_st + b*m_sb + c]
+ *     mask == NULL and p > 0 : Philox4x32-10 keyed by (seed, offset), one draw per element index
+ *     p == 0 : no dropout (eval mode)                                                            */
+int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb, float p,
+                         uint64_t seed, uint64_t offset, int method, int64_t factor, float* y,
+                         int64_t T, int64_t B, int64_t C, void* stream);
+/* dx (T,B,C) from dy (T_out,B,C); x and y (forward input/output) are needed for method 2 only. */
+int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const float* mask,
+                         int64_t m_st, int64_t m_sb, float p, uint64_t seed, uint64_t offset,
+                         int method, int64_t factor, float* dx,
+                         int64_t T, int64_t B, int64_t C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLU_HIP_H */

@@ -1,0 +1,286 @@
+"""GPU parity tests, kernel by kernel: every C-ABI entry point of libslu_hip.so (through the ctypes
+binding) against the CPU oracle / the golden fixtures generated from the reference.
+
+Tolerances (fp32): forward values 1e-5 absolute on O(1) data (north-star bound is 1e-4 on logits),
+gradients 1e-4 of the per-tensor max-abs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name)))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from slu_hip import lib, ops as _ops
+    lib.require_gfx950()
+    return _ops
+
+
+def cu(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a)) if not torch.is_tensor(a) else a
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def maxerr(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def assert_close(got, ref, atol, what=""):
+    e = maxerr(got, ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert e <= atol, "%s: max abs err %.3e > %.1e" % (what, e, atol)
+
+
+def assert_grad_close(got, ref, rel=1e-4, what=""):
+    scale = max(ref.detach().abs().max().item(), 1e-6)
+    e = maxerr(got, ref)
+    assert e <= rel * scale, "%s: max abs err %.3e > %.1e * %.3e" % (what, e, rel, scale)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_sinc_filters_fwd_bwd_vs_golden(ops):
+    d = load("g1_sinc_filters.npz")
+    for tag, K in (("default", 401), ("perturbed", 401), ("small", 41)):
+        f = ops.sinc_filters(cu(d["b1_" + tag]), cu(d["band_" + tag]), K, 16000)
+        assert_close(f, torch.from_numpy(d["filters_" + tag]), 2e-6, "filters_" + tag)
+    db1, dband = ops.sinc_filters_bwd(cu(d["b1_perturbed"]), cu(d["band_perturbed"]), cu(d["G"]), 401, 16000)
+    assert db1.dtype == torch.float64
+    assert_grad_close(db1, torch.from_numpy(d["grad_b1_perturbed"]), 3e-4, "d filt_b1")
+    assert_grad_close(dband, torch.from_numpy(d["grad_band_perturbed"]), 3e-4, "d filt_band")
+
+
+def _conv_ref(x_blc, w, bias, stride, do_abs, pool, slope):
+    """torch-CPU reference of the fused block on channels-last input -> channels-last output."""
+    h = torch.nn.functional.conv1d(x_blc.transpose(1, 2), w, bias, stride=stride, padding=w.shape[2] // 2)
+    if do_abs:
+        h = h.abs()
+    if pool > 1:
+        h = torch.nn.functional.max_pool1d(h, pool, ceil_mode=True)
+    h = torch.nn.functional.leaky_relu(h, slope)
+    return h.transpose(1, 2)
+
+
+@pytest.mark.parametrize("case", [
+    # B, L, Cin, Cout, K, stride, abs, pool, slope
+    (3, 4000, 1, 80, 401, 80, True, 2, 0.2),      # sinc geometry, L_conv = 50
+    (2, 4100, 1, 80, 401, 80, True, 2, 0.2),      # odd L_conv = 52 -> wait even; partial window below
+    (2, 4040, 1, 80, 401, 80, True, 2, 0.2),      # L_conv = 51: ceil-mode partial last window
+    (3, 150, 80, 60, 5, 1, False, 1, 0.2),        # conv1 geometry
+    (3, 77, 60, 60, 5, 1, False, 1, 0.2),         # conv2 geometry, ragged length
+    (2, 33, 6, 6, 3, 1, False, 1, 0.0),           # tiny, ReLU
+    (2, 64, 8, 20, 5, 1, False, 2, 0.2),          # pooled conv
+    (65, 700, 1, 8, 41, 10, True, 2, 0.2),        # many rows -> 128-frame workgroups
+])
+@pytest.mark.parametrize("time_major", [False, True])
+def test_wconv_fwd(ops, case, time_major):
+    B, L, Cin, Cout, K, stride, do_abs, pool, slope = case
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, L, Cin, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5
+    bias = None if Cin == 1 else torch.randn(Cout, generator=g)
+    ref = _conv_ref(x, w, bias, stride, do_abs, pool, slope)
+    out, route, l_conv = ops.wconv_fwd(cu(x), cu(w), None if bias is None else cu(bias), B, L, Cin,
+                                       stride, do_abs, pool, slope, time_major, True)
+    if time_major:
+        out = out.transpose(0, 1)
+    assert_close(out, ref, 2e-5, "wconv_fwd %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [
+    (3, 150, 80, 60, 5, 1, False, 1, 0.2),
+    (2, 77, 60, 60, 5, 1, False, 1, 0.2),
+    (2, 64, 8, 20, 5, 1, False, 2, 0.2),
+    (2, 33, 6, 6, 3, 1, False, 1, 0.0),
+    (3, 4040, 1, 80, 401, 80, True, 2, 0.2),
+    (2, 700, 1, 8, 41, 10, True, 2, 0.2),
+])
+def test_wconv_bwd(ops, case):
+    B, L, Cin, Cout, K, stride, do_abs, pool, slope = case
+    g = torch.Generator().manual_seed(7 + L)
+    x = torch.randn(B, L, Cin, generator=g).requires_grad_()
+    w = (torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5).requires_grad_()
+    bias = None if Cin == 1 else torch.randn(Cout, generator=g).requires_grad_()
+    ref = _conv_ref(x, w, bias, stride, do_abs, pool, slope)
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    xg, wg = cu(x.detach()).requires_grad_(stride == 1), cu(w.detach()).requires_grad_()
+    bg = None if bias is None else cu(bias.detach()).requires_grad_()
+    out = ops.ConvBlockFn.apply(xg, wg, bg, stride, do_abs, pool, slope, False)
+    assert_close(out, ref, 2e-5, "fwd")
+    (out * cu(gy)).sum().backward()
+    assert_grad_close(wg.grad, w.grad, 1e-4, "dW %s" % (case,))
+    if bias is not None:
+        assert_grad_close(bg.grad, bias.grad, 1e-4, "dbias")
+    if stride == 1:
+        assert_grad_close(xg.grad, x.grad, 1e-4, "dx %s" % (case,))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 384, 60), (128, 128, 16), (1, 60, 3000), (384, 60, 2500),
+                                    (257, 130, 19), (768, 256, 4800), (50, 768, 256)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm(ops, M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(K, M, generator=g).t() if ta else torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g).t() if tb else torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (a.double() @ b.double() + bias.double())
+    ag = cu(a.t().contiguous()).t() if ta else cu(a)
+    bg = cu(b.t().contiguous()).t() if tb else cu(b)
+    out = ops.gemm(ag, bg, cu(bias))
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-5
+    assert_close(out.double(), ref, tol * ref.abs().max().item() / 4 + 1e-5, "gemm")
+    # accumulate into a strided (column slice) output
+    big = torch.zeros(M, N + 7, device="cuda")
+    big[:, 3:3 + N] = 1.0
+    ops.gemm(ag, bg, None, out=big[:, 3:3 + N], accumulate=True)
+    ref2 = a.double() @ b.double() + 1.0
+    assert_close(big[:, 3:3 + N].double(), ref2, tol * ref.abs().max().item() / 4 + 1e-5, "gemm acc")
+    assert big[:, :3].abs().max().item() == 0 and big[:, 3 + N:].abs().max().item() == 0
+
+
+def test_colsum(ops):
+    x = torch.randn(1000, 130)
+    out = ops.colsum(cu(x))
+    assert_close(out.double(), x.double().sum(0), 1e-3, "colsum")
+
+
+def _gru_case(ops, d, bi, check_grads=True):
+    p = {k: torch.from_numpy(v) for k, v in d.items() if k.startswith(("weight_", "bias_"))}
+    x = torch.from_numpy(d["x"])                     # (B,T,I)
+    B, T, I = x.shape
+    H = p["weight_hh_l0"].shape[1]
+    gp = {k: cu(v).requires_grad_() for k, v in p.items()}
+    xg = cu(x.transpose(0, 1).contiguous()).requires_grad_()         # time-major
+    args = [xg, gp["weight_ih_l0"], gp["weight_hh_l0"], gp["bias_ih_l0"], gp["bias_hh_l0"]]
+    if bi:
+        args += [gp["weight_ih_l0_reverse"], gp["weight_hh_l0_reverse"], gp["bias_ih_l0_reverse"],
+                 gp["bias_hh_l0_reverse"]]
+    else:
+        args += [None, None, None, None]
+    y = ops.GRULayerFn.apply(*args, 0.0, None, 0, 0, "none", 1)      # (T,B,D*H)
+    assert_close(y.transpose(0, 1), torch.from_numpy(d["out"]), 1e-5, "gru out")
+    if not check_grads:
+        return
+    gy = cu(torch.from_numpy(d["g"]).transpose(0, 1).contiguous())
+    (y * gy).sum().backward()
+    assert_grad_close(xg.grad.transpose(0, 1), torch.from_numpy(d["dx"]), 1e-4, "gru dx")
+    for k, v in gp.items():
+        assert_grad_close(v.grad, torch.from_numpy(d["grad_" + k]), 1e-4, "gru grad " + k)
+
+
+@pytest.mark.parametrize("name", sorted(f for f in os.listdir(G) if f.startswith("g3_gru")))
+def test_gru_vs_golden(ops, name):
+    _gru_case(ops, load(name), name.endswith("_bi.npz"))
+
+
+@pytest.mark.parametrize("B,T,I,H", [(64, 40, 60, 128), (17, 23, 256, 128), (5, 9, 33, 64), (70, 3, 20, 32)])
+def test_gru_vs_oracle_ragged_batches(ops, B, T, I, H):
+    torch.manual_seed(B + T)
+    m = torch.nn.GRU(I, H, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, I, requires_grad=True)
+    p = {k: v.detach().clone().requires_grad_() for k, v in m.named_parameters()}
+    out = O.gru_layer(x, p, True, explicit=False)
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    d = {"x": x.detach().numpy(), "out": out.detach().numpy(), "g": g.numpy(), "dx": x.grad.numpy()}
+    for k, v in p.items():
+        d[k] = v.detach().numpy()
+        d["grad_" + k] = v.grad.numpy()
+    _gru_case(ops, d, True)
+
+
+@pytest.mark.parametrize("method", ["none", "avg", "max"])
+@pytest.mark.parametrize("factor", [1, 2, 3])
+@pytest.mark.parametrize("T", [1, 6, 25])
+def test_dropout_pool_mask_mode(ops, method, factor, T):
+    B, C = 3, 32
+    g = torch.Generator().manual_seed(T * 10 + factor)
+    x = torch.randn(B, T, C, generator=g, requires_grad=True)
+    mask_mem = torch.empty(T, B, C).bernoulli_(0.5, generator=g)       # (T,B,C) memory order
+    ref = O.downsample(O.dropout_with_mask(x, 0.5, mask_mem.transpose(0, 1)), method, factor)
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    xt = cu(x.detach().transpose(0, 1).contiguous())
+    y = ops.dropout_pool_fwd(xt, cu(mask_mem), 0.5, 0, 0, method, factor)
+    assert_close(y.transpose(0, 1), ref, 1e-6, "pool fwd")
+    dx = ops.dropout_pool_bwd(cu(gy.transpose(0, 1).contiguous()), xt, cu(mask_mem), 0.5, 0, 0, method, factor)
+    assert_close(dx.transpose(0, 1), x.grad, 1e-6, "pool bwd")
+    # eval mode (p = 0)
+    y0 = ops.dropout_pool_fwd(xt, None, 0.0, 0, 0, method, factor)
+    assert_close(y0.transpose(0, 1), O.downsample(x.detach(), method, factor), 1e-6, "pool eval")
+
+
+def test_dropout_philox_statistics_and_consistency(ops):
+    T, B, C = 40, 16, 256
+    x = torch.ones(T, B, C, device="cuda")
+    y = ops.dropout_pool_fwd(x, None, 0.5, 1234, 7, "none", 1)
+    vals = torch.unique(y).cpu().tolist()
+    assert vals == [0.0, 2.0]
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+    y2 = ops.dropout_pool_fwd(x, None, 0.5, 1234, 7, "none", 1)
+    assert torch.equal(y, y2)                                   # same (seed, offset) -> same mask
+    y3 = ops.dropout_pool_fwd(x, None, 0.5, 1234, 8, "none", 1)
+    assert not torch.equal(y, y3)
+    # backward uses the same mask
+    dx = ops.dropout_pool_bwd(torch.ones_like(y), x, None, 0.5, 1234, 7, "none", 1)
+    assert torch.equal(dx, y)
+    # consecutive channels are uncorrelated
+    a = (y[:, :, :-1] > 0).float() - 0.5
+    b = (y[:, :, 1:] > 0).float() - 0.5
+    assert abs((a * b).mean().item()) < 0.01
+
+
+def test_gru_layer_with_dropout_and_avg_pool_grads(ops):
+    B, T, I, H = 20, 15, 24, 64
+    torch.manual_seed(3)
+    m = torch.nn.GRU(I, H, batch_first=True, bidirectional=True)
+    p = {k: v.detach().clone().requires_grad_() for k, v in m.named_parameters()}
+    x = torch.randn(B, T, I, requires_grad=True)
+    mask_mem = torch.empty(T, B, 2 * H).bernoulli_(0.5)
+    ref = O.downsample(O.dropout_with_mask(O.gru_layer(x, p, True, explicit=False), 0.5, mask_mem.transpose(0, 1)), "avg", 2)
+    gy = torch.randn_like(ref)
+    (ref * gy).sum().backward()
+    gp = {k: cu(v.detach()).requires_grad_() for k, v in p.items()}
+    xg = cu(x.detach().transpose(0, 1).contiguous()).requires_grad_()
+    y = ops.GRULayerFn.apply(xg, gp["weight_ih_l0"], gp["weight_hh_l0"], gp["bias_ih_l0"], gp["bias_hh_l0"],
+                             gp["weight_ih_l0_reverse"], gp["weight_hh_l0_reverse"], gp["bias_ih_l0_reverse"],
+                             gp["bias_hh_l0_reverse"], 0.5, cu(mask_mem), 0, 0, "avg", 2)
+    assert_close(y.transpose(0, 1), ref, 1e-5, "layer out")
+    (y * cu(gy.transpose(0, 1).contiguous())).sum().backward()
+    assert_grad_close(xg.grad.transpose(0, 1), x.grad, 1e-4, "dx")
+    for k, v in gp.items():
+        assert_grad_close(v.grad, p[k].grad, 1e-4, k)
+
+
+def test_sinc_block_grads_vs_oracle(ops):
+    B, T = 3, 2400
+    g = torch.Generator().manual_seed(5)
+    x = 0.1 * torch.randn(B, T, generator=g)
+    b1n, bandn = O.sinc_mel_init(80, 16000)
+    b1 = torch.from_numpy(b1n).requires_grad_()
+    band = torch.from_numpy(bandn).requires_grad_()
+    h = O.sinc_layer(x.unsqueeze(1), b1, band, 401, 16000, 80, 200)
+    ref = O.activation(O.max_pool_ceil(h.abs(), 2), "leaky_relu").transpose(1, 2)   # (B, L/2, 80)
+    gy = torch.randn(ref.shape, generator=g)
+    (ref * gy).sum().backward()
+    b1g, bandg = cu(b1.detach()).requires_grad_(), cu(band.detach()).requires_grad_()
+    out = ops.SincBlockFn.apply(cu(x), b1g, bandg, 401, 16000, 80, 2, 0.2, False)
+    assert_close(out, ref, 1e-5, "sinc block fwd")
+    (out * cu(gy)).sum().backward()
+    assert_grad_close(b1g.grad, b1.grad, 5e-4, "d filt_b1")
+    assert_grad_close(bandg.grad, band.grad, 5e-4, "d filt_band")
