@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: SLU training steps (utterances/s) on synthetic 3 s @16 kHz waveforms,
+B = 64 per GPU — BASELINE.json `metric`, workload = configs[3] (no_unfreezing: frozen pre-trained
+SincNet/conv/biGRU encoder in train mode + intent GRU trained; forward, loss, backward, gradient
+all-reduce, Adam) — through models.Model / training.Trainer on the HIP kernels.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload no_unfreezing|unfreeze_all]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  `value` = utterances all ranks processed / max-over-ranks wall time of the
+K timed steps (inputs resident in HBM, barrier + synchronize on both sides).  `roofline` is for the
+dominant kernel (the persistent GRU recurrence, fp32 MFMA bound): algorithmic flops of its launches
+in the timed region / their HIP-event durations.  `cpu_baseline` times the CPU oracle (torch-CPU
+restatement of the reference path) on a bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "end-to-end-slu_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 CUs @ 2.4 GHz
+BATCH = 64
+SECONDS = 3
+FS = 16000
+
+
+def setup(workload, rank, batch, samples, n_batches):
+    """read_config on the package's synthetic cfg, synthetic pre-training checkpoint, Model, Trainer."""
+    import data
+    import models
+    import training
+    from oracle import slu_oracle as O      # only its reference-format weight initialiser is used here
+
+    work = tempfile.mkdtemp(prefix="slu_bench_")
+    os.makedirs(os.path.join(work, "experiments"))
+    name = "no_unfreezing_synthetic.cfg" if workload == "no_unfreezing" else "unfreeze_all_layers_synthetic.cfg"
+    shutil.copy(os.path.join(PKG, "experiments", name), os.path.join(work, "experiments", name))
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        config = data.read_config(os.path.join("experiments", name))
+        config.folder = os.path.join(work, config.folder)
+        config.slu_path = "synthetic:%dx%dx%d" % (n_batches, batch, samples)
+        config.seed = 1234 + rank                      # per-rank synthetic data
+        train_ds, _, _ = data.get_SLU_datasets(config)
+        torch.manual_seed(4321)                        # synthetic "pre-trained" encoder (no .pth published)
+        torch.save(O.init_pretrained_state_dict(config), os.path.join(config.folder, "pretraining", "model_state.pth"))
+        torch.manual_seed(1234)
+        model = models.Model(config)
+        if workload == "unfreeze_all":
+            for p in model.pretrained_model.phoneme_layers.parameters():
+                p.requires_grad = True
+            for p in model.pretrained_model.word_layers.parameters():
+                p.requires_grad = True
+        models.set_dropout_seed(1234 + 7919 * rank)
+        trainer = training.Trainer(model=model, config=config)
+    finally:
+        os.chdir(cwd)
+    return config, model, trainer, train_ds, work
+
+
+def run_steps(model, trainer, batches, n):
+    dev = next(model.parameters()).device
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    for i in range(n):
+        x, y = batches[i % len(batches)]
+        loss, acc = model(x, y)
+        trainer._step(loss)
+        sums += torch.stack([loss.detach().double(), acc.detach().double()])
+    return sums
+
+
+def cpu_baseline(config, batch, samples, budget_s=20.0):
+    """The CPU oracle (torch-CPU restatement of the reference path, ATen GRU like the reference) on
+    the same workload: train-mode forward + backward of the trainable part + Adam, all host cores."""
+    from oracle import slu_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    sd = O.init_model_state_dict(config)
+    trainable = [k for k in sd if k.startswith("intent_layers")]
+    if config.unfreezing_type == 2:
+        trainable = [k for k in sd if not k.startswith(("pretrained_model.phoneme_linear", "pretrained_model.word_linear"))]
+    for k in trainable:
+        sd[k].requires_grad_()
+    opt = torch.optim.Adam([sd[k] for k in trainable], lr=1e-3)
+    g = torch.Generator().manual_seed(1234)
+    x = 0.1 * torch.randn(batch, samples, generator=g)
+    y = torch.stack([torch.randint(0, n, (batch,), generator=g) for n in config.values_per_slot], dim=1)
+
+    def step(faithful):
+        masks = O.draw_dropout_masks(config, x, seed=1)        # the reference draws them per step too
+        opt.zero_grad()
+        loss, _, _, _ = O.slu_forward(sd, x, y, config, masks, explicit_gru=False, faithful_sinc=faithful)
+        loss.backward()
+        opt.step()
+
+    step(False)                                                # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s * 0.7 and n < 50):
+        step(False)
+        n += 1
+    dedup = n * batch / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    step(True)                                                 # one step with the 80 in-loop convolutions
+    faithful = batch / (time.perf_counter() - t0)
+    return {"value": round(dedup, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps of B=%d x %d s on %d torch-CPU threads (oracle, ATen GRU, one conv per "
+                      "Sinc forward); reference-faithful variant with the 80 redundant in-loop convolutions "
+                      "(models.py:98-108): %.2f utterances/s" % (n, batch, samples // FS, cores, faithful)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="no_unfreezing", choices=["no_unfreezing", "unfreeze_all"])
+    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=SECONDS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from slu_hip import dp, lib, ops
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    lib.require_gfx950()
+    samples = int(args.seconds * FS)
+    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4)
+    dev = torch.device("cuda", local)
+    batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]       # inputs resident in HBM
+    model.train()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(model, trainer, batches, args.warmup)
+    fence()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    sums = run_steps(model, trainer, batches, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    elapsed = tmax.item()
+    loss_mean = (sums[0] / args.steps).item()
+
+    # dominant kernel: the persistent GRU recurrence (5 launches per step)
+    kflops = sum(p[3] for p in prof)
+    kms = sum(p[1].elapsed_time(p[2]) for p in prof)
+    achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    payload = trainer.bucket.nbytes() if trainer.bucket is not None else 0
+
+    if rank == 0:
+        out = {
+            "metric": "utterances/sec (train step, 3 s @16 kHz, B=64)",
+            "value": round(world * args.batch * args.steps / elapsed, 2),
+            "unit": "utterances/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("experiments/no_unfreezing.cfg SLU train step (frozen SincNet/conv/biGRU "
+                                    "encoder in train mode + intent biGRU trained): fwd + 3-slot CE + bwd + "
+                                    "grad all-reduce + Adam" if args.workload == "no_unfreezing" else
+                                    "SLU train step with every encoder layer unfrozen (unfreeze_all_layers "
+                                    "end state): fwd + CE + full bwd + grad all-reduce + Adam"),
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "samples_per_utterance": samples, "parallelism": "dp%d" % world,
+                       "allreduce_bytes_per_step": payload, "mean_loss": round(loss_mean, 5)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
+                         "kernel": "gru_seq_fwd_kernel<128>",
+                         "launches": len(prof), "avg_launch_ms": round(kms / max(len(prof), 1), 4),
+                         "note": "fp32 MFMA flops of h(BxH)*W_hh^T(Hx3H) per step, both directions; B=%d gives "
+                                 "%d workgroups (one 16-sequence tile x direction each) on 256 CUs" %
+                                 (args.batch, 2 * -(-args.batch // 16))},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

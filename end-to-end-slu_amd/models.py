@@ -1,0 +1,535 @@
+"""MI355X-native mirror of the reference's `models.py` API surface for the speech-encoder hot path.
+
+Same public names, constructor arguments, method signatures, `state_dict` keys/shapes/dtypes,
+per-layer `.name` attributes and freezing semantics as the reference
+(lorenlugosch/end-to-end-SLU `models.py`: SincLayer :49-110, Downsample :26-46, PretrainedModel
+:170-361, freeze helpers :363-379, Model :653-874), so `experiments/*.cfg`, `training.Trainer`
+and user scripts run unchanged — but every hot operator executes in hand-written HIP kernels for
+gfx950 (libslu_hip.so, C ABI in include/slu_hip.h) instead of ATen:
+
+  reference module chain (one ATen op each)             this file (one fused HIP stage each)
+  sinc0, abs0, pool0, act0, dropout0                 -> ops.SincBlockFn   (filter build + MFMA conv
+                                                         + |.| + max-pool + LeakyReLU epilogue)
+  convN, poolN, actN, dropoutN                       -> ops.ConvBlockFn   (same kernel, dense taps)
+  ncl2nlc                                            -> free: kernels write channels-last /
+                                                         time-major directly
+  *_rnnN, *_rnn_selectN, *_dropoutN, *_downsampleN   -> ops.GRULayerFn    (MFMA input projection,
+                                                         persistent recurrence, dropout+pool)
+
+The `phoneme_layers` / `word_layers` / `intent_layers` ModuleLists keep the reference's indices
+(so checkpoints interchange) and still work layer-by-layer, but `compute_features`, `forward`
+and `predict_intents` run the fused stage plan.  There is no CPU path: without a gfx950 device
+the forward methods raise.  The seq2seq head (models.py:381-651) is outside the hot path and is
+not provided.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+from slu_hip import ops as _ops
+from slu_hip import lib as _lib
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout control (train-mode masks): Philox in-kernel by default, injected masks for parity tests
+# ------------------------------------------------------------------------------------------------
+class _DropoutState:
+    masks = None        # dict: layer name ("phone_dropout0", ...) -> float {0,1} mask, logical (B,T,C)
+    seed = None         # None -> torch.initial_seed()
+    counter = 0         # advances once per dropout site per forward
+
+
+def set_dropout_masks(masks):
+    """Parity hook: use these keep-masks (as `torch.nn.Dropout` would have drawn them, logical
+    shape (B,T,C)) instead of the in-kernel Philox stream.  Pass None to restore Philox."""
+    _DropoutState.masks = masks
+
+
+def set_dropout_seed(seed):
+    """Seed of the in-kernel Philox stream (per-rank streams under data parallelism)."""
+    _DropoutState.seed = seed
+    _DropoutState.counter = 0
+
+
+def _dropout_args(name, p, training):
+    """-> (p_eff, mask_time_major_or_None, seed, offset)"""
+    if not training or p == 0.0:
+        return 0.0, None, 0, 0
+    if _DropoutState.masks is not None:
+        m = _DropoutState.masks[name]
+        return p, m.transpose(0, 1), 0, 0          # (T,B,C) view; kernel takes its strides
+    seed = _DropoutState.seed if _DropoutState.seed is not None else torch.initial_seed()
+    _DropoutState.counter += 1
+    return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.counter
+
+
+def _require_device(t):
+    if not t.is_cuda:
+        raise _lib.SluHipError("the HIP kernels are the only compute path of this package: move the "
+                               "model to a gfx950 (MI355X) device; there is no CPU fallback")
+
+
+# ------------------------------------------------------------------------------------------------
+# thin layer modules (API/state_dict compatibility; each also runs stand-alone)
+# ------------------------------------------------------------------------------------------------
+class Downsample(torch.nn.Module):
+    """Time-axis downsampling (reference models.py:26-46): "none" = x[:, ::factor], "avg"/"max" =
+    ceil-mode pooling.  Stand-alone it takes (B,T,C) like the reference."""
+
+    def __init__(self, method="none", factor=1, axis=1):
+        super().__init__()
+        self.factor = factor
+        self.method = method
+        self.axis = axis
+        if self.method not in ("none", "avg", "max"):
+            print("Error: downsampling method must be one of the following: \"none\", \"avg\", \"max\"")
+            sys.exit()
+
+    def forward(self, x):
+        _require_device(x)
+        if self.axis != 1 or x.dim() != 3:
+            raise NotImplementedError("Downsample: only axis=1 of a (B,T,C) tensor is supported")
+        xt = x.transpose(0, 1).contiguous()
+        return _PoolOnlyFn.apply(xt, self.method, self.factor).transpose(0, 1)
+
+
+class _PoolOnlyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xt, method, factor):
+        ctx.cfg = (method, factor)
+        ctx.save_for_backward(xt)
+        return _ops.dropout_pool_fwd(xt, None, 0.0, 0, 0, method, factor)
+
+    @staticmethod
+    def backward(ctx, dy):
+        method, factor = ctx.cfg
+        (xt,) = ctx.saved_tensors
+        return _ops.dropout_pool_bwd(dy, xt, None, 0.0, 0, 0, method, factor), None, None
+
+
+class SincLayer(torch.nn.Module):
+    """SincNet band-pass filterbank layer (reference models.py:49-110).  Two float64 parameters
+    per filter; mel-spaced deterministic initialisation (no RNG draw)."""
+
+    def __init__(self, N_filt, Filt_dim, fs, stride=1, padding=0, is_cuda=False):
+        super().__init__()
+        mel_hi = 2595 * np.log10(1 + (fs / 2) / 700)
+        hz = 700 * (10 ** (np.linspace(80, mel_hi, N_filt) / 2595) - 1)
+        lo, hi = np.roll(hz, 1), np.roll(hz, -1)
+        lo[0] = 30
+        hi[-1] = (fs / 2) - 100
+        self.freq_scale = fs * 1.0
+        self.filt_b1 = torch.nn.Parameter(torch.from_numpy(lo / self.freq_scale))
+        self.filt_band = torch.nn.Parameter(torch.from_numpy((hi - lo) / self.freq_scale))
+        self.N_filt, self.Filt_dim, self.fs = N_filt, Filt_dim, fs
+        self.stride, self.padding, self.is_cuda = stride, padding, is_cuda
+        if padding != Filt_dim // 2:
+            raise NotImplementedError("SincLayer: only padding == Filt_dim // 2 is supported")
+
+    def filters(self):
+        """(N_filt, Filt_dim) float32 filterbank built on the device."""
+        _require_device(self.filt_b1)
+        return _ops.sinc_filters(self.filt_b1.detach(), self.filt_band.detach(), self.Filt_dim, self.fs)
+
+    def forward(self, x):
+        """x (B,1,T) -> (B,N_filt,L), the plain strided convolution (no abs/pool)."""
+        _require_device(x)
+        out = _ops.SincBlockFn.apply(x.reshape(x.shape[0], -1), self.filt_b1, self.filt_band,
+                                     self.Filt_dim, self.fs, self.stride, 1, 1.0, False, False)
+        return out.transpose(1, 2)
+
+
+class Conv1d(torch.nn.Module):
+    """Dense Conv1d(Cin, Cout, k, stride, padding=k//2) with torch's parameter names and default
+    initialisation (reference models.py:190,200 use torch.nn.Conv1d)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        proto = torch.nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding)
+        self.weight, self.bias = proto.weight, proto.bias        # same RNG draw as the reference
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        if padding != kernel_size // 2:
+            raise NotImplementedError("Conv1d: only padding == kernel_size // 2 is supported")
+
+    def forward(self, x):
+        """x (B,Cin,L) -> (B,Cout,L')"""
+        _require_device(x)
+        out = _ops.ConvBlockFn.apply(x.transpose(1, 2).contiguous(), self.weight, self.bias,
+                                     self.stride, False, 1, 1.0, False)
+        return out.transpose(1, 2)
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=(%d,), stride=(%d,), padding=(%d,)" % (
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding)
+
+
+class GRU(torch.nn.Module):
+    """Single-layer (bi)GRU with torch.nn.GRU's parameter names/shapes/initialisation
+    (reference models.py:232,262,686).  Stand-alone it mimics nn.GRU(batch_first=True):
+    returns (output (B,T,D*H), None)."""
+
+    def __init__(self, input_size, hidden_size, batch_first=True, bidirectional=False):
+        super().__init__()
+        if not batch_first:
+            raise NotImplementedError("GRU: batch_first=True only (as the reference uses it)")
+        proto = torch.nn.GRU(input_size=input_size, hidden_size=hidden_size, batch_first=True,
+                             bidirectional=bidirectional)
+        for k, v in proto.named_parameters():
+            self.register_parameter(k, v)
+        self.input_size, self.hidden_size, self.bidirectional = input_size, hidden_size, bidirectional
+        self.batch_first = True
+
+    def _params(self):
+        fw = (self.weight_ih_l0, self.weight_hh_l0, self.bias_ih_l0, self.bias_hh_l0)
+        if self.bidirectional:
+            return fw + (self.weight_ih_l0_reverse, self.weight_hh_l0_reverse,
+                         self.bias_ih_l0_reverse, self.bias_hh_l0_reverse)
+        return fw + (None, None, None, None)
+
+    def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1):
+        return _ops.GRULayerFn.apply(xt, *self._params(), p, mask, seed, offset, method, factor)
+
+    def forward(self, x):
+        _require_device(x)
+        return self.run_time_major(x.transpose(0, 1)).transpose(0, 1), None
+
+    def extra_repr(self):
+        return "%d, %d, batch_first=True, bidirectional=%s" % (self.input_size, self.hidden_size, self.bidirectional)
+
+
+class FinalPool(torch.nn.Module):
+    """max over time of (B,T,C) (reference models.py:112-123)."""
+
+    def forward(self, input):
+        return input.max(dim=1)[0]
+
+
+class NCL2NLC(torch.nn.Module):
+    """(B,C,L) -> (B,L,C) view (reference models.py:125-136)."""
+
+    def forward(self, input):
+        return input.transpose(1, 2)
+
+
+class RNNSelect(torch.nn.Module):
+    """keeps the output sequence of an RNN's (output, h_n) tuple (reference models.py:138-149)."""
+
+    def forward(self, input):
+        return input[0]
+
+
+class Abs(torch.nn.Module):
+    """reference models.py:163-168"""
+
+    def forward(self, input):
+        return torch.abs(input)
+
+
+def _named(layer, name):
+    layer.name = name
+    return layer
+
+
+# ------------------------------------------------------------------------------------------------
+# fused stage plan
+# ------------------------------------------------------------------------------------------------
+class _ConvStage:
+    """[conv|sinc, (abs), pool, act, dropout] of one CNN block (reference models.py:182-220)."""
+
+    def __init__(self, conv, is_sinc, do_abs, pool, act, drop):
+        self.conv, self.is_sinc, self.do_abs, self.pool, self.drop = conv, is_sinc, do_abs, pool, drop
+        self.slope = 0.2 if act == "leaky_relu" else 0.0
+
+    def run(self, h, training, time_major):
+        """h: (B,T) for the first block, else channels-last (B,L,C)."""
+        fused_pool = self.pool in (1, 2)
+        tm = time_major and fused_pool and self.drop == 0.0
+        pool = self.pool if fused_pool else 1
+        slope = self.slope if fused_pool else 1.0
+        if self.is_sinc:
+            h = _ops.SincBlockFn.apply(h, self.conv.filt_b1, self.conv.filt_band, self.conv.Filt_dim,
+                                       self.conv.fs, self.conv.stride, pool, slope, tm,
+                                       self.do_abs and fused_pool)
+        else:
+            if h.dim() == 2:
+                h = h.unsqueeze(2)
+            h = _ops.ConvBlockFn.apply(h, self.conv.weight, self.conv.bias, self.conv.stride,
+                                       self.do_abs and fused_pool, pool, slope, tm)
+        if not fused_pool:          # unusual pool widths: generic (unfused) tail
+            h = h.transpose(1, 2)
+            if self.do_abs:
+                h = h.abs()
+            h = torch.nn.functional.max_pool1d(h, self.pool, ceil_mode=True)
+            h = torch.nn.functional.leaky_relu(h, self.slope).transpose(1, 2)
+        if self.drop > 0.0:
+            h = torch.nn.functional.dropout(h, self.drop, training)
+        if time_major and not tm:
+            h = h.transpose(0, 1).contiguous()
+        return h
+
+
+class _RnnStage:
+    """[gru, select, dropout, downsample] (reference models.py:230-253, 260-283, 684-707)."""
+
+    def __init__(self, gru, drop_name, p, method, factor):
+        self.gru, self.drop_name, self.p, self.method, self.factor = gru, drop_name, p, method, factor
+
+    def run(self, xt, training):
+        p, mask, seed, offset = _dropout_args(self.drop_name, self.p, training)
+        return self.gru.run_time_major(xt, p, mask, seed, offset, self.method, self.factor)
+
+
+def _build_rnn_stack(layers, stages, prefix, in_dim, hidden, bidirectional, drops, ds_types, ds_lens):
+    """Appends the reference's 4 modules per RNN layer to `layers` and one fused stage to `stages`."""
+    out_dim = in_dim
+    for idx, H in enumerate(hidden):
+        gru = _named(GRU(input_size=out_dim, hidden_size=H, batch_first=True, bidirectional=bidirectional),
+                     "%s_rnn%d" % (prefix, idx))
+        layers.append(gru)
+        out_dim = H * (2 if bidirectional else 1)
+        layers.append(_named(RNNSelect(), "%s_rnn_select%d" % (prefix, idx)))
+        layers.append(_named(torch.nn.Dropout(p=drops[idx]), "%s_dropout%d" % (prefix, idx)))
+        layers.append(_named(Downsample(method=ds_types[idx], factor=ds_lens[idx], axis=1),
+                             "%s_downsample%d" % (prefix, idx)))
+        stages.append(_RnnStage(gru, "%s_dropout%d" % (prefix, idx), drops[idx], ds_types[idx], ds_lens[idx]))
+    return out_dim
+
+
+class PretrainedModel(torch.nn.Module):
+    """Encoder pre-trained to recognise phonemes and words (reference models.py:170-361)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.is_cuda = torch.cuda.is_available()
+        phoneme_layers, self._cnn_stages, self._phone_stages = [], [], []
+        n_conv = len(config.cnn_N_filt)
+        for idx in range(n_conv):
+            k, stride = config.cnn_len_filt[idx], config.cnn_stride[idx]
+            is_sinc = idx == 0 and config.use_sincnet
+            if is_sinc:
+                conv = _named(SincLayer(config.cnn_N_filt[0], k, config.fs, stride=stride, padding=k // 2,
+                                        is_cuda=self.is_cuda), "sinc0")
+            else:
+                cin = 1 if idx == 0 else config.cnn_N_filt[idx - 1]
+                conv = _named(Conv1d(cin, config.cnn_N_filt[idx], k, stride=stride, padding=k // 2),
+                              "conv%d" % idx)
+            phoneme_layers.append(conv)
+            if idx == 0:
+                phoneme_layers.append(_named(Abs(), "abs0"))
+            phoneme_layers.append(_named(torch.nn.MaxPool1d(config.cnn_max_pool_len[idx], ceil_mode=True),
+                                         "pool%d" % idx))
+            act = torch.nn.LeakyReLU(0.2) if config.cnn_act[idx] == "leaky_relu" else torch.nn.ReLU()
+            phoneme_layers.append(_named(act, "act%d" % idx))
+            phoneme_layers.append(_named(torch.nn.Dropout(p=config.cnn_drop[idx]), "dropout%d" % idx))
+            self._cnn_stages.append(_ConvStage(conv, is_sinc, idx == 0, config.cnn_max_pool_len[idx],
+                                               config.cnn_act[idx], config.cnn_drop[idx]))
+        phoneme_layers.append(_named(NCL2NLC(), "ncl2nlc"))
+        out_dim = _build_rnn_stack(phoneme_layers, self._phone_stages, "phone", config.cnn_N_filt[-1],
+                                   config.phone_rnn_num_hidden, config.phone_rnn_bidirectional,
+                                   config.phone_rnn_drop, config.phone_downsample_type,
+                                   config.phone_downsample_len)
+        self.phoneme_layers = torch.nn.ModuleList(phoneme_layers)
+        self.phoneme_linear = torch.nn.Linear(out_dim, config.num_phonemes)
+
+        word_layers, self._word_stages = [], []
+        out_dim = _build_rnn_stack(word_layers, self._word_stages, "word", out_dim,
+                                   config.word_rnn_num_hidden, config.word_rnn_bidirectional,
+                                   config.word_rnn_drop, config.word_downsample_type,
+                                   config.word_downsample_len)
+        self.word_layers = torch.nn.ModuleList(word_layers)
+        self.word_linear = torch.nn.Linear(out_dim, config.vocabulary_size)
+        self.pretraining_type = config.pretraining_type
+        if self.is_cuda:
+            self.cuda()
+
+    # -- fused execution ------------------------------------------------------------------------
+    def _to_device(self, *tensors):
+        self.is_cuda = next(self.parameters()).is_cuda
+        if not self.is_cuda:
+            raise _lib.SluHipError("model parameters are not on a GPU: the HIP kernels are the only "
+                                   "compute path (no CPU fallback)")
+        dev = next(self.parameters()).device
+        return [t.to(dev, non_blocking=True) if t is not None else None for t in tensors]
+
+    def _phoneme_features_tm(self, x):
+        """x (B,T) on device -> time-major (T', B, C) output of the phoneme module."""
+        h = x.float()
+        last = len(self._cnn_stages) - 1
+        for i, st in enumerate(self._cnn_stages):
+            h = st.run(h, self.training, time_major=(i == last))
+        for st in self._phone_stages:
+            h = st.run(h, self.training)
+        return h
+
+    def _word_features_tm(self, h):
+        for st in self._word_stages:
+            h = st.run(h, self.training)
+        return h
+
+    def _features_tm(self, x):
+        return self._word_features_tm(self._phoneme_features_tm(x))
+
+    # -- reference API --------------------------------------------------------------------------
+    def forward(self, x, y_phoneme, y_word):
+        """x (B,T), y_phoneme (B,T'), y_word (B,T'') -> (phoneme_loss, word_loss, phoneme_acc,
+        word_acc); cross-entropy ignores label -1 (reference models.py:291-331)."""
+        x, y_phoneme, y_word = self._to_device(x, y_phoneme, y_word)
+        ph_tm = self._phoneme_features_tm(x)                         # (T',B,C)
+        logits = self.phoneme_linear(ph_tm.transpose(0, 1))          # (B,T',P)
+        logits = logits.reshape(logits.shape[0] * logits.shape[1], -1)
+        yp = y_phoneme.reshape(-1)
+        phoneme_loss = torch.nn.functional.cross_entropy(logits, yp, ignore_index=-1)
+        keep = yp != -1
+        phoneme_acc = (logits.max(1)[1][keep] == yp[keep]).float().mean()
+        if self.pretraining_type == 1:
+            return phoneme_loss, torch.tensor([0.]), phoneme_acc, torch.tensor([0.])
+        wd_tm = self._word_features_tm(ph_tm)
+        wlogits = self.word_linear(wd_tm.transpose(0, 1))
+        wlogits = wlogits.reshape(wlogits.shape[0] * wlogits.shape[1], -1)
+        yw = y_word.reshape(-1)
+        word_loss = torch.nn.functional.cross_entropy(wlogits, yw, ignore_index=-1)
+        keepw = yw != -1
+        word_acc = (wlogits.max(1)[1][keepw] == yw[keepw]).float().mean()
+        return phoneme_loss, word_loss, phoneme_acc, word_acc
+
+    def compute_posteriors(self, x):
+        (x,) = self._to_device(x)
+        ph_tm = self._phoneme_features_tm(x)
+        phoneme_logits = self.phoneme_linear(ph_tm.transpose(0, 1))
+        word_logits = self.word_linear(self._word_features_tm(ph_tm).transpose(0, 1))
+        return phoneme_logits, word_logits
+
+    def compute_features(self, x):
+        """(B,T) waveform -> (B,T',C) encoder features (reference models.py:349-361)."""
+        (x,) = self._to_device(x)
+        return self._features_tm(x).transpose(0, 1)
+
+
+def freeze_layer(layer):
+    for param in layer.parameters():
+        param.requires_grad = False
+
+
+def unfreeze_layer(layer):
+    for param in layer.parameters():
+        param.requires_grad = True
+
+
+def has_params(layer):
+    return sum(p.numel() for p in layer.parameters()) > 0
+
+
+def is_frozen(layer):
+    return not any(p.requires_grad for p in layer.parameters())
+
+
+class Model(torch.nn.Module):
+    """End-to-end SLU model: pre-trained encoder + intent module (reference models.py:653-874,
+    fixed-length multi-slot output; the seq2seq variant is not part of this package)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.is_cuda = torch.cuda.is_available()
+        self.Sy_intent = config.Sy_intent
+        pretrained_model = PretrainedModel(config)
+        if config.pretraining_type != 0:
+            path = os.path.join(config.folder, "pretraining", "model_state.pth")
+            pretrained_model.load_state_dict(torch.load(path, map_location=None if self.is_cuda else "cpu"))
+        self.pretrained_model = pretrained_model
+        self.unfreezing_type = config.unfreezing_type
+        self.unfreezing_index = config.starting_unfreezing_index
+        if config.pretraining_type != 0:
+            self.freeze_all_layers()
+        self.seq2seq = config.seq2seq
+        if self.seq2seq:
+            raise NotImplementedError("the seq2seq decoder head (reference models.py:381-651) is outside "
+                                      "the MI355X hot path of this package")
+        out_dim = config.word_rnn_num_hidden[-1] * (2 if config.word_rnn_bidirectional else 1)
+        self.values_per_slot = config.values_per_slot
+        self.num_values_total = sum(self.values_per_slot)
+        intent_layers, self._intent_stages = [], []
+        out_dim = _build_rnn_stack(intent_layers, self._intent_stages, "intent", out_dim,
+                                   config.intent_rnn_num_hidden, config.intent_rnn_bidirectional,
+                                   config.intent_rnn_drop, config.intent_downsample_type,
+                                   config.intent_downsample_len)
+        intent_layers.append(_named(torch.nn.Linear(out_dim, self.num_values_total), "final_classifier"))
+        intent_layers.append(_named(FinalPool(), "final_pool"))
+        self.intent_layers = torch.nn.ModuleList(intent_layers)
+        if self.is_cuda:
+            self.cuda()
+
+    # -- freezing schedule (reference models.py:738-795) -----------------------------------------
+    def freeze_all_layers(self):
+        for layer in list(self.pretrained_model.phoneme_layers) + list(self.pretrained_model.word_layers):
+            freeze_layer(layer)
+
+    def print_frozen(self):
+        for layer in list(self.pretrained_model.phoneme_layers) + list(self.pretrained_model.word_layers):
+            if has_params(layer):
+                print(layer.name + ": " + ("frozen" if is_frozen(layer) else "unfrozen"))
+
+    def unfreeze_one_layer(self):
+        """ULMFiT-style: each call unfreezes, from the top of the encoder down, every layer up to the
+        `unfreezing_index`-th parametrised one, then advances the index.  Type 1 walks the word
+        module only, type 2 continues into the phoneme module, type 0 does nothing."""
+        if self.unfreezing_type not in (1, 2):
+            return
+        groups = [self.pretrained_model.word_layers]
+        if self.unfreezing_type == 2:
+            groups.append(self.pretrained_model.phoneme_layers)
+        trainable_seen = 0
+        for group in groups:
+            for layer in reversed(list(group)):
+                unfreeze_layer(layer)
+                if has_params(layer):
+                    trainable_seen += 1
+                if trainable_seen == self.unfreezing_index:
+                    self.unfreezing_index += 1
+                    return
+
+    # -- forward paths ---------------------------------------------------------------------------
+    def _intent_logits(self, x):
+        feats = self.pretrained_model._features_tm(self.pretrained_model._to_device(x)[0])
+        h = feats
+        for st in self._intent_stages:
+            h = st.run(h, self.training)
+        logits_t = self.intent_layers[-2](h)                 # (T,B,V) time-major
+        return logits_t.max(dim=0)[0]                        # FinalPool: max over time
+
+    def _slot_slices(self):
+        start = 0
+        for n in self.values_per_slot:
+            yield start, start + n
+            start += n
+
+    def forward(self, x, y_intent):
+        """x (B,T), y_intent (B,num_slots) -> (loss = sum of per-slot CE, acc = all slots right)
+        (reference models.py:797-823)."""
+        logits = self._intent_logits(x)
+        y_intent = y_intent.to(logits.device)
+        loss = 0.
+        preds = []
+        for slot, (s, e) in enumerate(self._slot_slices()):
+            sub = logits[:, s:e]
+            loss = loss + torch.nn.functional.cross_entropy(sub, y_intent[:, slot])
+            preds.append(sub.max(1)[1])
+        pred = torch.stack(preds, dim=1)
+        acc = (pred == y_intent).prod(1).float().mean()
+        return loss, acc
+
+    def predict_intents(self, x):
+        logits = self._intent_logits(x)
+        pred = torch.stack([logits[:, s:e].max(1)[1] for s, e in self._slot_slices()], dim=1)
+        return logits, pred
+
+    def decode_intents(self, x):
+        """-> list (batch) of lists (slots) of slot-value strings (reference models.py:853-865)."""
+        _, pred = self.predict_intents(x)
+        pred = pred.cpu()
+        inverse = [{idx: value for value, idx in self.Sy_intent[slot].items()} for slot in self.Sy_intent]
+        return [[inverse[s][int(row[s])] for s in range(len(inverse)) if int(row[s]) in inverse[s]]
+                for row in pred]

@@ -28,6 +28,22 @@ def _f32c(t, what):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Optional per-launch timing of the recurrence kernels (bench.py): a list of
+# (kernel name, start event, end event, algorithmic flops) recorded on the launch stream.
+_PROFILE = None
+
+
+def profile_start():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_stop():
+    global _PROFILE
+    out, _PROFILE = _PROFILE, None
+    return out
+
+
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -154,9 +170,16 @@ def gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, want_reserve):
     reserve = None
     if want_reserve:
         reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=gx.device)
+    if _PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(L.slu_gru_seq_fwd(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(),
                                  _ptr(b_hh_r), out.data_ptr(), _ptr(reserve), T, B, H, D, _stream()),
                "slu_gru_seq_fwd")
+    if _PROFILE is not None:
+        ev1.record()
+        # h_{t-1} (B x H) times W_hh^T (H x 3H), per direction and step: 2*B*H*3H flops
+        _PROFILE.append(("gru_seq_fwd_kernel", ev0, ev1, 2.0 * B * H * 3 * H * D * T))
     return out, reserve
 
 
@@ -215,26 +238,26 @@ class SincBlockFn(torch.autograd.Function):
     x (B,T) -> (B, L_out, N_filt) channels-last, or (L_out, B, N_filt) when time_major."""
 
     @staticmethod
-    def forward(ctx, x, b1, band, filt_dim, fs, stride, pool, slope, time_major):
+    def forward(ctx, x, b1, band, filt_dim, fs, stride, pool, slope, time_major, do_abs=True):
         B, T = x.shape
         filters = sinc_filters(b1, band, filt_dim, fs)
         need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        out, route, l_conv = wconv_fwd(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, True,
-                                       pool, slope, time_major, need)
-        ctx.cfg = (B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv)
+        out, route, l_conv = wconv_fwd(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, do_abs,
+                                       pool, slope, time_major, need and (do_abs or pool != 1))
+        ctx.cfg = (B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv, do_abs)
         if need:
             ctx.save_for_backward(x, b1, band, out, route)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv = ctx.cfg
+        B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv, do_abs = ctx.cfg
         x, b1, band, out, route = ctx.saved_tensors
         n = b1.numel()
-        d_conv = wconv_bwd_act(dy, out, route, B, l_conv, n, True, pool, slope, time_major)
+        d_conv = wconv_bwd_act(dy, out, route, B, l_conv, n, do_abs, pool, slope, time_major)
         dW, _ = wconv_bwd_weight(d_conv, x, B, T, 1, n, filt_dim, stride, False)
         db1, dband = sinc_filters_bwd(b1, band, dW.view(n, filt_dim), filt_dim, fs)
-        return None, db1, dband, None, None, None, None, None, None
+        return None, db1, dband, None, None, None, None, None, None, None
 
 
 class ConvBlockFn(torch.autograd.Function):

@@ -1,0 +1,158 @@
+"""`training.Trainer` with the reference's interface (reference training.py:9-171) on top of the
+MI355X-native model, plus what the reference lacks: data-parallel training over the GPUs of a node
+(one RCCL all-reduce of a flat gradient bucket per step) and a step loop without a host
+synchronisation per batch.
+
+Kept from the reference: constructor signature and attributes (`lr`, `checkpoint_path`,
+`optimizer` = Adam over ALL model parameters, `epoch`, `df`), `train(dataset, print_interval)` /
+`test(dataset)` return tuples and their order, the per-epoch `unfreeze_one_layer()` call, the
+`log.csv` format (test rows are labelled "valid" as well), `model_state.pth` checkpoints, and the
+printed messages.  Deliberate differences: metrics are accumulated on the device (float64) and read
+back once per print interval / epoch instead of four `.cpu()` round trips per step
+(training.py:99-100 — the values logged are the same); `test()` stays on the GPU (the reference
+moves the model to the CPU for its seq2seq beam search, training.py:150,166, and crashes on a
+CPU-only host); under torch.distributed only rank 0 prints, logs and writes checkpoints.
+"""
+import os
+
+import pandas as pd
+import torch
+from tqdm import tqdm
+
+from data import SLUDataset, ASRDataset
+from models import PretrainedModel, Model
+from slu_hip import dp
+
+
+class Trainer:
+    def __init__(self, model, config):
+        self.model = model
+        self.config = config
+        if isinstance(self.model, PretrainedModel):
+            self.lr = config.pretraining_lr
+            self.checkpoint_path = os.path.join(self.config.folder, "pretraining")
+        else:
+            self.lr = config.training_lr
+            self.checkpoint_path = os.path.join(self.config.folder, "training")
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=self.lr)
+        self.epoch = 0
+        self.df = None
+        self.rank, self.world_size = dp.world()
+        self.bucket = dp.GradBucket(model.parameters()) if self.world_size > 1 else None
+
+    # -- checkpoints / log (reference training.py:23-45) -------------------------------------------
+    def load_checkpoint(self):
+        path = os.path.join(self.checkpoint_path, "model_state.pth")
+        if os.path.isfile(path):
+            try:
+                dev = next(self.model.parameters()).device
+                self.model.load_state_dict(torch.load(path, map_location=dev))
+            except Exception:
+                print("Could not load previous model; starting from scratch")
+        else:
+            print("No previous model; starting from scratch")
+
+    def save_checkpoint(self):
+        if self.rank != 0:
+            return
+        try:
+            torch.save(self.model.state_dict(), os.path.join(self.checkpoint_path, "model_state.pth"))
+        except Exception:
+            print("Could not save model")
+
+    def log(self, results):
+        if self.rank != 0:
+            return
+        if self.df is None:
+            self.df = pd.DataFrame(columns=[field for field in results])
+        self.df.loc[len(self.df)] = results
+        self.df.to_csv(os.path.join(self.checkpoint_path, "log.csv"))
+
+    # -- one optimisation step ---------------------------------------------------------------------
+    def _step(self, loss):
+        if self.bucket is not None and self.bucket.active:
+            self.bucket.zero()
+        else:
+            self.optimizer.zero_grad()
+        loss.backward()
+        if self.bucket is not None:
+            self.bucket.allreduce_mean()
+        self.optimizer.step()
+
+    def _is_asr(self, dataset):
+        return isinstance(dataset, ASRDataset)
+
+    def _say(self, text):
+        if self.rank == 0:
+            print(text)
+
+    def _epoch_means(self, sums, num_examples, device):
+        tot = dp.allreduce_sums([float(s) for s in sums] + [float(num_examples)], device)
+        return [v / tot[-1] for v in tot[:-1]]
+
+    def _run(self, dataset, train, print_interval):
+        asr = self._is_asr(dataset)
+        names = (["phoneme loss", "word loss", "phoneme acc", "word acc"] if asr
+                 else ["intent loss", "intent acc"])
+        dev = next(self.model.parameters()).device
+        sums = torch.zeros(len(names), dtype=torch.float64, device=dev)
+        num_examples = 0
+        self.model.train(train)
+        if train and not asr:
+            if self.rank == 0:
+                self.model.print_frozen()
+        it = dataset.loader
+        if train and self.rank == 0:
+            it = tqdm(it)
+        for idx, batch in enumerate(it):
+            batch_size = len(batch[0])
+            num_examples += batch_size
+            with torch.set_grad_enabled(train):
+                if asr:
+                    x, y_phoneme, y_word = batch
+                    phoneme_loss, word_loss, phoneme_acc, word_acc = self.model(x, y_phoneme, y_word)
+                    vals = [phoneme_loss, word_loss, phoneme_acc, word_acc]
+                    ptype = self.config.pretraining_type
+                    loss = {1: phoneme_loss, 3: word_loss}.get(ptype)
+                    if ptype == 2:
+                        loss = phoneme_loss + word_loss
+                else:
+                    x, y_intent = batch
+                    intent_loss, intent_acc = self.model(x, y_intent)
+                    vals = [intent_loss, intent_acc]
+                    loss = intent_loss
+                if train:
+                    self._step(loss)
+            step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
+            sums += step_vals * batch_size
+            if train and idx % print_interval == 0 and self.rank == 0:
+                for n, v in zip(names, step_vals.tolist()):       # one host sync per print interval
+                    print(n + ": " + str(v))
+        return self._epoch_means(sums.tolist(), num_examples, dev)
+
+    # -- reference API -----------------------------------------------------------------------------
+    def train(self, dataset, print_interval=100):
+        if self._is_asr(dataset):
+            phone_loss, word_loss, phone_acc, word_acc = self._run(dataset, True, print_interval)
+            self.log({"phone_loss": phone_loss, "phone_acc": phone_acc, "word_loss": word_loss,
+                      "word_acc": word_acc, "set": "train"})
+            self.epoch += 1
+            return phone_acc, phone_loss, word_acc, word_loss
+        intent_loss, intent_acc = self._run(dataset, True, print_interval)
+        before = [p.requires_grad for p in self.model.parameters()]
+        self.model.unfreeze_one_layer()
+        if self.bucket is not None and before != [p.requires_grad for p in self.model.parameters()]:
+            self.bucket.reset()            # the set of parameters receiving gradients changed
+        self.log({"intent_loss": intent_loss, "intent_acc": intent_acc, "set": "train"})
+        self.epoch += 1
+        return intent_acc, intent_loss
+
+    def test(self, dataset):
+        if self._is_asr(dataset):
+            phone_loss, word_loss, phone_acc, word_acc = self._run(dataset, False, 0)
+            self.log({"phone_loss": phone_loss, "phone_acc": phone_acc, "word_loss": word_loss,
+                      "word_acc": word_acc, "set": "valid"})
+            return phone_acc, phone_loss, word_acc, word_loss
+        intent_loss, intent_acc = self._run(dataset, False, 0)
+        self.log({"intent_loss": intent_loss, "intent_acc": intent_acc, "set": "valid"})
+        return intent_acc, intent_loss

@@ -23,6 +23,7 @@ Fixtures:
                         SHA-256 per tensor (weights are re-drawn, not stored), eval logits/loss/acc,
                         train-mode loss + grad digests, one Trainer.train step (post-Adam digests,
                         log.csv row)
+  g9_unfreeze.json      gradual-unfreezing schedule (layer names unfrozen after each call)
   g8_config.json        for all 29 reference cfgs: cfg text (input) and vars(read_config(cfg))
                         or the exception the reference raises (output)
 """
@@ -427,7 +428,39 @@ def g8():
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def g9():
+    """Freezing schedule: names of unfrozen parametrised encoder layers after each
+    Model.unfreeze_one_layer() call, for unfreezing_type 0/1/2 (pretraining_type 2) and the
+    starting index of pretraining_type 1."""
+    work = tempfile.mkdtemp()
+    res = {}
+    try:
+        os.mkdir(os.path.join(work, "pretraining"))
+        for ptype, utype in [(2, 0), (2, 1), (2, 2), (1, 1), (1, 2)]:
+            cfg = tiny_cfg(pretraining_type=ptype, unfreezing_type=utype, folder=work)
+            cfg.starting_unfreezing_index = {1: 1 + len(cfg.word_rnn_num_hidden), 2: 1}[ptype]
+            torch.save(ref_models.PretrainedModel(cfg).state_dict(), os.path.join(work, "pretraining", "model_state.pth"))
+            model = ref_models.Model(cfg)
+            seq = []
+            for _ in range(9):
+                model.unfreeze_one_layer()
+                names = []
+                for layer in list(model.pretrained_model.phoneme_layers) + list(model.pretrained_model.word_layers):
+                    if ref_models.has_params(layer) and not ref_models.is_frozen(layer):
+                        names.append(layer.name)
+                seq.append(names)
+            res["ptype%d_utype%d" % (ptype, utype)] = seq
+    finally:
+        shutil.rmtree(work)
+    with open(os.path.join(OUT, "g9_unfreeze.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    g1(); g2(); g3(); g4(); g5(); g6(); g8()
+    only = os.environ.get("GOLDEN_ONLY")
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9}
+    for k, fn in fns.items():
+        if only is None or k in only.split(","):
+            fn()
     for fn in sorted(os.listdir(OUT)):
         print("%9d  %s" % (os.path.getsize(os.path.join(OUT, fn)), fn))
