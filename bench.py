@@ -86,7 +86,9 @@ def cpu_baseline(config, batch, samples, budget_s=20.0):
     """The CPU oracle (torch-CPU restatement of the reference path, ATen GRU like the reference) on
     the same workload: train-mode forward + backward of the trainable part + Adam, all host cores."""
     from oracle import slu_oracle as O
-    cores = os.cpu_count() or 1
+    # torch's default intra-op pool (what the reference would run with on this host), capped: with
+    # one thread per SMT sibling (256 on the MI355X host) ATen's small per-step GRU matmuls thrash.
+    cores = max(1, min(torch.get_num_threads(), 64))
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     sd = O.init_model_state_dict(config)
@@ -107,10 +109,12 @@ def cpu_baseline(config, batch, samples, budget_s=20.0):
         loss.backward()
         opt.step()
 
+    t0 = time.perf_counter()
     step(False)                                                # warm-up
+    first = time.perf_counter() - t0
     t0 = time.perf_counter()
     n = 0
-    while n < 3 or (time.perf_counter() - t0 < budget_s * 0.7 and n < 50):
+    while n < 1 or (n < 3 and first < budget_s / 4) or (time.perf_counter() - t0 + first < budget_s * 0.6 and n < 50):
         step(False)
         n += 1
     dedup = n * batch / (time.perf_counter() - t0)
@@ -121,6 +125,14 @@ def cpu_baseline(config, batch, samples, budget_s=20.0):
             "sample": "%d train steps of B=%d x %d s on %d torch-CPU threads (oracle, ATen GRU, one conv per "
                       "Sinc forward); reference-faithful variant with the 80 redundant in-loop convolutions "
                       "(models.py:98-108): %.2f utterances/s" % (n, batch, samples // FS, cores, faithful)}
+
+
+def note(msg):
+    if os.environ.get("SLU_BENCH_VERBOSE"):
+        print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def main():
@@ -141,6 +153,7 @@ def main():
     torch.cuda.set_device(local)
     lib.require_gfx950()
     samples = int(args.seconds * FS)
+    note("setup")
     config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4)
     dev = torch.device("cuda", local)
     batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]       # inputs resident in HBM
@@ -152,14 +165,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    note("warmup")
     run_steps(model, trainer, batches, args.warmup)
     fence()
+    note("timed region")
     ops.profile_start()
     t0 = time.perf_counter()
     sums = run_steps(model, trainer, batches, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     prof = ops.profile_stop()
+    note("timed region done: %.3f s" % elapsed)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -197,6 +213,7 @@ def main():
                                  "%d workgroups (one 16-sequence tile x direction each) on 256 CUs" %
                                  (args.batch, 2 * -(-args.batch // 16))},
         }
+        note("cpu baseline")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)
         print(json.dumps(out), flush=True)

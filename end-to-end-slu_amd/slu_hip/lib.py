@@ -59,6 +59,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (libamdhip64); it must be the one already resident when
+    # libslu_hip.so is mapped, or the process ends up with two runtimes and no visible device.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise SluHipError(
             "libslu_hip.so not found at %s — build it with end-to-end-slu_amd/csrc/build.sh "

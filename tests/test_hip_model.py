@@ -49,6 +49,7 @@ def full_cfg(folder, **kw):
     c = O.OracleConfig(**kw)
     c.folder = str(folder)
     c.starting_unfreezing_index = 1
+    c.training_lr = 0.001                    # experiments/no_unfreezing.cfg
     c.Sy_intent = _sy(c.values_per_slot)
     return c
 
