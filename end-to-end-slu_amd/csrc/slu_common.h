@@ -30,6 +30,11 @@ void set_error(const char* fmt, ...);
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// two-stage deterministic column sum (slu_gemm.hip); ws must hold colsum_splits(M) * N floats
+int colsum_splits(int64_t M);
+int colsum_two_stage(const float* X, int64_t rs, float* out, int64_t M, int64_t N, float* ws,
+                     hipStream_t st);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact fp32 (an fmaf chain over k).

@@ -207,11 +207,57 @@ colsum_kernel(const float* __restrict__ X, long long rs, float* __restrict__ out
   }
 }
 
+// Two-stage, atomic-free column sum for tall matrices: partial[rsplit][n] then a fixed-order reduce.
+__global__ void __launch_bounds__(256)
+colsum_partial_kernel(const float* __restrict__ X, long long rs, float* __restrict__ part, int M,
+                      int N, int rows_per_split) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const int m0 = blockIdx.y * rows_per_split;
+  const int m1 = min(M, m0 + rows_per_split);
+  float s = 0.0f;
+  if (n < N)
+    for (int m = m0 + w; m < m1; m += 4) s += X[(long long)m * rs + n];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && n < N)
+    part[(size_t)blockIdx.y * N + n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+__global__ void __launch_bounds__(256)
+colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int RS) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.0f;
+  for (int r = 0; r < RS; ++r) s += part[(size_t)r * N + n];
+  out[n] = s;
+}
+
+int colsum_splits(int64_t M) {
+  int64_t rs = cdiv(M, 64);
+  return (int)(rs > 256 ? 256 : (rs < 1 ? 1 : rs));
+}
+
+// out[n] = sum_m X[m*rs + n] using `ws` (colsum_splits(M) * N floats).
+int colsum_two_stage(const float* X, int64_t rs, float* out, int64_t M, int64_t N, float* ws,
+                     hipStream_t st) {
+  const int RS = colsum_splits(M);
+  const int rows = (int)cdiv(M, RS);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)RS), dim3(256), 0, st,
+                     X, (long long)rs, ws, (int)M, (int)N, rows);
+  SLU_CHECK_LAUNCH("colsum_partial_kernel");
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st,
+                     (const float*)ws, out, (int)N, RS);
+  SLU_CHECK_LAUNCH("colsum_final_kernel");
+  return SLU_OK;
+}
+
 static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper) {
   const int64_t tiles = cdiv(M, GM_BM) * cdiv(N, GM_BN);
   int64_t ks = 1;
   if (tiles < 128 && K >= 512) {
-    ks = cdiv(512, tiles);
+    ks = cdiv(256, tiles);
     const int64_t max_ks = K / 128;            // keep >= 128 k per split
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;

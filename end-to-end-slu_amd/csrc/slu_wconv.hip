@@ -478,7 +478,7 @@ extern "C" size_t slu_wconv_bwd_weight_workspace_bytes(int64_t B, int64_t l_in, 
                                                        int64_t c_out, int64_t k_t, int64_t stride_t) {
   int64_t l_conv; int QGn, KS, cps, cpr;
   dw_geometry(B, l_in, c_in, c_out, k_t, stride_t, &l_conv, &QGn, &KS, &cps, &cpr);
-  return (size_t)KS * c_out * k_t * c_in * sizeof(float);
+  return ((size_t)KS * c_out * k_t * c_in + (size_t)colsum_splits(B * l_conv) * c_out) * sizeof(float);
 }
 
 extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float* d_weight,
@@ -489,7 +489,8 @@ extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float*
   hipStream_t st = (hipStream_t)stream;
   int64_t l_conv; int QGn, KS, cps, cpr;
   dw_geometry(B, l_in, c_in, c_out, k_t, stride_t, &l_conv, &QGn, &KS, &cps, &cpr);
-  const size_t need = (size_t)KS * c_out * k_t * c_in * sizeof(float);
+  const size_t dw_floats = (size_t)KS * c_out * k_t * c_in;
+  const size_t need = (dw_floats + (size_t)colsum_splits(B * l_conv) * c_out) * sizeof(float);
   if (!workspace || workspace_bytes < need)
     SLU_FAIL(SLU_ERR_WORKSPACE, "slu_wconv_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes, need);
   const int MTC = (int)cdiv(c_out, 16);
@@ -520,6 +521,8 @@ extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float*
   hipLaunchKernelGGL(wconv_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st,
                      (const float*)p.ws, d_weight, KS, (int)c_out, (int)c_in, (int)k_t);
   SLU_CHECK_LAUNCH("wconv_dw_reduce_kernel");
-  if (d_bias) return slu_colsum_f32(d_conv, c_out, d_bias, B * l_conv, c_out, 0, stream);
+  if (d_bias)
+    return colsum_two_stage(d_conv, c_out, d_bias, B * l_conv, c_out,
+                            reinterpret_cast<float*>(workspace) + dw_floats, st);
   return SLU_OK;
 }
