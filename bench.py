@@ -127,6 +127,35 @@ def cpu_baseline(config, batch, samples, budget_s=20.0):
                       "(models.py:98-108): %.2f utterances/s" % (n, batch, samples // FS, cores, faithful)}
 
 
+def large_batch_point(rank, samples, batch=2048, steps=3):
+    """The same train step at B = 2048 per GPU (128 sequence tiles x 2 directions = 256 recurrence
+    workgroups, one per CU): where the recurrence stops being bound by the 8-workgroup latency chain.
+    Reported next to the headline number, never as `value`."""
+    from slu_hip import ops
+    config, model, trainer, train_ds, work = setup("no_unfreezing", rank, batch, samples, 1)
+    dev = next(model.parameters()).device
+    batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]
+    model.train()
+    run_steps(model, trainer, batches, 1)
+    torch.cuda.synchronize()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    run_steps(model, trainer, batches, steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    kflops = sum(p[3] for p in prof)
+    kms = sum(p[1].elapsed_time(p[2]) for p in prof)
+    ach = kflops / (kms * 1e-3) / 1e12
+    shutil.rmtree(work, ignore_errors=True)
+    del model, trainer, batches
+    torch.cuda.empty_cache()
+    return {"batch_per_gpu": batch, "utterances_per_s": round(batch * steps / dt, 1),
+            "ms_per_step": round(1e3 * dt / steps, 3),
+            "gru_seq_fwd_kernel_tflops": round(ach, 2), "gru_seq_fwd_kernel_frac_of_fp32_mfma_peak":
+            round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
 def note(msg):
     if os.environ.get("SLU_BENCH_VERBOSE"):
         print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
@@ -144,6 +173,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-batch", action="store_true",
+                    help="skip the extra large-batch point (B=2048/GPU, forward-dominant kernels throughput-bound)")
     args = ap.parse_args()
 
     from slu_hip import dp, lib, ops
@@ -213,6 +244,9 @@ def main():
                                  "%d workgroups (one 16-sequence tile x direction each) on 256 CUs" %
                                  (args.batch, 2 * -(-args.batch // 16))},
         }
+        if not args.no_large_batch and args.workload == "no_unfreezing":
+            note("large-batch point")
+            out["large_batch_point"] = large_batch_point(rank, samples)
         note("cpu baseline")
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)

@@ -92,9 +92,7 @@ gru_seq_fwd_kernel(const GruFwdParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float* g = gxd + (size_t)t0 * gx_ts + grow[r] * D * 3 * H;
-      gr[r] = rowok[r] ? g[0] : 0.f;
-      gz[r] = rowok[r] ? g[H] : 0.f;
-      gn[r] = rowok[r] ? g[2 * H] : 0.f;
+      gr[r] = g[0]; gz[r] = g[H]; gn[r] = g[2 * H];   // padded rows read row 0 (never stored)
     }
   }
   __syncthreads();
@@ -109,9 +107,7 @@ gru_seq_fwd_kernel(const GruFwdParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float* g = gxd + (size_t)tn * gx_ts + grow[r] * D * 3 * H;
-        ngr[r] = rowok[r] ? g[0] : 0.f;
-        ngz[r] = rowok[r] ? g[H] : 0.f;
-        ngn[r] = rowok[r] ? g[2 * H] : 0.f;
+        ngr[r] = g[0]; ngz[r] = g[H]; ngn[r] = g[2 * H];
       }
     } else {
 #pragma unroll
@@ -120,9 +116,13 @@ gru_seq_fwd_kernel(const GruFwdParams p) {
 
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ hrow = &hbuf[cur][i * LD + kg * KQ];
+    float2 af[KQ / 2];
+#pragma unroll
+    for (int v = 0; v < KQ / 2; ++v) af[v] = *reinterpret_cast<const float2*>(hrow + 2 * v);
+    __builtin_amdgcn_sched_barrier(0);     // keep all 16 LDS reads in flight ahead of the MFMA chain
 #pragma unroll
     for (int v = 0; v < KQ / 2; ++v) {
-      const float2 a = *reinterpret_cast<const float2*>(hrow + 2 * v);
+      const float2 a = af[v];
       ar = mfma16(a.x, wr[2 * v], ar);
       az = mfma16(a.x, wz[2 * v], az);
       an = mfma16(a.x, wn[2 * v], an);
@@ -229,7 +229,10 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
     const float4* rs = rsv(t);
     c_r = rs[0]; c_z = rs[64]; c_n = rs[128]; c_q = rs[192]; c_h = rs[256];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c_do[r] = rowok[r] ? dod[(size_t)t * out_ts + grow[r] * D * H] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+      const float v = dod[(size_t)t * out_ts + grow[r] * D * H];
+      c_do[r] = rowok[r] ? v : 0.f;
+    }
   }
 
   for (int s = 0; s < T; ++s) {
@@ -242,7 +245,10 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
       const float4* rs = rsv(tn);
       n_r = rs[0]; n_z = rs[64]; n_n = rs[128]; n_q = rs[192]; n_h = rs[256];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) n_do[r] = rowok[r] ? dod[(size_t)tn * out_ts + grow[r] * D * H] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const float v = dod[(size_t)tn * out_ts + grow[r] * D * H];
+        n_do[r] = rowok[r] ? v : 0.f;
+      }
     }
 
     const float rr[4] = {c_r.x, c_r.y, c_r.z, c_r.w};
@@ -277,11 +283,17 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
 
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ grow_l = &gbuf[cur][i * LDB + kg * KQ];
+    float2 g0[KQ / 2], g1[KQ / 2], g2[KQ / 2];
 #pragma unroll
     for (int v = 0; v < KQ / 2; ++v) {
-      const float2 a0 = *reinterpret_cast<const float2*>(grow_l + 0 * H + 2 * v);
-      const float2 a1 = *reinterpret_cast<const float2*>(grow_l + 1 * H + 2 * v);
-      const float2 a2 = *reinterpret_cast<const float2*>(grow_l + 2 * H + 2 * v);
+      g0[v] = *reinterpret_cast<const float2*>(grow_l + 0 * H + 2 * v);
+      g1[v] = *reinterpret_cast<const float2*>(grow_l + 1 * H + 2 * v);
+      g2[v] = *reinterpret_cast<const float2*>(grow_l + 2 * H + 2 * v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < KQ / 2; ++v) {
+      const float2 a0 = g0[v], a1 = g1[v], a2 = g2[v];
       ar = mfma16(a0.x, wr[2 * v], ar);
       az = mfma16(a1.x, wz[2 * v], az);
       an = mfma16(a2.x, wn[2 * v], an);

@@ -1,0 +1,101 @@
+"""GPU: the reference's driver flow end to end on synthetic data — `main.py --pretrain --train` with a
+synthetic cfg (read_config -> datasets -> PretrainedModel/Model -> Trainer epochs -> checkpoints ->
+log.csv), and the Trainer's ASR branch against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "end-to-end-slu_amd")
+
+
+def test_main_pretrain_then_train_on_synthetic_cfg(tmp_path):
+    os.makedirs(tmp_path / "experiments")
+    text = open(os.path.join(PKG, "experiments", "unfreeze_all_layers_synthetic.cfg")).read()
+    text = text.replace("asr_path=synthetic:8x64x36000", "asr_path=synthetic:3x8x16000")
+    text = text.replace("slu_path=synthetic:8x64x48000", "slu_path=synthetic:4x8x16000")
+    text = text.replace("training_num_epochs=2", "training_num_epochs=3")
+    (tmp_path / "experiments" / "e2e.cfg").write_text(text.replace("unfreeze_all_layers_synthetic", "e2e"))
+    env = dict(os.environ, PYTHONPATH=PKG)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "main.py"), "--pretrain", "--train",
+                        "--config_path=experiments/e2e.cfg"], cwd=tmp_path, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = r.stdout
+    assert "========= Epoch 1 of 1 =========" in out and "========= Test results =========" in out
+    # gradual unfreezing (type 2) is visible in the printed schedule: epoch 1 all frozen, epoch 3 two layers
+    assert "word_rnn1: frozen" in out and "word_rnn1: unfrozen" in out and "word_rnn0: unfrozen" in out
+    folder = tmp_path / "experiments" / "e2e"
+    assert (folder / "experiment.cfg").is_file()
+    pre = torch.load(folder / "pretraining" / "model_state.pth", map_location="cpu")
+    sd = torch.load(folder / "training" / "model_state.pth", map_location="cpu")
+    assert len(pre) == 42 and len(sd) == 52 and sd["pretrained_model.phoneme_layers.0.filt_b1"].dtype == torch.float64
+    # the encoder inside the SLU checkpoint started from the pre-training checkpoint; conv1 never unfroze
+    assert torch.equal(sd["pretrained_model.phoneme_layers.5.weight"], pre["phoneme_layers.5.weight"])
+    assert not torch.equal(sd["pretrained_model.word_layers.4.weight_hh_l0"], pre["word_layers.4.weight_hh_l0"])
+    plog = open(folder / "pretraining" / "log.csv").read().splitlines()
+    tlog = open(folder / "training" / "log.csv").read().splitlines()
+    assert plog[0] == ",phone_loss,phone_acc,word_loss,word_acc,set" and len(plog) == 3
+    assert tlog[0] == ",intent_loss,intent_acc,set" and len(tlog) == 1 + 3 * 2 + 1
+    assert all(np.isfinite(float(v)) for line in tlog[1:] for v in line.split(",")[1:3])
+
+
+def test_trainer_asr_step_matches_oracle(tmp_path):
+    sys.path.insert(0, PKG)
+    import data
+    import models
+    import training
+    cfg = O.OracleConfig(cnn_N_filt=[8, 6, 6], cnn_len_filt=[41, 5, 3], cnn_stride=[10, 1, 1],
+                         phone_rnn_num_hidden=[16, 16], word_rnn_num_hidden=[16, 16],
+                         intent_rnn_num_hidden=[16], vocabulary_size=50, num_phonemes=11,
+                         pretraining_type=2)
+    cfg.folder = str(tmp_path)
+    cfg.pretraining_lr = 0.001
+    cfg.phone_downsample_factor, cfg.word_downsample_factor = 10 * 2 * 4, 10 * 2 * 16
+    os.makedirs(tmp_path / "pretraining")
+    torch.manual_seed(9)
+    pm = models.PretrainedModel(cfg)
+    sd0 = {k: v.detach().cpu().clone() for k, v in pm.state_dict().items()}
+    ds = data.ASRDataset(2, 4, 3200, cfg, seed=3)
+    trainer = training.Trainer(pm, cfg)
+    masks = [O.draw_dropout_masks(cfg, ds.batches[i][0], seed=50 + i, include_intent=False) for i in range(2)]
+
+    class Seq:            # feed batch i with mask set i
+        def __init__(self):
+            self.i = 0
+
+    it = iter(range(2))
+    orig = pm.forward
+
+    def fwd(x, yp, yw):
+        models.set_dropout_masks({k: v.cuda() for k, v in masks[next(it)].items()})
+        return orig(x, yp, yw)
+    pm.forward = fwd
+    try:
+        res = trainer.train(ds)
+    finally:
+        models.set_dropout_masks(None)
+    # oracle: same two Adam steps on CPU
+    sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=cfg.pretraining_lr)
+    tot = np.zeros(4)
+    for i, (x, yp, yw) in enumerate(ds.batches):
+        opt.zero_grad()
+        pl, wl, pa, wa = O.asr_forward(sd, x, yp, yw, cfg, masks[i])
+        (pl + wl).backward()
+        opt.step()
+        tot += np.array([pa.item(), pl.item(), wa.item(), wl.item()]) * len(x)
+    tot /= 8
+    assert np.allclose(np.array(res), tot, atol=2e-5), (res, tot)
+    for k, v in pm.state_dict().items():
+        assert (v.cpu().double() - sd[k].detach().double()).abs().max().item() <= 2e-5, k
+    log = open(tmp_path / "pretraining" / "log.csv").read().splitlines()
+    assert log[0] == ",phone_loss,phone_acc,word_loss,word_acc,set" and log[1].endswith("train")
