@@ -3,10 +3,11 @@
 //
 //   C(m,n) = [C(m,n)] + sum_k A(m,k) B(k,n) + [bias_n(n)]
 //
-// 128 x 128 x 16 workgroup tile, 256 threads = 2 x 2 waves of 64 x 64 (4 x 4 tiles of
-// v_mfma_f32_16x16x4_f32).  Operands are staged k-major in LDS ([k][m], row stride 144 floats, so
-// the four k-groups of a wave hit disjoint banks) through registers with a one-tile prefetch and
-// two LDS buffers (one barrier per k-tile).  The global->register mapping follows whichever
+// 128 x 128 x 32 workgroup tile, 256 threads = 2 x 2 waves of 64 x 64 (4 x 4 tiles of
+// v_mfma_f32_16x16x4_f32, 128 MFMAs per wave per k-tile = 4096 cycles, enough to cover the global
+// load latency of the next tile even with one workgroup per CU).  Operands are staged k-major in
+// LDS ([k][m], row stride 144 floats, so the four k-groups of a wave hit disjoint banks) through
+// registers with a one-tile prefetch (next tile's global loads are in flight during the MFMAs).  The global->register mapping follows whichever
 // operand dimension is contiguous, so A may be row- or column-major (likewise B) without a
 // transposed copy.  Small-output / long-K problems (weight gradients) are split along K into a
 // workspace and reduced in a fixed order (deterministic).
@@ -14,7 +15,9 @@
 
 namespace slu {
 
-constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 16, GM_LD = 144, GM_THREADS = 256;
+constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 32, GM_LD = 144, GM_THREADS = 256;
+constexpr int GM_PASSES = GM_BK / 8;        // float4 loads per thread per operand tile
+constexpr int GM_REGS = 4 * GM_PASSES;
 
 struct GemmParams {
   const float* A; long long a_rs, a_cs;
@@ -27,18 +30,19 @@ struct GemmParams {
   int accumulate;
 };
 
-// Loads the 8 elements thread `tid` owns of a (128 x 16) operand tile into r[8].
-//   X(row, k) = X[row*rs + k*cs], rows [row0, row0+128) limited by nrows, k in [k0, k0+16) limited by kend.
-//   KFAST: k is the contiguous dimension -> thread owns rows {tid/4, tid/4+64}, k-quad tid%4.
-//   else : row is contiguous          -> thread owns k {tid/32, tid/32+8}, row-quad tid%32.
+// Loads the GM_REGS elements thread `tid` owns of a (128 x GM_BK) operand tile into r[].
+//   X(row, k) = X[row*rs + k*cs], rows [row0, row0+128) limited by nrows, k in [k0, k0+BK) limited by kend.
+//   KFAST: k is the contiguous dimension -> thread owns k-quad tid % (BK/4) of rows tid/(BK/4) + 1024/BK*h.
+//   else : row is contiguous          -> thread owns row-quad tid % 32 of k = tid/32 + 8*h.
 template <bool KFAST>
 __device__ __forceinline__ void load_tile(const float* __restrict__ X, long long rs, long long cs,
-                                          int row0, int nrows, int k0, int kend, int tid, float (&r)[8]) {
+                                          int row0, int nrows, int k0, int kend, int tid, float (&r)[GM_REGS]) {
+  constexpr int TPR = GM_BK / 4;              // threads per row (k-fast)
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < GM_PASSES; ++h) {
     if (KFAST) {
-      const int row = row0 + (tid >> 2) + 64 * h;
-      const int k = k0 + 4 * (tid & 3);
+      const int row = row0 + tid / TPR + (GM_THREADS / TPR) * h;
+      const int k = k0 + 4 * (tid % TPR);
       const float* p = X + (long long)row * rs + (long long)k * cs;
       if (row < nrows && k + 3 < kend && cs == 1 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
         const float4 v = *reinterpret_cast<const float4*>(p);
@@ -62,14 +66,15 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, long long
   }
 }
 
-// Stores r[8] into the k-major LDS tile s[k][row] (row stride GM_LD).
+// Stores r[] into the k-major LDS tile s[k][row] (row stride GM_LD).
 template <bool KFAST>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float (&r)[8]) {
+__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float (&r)[GM_REGS]) {
+  constexpr int TPR = GM_BK / 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < GM_PASSES; ++h) {
     if (KFAST) {
-      const int row = (tid >> 2) + 64 * h;
-      const int k = 4 * (tid & 3);
+      const int row = tid / TPR + (GM_THREADS / TPR) * h;
+      const int k = 4 * (tid % TPR);
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[(k + j) * GM_LD + row] = r[4 * h + j];
     } else {
@@ -83,8 +88,8 @@ __device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const
 template <bool A_KFAST, bool B_KFAST>
 __global__ void __launch_bounds__(GM_THREADS)
 gemm_f32_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float sA[2][GM_BK * GM_LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][GM_BK * GM_LD];
+  __shared__ __attribute__((aligned(16))) float sA[GM_BK * GM_LD];
+  __shared__ __attribute__((aligned(16))) float sB[GM_BK * GM_LD];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -100,24 +105,23 @@ gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float ra[8], rb[8];
+  float ra[GM_REGS], rb[GM_REGS];
   // B(k,n) = B[k*b_rs + n*b_cs]: as an (n-rows x k) operand its row stride is b_cs, k stride b_rs.
   if (ntiles > 0) {
     load_tile<A_KFAST>(p.A, p.a_rs, p.a_cs, m0, p.M, kbeg, kend, tid, ra);
     load_tile<B_KFAST>(p.B, p.b_cs, p.b_rs, n0, p.N, kbeg, kend, tid, rb);
-    store_tile<A_KFAST>(sA[0], tid, ra);
-    store_tile<B_KFAST>(sB[0], tid, rb);
   }
-  __syncthreads();
+  const float* __restrict__ a_s = sA + wm * 64 + i;
+  const float* __restrict__ b_s = sB + wn * 64 + i;
   for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntiles) {
+    store_tile<A_KFAST>(sA, tid, ra);
+    store_tile<B_KFAST>(sB, tid, rb);
+    __syncthreads();
+    if (t + 1 < ntiles) {                       // next tile's loads fly during this tile's MFMAs
       const int k0 = kbeg + (t + 1) * GM_BK;
       load_tile<A_KFAST>(p.A, p.a_rs, p.a_cs, m0, p.M, k0, kend, tid, ra);
       load_tile<B_KFAST>(p.B, p.b_cs, p.b_rs, n0, p.N, k0, kend, tid, rb);
     }
-    const float* __restrict__ a_s = sA[cur] + wm * 64 + i;
-    const float* __restrict__ b_s = sB[cur] + wn * 64 + i;
 #pragma unroll
     for (int kk = 0; kk < GM_BK / 4; ++kk) {
       const int krow = (kk * 4 + kg) * GM_LD;
@@ -130,10 +134,6 @@ gemm_f32_kernel(const GemmParams p) {
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
-    }
-    if (t + 1 < ntiles) {
-      store_tile<A_KFAST>(sA[cur ^ 1], tid, ra);
-      store_tile<B_KFAST>(sB[cur ^ 1], tid, rb);
     }
     __syncthreads();
   }

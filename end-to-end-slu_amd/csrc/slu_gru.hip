@@ -19,20 +19,15 @@
 
 namespace slu {
 
-#ifdef SLU_GRU_ACCURATE_MATH
-__device__ __forceinline__ float act_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float act_tanh(float x) { return tanhf(x); }
-#else
-// v_exp_f32 / v_rcp_f32 (1 ulp each): absolute error of the gate values < 3e-7.
+// Gate non-linearities use v_exp_f32 / v_rcp_f32 (1 ulp each): sigmoid(x) = rcp(1 + exp2(-x log2 e)),
+// tanh(x) = 1 - 2 rcp(1 + exp2(2 x log2 e)); absolute error of the gate values < 3e-7.
+
 __device__ __forceinline__ float act_sigmoid(float x) {
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x);
-  return __builtin_amdgcn_rcpf(1.0f + e);
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float act_tanh(float x) {
-  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);   // exp(2x)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
-#endif
 
 struct GruFwdParams {
   const float* gx;        // (T, B, D*3H)
@@ -222,14 +217,27 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
                p.reserve + ((((size_t)dir * T + t) * NBT + btile) * NW + w) * (5 * 256)) + lane;
   };
 
-  float4 c_r, c_z, c_n, c_q, c_h;
-  float c_do[4];
+  // Per step, everything that does not depend on dh_t is folded into three coefficients per element
+  //   cN = (1-z)(1-n^2)      dn_pre = dh * cN
+  //   cZ = (h_prev-n) z(1-z)  dz_pre = dh * cZ
+  //   cR = q r(1-r)           dr_pre = dn_pre * cR,   dq = dn_pre * r,   dh_direct = dh * z
+  // computed for step s+1 in the shadow of step s's MFMAs, so that only 5 multiplies per element sit
+  // between the arrival of dh (previous MFMA chain) and the LDS store that feeds the next one.
+  float cN[4], cZ[4], cR[4], cr[4], cz[4], c_do[4];
   {
     const int t = tindex(0);
     const float4* rs = rsv(t);
-    c_r = rs[0]; c_z = rs[64]; c_n = rs[128]; c_q = rs[192]; c_h = rs[256];
+    const float4 v_r = rs[0], v_z = rs[64], v_n = rs[128], v_q = rs[192], v_h = rs[256];
+    const float rr[4] = {v_r.x, v_r.y, v_r.z, v_r.w}, zz[4] = {v_z.x, v_z.y, v_z.z, v_z.w};
+    const float nn[4] = {v_n.x, v_n.y, v_n.z, v_n.w}, qq[4] = {v_q.x, v_q.y, v_q.z, v_q.w};
+    const float hp[4] = {v_h.x, v_h.y, v_h.z, v_h.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      const float omz = 1.0f - zz[r];
+      cN[r] = omz * (1.0f - nn[r] * nn[r]);
+      cZ[r] = (hp[r] - nn[r]) * (zz[r] * omz);
+      cR[r] = qq[r] * (rr[r] * (1.0f - rr[r]));
+      cr[r] = rr[r]; cz[r] = zz[r];
       const float v = dod[(size_t)t * out_ts + grow[r] * D * H];
       c_do[r] = rowok[r] ? v : 0.f;
     }
@@ -238,36 +246,27 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
   for (int s = 0; s < T; ++s) {
     const int t = tindex(s);
     const int cur = s & 1;
-    float4 n_r = c_r, n_z = c_z, n_n = c_n, n_q = c_q, n_h = c_h;
-    float n_do[4] = {0.f, 0.f, 0.f, 0.f};
-    if (s + 1 < T) {
-      const int tn = tindex(s + 1);
-      const float4* rs = rsv(tn);
-      n_r = rs[0]; n_z = rs[64]; n_n = rs[128]; n_q = rs[192]; n_h = rs[256];
+    // next step's saved gates / upstream gradient (the last step re-reads its own: unused)
+    const int tn = tindex(s + 1 < T ? s + 1 : s);
+    const float4* rsn = rsv(tn);
+    const float4 n_r = rsn[0], n_z = rsn[64], n_n = rsn[128], n_q = rsn[192], n_h = rsn[256];
+    float n_do[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = dod[(size_t)tn * out_ts + grow[r] * D * H];
-        n_do[r] = rowok[r] ? v : 0.f;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float v = dod[(size_t)tn * out_ts + grow[r] * D * H];
+      n_do[r] = rowok[r] ? v : 0.f;
     }
 
-    const float rr[4] = {c_r.x, c_r.y, c_r.z, c_r.w};
-    const float zz[4] = {c_z.x, c_z.y, c_z.z, c_z.w};
-    const float nn[4] = {c_n.x, c_n.y, c_n.z, c_n.w};
-    const float qq[4] = {c_q.x, c_q.y, c_q.z, c_q.w};
-    const float hp[4] = {c_h.x, c_h.y, c_h.z, c_h.w};
     float ddirect[4];
     float* __restrict__ gcur = &gbuf[cur][0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float dh = dcarry[r] + c_do[r];
-      const float dn = dh * (1.0f - zz[r]);
-      const float dz = dh * (hp[r] - nn[r]);
-      ddirect[r] = dh * zz[r];
-      const float dn_pre = dn * (1.0f - nn[r] * nn[r]);
-      const float dz_pre = dz * zz[r] * (1.0f - zz[r]);
-      const float dq = dn_pre * rr[r];
-      const float dr_pre = (dn_pre * qq[r]) * rr[r] * (1.0f - rr[r]);
+      const float dn_pre = dh * cN[r];
+      const float dz_pre = dh * cZ[r];
+      const float dq = dn_pre * cr[r];
+      const float dr_pre = dn_pre * cR[r];
+      ddirect[r] = dh * cz[r];
       const int brow = 4 * kg + r;
       gcur[brow * LDB + 0 * H + j] = dr_pre;
       gcur[brow * LDB + 1 * H + j] = dz_pre;
@@ -283,30 +282,43 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
 
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ grow_l = &gbuf[cur][i * LDB + kg * KQ];
-    float2 g0[KQ / 2], g1[KQ / 2], g2[KQ / 2];
+    const float nr[4] = {n_r.x, n_r.y, n_r.z, n_r.w}, nz[4] = {n_z.x, n_z.y, n_z.z, n_z.w};
+    const float nnv[4] = {n_n.x, n_n.y, n_n.z, n_n.w}, nq[4] = {n_q.x, n_q.y, n_q.z, n_q.w};
+    const float nh[4] = {n_h.x, n_h.y, n_h.z, n_h.w};
+    float t0[4], t1[4], xN[4], xZ[4], xR[4];
+    constexpr int NV = KQ / 2;
 #pragma unroll
-    for (int v = 0; v < KQ / 2; ++v) {
-      g0[v] = *reinterpret_cast<const float2*>(grow_l + 0 * H + 2 * v);
-      g1[v] = *reinterpret_cast<const float2*>(grow_l + 1 * H + 2 * v);
-      g2[v] = *reinterpret_cast<const float2*>(grow_l + 2 * H + 2 * v);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int v = 0; v < KQ / 2; ++v) {
-      const float2 a0 = g0[v], a1 = g1[v], a2 = g2[v];
+    for (int v = 0; v < NV; ++v) {
+      const float2 a0 = *reinterpret_cast<const float2*>(grow_l + 0 * H + 2 * v);
+      const float2 a1 = *reinterpret_cast<const float2*>(grow_l + 1 * H + 2 * v);
+      const float2 a2 = *reinterpret_cast<const float2*>(grow_l + 2 * H + 2 * v);
       ar = mfma16(a0.x, wr[2 * v], ar);
       az = mfma16(a1.x, wz[2 * v], az);
       an = mfma16(a2.x, wn[2 * v], an);
       ar = mfma16(a0.y, wr[2 * v + 1], ar);
       az = mfma16(a1.y, wz[2 * v + 1], az);
       an = mfma16(a2.y, wn[2 * v + 1], an);
+      // coefficient stages for step s+1, one per MFMA group from the middle of the chain on
+      // (by then the prefetched gates have landed); all at the end for small H
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool here = (NV >= 8) ? (k == v - NV / 2) : (v == NV - 1);
+        if (!here) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (k == 0) { t0[r] = 1.0f - nz[r]; t1[r] = 1.0f - nnv[r] * nnv[r]; }
+          if (k == 1) { xN[r] = t0[r] * t1[r]; t0[r] = nz[r] * t0[r]; }
+          if (k == 2) { xZ[r] = (nh[r] - nnv[r]) * t0[r]; t1[r] = nr[r] * (1.0f - nr[r]); }
+          if (k == 3) { xR[r] = nq[r] * t1[r]; }
+        }
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dcarry[r] = ddirect[r] + ((ar[r] + az[r]) + an[r]);
-
-    c_r = n_r; c_z = n_z; c_n = n_n; c_q = n_q; c_h = n_h;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) c_do[r] = n_do[r];
+    for (int r = 0; r < 4; ++r) {
+      dcarry[r] = ddirect[r] + ((ar[r] + az[r]) + an[r]);
+      cN[r] = xN[r]; cZ[r] = xZ[r]; cR[r] = xR[r]; cr[r] = nr[r]; cz[r] = nz[r];
+      c_do[r] = n_do[r];
+    }
     // gbuf[cur] is rewritten two steps from now; the barrier of the next step orders that.
   }
 

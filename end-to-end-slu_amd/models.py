@@ -183,15 +183,27 @@ class GRU(torch.nn.Module):
         self.input_size, self.hidden_size, self.bidirectional = input_size, hidden_size, bidirectional
         self.batch_first = True
 
-    def _params(self):
-        fw = (self.weight_ih_l0, self.weight_hh_l0, self.bias_ih_l0, self.bias_hh_l0)
-        if self.bidirectional:
-            return fw + (self.weight_ih_l0_reverse, self.weight_hh_l0_reverse,
-                         self.bias_ih_l0_reverse, self.bias_hh_l0_reverse)
-        return fw + (None, None, None, None)
+    def _stacked_ih(self):
+        """(W_ih, b_ih) of both directions stacked to (D*3H, I) / (D*3H) so that the input projection
+        is one GEMM.  Frozen weights are stacked once and cached (keyed on the tensors' version
+        counters); trainable ones are concatenated inside the autograd graph every forward."""
+        if not self.bidirectional:
+            return self.weight_ih_l0, self.bias_ih_l0
+        parts = (self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse)
+        if any(t.requires_grad for t in parts) and torch.is_grad_enabled():
+            return torch.cat(parts[:2]), torch.cat(parts[2:])
+        key = tuple((t.data_ptr(), t._version) for t in parts)
+        if getattr(self, "_ih_cache_key", None) != key:
+            with torch.no_grad():
+                self._ih_cache = (torch.cat(parts[:2]), torch.cat(parts[2:]))
+            self._ih_cache_key = key
+        return self._ih_cache
 
     def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1):
-        return _ops.GRULayerFn.apply(xt, *self._params(), p, mask, seed, offset, method, factor)
+        w_ih, b_ih = self._stacked_ih()
+        rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse) if self.bidirectional else (None, None)
+        return _ops.GRULayerFn.apply(xt, w_ih, b_ih, self.weight_hh_l0, self.bias_hh_l0, rev[0], rev[1],
+                                     p, mask, seed, offset, method, factor)
 
     def forward(self, x):
         _require_device(x)

@@ -295,72 +295,65 @@ class ConvBlockFn(torch.autograd.Function):
 
 class GRULayerFn(torch.autograd.Function):
     """nn.GRU (1 layer, h0 = 0) -> RNNSelect -> Dropout -> Downsample  (models.py:232-253).
-    x time-major (T, B, I) -> (T_out, B, D*H)."""
+    x time-major (T, B, I) -> (T_out, B, D*H).
+    w_ih (D*3H, I) / b_ih (D*3H): weight_ih_l0 [; weight_ih_l0_reverse] stacked, so that the input
+    projection of both directions is ONE GEMM launch (N = 768) and so are its two gradients."""
 
     @staticmethod
-    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r,
-                p, mask, seed, offset, method, factor):
+    def forward(ctx, x, w_ih, b_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p, mask, seed, offset, method, factor):
         x = x.contiguous()
         T, B, I = x.shape
         H = w_hh_f.shape[1]
-        D = 1 if w_ih_r is None else 2
-        x2 = x.view(T * B, I)
-        gx = torch.empty(T * B, D * 3 * H, dtype=torch.float32, device=x.device)
-        gemm(x2, w_ih_f.t(), b_ih_f, out=gx[:, :3 * H])
-        if D == 2:
-            gemm(x2, w_ih_r.t(), b_ih_r, out=gx[:, 3 * H:])
-        params = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
-        need = any(ctx.needs_input_grad[:9])
+        D = 1 if w_hh_r is None else 2
+        gx = gemm(x.view(T * B, I), w_ih.t(), b_ih)                       # (T*B, D*3H)
+        need = any(ctx.needs_input_grad[:7])
         raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
         if p == 0.0 and (factor == 1):
             y = raw
         else:
             y = dropout_pool_fwd(raw, mask, p, seed, offset, method, factor)
         if need:
-            ctx.save_for_backward(x, raw, reserve, mask, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+            ctx.save_for_backward(x, raw, reserve, mask, w_ih, w_hh_f, w_hh_r)
             ctx.cfg = (T, B, I, H, D, p, seed, offset, method, factor)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         T, B, I, H, D, p, seed, offset, method, factor = ctx.cfg
-        x, raw, reserve, mask, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
+        x, raw, reserve, mask, w_ih, w_hh_f, w_hh_r = ctx.saved_tensors
         if p == 0.0 and factor == 1:
             d_raw = dy
         else:
             d_raw = dropout_pool_bwd(dy, raw, mask, p, seed, offset, method, factor)
         d_gx, d_q, dbp = gru_seq_bwd(d_raw, reserve, w_hh_f, w_hh_r, T, B, H, D)
-        dbp = dbp.sum(0)                                   # (D, 4H): [d_gx sums (3H) | d_q sums (H)]
+        ng = ctx.needs_input_grad
+        if ng[2] or ng[4] or ng[6]:
+            dbp = dbp.sum(0)                               # (D, 4H): [d_gx sums (3H) | d_q sums (H)]
         x2 = x.view(T * B, I)
         g2 = d_gx.view(T * B, D * 3 * H)
         q2 = d_q.view(T * B, D * H)
         r2 = raw.view(T * B, D * H)
-        ng = ctx.needs_input_grad
-        grads = [None] * 15
-        w_ih = (w_ih_f, w_ih_r)
+        grads = [None] * 13
+        if ng[0]:                                          # dx = d_gx W_ih (both directions, K = D*3H)
+            grads[0] = gemm(g2, w_ih).view(T, B, I)
+        if ng[1]:                                          # dW_ih = d_gx^T x
+            grads[1] = gemm(g2.t(), x2)
+        if ng[2]:
+            grads[2] = dbp[:, :3 * H].reshape(-1)
         for d in range(D):
-            base = 1 + 4 * d                               # positions of (w_ih, w_hh, b_ih, b_hh)
-            gd = g2[:, d * 3 * H:(d + 1) * 3 * H]
-            if ng[base]:                                   # dW_ih = d_gx^T x
-                grads[base] = gemm(gd.t(), x2)
-            if ng[base + 1]:                               # dW_hh = dG_h^T h_{t-1}
+            wpos, bpos = 3 + 2 * d, 4 + 2 * d              # (w_hh, b_hh) of direction d
+            if ng[wpos]:                                   # dW_hh = dG_h^T h_{t-1}
                 dW = torch.zeros(3 * H, H, dtype=torch.float32, device=x.device)
                 if T > 1:
                     n = (T - 1) * B
+                    gd = g2[:, d * 3 * H:(d + 1) * 3 * H]
                     if d == 0:     # h_{t-1} = raw[t-1]: gradient rows t >= 1 against raw rows t-1
                         ga, qa, hp = gd[B:], q2[B:, :H], r2[:n, :H]
                     else:          # reverse scan: h_prev(t) = raw[t+1]
                         ga, qa, hp = gd[:n], q2[:n, H:], r2[B:, H:]
                     gemm(ga[:, :2 * H].t(), hp, out=dW[:2 * H])
                     gemm(qa.t(), hp, out=dW[2 * H:])
-                grads[base + 1] = dW
-            if ng[base + 2]:
-                grads[base + 2] = dbp[d, :3 * H].clone()
-            if ng[base + 3]:
-                grads[base + 3] = torch.cat([dbp[d, :2 * H], dbp[d, 3 * H:]])
-        if ng[0]:
-            dx = gemm(g2[:, :3 * H], w_ih_f)
-            if D == 2:
-                gemm(g2[:, 3 * H:], w_ih_r, out=dx, accumulate=True)
-            grads[0] = dx.view(T, B, I)
+                grads[wpos] = dW
+            if ng[bpos]:
+                grads[bpos] = torch.cat([dbp[d, :2 * H], dbp[d, 3 * H:]])
         return tuple(grads)

@@ -158,6 +158,15 @@ def test_colsum(ops):
     assert_close(out.double(), x.double().sum(0), 1e-3, "colsum")
 
 
+def _layer_args(xg, gp, bi):
+    """(x, W_ih stacked over directions, b_ih stacked, W_hh, b_hh[, reverse W_hh, b_hh])"""
+    if bi:
+        return [xg, torch.cat([gp["weight_ih_l0"], gp["weight_ih_l0_reverse"]]),
+                torch.cat([gp["bias_ih_l0"], gp["bias_ih_l0_reverse"]]),
+                gp["weight_hh_l0"], gp["bias_hh_l0"], gp["weight_hh_l0_reverse"], gp["bias_hh_l0_reverse"]]
+    return [xg, gp["weight_ih_l0"], gp["bias_ih_l0"], gp["weight_hh_l0"], gp["bias_hh_l0"], None, None]
+
+
 def _gru_case(ops, d, bi, check_grads=True):
     p = {k: torch.from_numpy(v) for k, v in d.items() if k.startswith(("weight_", "bias_"))}
     x = torch.from_numpy(d["x"])                     # (B,T,I)
@@ -165,13 +174,7 @@ def _gru_case(ops, d, bi, check_grads=True):
     H = p["weight_hh_l0"].shape[1]
     gp = {k: cu(v).requires_grad_() for k, v in p.items()}
     xg = cu(x.transpose(0, 1).contiguous()).requires_grad_()         # time-major
-    args = [xg, gp["weight_ih_l0"], gp["weight_hh_l0"], gp["bias_ih_l0"], gp["bias_hh_l0"]]
-    if bi:
-        args += [gp["weight_ih_l0_reverse"], gp["weight_hh_l0_reverse"], gp["bias_ih_l0_reverse"],
-                 gp["bias_hh_l0_reverse"]]
-    else:
-        args += [None, None, None, None]
-    y = ops.GRULayerFn.apply(*args, 0.0, None, 0, 0, "none", 1)      # (T,B,D*H)
+    y = ops.GRULayerFn.apply(*_layer_args(xg, gp, bi), 0.0, None, 0, 0, "none", 1)      # (T,B,D*H)
     assert_close(y.transpose(0, 1), torch.from_numpy(d["out"]), 1e-5, "gru out")
     if not check_grads:
         return
@@ -257,9 +260,7 @@ def test_gru_layer_with_dropout_and_avg_pool_grads(ops):
     (ref * gy).sum().backward()
     gp = {k: cu(v.detach()).requires_grad_() for k, v in p.items()}
     xg = cu(x.detach().transpose(0, 1).contiguous()).requires_grad_()
-    y = ops.GRULayerFn.apply(xg, gp["weight_ih_l0"], gp["weight_hh_l0"], gp["bias_ih_l0"], gp["bias_hh_l0"],
-                             gp["weight_ih_l0_reverse"], gp["weight_hh_l0_reverse"], gp["bias_ih_l0_reverse"],
-                             gp["bias_hh_l0_reverse"], 0.5, cu(mask_mem), 0, 0, "avg", 2)
+    y = ops.GRULayerFn.apply(*_layer_args(xg, gp, True), 0.5, cu(mask_mem), 0, 0, "avg", 2)
     assert_close(y.transpose(0, 1), ref, 1e-5, "layer out")
     (y * cu(gy.transpose(0, 1).contiguous())).sum().backward()
     assert_grad_close(xg.grad.transpose(0, 1), x.grad, 1e-4, "dx")

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Runs one kernel shape repeatedly (for rocprofv3 --pmc passes): python tools/run_one.py gemm|gru"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "end-to-end-slu_amd"))
+import torch
+from slu_hip import ops
+what = sys.argv[1]
+if what == "gemm":
+    M, N, K = 128, 128, 256
+    a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); out = torch.empty(M, N, device="cuda")
+    for _ in range(20):
+        ops.gemm(a, w.t(), None, out=out)
+elif what == "gemmbig":
+    M, N, K = 19200, 768, 256
+    a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); out = torch.empty(M, N, device="cuda")
+    for _ in range(10):
+        ops.gemm(a, w.t(), None, out=out)
+elif what == "gru":
+    T, B, H = 300, 64, 128
+    gx = torch.randn(T, B, 6 * H, device="cuda")
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    for _ in range(5):
+        ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, 2, False)
+torch.cuda.synchronize()
