@@ -1,0 +1,212 @@
+// Fused intent head of the SLU model (reference models.py:709 final_classifier Linear, :112-123
+// FinalPool max over time, :811-821 per-slot cross-entropy + accuracy, :839-844 per-slot argmax).
+//
+//   logits_t[t][b][v] = h[t][b][:] . W[v][:] + bias[v]        (T x B x V, never materialised in HBM)
+//   logits[b][v]      = max_t logits_t[t][b][v]               (+ arg-max t for the backward pass)
+//   loss              = sum_slots mean_b CE(logits[b][slot], y[b][slot]);  acc = mean_b [all slots right]
+//
+// One workgroup per utterance: its (T x C) feature rows and the (V x C) classifier are staged in LDS,
+// every thread owns a few (t, v) dot products, the max over time and the per-slot softmax run on
+// the first V threads.  V = 24 and T = 19 for the reference architecture: this is latency-bound
+// glue, fused to replace ~35 small ATen launches per training step by 4.
+#include "slu_common.h"
+
+namespace slu {
+
+constexpr int HEAD_THREADS = 256;
+constexpr int HEAD_MAX_SLOTS = 8;
+
+struct HeadParams {
+  const float* h;          // (T, B, C) time-major
+  const float* W;          // (V, C)
+  const float* bias;       // (V)
+  const long long* y;      // (B, S) or null (inference: no loss)
+  float* logits;           // (B, V)
+  int* argmax_t;           // (B, V)
+  long long* pred;         // (B, S)
+  float* d_logits;         // (B, V) or null: d loss / d logits
+  float* row_stats;        // (B, 2): per-utterance loss and all-slots-correct flag
+  int T, B, C, V, S;
+  int slot_begin[HEAD_MAX_SLOTS + 1];
+};
+
+__global__ void __launch_bounds__(HEAD_THREADS)
+head_fwd_kernel(const HeadParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sh = reinterpret_cast<float*>(smem);          // [T][C+1]
+  float* sw = sh + (size_t)p.T * (p.C + 1);            // [V][C+1]
+  float* sl = sw + (size_t)p.V * (p.C + 1);            // [T][V] logits_t
+  float* sm = sl + (size_t)p.T * p.V;                  // [V] pooled logits
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int T = p.T, C = p.C, V = p.V, LD = p.C + 1;
+  for (int idx = tid; idx < T * C; idx += HEAD_THREADS) {
+    const int t = idx / C, c = idx - t * C;
+    sh[t * LD + c] = p.h[((size_t)t * p.B + b) * C + c];
+  }
+  for (int idx = tid; idx < V * C; idx += HEAD_THREADS) {
+    const int v = idx / C, c = idx - v * C;
+    sw[v * LD + c] = p.W[idx];
+  }
+  __syncthreads();
+  for (int o = tid; o < T * V; o += HEAD_THREADS) {
+    const int t = o / V, v = o - t * V;
+    const float* a = sh + t * LD;
+    const float* w = sw + v * LD;
+    float acc = 0.0f;
+    for (int c = 0; c < C; ++c) acc = fmaf(a[c], w[c], acc);
+    sl[o] = acc + p.bias[v];
+  }
+  __syncthreads();
+  if (tid < V) {
+    float best = sl[tid];
+    int arg = 0;
+    for (int t = 1; t < T; ++t) {
+      const float x = sl[t * V + tid];
+      if (x > best) { best = x; arg = t; }          // first maximum wins, like torch.max
+    }
+    sm[tid] = best;
+    p.logits[(size_t)b * V + tid] = best;
+    p.argmax_t[(size_t)b * V + tid] = arg;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float loss = 0.0f;
+    bool all_ok = true;
+    for (int s = 0; s < p.S; ++s) {
+      const int v0 = p.slot_begin[s], v1 = p.slot_begin[s + 1];
+      float mx = sm[v0];
+      int am = v0;
+      for (int v = v0 + 1; v < v1; ++v) if (sm[v] > mx) { mx = sm[v]; am = v; }
+      p.pred[(size_t)b * p.S + s] = am - v0;
+      if (p.y) {
+        float den = 0.0f;
+        for (int v = v0; v < v1; ++v) den += expf(sm[v] - mx);
+        const int yv = (int)p.y[(size_t)b * p.S + s];
+        loss += logf(den) - (sm[v0 + yv] - mx);       // -log softmax[y]
+        all_ok = all_ok && (am - v0 == yv);
+        if (p.d_logits) {
+          const float inv = 1.0f / (den * (float)p.B);
+          for (int v = v0; v < v1; ++v)
+            p.d_logits[(size_t)b * V + v] = expf(sm[v] - mx) * inv - ((v - v0 == yv) ? 1.0f / (float)p.B : 0.0f);
+        }
+      }
+    }
+    if (p.y) {
+      p.row_stats[2 * b] = loss;
+      p.row_stats[2 * b + 1] = all_ok ? 1.0f : 0.0f;
+    }
+  }
+}
+
+// loss = sum_b row_loss / B (each slot's CE is a mean over the batch), acc = mean_b correct
+__global__ void __launch_bounds__(256)
+head_reduce_kernel(const float* __restrict__ row_stats, float* __restrict__ loss_acc, int B) {
+  __shared__ float r0[256], r1[256];
+  float a = 0.0f, c = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 256) { a += row_stats[2 * b]; c += row_stats[2 * b + 1]; }
+  r0[threadIdx.x] = a; r1[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { loss_acc[0] = r0[0] / (float)B; loss_acc[1] = r1[0] / (float)B; }
+}
+
+// d_h[t][b][c] = g * sum_v [t == argmax_t[b][v]] d_logits[b][v] W[v][c]
+__global__ void __launch_bounds__(HEAD_THREADS)
+head_bwd_dh_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
+                   const float* __restrict__ W, const float* __restrict__ gscale,
+                   float* __restrict__ d_h, int T, int B, int C, int V) {
+  const int b = blockIdx.x;
+  const float g = gscale[0];
+  for (int idx = threadIdx.x; idx < T * C; idx += HEAD_THREADS) {
+    const int t = idx / C, c = idx - t * C;
+    float acc = 0.0f;
+    for (int v = 0; v < V; ++v)
+      if (argmax_t[(size_t)b * V + v] == t) acc = fmaf(d_logits[(size_t)b * V + v], W[(size_t)v * C + c], acc);
+    d_h[((size_t)t * B + b) * C + c] = acc * g;
+  }
+}
+
+// d_W[v][c] = g * sum_b d_logits[b][v] h[argmax_t[b][v]][b][c];   d_bias[v] = g * sum_b d_logits[b][v]
+__global__ void __launch_bounds__(HEAD_THREADS)
+head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
+                   const float* __restrict__ h, const float* __restrict__ gscale,
+                   float* __restrict__ d_W, float* __restrict__ d_bias, int T, int B, int C, int V) {
+  const int v = blockIdx.x;
+  const float g = gscale[0];
+  for (int c = threadIdx.x; c < C; c += HEAD_THREADS) {
+    float acc = 0.0f;
+    for (int b = 0; b < B; ++b) {
+      const int t = argmax_t[(size_t)b * V + v];
+      acc = fmaf(d_logits[(size_t)b * V + v], h[((size_t)t * B + b) * C + c], acc);
+    }
+    d_W[(size_t)v * C + c] = acc * g;
+  }
+  if (threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += d_logits[(size_t)b * V + v];
+    d_bias[v] = s * g;
+  }
+  (void)T;
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const float* bias,
+                                      const int64_t* y, const int64_t* values_per_slot,
+                                      int64_t num_slots, float* logits, int32_t* argmax_t,
+                                      int64_t* pred, float* d_logits, float* row_stats,
+                                      float* loss_acc, int64_t T, int64_t B, int64_t C,
+                                      void* stream) {
+  SLU_REQUIRE(h && weight && bias && logits && argmax_t && pred && values_per_slot, "slu_cls_maxpool_ce_fwd: null pointer");
+  SLU_REQUIRE(num_slots >= 1 && num_slots <= HEAD_MAX_SLOTS, "slu_cls_maxpool_ce_fwd: 1..%d slots supported", HEAD_MAX_SLOTS);
+  SLU_REQUIRE(!y || (row_stats && loss_acc), "slu_cls_maxpool_ce_fwd: row_stats / loss_acc required with labels");
+  SLU_REQUIRE(T > 0 && B > 0 && C > 0, "slu_cls_maxpool_ce_fwd: non-positive size");
+  HeadParams p;
+  p.h = h; p.W = weight; p.bias = bias; p.y = (const long long*)y; p.logits = logits; p.argmax_t = argmax_t;
+  p.pred = (long long*)pred; p.d_logits = d_logits; p.row_stats = row_stats;
+  p.T = (int)T; p.B = (int)B; p.C = (int)C; p.S = (int)num_slots;
+  int V = 0;
+  for (int s = 0; s < num_slots; ++s) { p.slot_begin[s] = V; V += (int)values_per_slot[s]; }
+  p.slot_begin[num_slots] = V;
+  p.V = V;
+  SLU_REQUIRE(V >= 1 && V <= HEAD_THREADS, "slu_cls_maxpool_ce_fwd: 1..%d classifier outputs supported", HEAD_THREADS);
+  const size_t lds = ((size_t)(T + V) * (C + 1) + (size_t)T * V + V) * sizeof(float);
+  if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_cls_maxpool_ce_fwd: T=%lld x C=%lld does not fit the LDS", (long long)T, (long long)C);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_cls_maxpool_ce_fwd: %s", hipGetErrorString(e));
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)B), dim3(HEAD_THREADS), lds, st, p);
+  SLU_CHECK_LAUNCH("head_fwd_kernel");
+  if (y) {
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)row_stats, loss_acc, (int)B);
+    SLU_CHECK_LAUNCH("head_reduce_kernel");
+  }
+  return SLU_OK;
+}
+
+extern "C" int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const float* h,
+                                      const float* weight, const float* grad_scale, float* d_h,
+                                      float* d_weight, float* d_bias, int64_t T, int64_t B,
+                                      int64_t C, int64_t V, void* stream) {
+  SLU_REQUIRE(d_logits && argmax_t && h && weight && grad_scale, "slu_cls_maxpool_ce_bwd: null pointer");
+  SLU_REQUIRE((d_weight == nullptr) == (d_bias == nullptr), "slu_cls_maxpool_ce_bwd: d_weight and d_bias go together");
+  hipStream_t st = (hipStream_t)stream;
+  if (d_h) {
+    hipLaunchKernelGGL(head_bwd_dh_kernel, dim3((unsigned)B), dim3(HEAD_THREADS), 0, st, d_logits, argmax_t,
+                       weight, grad_scale, d_h, (int)T, (int)B, (int)C, (int)V);
+    SLU_CHECK_LAUNCH("head_bwd_dh_kernel");
+  }
+  if (d_weight) {
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)V), dim3(HEAD_THREADS), 0, st, d_logits, argmax_t, h,
+                       grad_scale, d_weight, d_bias, (int)T, (int)B, (int)C, (int)V);
+    SLU_CHECK_LAUNCH("head_bwd_dw_kernel");
+  }
+  return SLU_OK;
+}

@@ -504,38 +504,27 @@ class Model(torch.nn.Module):
                     return
 
     # -- forward paths ---------------------------------------------------------------------------
-    def _intent_logits(self, x):
-        feats = self.pretrained_model._features_tm(self.pretrained_model._to_device(x)[0])
-        h = feats
+    def _intent_features_tm(self, x):
+        h = self.pretrained_model._features_tm(self.pretrained_model._to_device(x)[0])
         for st in self._intent_stages:
             h = st.run(h, self.training)
-        logits_t = self.intent_layers[-2](h)                 # (T,B,V) time-major
-        return logits_t.max(dim=0)[0]                        # FinalPool: max over time
-
-    def _slot_slices(self):
-        start = 0
-        for n in self.values_per_slot:
-            yield start, start + n
-            start += n
+        return h                                                 # (T,B,C) time-major
 
     def forward(self, x, y_intent):
         """x (B,T), y_intent (B,num_slots) -> (loss = sum of per-slot CE, acc = all slots right)
-        (reference models.py:797-823)."""
-        logits = self._intent_logits(x)
-        y_intent = y_intent.to(logits.device)
-        loss = 0.
-        preds = []
-        for slot, (s, e) in enumerate(self._slot_slices()):
-            sub = logits[:, s:e]
-            loss = loss + torch.nn.functional.cross_entropy(sub, y_intent[:, slot])
-            preds.append(sub.max(1)[1])
-        pred = torch.stack(preds, dim=1)
-        acc = (pred == y_intent).prod(1).float().mean()
+        (reference models.py:797-823); classifier, max over time, CE and accuracy are one fused op."""
+        h = self._intent_features_tm(x)
+        cls = self.intent_layers[-2]
+        loss, acc, _, _ = _ops.IntentHeadFn.apply(h, cls.weight, cls.bias, y_intent.to(h.device),
+                                                  tuple(self.values_per_slot))
         return loss, acc
 
     def predict_intents(self, x):
-        logits = self._intent_logits(x)
-        pred = torch.stack([logits[:, s:e].max(1)[1] for s, e in self._slot_slices()], dim=1)
+        """-> (intent_logits (B, num_values_total), predicted_intent (B, num_slots)) (models.py:830-846)"""
+        h = self._intent_features_tm(x).contiguous()
+        cls = self.intent_layers[-2]
+        _, logits, pred, _, _ = _ops.cls_maxpool_ce_fwd(h.detach(), cls.weight.detach(), cls.bias.detach(), None,
+                                                        tuple(self.values_per_slot), False)
         return logits, pred
 
     def decode_intents(self, x):

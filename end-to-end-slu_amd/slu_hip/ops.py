@@ -229,9 +229,66 @@ def dropout_pool_bwd(dy, x, mask, p, seed, offset, method, factor):
     return dx
 
 
+def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad):
+    """-> (loss_acc (2) or None, logits (B,V), pred (B,S), argmax_t (B,V) int32, d_logits or None)"""
+    import ctypes
+    L = _lib.load()
+    T, B, C = h.shape
+    S = len(values_per_slot)
+    V = int(sum(values_per_slot))
+    dev = h.device
+    logits = torch.empty(B, V, dtype=torch.float32, device=dev)
+    argmax_t = torch.empty(B, V, dtype=torch.int32, device=dev)
+    pred = torch.empty(B, S, dtype=torch.int64, device=dev)
+    d_logits = torch.empty(B, V, dtype=torch.float32, device=dev) if (want_grad and y is not None) else None
+    row_stats = torch.empty(B, 2, dtype=torch.float32, device=dev) if y is not None else None
+    loss_acc = torch.empty(2, dtype=torch.float32, device=dev) if y is not None else None
+    vps = (ctypes.c_int64 * S)(*[int(v) for v in values_per_slot])
+    _lib.check(L.slu_cls_maxpool_ce_fwd(h.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(y), vps, S,
+                                        logits.data_ptr(), argmax_t.data_ptr(), pred.data_ptr(), _ptr(d_logits),
+                                        _ptr(row_stats), _ptr(loss_acc), T, B, C, _stream()),
+               "slu_cls_maxpool_ce_fwd")
+    return loss_acc, logits, pred, argmax_t, d_logits
+
+
 # ------------------------------------------------------------------------------------------------
 # autograd Functions (one per fused stage of the encoder)
 # ------------------------------------------------------------------------------------------------
+class IntentHeadFn(torch.autograd.Function):
+    """final_classifier Linear -> FinalPool (max over time) -> per-slot cross-entropy / accuracy
+    (reference models.py:709, :112-123, :811-821).  h time-major (T,B,C), y (B,S) int64.
+    Returns (loss, acc, logits (B,V), pred (B,S)); only `loss` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, y, values_per_slot):
+        h = h.contiguous()
+        y = y.contiguous()
+        need = any(ctx.needs_input_grad[:3])
+        loss_acc, logits, pred, argmax_t, d_logits = cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, need)
+        if need:
+            ctx.save_for_backward(h, weight, argmax_t, d_logits)
+        ctx.mark_non_differentiable(logits, pred)
+        acc = loss_acc[1]
+        ctx.mark_non_differentiable(acc)
+        return loss_acc[0], acc, logits, pred
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_acc, _d_logits, _d_pred):
+        L = _lib.load()
+        h, weight, argmax_t, d_logits = ctx.saved_tensors
+        T, B, C = h.shape
+        V = weight.shape[0]
+        g = d_loss.contiguous().float()
+        dh = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dW = torch.empty_like(weight) if need_w else None
+        db = torch.empty(V, dtype=torch.float32, device=h.device) if need_w else None
+        _lib.check(L.slu_cls_maxpool_ce_bwd(d_logits.data_ptr(), argmax_t.data_ptr(), h.data_ptr(),
+                                            weight.data_ptr(), g.data_ptr(), _ptr(dh), _ptr(dW), _ptr(db),
+                                            T, B, C, V, _stream()), "slu_cls_maxpool_ce_bwd")
+        return dh, dW, db, None, None
+
+
 
 class SincBlockFn(torch.autograd.Function):
     """SincLayer -> Abs -> MaxPool1d(ceil) -> LeakyReLU  (models.py:77-110, :163-168, :205, :211).

@@ -150,6 +150,25 @@ int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const 
                          int method, int64_t factor, float* dx,
                          int64_t T, int64_t B, int64_t C, void* stream);
 
+/* -------- intent head: Linear "final_classifier" (models.py:709) -> FinalPool max over time
+ * (:112-123) -> per-slot cross-entropy, accuracy and arg-max (:811-821, :839-844) ------------------
+ *   h (T,B,C) time-major intent-GRU output; weight (V,C), bias (V), V = sum(values_per_slot);
+ *   y (B,S) int64 labels or NULL (inference: logits / pred only);
+ *   values_per_slot: HOST array of S entries (S <= 8) — the only host pointer of this ABI;
+ *   logits (B,V) = max over t of h_t W^T + b;  argmax_t (B,V) int32;  pred (B,S) int64;
+ *   d_logits (B,V) or NULL: d loss / d logits (softmax - onehot)/B per slot;
+ *   row_stats (B,2) scratch;  loss_acc (2): loss = sum_slots mean_b CE, acc = mean_b [all slots right].
+ * Backward: d_h (T,B,C), d_weight (V,C), d_bias (V), all scaled by the device scalar *grad_scale;
+ * d_h or the (d_weight, d_bias) pair may be NULL.                                                  */
+int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const float* bias, const int64_t* y,
+                           const int64_t* values_per_slot, int64_t num_slots, float* logits,
+                           int32_t* argmax_t, int64_t* pred, float* d_logits, float* row_stats,
+                           float* loss_acc, int64_t T, int64_t B, int64_t C, void* stream);
+int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const float* h,
+                           const float* weight, const float* grad_scale, float* d_h,
+                           float* d_weight, float* d_bias, int64_t T, int64_t B, int64_t C,
+                           int64_t V, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,3 +285,27 @@ def test_sinc_block_grads_vs_oracle(ops):
     (out * cu(gy)).sum().backward()
     assert_grad_close(b1g.grad, b1.grad, 5e-4, "d filt_b1")
     assert_grad_close(bandg.grad, band.grad, 5e-4, "d filt_band")
+
+
+@pytest.mark.parametrize("T,B,C,vps", [(19, 64, 256, (6, 14, 4)), (4, 3, 32, (3, 4, 2)), (1, 5, 16, (2,)), (7, 130, 64, (5, 5, 5, 5))])
+def test_intent_head_fused_vs_torch(ops, T, B, C, vps):
+    g = torch.Generator().manual_seed(T * 100 + B)
+    V = sum(vps)
+    h = torch.randn(T, B, C, generator=g, requires_grad=True)
+    W = (torch.randn(V, C, generator=g) / C ** 0.5).requires_grad_()
+    bias = torch.randn(V, generator=g).requires_grad_()
+    y = torch.stack([torch.randint(0, n, (B,), generator=g) for n in vps], dim=1)
+    logits = (h @ W.t() + bias).max(dim=0)[0]                       # FinalPool over time
+    loss, acc, pred = O.slu_loss_acc(logits, y, list(vps))
+    (loss * 1.7).backward()
+    hg, Wg, bg = cu(h.detach()).requires_grad_(), cu(W.detach()).requires_grad_(), cu(bias.detach()).requires_grad_()
+    l2, a2, lg2, p2 = ops.IntentHeadFn.apply(hg, Wg, bg, cu(y), vps)
+    assert_close(lg2, logits, 2e-5, "pooled logits")
+    assert torch.equal(p2.cpu(), pred) and abs(l2.item() - loss.item()) <= 1e-5 and a2.item() == acc.item()
+    (l2 * 1.7).backward()
+    assert_grad_close(hg.grad, h.grad, 1e-4, "d h")
+    assert_grad_close(Wg.grad, W.grad, 1e-4, "d W")
+    assert_grad_close(bg.grad, bias.grad, 1e-4, "d bias")
+    # inference form: no labels
+    _, lg3, p3, _, _ = ops.cls_maxpool_ce_fwd(hg.detach(), Wg.detach(), bg.detach(), None, vps, False)
+    assert torch.equal(lg3, lg2) and torch.equal(p3, p2)
