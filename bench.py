@@ -72,13 +72,13 @@ def setup(workload, rank, batch, samples, n_batches):
 
 
 def run_steps(model, trainer, batches, n):
+    """n optimisation steps through Trainer's own step loop (forward, loss, backward, gradient
+    all-reduce, Adam; with the frozen-encoder look-ahead pipeline when it applies)."""
     dev = next(model.parameters()).device
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
-    for i in range(n):
-        x, y = batches[i % len(batches)]
-        loss, acc = model(x, y)
-        trainer._step(loss)
-        sums += torch.stack([loss.detach().double(), acc.detach().double()])
+    loader = [batches[i % len(batches)] for i in range(n)]
+    for vals, _ in trainer._iterate(loader, True, False):
+        sums += torch.stack([v.detach().double() for v in vals])
     return sums
 
 
@@ -235,7 +235,8 @@ def main():
                                     "end state): fwd + CE + full bwd + grad all-reduce + Adam"),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "samples_per_utterance": samples, "parallelism": "dp%d" % world,
-                       "allreduce_bytes_per_step": payload, "mean_loss": round(loss_mean, 5)},
+                       "allreduce_bytes_per_step": payload, "mean_loss": round(loss_mean, 5),
+                       "encoder_lookahead_batches": trainer.lookahead_depth(True, False)[0]},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
                          "kernel": "gru_seq_fwd_kernel<128>",

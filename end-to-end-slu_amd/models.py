@@ -39,7 +39,8 @@ from slu_hip import lib as _lib
 class _DropoutState:
     masks = None        # dict: layer name ("phone_dropout0", ...) -> float {0,1} mask, logical (B,T,C)
     seed = None         # None -> torch.initial_seed()
-    counter = 0         # advances once per dropout site per forward
+    step = 0            # index of the last top-level forward; Philox offset = step * 16 + dropout site
+    current = 0         # step the stages running right now belong to
 
 
 def set_dropout_masks(masks):
@@ -51,10 +52,19 @@ def set_dropout_masks(masks):
 def set_dropout_seed(seed):
     """Seed of the in-kernel Philox stream (per-rank streams under data parallelism)."""
     _DropoutState.seed = seed
-    _DropoutState.counter = 0
+    _DropoutState.step = _DropoutState.current = 0
 
 
-def _dropout_args(name, p, training):
+def next_rng_step():
+    """Reserve the dropout stream index of one top-level forward.  Every dropout site of that
+    forward draws from Philox(seed, offset = step*16 + site), whichever HIP stream or order its
+    stages run in — which is what lets the trainer run the frozen part of the encoder ahead of
+    time on side streams and still produce exactly the sequential run's masks."""
+    _DropoutState.step += 1
+    return _DropoutState.step
+
+
+def _dropout_args(name, site, p, training):
     """-> (p_eff, mask_time_major_or_None, seed, offset)"""
     if not training or p == 0.0:
         return 0.0, None, 0, 0
@@ -62,8 +72,7 @@ def _dropout_args(name, p, training):
         m = _DropoutState.masks[name]
         return p, m.transpose(0, 1), 0, 0          # (T,B,C) view; kernel takes its strides
     seed = _DropoutState.seed if _DropoutState.seed is not None else torch.initial_seed()
-    _DropoutState.counter += 1
-    return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.counter
+    return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.current * 16 + site
 
 
 def _require_device(t):
@@ -255,9 +264,14 @@ class _ConvStage:
     def __init__(self, conv, is_sinc, do_abs, pool, act, drop):
         self.conv, self.is_sinc, self.do_abs, self.pool, self.drop = conv, is_sinc, do_abs, pool, drop
         self.slope = 0.2 if act == "leaky_relu" else 0.0
+        self.time_major = False       # set on the last CNN stage: its output feeds the RNN stack
 
-    def run(self, h, training, time_major):
+    def parameters(self):
+        return list(self.conv.parameters())
+
+    def run(self, h, training):
         """h: (B,T) for the first block, else channels-last (B,L,C)."""
+        time_major = self.time_major
         fused_pool = self.pool in (1, 2)
         tm = time_major and fused_pool and self.drop == 0.0
         pool = self.pool if fused_pool else 1
@@ -287,11 +301,18 @@ class _ConvStage:
 class _RnnStage:
     """[gru, select, dropout, downsample] (reference models.py:230-253, 260-283, 684-707)."""
 
+    SITES = {"phone": 0, "word": 4, "intent": 8}      # dropout-site numbering (<= 4 layers per module)
+
     def __init__(self, gru, drop_name, p, method, factor):
         self.gru, self.drop_name, self.p, self.method, self.factor = gru, drop_name, p, method, factor
+        module, idx = drop_name.split("_dropout")
+        self.site = self.SITES[module] + int(idx)
+
+    def parameters(self):
+        return list(self.gru.parameters())
 
     def run(self, xt, training):
-        p, mask, seed, offset = _dropout_args(self.drop_name, self.p, training)
+        p, mask, seed, offset = _dropout_args(self.drop_name, self.site, self.p, training)
         return self.gru.run_time_major(xt, p, mask, seed, offset, self.method, self.factor)
 
 
@@ -367,29 +388,54 @@ class PretrainedModel(torch.nn.Module):
         dev = next(self.parameters()).device
         return [t.to(dev, non_blocking=True) if t is not None else None for t in tensors]
 
+    def _stages(self):
+        return self._cnn_stages + self._phone_stages + self._word_stages
+
+    def run_stages(self, h, first, last):
+        """Run fused stages [first, last) of the encoder (CNN blocks, then phoneme and word RNN
+        layers).  Hand-off layouts: (B,T) waveform -> channels-last (B,L,C) between CNN blocks ->
+        time-major (T,B,C) from the last CNN block on."""
+        self._cnn_stages[-1].time_major = True
+        if first == 0:
+            h = h.float()
+        for st in self._stages()[first:last]:
+            h = st.run(h, self.training)
+        return h
+
+    def frozen_prefix_len(self):
+        """Number of leading stages none of whose parameters is trainable."""
+        n = 0
+        for st in self._stages():
+            if any(p.requires_grad for p in st.parameters()):
+                break
+            n += 1
+        return n
+
+    def warm_weight_caches(self):
+        """Materialise the cached stacked input-projection weights of the frozen GRU layers on the
+        current stream (so that side streams only ever read them)."""
+        for st in self._phone_stages + self._word_stages:
+            if not any(p.requires_grad for p in st.parameters()):
+                with torch.no_grad():
+                    st.gru._stacked_ih()
+
     def _phoneme_features_tm(self, x):
         """x (B,T) on device -> time-major (T', B, C) output of the phoneme module."""
-        h = x.float()
-        last = len(self._cnn_stages) - 1
-        for i, st in enumerate(self._cnn_stages):
-            h = st.run(h, self.training, time_major=(i == last))
-        for st in self._phone_stages:
-            h = st.run(h, self.training)
-        return h
+        return self.run_stages(x, 0, len(self._cnn_stages) + len(self._phone_stages))
 
     def _word_features_tm(self, h):
-        for st in self._word_stages:
-            h = st.run(h, self.training)
-        return h
+        n = len(self._cnn_stages) + len(self._phone_stages)
+        return self.run_stages(h, n, n + len(self._word_stages))
 
     def _features_tm(self, x):
-        return self._word_features_tm(self._phoneme_features_tm(x))
+        return self.run_stages(x, 0, len(self._stages()))
 
     # -- reference API --------------------------------------------------------------------------
     def forward(self, x, y_phoneme, y_word):
         """x (B,T), y_phoneme (B,T'), y_word (B,T'') -> (phoneme_loss, word_loss, phoneme_acc,
         word_acc); cross-entropy ignores label -1 (reference models.py:291-331)."""
         x, y_phoneme, y_word = self._to_device(x, y_phoneme, y_word)
+        _DropoutState.current = next_rng_step()
         ph_tm = self._phoneme_features_tm(x)                         # (T',B,C)
         logits = self.phoneme_linear(ph_tm.transpose(0, 1))          # (B,T',P)
         logits = logits.reshape(logits.shape[0] * logits.shape[1], -1)
@@ -410,6 +456,7 @@ class PretrainedModel(torch.nn.Module):
 
     def compute_posteriors(self, x):
         (x,) = self._to_device(x)
+        _DropoutState.current = next_rng_step()
         ph_tm = self._phoneme_features_tm(x)
         phoneme_logits = self.phoneme_linear(ph_tm.transpose(0, 1))
         word_logits = self.word_linear(self._word_features_tm(ph_tm).transpose(0, 1))
@@ -418,6 +465,7 @@ class PretrainedModel(torch.nn.Module):
     def compute_features(self, x):
         """(B,T) waveform -> (B,T',C) encoder features (reference models.py:349-361)."""
         (x,) = self._to_device(x)
+        _DropoutState.current = next_rng_step()
         return self._features_tm(x).transpose(0, 1)
 
 
@@ -505,19 +553,42 @@ class Model(torch.nn.Module):
 
     # -- forward paths ---------------------------------------------------------------------------
     def _intent_features_tm(self, x):
+        _DropoutState.current = next_rng_step()
         h = self.pretrained_model._features_tm(self.pretrained_model._to_device(x)[0])
         for st in self._intent_stages:
             h = st.run(h, self.training)
         return h                                                 # (T,B,C) time-major
 
-    def forward(self, x, y_intent):
-        """x (B,T), y_intent (B,num_slots) -> (loss = sum of per-slot CE, acc = all slots right)
-        (reference models.py:797-823); classifier, max over time, CE and accuracy are one fused op."""
-        h = self._intent_features_tm(x)
+    # -- split execution for the trainer's encoder look-ahead pipeline ---------------------------
+    def frozen_prefix_len(self):
+        """Leading encoder stages with no trainable parameter (the whole encoder for
+        unfreezing_type 0): their outputs do not depend on earlier optimisation steps, so they may
+        be computed ahead of time for upcoming batches."""
+        return self.pretrained_model.frozen_prefix_len()
+
+    def prefix_features(self, x, n_stages, rng_step):
+        """Frozen stages [0, n_stages) for one batch, without autograd, on the CURRENT stream."""
+        with torch.no_grad():
+            _DropoutState.current = rng_step
+            return self.pretrained_model.run_stages(self.pretrained_model._to_device(x)[0], 0, n_stages)
+
+    def forward_from(self, h, n_stages, y_intent, rng_step):
+        """The rest of Model.forward given the output of stages [0, n_stages)."""
+        pm = self.pretrained_model
+        _DropoutState.current = rng_step
+        h = pm.run_stages(h, n_stages, len(pm._stages()))
+        for st in self._intent_stages:
+            h = st.run(h, self.training)
         cls = self.intent_layers[-2]
         loss, acc, _, _ = _ops.IntentHeadFn.apply(h, cls.weight, cls.bias, y_intent.to(h.device),
                                                   tuple(self.values_per_slot))
         return loss, acc
+
+    def forward(self, x, y_intent):
+        """x (B,T), y_intent (B,num_slots) -> (loss = sum of per-slot CE, acc = all slots right)
+        (reference models.py:797-823); classifier, max over time, CE and accuracy are one fused op."""
+        x = self.pretrained_model._to_device(x)[0]
+        return self.forward_from(x, 0, y_intent, next_rng_step())
 
     def predict_intents(self, x):
         """-> (intent_logits (B, num_values_total), predicted_intent (B, num_slots)) (models.py:830-846)"""

@@ -24,6 +24,11 @@ from models import PretrainedModel, Model
 from slu_hip import dp
 
 
+def models_masks_injected():
+    import models
+    return models._DropoutState.masks is not None
+
+
 class Trainer:
     def __init__(self, model, config):
         self.model = model
@@ -93,6 +98,85 @@ class Trainer:
         tot = dp.allreduce_sums([float(s) for s in sums] + [float(num_examples)], device)
         return [v / tot[-1] for v in tot[:-1]]
 
+    def _forward_losses(self, batch, asr):
+        if asr:
+            x, y_phoneme, y_word = batch
+            phoneme_loss, word_loss, phoneme_acc, word_acc = self.model(x, y_phoneme, y_word)
+            ptype = self.config.pretraining_type
+            loss = {1: phoneme_loss, 3: word_loss}.get(ptype)
+            if ptype == 2:
+                loss = phoneme_loss + word_loss
+            return [phoneme_loss, word_loss, phoneme_acc, word_acc], loss
+        x, y_intent = batch
+        intent_loss, intent_acc = self.model(x, y_intent)
+        return [intent_loss, intent_acc], intent_loss
+
+    def lookahead_depth(self, train, asr):
+        """How many batches ahead the FROZEN prefix of the encoder is evaluated on side HIP streams
+        (0 = plain sequential steps).  Only SLU training with a frozen prefix qualifies: a frozen
+        stage's output does not depend on earlier optimisation steps.  At 64 utterances per step a
+        recurrence occupies 8 of 256 CUs, so several batches' encoders run concurrently for free;
+        the per-batch dropout streams are step-indexed, so the result is the sequential one."""
+        depth = int(os.environ.get("SLU_LOOKAHEAD", "4"))
+        if not train or asr or depth < 2 or not hasattr(self.model, "prefix_features"):
+            return 0, 0
+        if not all(p.is_cuda for p in self.model.parameters()) or models_masks_injected():
+            return 0, 0
+        n = self.model.frozen_prefix_len()
+        return (depth, n) if n > 0 else (0, 0)
+
+    def _iterate(self, loader, train, asr):
+        """Yields ([metric tensors], batch_size) per batch, doing the optimisation step when `train`."""
+        depth, n_prefix = self.lookahead_depth(train, asr)
+        if depth == 0:
+            for batch in loader:
+                with torch.set_grad_enabled(train):
+                    vals, loss = self._forward_losses(batch, asr)
+                    if train:
+                        self._step(loss)
+                yield vals, len(batch[0])
+            return
+        # ---- encoder look-ahead pipeline -----------------------------------------------------------
+        import collections
+        from models import next_rng_step
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_streams", None) is None or len(self._side_streams) != depth:
+            self._side_streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.model.pretrained_model.warm_weight_caches()
+        for st in self._side_streams:
+            st.wait_stream(main)
+        pending = collections.deque()
+        it = iter(loader)
+        launched = 0
+
+        def launch_next():
+            nonlocal launched
+            try:
+                batch = next(it)
+            except StopIteration:
+                return False
+            side = self._side_streams[launched % depth]
+            launched += 1
+            step = next_rng_step()
+            with torch.cuda.stream(side):
+                feats = self.model.prefix_features(batch[0], n_prefix, step)
+                done = torch.cuda.Event()
+                done.record(side)
+            pending.append((batch, feats, done, step))
+            return True
+
+        for _ in range(depth):
+            if not launch_next():
+                break
+        while pending:
+            batch, feats, done, step = pending.popleft()
+            main.wait_event(done)
+            feats.record_stream(main)
+            loss, acc = self.model.forward_from(feats, n_prefix, batch[1], step)
+            self._step(loss)
+            launch_next()
+            yield [loss, acc], len(batch[0])
+
     def _run(self, dataset, train, print_interval):
         asr = self._is_asr(dataset)
         names = (["phoneme loss", "word loss", "phoneme acc", "word acc"] if asr
@@ -107,25 +191,8 @@ class Trainer:
         it = dataset.loader
         if train and self.rank == 0:
             it = tqdm(it)
-        for idx, batch in enumerate(it):
-            batch_size = len(batch[0])
+        for idx, (vals, batch_size) in enumerate(self._iterate(it, train, asr)):
             num_examples += batch_size
-            with torch.set_grad_enabled(train):
-                if asr:
-                    x, y_phoneme, y_word = batch
-                    phoneme_loss, word_loss, phoneme_acc, word_acc = self.model(x, y_phoneme, y_word)
-                    vals = [phoneme_loss, word_loss, phoneme_acc, word_acc]
-                    ptype = self.config.pretraining_type
-                    loss = {1: phoneme_loss, 3: word_loss}.get(ptype)
-                    if ptype == 2:
-                        loss = phoneme_loss + word_loss
-                else:
-                    x, y_intent = batch
-                    intent_loss, intent_acc = self.model(x, y_intent)
-                    vals = [intent_loss, intent_acc]
-                    loss = intent_loss
-                if train:
-                    self._step(loss)
             step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
             sums += step_vals * batch_size
             if train and idx % print_interval == 0 and self.rank == 0:

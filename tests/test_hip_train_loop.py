@@ -99,3 +99,49 @@ def test_trainer_asr_step_matches_oracle(tmp_path):
         assert (v.cpu().double() - sd[k].detach().double()).abs().max().item() <= 2e-5, k
     log = open(tmp_path / "pretraining" / "log.csv").read().splitlines()
     assert log[0] == ",phone_loss,phone_acc,word_loss,word_acc,set" and log[1].endswith("train")
+
+
+def test_lookahead_pipeline_equals_sequential_training(tmp_path, monkeypatch):
+    """Trainer's frozen-encoder look-ahead (prefix of upcoming batches on side HIP streams) must give
+    exactly the sequential run: same per-step losses, same parameters (Philox streams are indexed by
+    (step, dropout site), not by call order)."""
+    sys.path.insert(0, PKG)
+    import data
+    import models
+    import training
+    cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                         phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                         intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=2)
+    cfg.folder = str(tmp_path)
+    cfg.training_lr = 0.003
+    cfg.starting_unfreezing_index = 1
+    cfg.unfreezing_type = 1
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    os.makedirs(tmp_path / "pretraining")
+    os.makedirs(tmp_path / "training")
+    torch.manual_seed(1)
+    torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
+    ds = data.SLUDataset(7, 8, 6000, cfg.values_per_slot, seed=5)
+    results = {}
+    for depth in ("0", "3"):
+        monkeypatch.setenv("SLU_LOOKAHEAD", depth)
+        torch.manual_seed(2)
+        model = models.Model(cfg)
+        models.set_dropout_seed(77)
+        trainer = training.Trainer(model, cfg)
+        assert trainer.lookahead_depth(True, False) == ((3, 7) if depth == "3" else (0, 0))
+        losses = []
+        model.train()
+        for vals, _ in trainer._iterate(ds.loader, True, False):
+            losses.append(vals[0].item())
+        # epoch 2 after one unfreezing step: the frozen prefix shrinks to 6 stages (word_rnn1 trainable)
+        model.unfreeze_one_layer()
+        assert model.frozen_prefix_len() == 6
+        for vals, _ in trainer._iterate(ds.loader, True, False):
+            losses.append(vals[0].item())
+        torch.cuda.synchronize()
+        results[depth] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    assert results["0"][0] == results["3"][0]
+    for k, v in results["0"][1].items():
+        assert torch.equal(v, results["3"][1][k]), k
+    assert len(set(results["0"][0])) == len(results["0"][0])         # dropout really varied step to step
