@@ -48,13 +48,19 @@ head_fwd_kernel(const HeadParams p) {
     sw[v * LD + c] = p.W[idx];
   }
   __syncthreads();
-  for (int o = tid; o < T * V; o += HEAD_THREADS) {
-    const int t = o / V, v = o - t * V;
-    const float* a = sh + t * LD;
-    const float* w = sw + v * LD;
-    float acc = 0.0f;
-    for (int c = 0; c < C; ++c) acc = fmaf(a[c], w[c], acc);
-    sl[o] = acc + p.bias[v];
+  {
+    // one wave per (t, v) output: lanes stride over C, then a 6-step butterfly reduction
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int o = wave; o < T * V; o += HEAD_THREADS / 64) {
+      const int t = o / V, v = o - t * V;
+      const float* a = sh + t * LD;
+      const float* w = sw + v * LD;
+      float acc = 0.0f;
+      for (int c = lane; c < C; c += 64) acc = fmaf(a[c], w[c], acc);
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+      if (lane == 0) sl[o] = acc + p.bias[v];
+    }
   }
   __syncthreads();
   if (tid < V) {
@@ -114,41 +120,67 @@ head_reduce_kernel(const float* __restrict__ row_stats, float* __restrict__ loss
 }
 
 // d_h[t][b][c] = g * sum_v [t == argmax_t[b][v]] d_logits[b][v] W[v][c]
+// One workgroup per utterance; thread c owns column c of a (T x C) LDS accumulator and adds, for
+// each classifier output v, d_logits[v] * W[v][c] into the row of v's arg-max time step.
 __global__ void __launch_bounds__(HEAD_THREADS)
 head_bwd_dh_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
                    const float* __restrict__ W, const float* __restrict__ gscale,
                    float* __restrict__ d_h, int T, int B, int C, int V) {
-  const int b = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* acc = reinterpret_cast<float*>(smem);          // [T][C]
+  __shared__ float s_dl[HEAD_THREADS];
+  __shared__ int s_at[HEAD_THREADS];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float g = gscale[0];
-  for (int idx = threadIdx.x; idx < T * C; idx += HEAD_THREADS) {
+  if (tid < V) { s_dl[tid] = d_logits[(size_t)b * V + tid] * g; s_at[tid] = argmax_t[(size_t)b * V + tid]; }
+  for (int idx = tid; idx < T * C; idx += HEAD_THREADS) acc[idx] = 0.0f;
+  __syncthreads();
+  for (int c = tid; c < C; c += HEAD_THREADS)
+    for (int v = 0; v < V; ++v) acc[s_at[v] * C + c] = fmaf(s_dl[v], W[(size_t)v * C + c], acc[s_at[v] * C + c]);
+  __syncthreads();
+  for (int idx = tid; idx < T * C; idx += HEAD_THREADS) {
     const int t = idx / C, c = idx - t * C;
-    float acc = 0.0f;
-    for (int v = 0; v < V; ++v)
-      if (argmax_t[(size_t)b * V + v] == t) acc = fmaf(d_logits[(size_t)b * V + v], W[(size_t)v * C + c], acc);
-    d_h[((size_t)t * B + b) * C + c] = acc * g;
+    d_h[((size_t)t * B + b) * C + c] = acc[idx];
   }
 }
 
 // d_W[v][c] = g * sum_b d_logits[b][v] h[argmax_t[b][v]][b][c];   d_bias[v] = g * sum_b d_logits[b][v]
+// One workgroup per classifier output v: wave w accumulates utterances b = w, w+4, ... for its 64-lane
+// slices of C (fixed order -> deterministic), then the four partial rows are summed through LDS.
 __global__ void __launch_bounds__(HEAD_THREADS)
 head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
                    const float* __restrict__ h, const float* __restrict__ gscale,
                    float* __restrict__ d_W, float* __restrict__ d_bias, int T, int B, int C, int V) {
-  const int v = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* part = reinterpret_cast<float*>(smem);         // [4][C]
+  __shared__ float s_b[4];
+  const int v = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float g = gscale[0];
-  for (int c = threadIdx.x; c < C; c += HEAD_THREADS) {
-    float acc = 0.0f;
-    for (int b = 0; b < B; ++b) {
-      const int t = argmax_t[(size_t)b * V + v];
-      acc = fmaf(d_logits[(size_t)b * V + v], h[((size_t)t * B + b) * C + c], acc);
+  float bsum = 0.0f;
+  constexpr int KMAX = 16;                               // C <= 1024
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.0f;
+  for (int b = w; b < B; b += 4) {                       // independent loads across k: 4-16 in flight
+    const float dl = d_logits[(size_t)b * V + v];
+    const float* hr = h + ((size_t)argmax_t[(size_t)b * V + v] * B + b) * C;
+    bsum += dl;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int c = lane + 64 * k;
+      if (c < C) acc[k] = fmaf(dl, hr[c], acc[k]);
     }
-    d_W[(size_t)v * C + c] = acc * g;
   }
-  if (threadIdx.x == 0) {
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) s += d_logits[(size_t)b * V + v];
-    d_bias[v] = s * g;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) part[w * C + c] = acc[k];
   }
+  if (lane == 0) s_b[w] = bsum;
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += HEAD_THREADS)
+    d_W[(size_t)v * C + c] = (((part[c] + part[C + c]) + part[2 * C + c]) + part[3 * C + c]) * g;
+  if (threadIdx.x == 0) d_bias[v] = (((s_b[0] + s_b[1]) + s_b[2]) + s_b[3]) * g;
   (void)T;
 }
 
@@ -197,15 +229,22 @@ extern "C" int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argm
                                       int64_t C, int64_t V, void* stream) {
   SLU_REQUIRE(d_logits && argmax_t && h && weight && grad_scale, "slu_cls_maxpool_ce_bwd: null pointer");
   SLU_REQUIRE((d_weight == nullptr) == (d_bias == nullptr), "slu_cls_maxpool_ce_bwd: d_weight and d_bias go together");
+  SLU_REQUIRE(C <= 1024, "slu_cls_maxpool_ce_bwd: C <= 1024");
   hipStream_t st = (hipStream_t)stream;
   if (d_h) {
-    hipLaunchKernelGGL(head_bwd_dh_kernel, dim3((unsigned)B), dim3(HEAD_THREADS), 0, st, d_logits, argmax_t,
+    SLU_REQUIRE(V <= HEAD_THREADS && T * C * 4 <= 160 * 1024 - 4096, "slu_cls_maxpool_ce_bwd: T*C too large for the LDS");
+    const size_t lds = (size_t)T * C * sizeof(float);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)head_bwd_dh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_cls_maxpool_ce_bwd: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(head_bwd_dh_kernel, dim3((unsigned)B), dim3(HEAD_THREADS), lds, st, d_logits, argmax_t,
                        weight, grad_scale, d_h, (int)T, (int)B, (int)C, (int)V);
     SLU_CHECK_LAUNCH("head_bwd_dh_kernel");
   }
   if (d_weight) {
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)V), dim3(HEAD_THREADS), 0, st, d_logits, argmax_t, h,
-                       grad_scale, d_weight, d_bias, (int)T, (int)B, (int)C, (int)V);
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)V), dim3(HEAD_THREADS), (size_t)4 * C * sizeof(float), st,
+                       d_logits, argmax_t, h, grad_scale, d_weight, d_bias, (int)T, (int)B, (int)C, (int)V);
     SLU_CHECK_LAUNCH("head_bwd_dw_kernel");
   }
   return SLU_OK;

@@ -31,6 +31,9 @@ struct PoolParams {
   const float* mask; long long m_st, m_sb;
   float p, scale;
   unsigned long long seed, offset;
+  const unsigned long long* offset_dev;   // optional run-time addend (hipGraph replays)
+  unsigned long long sub_stride;          // offset increment between sub-batches
+  int sub_batch;                          // 0: the whole batch is one Philox index space
   int method, factor;
   int T, B, C, T_out;
 };
@@ -39,8 +42,16 @@ struct PoolParams {
 __device__ __forceinline__ float keep_scale(const PoolParams& q, int t, int b, int c) {
   if (q.p <= 0.0f) return 1.0f;
   if (q.mask) return q.mask[(long long)t * q.m_st + (long long)b * q.m_sb + c] * q.scale;
-  const uint64_t idx = ((uint64_t)t * q.B + b) * q.C + c;
-  return philox_uniform(q.seed, q.offset, idx) < (1.0f - q.p) ? q.scale : 0.0f;
+  uint64_t off = q.offset + (q.offset_dev ? *q.offset_dev : 0ull);
+  uint64_t idx;
+  if (q.sub_batch > 0) {
+    const int k = b / q.sub_batch, bl = b - k * q.sub_batch;
+    idx = ((uint64_t)t * q.sub_batch + bl) * q.C + c;
+    off += (uint64_t)k * q.sub_stride;
+  } else {
+    idx = ((uint64_t)t * q.B + b) * q.C + c;
+  }
+  return philox_uniform(q.seed, off, idx) < (1.0f - q.p) ? q.scale : 0.0f;
 }
 
 __global__ void __launch_bounds__(256)
@@ -102,13 +113,16 @@ dropout_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ 
 }
 
 static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t m_st, int64_t m_sb,
-                     float p, uint64_t seed, uint64_t offset, int method, int64_t factor, int64_t T,
+                     float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                     int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, int64_t T,
                      int64_t B, int64_t C) {
+  SLU_REQUIRE(sub_batch >= 0 && (sub_batch == 0 || B % sub_batch == 0), "%s: B must be a multiple of sub_batch", who);
+  q.sub_batch = (int)sub_batch; q.sub_stride = sub_stride;
   SLU_REQUIRE(T > 0 && B > 0 && C > 0 && factor > 0, "%s: non-positive size", who);
   SLU_REQUIRE(method >= 0 && method <= 2, "%s: downsampling method must be 0 (none), 1 (avg) or 2 (max)", who);
   SLU_REQUIRE(p >= 0.0f && p < 1.0f, "%s: dropout p must be in [0,1)", who);
   q.mask = mask; q.m_st = m_st; q.m_sb = m_sb; q.p = p; q.scale = 1.0f / (1.0f - p);
-  q.seed = seed; q.offset = offset; q.method = method; q.factor = (int)factor;
+  q.seed = seed; q.offset = offset; q.offset_dev = (const unsigned long long*)offset_dev; q.method = method; q.factor = (int)factor;
   q.T = (int)T; q.B = (int)B; q.C = (int)C; q.T_out = (int)cdiv(T, factor);
   return SLU_OK;
 }
@@ -118,12 +132,13 @@ static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t 
 using namespace slu;
 
 extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb,
-                                    float p, uint64_t seed, uint64_t offset, int method,
-                                    int64_t factor, float* y, int64_t T, int64_t B, int64_t C,
-                                    void* stream) {
+                                    float p, uint64_t seed, uint64_t offset,
+                                    const uint64_t* offset_dev, int64_t sub_batch,
+                                    uint64_t sub_stride, int method, int64_t factor, float* y,
+                                    int64_t T, int64_t B, int64_t C, void* stream) {
   SLU_REQUIRE(x && y, "slu_dropout_pool_fwd: null pointer");
   PoolParams q;
-  int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, p, seed, offset, method, factor, T, B, C);
+  int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
   const long long total = (long long)q.T_out * B * C;
   hipLaunchKernelGGL(dropout_pool_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
@@ -134,13 +149,15 @@ extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m
 
 extern "C" int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y,
                                     const float* mask, int64_t m_st, int64_t m_sb, float p,
-                                    uint64_t seed, uint64_t offset, int method, int64_t factor,
-                                    float* dx, int64_t T, int64_t B, int64_t C, void* stream) {
+                                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                    int64_t sub_batch, uint64_t sub_stride, int method,
+                                    int64_t factor, float* dx, int64_t T, int64_t B, int64_t C,
+                                    void* stream) {
   SLU_REQUIRE(dy && dx, "slu_dropout_pool_bwd: null pointer");
   SLU_REQUIRE(method != 2 || x, "slu_dropout_pool_bwd: x is required for max pooling");
   (void)y;
   PoolParams q;
-  int rc = pool_fill(q, "slu_dropout_pool_bwd", mask, m_st, m_sb, p, seed, offset, method, factor, T, B, C);
+  int rc = pool_fill(q, "slu_dropout_pool_bwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
   const long long total = (long long)T * B * C;
   hipLaunchKernelGGL(dropout_pool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,

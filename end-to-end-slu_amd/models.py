@@ -41,6 +41,8 @@ class _DropoutState:
     seed = None         # None -> torch.initial_seed()
     step = 0            # index of the last top-level forward; Philox offset = step * 16 + dropout site
     current = 0         # step the stages running right now belong to
+    current_dev = None  # or: 1-element int64 CUDA tensor holding step*16 (hipGraph-captured stages)
+    sub_batch = 0       # > 0: the batch is several steps' batches concatenated (consecutive steps)
 
 
 def set_dropout_masks(masks):
@@ -72,6 +74,10 @@ def _dropout_args(name, site, p, training):
         m = _DropoutState.masks[name]
         return p, m.transpose(0, 1), 0, 0          # (T,B,C) view; kernel takes its strides
     seed = _DropoutState.seed if _DropoutState.seed is not None else torch.initial_seed()
+    if _DropoutState.current_dev is not None:
+        return p, None, seed & 0xFFFFFFFFFFFFFFFF, (site, _DropoutState.current_dev, _DropoutState.sub_batch)
+    if _DropoutState.sub_batch:
+        return p, None, seed & 0xFFFFFFFFFFFFFFFF, (_DropoutState.current * 16 + site, None, _DropoutState.sub_batch)
     return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.current * 16 + site
 
 
@@ -566,19 +572,37 @@ class Model(torch.nn.Module):
         be computed ahead of time for upcoming batches."""
         return self.pretrained_model.frozen_prefix_len()
 
-    def prefix_features(self, x, n_stages, rng_step):
-        """Frozen stages [0, n_stages) for one batch, without autograd, on the CURRENT stream."""
+    def prefix_features(self, x, n_stages, rng_step, sub_batch=0):
+        """Frozen stages [0, n_stages) without autograd, on the CURRENT stream.
+        rng_step: int, or a 1-element int64 CUDA tensor holding step*16 (for hipGraph capture: the
+        dropout kernels then read the step from device memory at replay time).
+        sub_batch > 0: x is the concatenation of several upcoming batches of that size belonging to
+        consecutive steps rng_step, rng_step+1, ...; each draws its own step's dropout masks."""
         with torch.no_grad():
-            _DropoutState.current = rng_step
-            return self.pretrained_model.run_stages(self.pretrained_model._to_device(x)[0], 0, n_stages)
+            if torch.is_tensor(rng_step):
+                _DropoutState.current_dev = rng_step
+            else:
+                _DropoutState.current = rng_step
+            _DropoutState.sub_batch = sub_batch
+            try:
+                return self.pretrained_model.run_stages(self.pretrained_model._to_device(x)[0], 0, n_stages)
+            finally:
+                _DropoutState.current_dev = None
+                _DropoutState.sub_batch = 0
 
     def forward_from(self, h, n_stages, y_intent, rng_step):
         """The rest of Model.forward given the output of stages [0, n_stages)."""
         pm = self.pretrained_model
-        _DropoutState.current = rng_step
-        h = pm.run_stages(h, n_stages, len(pm._stages()))
-        for st in self._intent_stages:
-            h = st.run(h, self.training)
+        if torch.is_tensor(rng_step):              # hipGraph capture: step*16 lives on the device
+            _DropoutState.current_dev = rng_step
+        else:
+            _DropoutState.current = rng_step
+        try:
+            h = pm.run_stages(h, n_stages, len(pm._stages()))
+            for st in self._intent_stages:
+                h = st.run(h, self.training)
+        finally:
+            _DropoutState.current_dev = None
         cls = self.intent_layers[-2]
         loss, acc, _, _ = _ops.IntentHeadFn.apply(h, cls.weight, cls.bias, y_intent.to(h.device),
                                                   tuple(self.values_per_slot))

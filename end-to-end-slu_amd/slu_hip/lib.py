@@ -41,10 +41,10 @@ SIGNATURES = {
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "slu_gru_seq_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
     "slu_gru_seq_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
-    "slu_dropout_pool_fwd": (c_int, [vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, c_int, c_i64, vp,
-                                     c_i64, c_i64, c_i64, vp]),
-    "slu_dropout_pool_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, c_int,
+    "slu_dropout_pool_fwd": (c_int, [vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_int,
                                      c_i64, vp, c_i64, c_i64, c_i64, vp]),
+    "slu_dropout_pool_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64,
+                                     c_int, c_i64, vp, c_i64, c_i64, c_i64, vp]),
     "slu_cls_maxpool_ce_fwd": (c_int, [vp, vp, vp, vp, ctypes.POINTER(c_i64), c_i64, vp, vp, vp, vp, vp, vp,
                                        c_i64, c_i64, c_i64, vp]),
     "slu_cls_maxpool_ce_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),

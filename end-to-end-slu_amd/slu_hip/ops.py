@@ -205,26 +205,29 @@ def _mask_args(mask, T, B, C):
     return mask.data_ptr(), mask.stride(0), mask.stride(1)
 
 
-def dropout_pool_fwd(x, mask, p, seed, offset, method, factor):
+def dropout_pool_fwd(x, mask, p, seed, offset, method, factor, offset_dev=None, sub_batch=0):
+    """offset_dev: optional 1-element int64 CUDA tensor added to `offset` on the device;
+    sub_batch > 0: B is sub-batches of that size, sub-batch k uses offset + 16 k (consecutive steps)."""
     L = _lib.load()
     T, B, C = x.shape
     T_out = -(-T // factor)
     y = torch.empty(T_out, B, C, dtype=torch.float32, device=x.device)
     mp, mst, msb = _mask_args(mask, T, B, C)
     _lib.check(L.slu_dropout_pool_fwd(x.data_ptr(), mp, mst, msb, float(p), int(seed), int(offset),
-                                      METHODS[method], factor, y.data_ptr(), T, B, C, _stream()),
+                                      _ptr(offset_dev), int(sub_batch), 16, METHODS[method], factor, y.data_ptr(),
+                                      T, B, C, _stream()),
                "slu_dropout_pool_fwd")
     return y
 
 
-def dropout_pool_bwd(dy, x, mask, p, seed, offset, method, factor):
+def dropout_pool_bwd(dy, x, mask, p, seed, offset, method, factor, offset_dev=None):
     L = _lib.load()
     T, B, C = x.shape
     dy = _f32c(dy, "dy")
     dx = torch.empty(T, B, C, dtype=torch.float32, device=x.device)
     mp, mst, msb = _mask_args(mask, T, B, C)
     _lib.check(L.slu_dropout_pool_bwd(dy.data_ptr(), x.data_ptr(), 0, mp, mst, msb, float(p), int(seed),
-                                      int(offset), METHODS[method], factor, dx.data_ptr(), T, B, C,
+                                      int(offset), _ptr(offset_dev), 0, 16, METHODS[method], factor, dx.data_ptr(), T, B, C,
                                       _stream()), "slu_dropout_pool_bwd")
     return dx
 
@@ -365,12 +368,15 @@ class GRULayerFn(torch.autograd.Function):
         gx = gemm(x.view(T * B, I), w_ih.t(), b_ih)                       # (T*B, D*3H)
         need = any(ctx.needs_input_grad[:7])
         raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
+        offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
         if p == 0.0 and (factor == 1):
             y = raw
         else:
-            y = dropout_pool_fwd(raw, mask, p, seed, offset, method, factor)
+            y = dropout_pool_fwd(raw, mask, p, seed, offset, method, factor, offset_dev, sub_batch)
         if need:
             ctx.save_for_backward(x, raw, reserve, mask, w_ih, w_hh_f, w_hh_r)
+            assert sub_batch == 0, "sub-batched dropout streams are for no-grad (frozen) stages"
+            ctx.offset_dev = offset_dev          # not a graph tensor: a persistent 1-element buffer
             ctx.cfg = (T, B, I, H, D, p, seed, offset, method, factor)
         return y
 
@@ -381,7 +387,7 @@ class GRULayerFn(torch.autograd.Function):
         if p == 0.0 and factor == 1:
             d_raw = dy
         else:
-            d_raw = dropout_pool_bwd(dy, raw, mask, p, seed, offset, method, factor)
+            d_raw = dropout_pool_bwd(dy, raw, mask, p, seed, offset, method, factor, ctx.offset_dev)
         d_gx, d_q, dbp = gru_seq_bwd(d_raw, reserve, w_hh_f, w_hh_r, T, B, H, D)
         ng = ctx.needs_input_grad
         if ng[2] or ng[4] or ng[6]:

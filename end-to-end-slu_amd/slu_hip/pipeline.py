@@ -1,0 +1,125 @@
+"""Encoder look-ahead: the FROZEN prefix of the encoder is evaluated for the next few batches in one
+go (a "super-batch") on a side HIP stream, optionally replayed from a captured hipGraph, while the
+trainable remainder of each step runs on the training stream.
+
+Why: with 64 utterances per step a GRU recurrence is 8 persistent workgroups on a 256-CU chip and
+the step is a chain of ~580 dependent recurrence steps — latency-bound, 3 % of the machine.  The
+outputs of frozen stages do not depend on earlier optimisation steps, so P upcoming batches can
+share one pass: the recurrences launch 8P workgroups at the latency of 8, the GEMMs and convolutions
+see P times larger (more efficient) problems, and two slots alternate so that the next super-batch
+is computed while the current one is consumed step by step.  A prefix forward is ~60 kernel launches with fixed shapes and no autograd, i.e. an
+ideal hipGraph: replaying it costs the host a few microseconds instead of ~1 ms of Python dispatch,
+which is what keeps several slots busy at once.  Dropout inside a captured prefix reads its Philox
+offset (step*16) from device memory, so every replay draws the masks of its own step.
+"""
+import os
+
+import torch
+
+
+class PrefixSlot:
+    """One in-flight SUPER-BATCH: the frozen prefix of the encoder evaluated for several upcoming
+    batches at once (concatenated along the batch axis) on this slot's side stream.  The recurrence
+    kernels then launch (#batches x 8) workgroups instead of 8 and every other kernel sees a
+    proportionally larger problem, at (nearly) the latency of a single batch."""
+    MAX_GRAPHS = 4          # distinct (super-batch shape, prefix length, mode) keys kept per slot
+
+    def __init__(self, device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.rng = torch.zeros(1, dtype=torch.int64, device=device)      # step0*16, read by the kernels
+        self.graphs = {}
+        self.consumed = None       # event: the main stream is done with this slot's last output
+        self.signature = None      # versions of the frozen parameters the graphs were captured with
+
+    def invalidate(self):
+        self.graphs = {}
+
+    def run(self, model, xs, n_prefix, step0, use_graph):
+        """Enqueue stages [0, n_prefix) for the batches `xs` (equal shapes; consecutive dropout steps
+        step0, step0+1, ...) on this slot's stream.  Returns (features of the concatenated batch,
+        event recorded when they are complete)."""
+        B, T = xs[0].shape
+        with torch.cuda.stream(self.stream):
+            if self.consumed is not None:
+                self.stream.wait_event(self.consumed)
+            feats = None
+            if use_graph:
+                key = (len(xs), B, T, n_prefix, bool(model.training))
+                entry = self.graphs.get(key)
+                if entry is None and len(self.graphs) < self.MAX_GRAPHS:
+                    entry = self._capture(model, xs, n_prefix, step0, key)
+                if entry is not None:
+                    graph, x_static, feats = entry
+                    self._fill(x_static, xs)
+                    self.rng.fill_(step0 * 16)
+                    graph.replay()
+            if feats is None:
+                x_cat = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
+                self._fill(x_cat, xs)
+                feats = model.prefix_features(x_cat, n_prefix, step0, sub_batch=B if len(xs) > 1 else 0)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        return feats, done
+
+    @staticmethod
+    def _fill(x_cat, xs):
+        B = xs[0].shape[0]
+        for k, x in enumerate(xs):
+            x_cat[k * B:(k + 1) * B].copy_(x, non_blocking=True)
+
+    def _capture(self, model, xs, n_prefix, step0, key):
+        B, T = xs[0].shape
+        sub = B if len(xs) > 1 else 0
+        x_static = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
+        self._fill(x_static, xs)
+        self.rng.fill_(step0 * 16)
+        model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)      # warm-up (lazy initialisation)
+        self.stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self.stream):
+            feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)
+        entry = (graph, x_static, feats)
+        self.graphs[key] = entry
+        return entry
+
+
+class StepGraph:
+    """The trainable remainder of one SLU training step, captured as two hipGraphs around the
+    gradient all-reduce:  G1 = zero the flat gradient bucket, forward from the prefix features, loss,
+    backward;  [RCCL all-reduce of the bucket, eager];  G2 = Adam.  Inputs (features, labels, the
+    dropout step) are static device buffers refreshed before each replay."""
+
+    def __init__(self, trainer, feats, y, n_prefix, stream):
+        model, dev = trainer.model, feats.device
+        self.trainer = trainer
+        self.feats = torch.empty_like(feats)
+        self.y = torch.empty(tuple(y.shape), dtype=torch.int64, device=dev)
+        self.rng = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.feats.copy_(feats)
+        self.y.copy_(y)
+        bucket = trainer.bucket
+        assert bucket is not None and bucket.active
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1, stream=stream):
+            bucket.zero()
+            self.loss, self.acc = model.forward_from(self.feats, n_prefix, self.y, self.rng)
+            self.loss.backward()
+        self.g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g2, stream=stream):
+            trainer.optimizer.step()
+        self.signature = bucket.signature
+
+    def run(self, feats, y, step):
+        self.feats.copy_(feats, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.rng.fill_(step * 16)
+        self.g1.replay()
+        self.trainer.bucket.allreduce_mean()       # no-op for one process; one RCCL call otherwise
+        self.g2.replay()
+        return self.loss, self.acc
+
+
+def graphs_enabled():
+    return os.environ.get("SLU_GRAPHS", "1") != "0"

@@ -42,11 +42,15 @@ class Trainer:
         # same optimiser and defaults as the reference (training.py:19); on a GPU torch's single-kernel
         # "fused" implementation is selected (same update rule, one launch instead of ~10 per step)
         on_gpu = all(p.is_cuda for p in model.parameters())
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=self.lr, **({"fused": True} if on_gpu else {}))
+        self.optimizer = torch.optim.Adam(model.parameters(), lr=self.lr,
+                                          **({"fused": True, "capturable": True} if on_gpu else {}))
         self.epoch = 0
         self.df = None
         self.rank, self.world_size = dp.world()
-        self.bucket = dp.GradBucket(model.parameters()) if self.world_size > 1 else None
+        # flat gradient bucket: the unit of the per-step all-reduce under data parallelism, and (on a
+        # GPU) what gives the gradients fixed addresses for hipGraph-captured steps
+        self.bucket = dp.GradBucket(model.parameters()) if (self.world_size > 1 or on_gpu) else None
+        self._step_graphs, self._eager_steps = {}, {}
 
     # -- checkpoints / log (reference training.py:23-45) -------------------------------------------
     def load_checkpoint(self):
@@ -136,46 +140,96 @@ class Trainer:
                         self._step(loss)
                 yield vals, len(batch[0])
             return
-        # ---- encoder look-ahead pipeline -----------------------------------------------------------
+        # ---- encoder look-ahead pipeline (slu_hip/pipeline.py) --------------------------------------
         import collections
         from models import next_rng_step
-        main = torch.cuda.current_stream()
-        if getattr(self, "_side_streams", None) is None or len(self._side_streams) != depth:
-            self._side_streams = [torch.cuda.Stream() for _ in range(depth)]
-        self.model.pretrained_model.warm_weight_caches()
-        for st in self._side_streams:
-            st.wait_stream(main)
+        from slu_hip import pipeline
+        # The trainable part runs on a dedicated non-default stream: autograd pins each parameter's
+        # gradient-accumulation node to the stream of its first use, and hipGraph capture (which cannot
+        # happen on the default stream) needs the eager warm-up steps and the capture to agree on it.
+        outer = torch.cuda.current_stream()
+        dev = next(self.model.parameters()).device
+        if getattr(self, "_train_stream", None) is None:
+            self._train_stream = torch.cuda.Stream(dev)
+        main = self._train_stream
+        main.wait_stream(outer)
+        if getattr(self, "_slots", None) is None:
+            self._slots = [pipeline.PrefixSlot(dev) for _ in range(2)]      # double-buffered super-batches
+        pm = self.model.pretrained_model
+        with torch.cuda.stream(main):
+            pm.warm_weight_caches()
+        frozen = [p for st in pm._stages()[:n_prefix] for p in st.parameters()]
+        signature = tuple(p._version for p in frozen)
+        for slot in self._slots:
+            if slot.signature != signature:          # frozen weights were reloaded: re-capture
+                slot.invalidate()
+                slot.signature = signature
+            slot.stream.wait_stream(main)
+        use_graph = pipeline.graphs_enabled()
         pending = collections.deque()
         it = iter(loader)
+        carry = []                                    # a batch read ahead that did not fit its group
         launched = 0
 
         def launch_next():
+            """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
             nonlocal launched
-            try:
-                batch = next(it)
-            except StopIteration:
+            group = [carry.pop()] if carry else []
+            while len(group) < depth:
+                try:
+                    batch = next(it)
+                except StopIteration:
+                    break
+                if group and tuple(batch[0].shape) != tuple(group[0][0].shape):
+                    carry.append(batch)
+                    break
+                group.append(batch)
+            if not group:
                 return False
-            side = self._side_streams[launched % depth]
+            slot = self._slots[launched % 2]
             launched += 1
-            step = next_rng_step()
-            with torch.cuda.stream(side):
-                feats = self.model.prefix_features(batch[0], n_prefix, step)
-                done = torch.cuda.Event()
-                done.record(side)
-            pending.append((batch, feats, done, step))
+            steps = [next_rng_step() for _ in group]                        # consecutive by construction
+            feats, done = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph)
+            pending.append((group, feats, done, steps, slot))
             return True
 
-        for _ in range(depth):
-            if not launch_next():
-                break
+        launch_next()
+        launch_next()
         while pending:
-            batch, feats, done, step = pending.popleft()
-            main.wait_event(done)
-            feats.record_stream(main)
-            loss, acc = self.model.forward_from(feats, n_prefix, batch[1], step)
-            self._step(loss)
-            launch_next()
-            yield [loss, acc], len(batch[0])
+            group, feats_cat, done, steps, slot = pending.popleft()
+            B = group[0][0].shape[0]
+            for k, batch in enumerate(group):
+                with torch.cuda.stream(main):
+                    if k == 0:
+                        main.wait_event(done)
+                        feats_cat.record_stream(main)
+                    feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
+                    y = batch[1]
+                    key = (tuple(feats.shape), tuple(y.shape), n_prefix)
+                    sg = self._step_graphs.get(key)
+                    if sg is not None and sg.signature != self.bucket.signature:
+                        sg = None                                   # trainable set changed since capture
+                    if sg is None and use_graph and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:
+                        try:
+                            sg = pipeline.StepGraph(self, feats, y, n_prefix, main)
+                            self._step_graphs[key] = sg
+                        except Exception as e:                      # keep training eagerly if capture fails
+                            print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
+                            self._eager_steps[key] = -(1 << 30)
+                    if sg is not None:
+                        loss, acc = sg.run(feats, y, steps[k])
+                    else:
+                        self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
+                        loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
+                        self._step(loss)
+                    if k == len(group) - 1:
+                        slot.consumed = torch.cuda.Event()
+                        slot.consumed.record(main)
+                if k == len(group) - 1:
+                    launch_next()
+                outer.wait_stream(main)
+                yield [loss, acc], len(batch[0])
+                main.wait_stream(outer)
 
     def _run(self, dataset, train, print_interval):
         asr = self._is_asr(dataset)

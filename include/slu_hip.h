@@ -139,16 +139,25 @@ int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_
  *   ceil_mode (partial last window uses the frames that exist); T_out = ceil(T / factor).
  *   Dropout keep-mask, applied BEFORE pooling, scaled by 1/(1-p):
  *     mask != NULL : float {0,1} values, element (t,b,c) at mask[t*m_st + b*m_sb + c]
- *     mask == NULL and p > 0 : Philox4x32-10 keyed by (seed, offset), one draw per element index
+ *     mask == NULL and p > 0 : Philox4x32-10 keyed by (seed, offset), one draw per element index;
+ *                              offset_dev (NULL or a device uint64) is added to `offset` at run
+ *                              time, so a captured hipGraph can be replayed with fresh masks;
+ *                              sub_batch > 0 treats the B sequences as B/sub_batch independent
+ *                              batches of sub_batch: element indices are local to a sub-batch and
+ *                              sub-batch k draws from offset + k*sub_stride (several training
+ *                              steps' frozen stages evaluated in one launch, each with the masks
+ *                              its own step would have drawn)
  *     p == 0 : no dropout (eval mode)                                                            */
 int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb, float p,
-                         uint64_t seed, uint64_t offset, int method, int64_t factor, float* y,
+                         uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                         int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, float* y,
                          int64_t T, int64_t B, int64_t C, void* stream);
 /* dx (T,B,C) from dy (T_out,B,C); x and y (forward input/output) are needed for method 2 only. */
 int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const float* mask,
                          int64_t m_st, int64_t m_sb, float p, uint64_t seed, uint64_t offset,
-                         int method, int64_t factor, float* dx,
-                         int64_t T, int64_t B, int64_t C, void* stream);
+                         const uint64_t* offset_dev, int64_t sub_batch, uint64_t sub_stride,
+                         int method, int64_t factor, float* dx, int64_t T, int64_t B, int64_t C,
+                         void* stream);
 
 /* -------- intent head: Linear "final_classifier" (models.py:709) -> FinalPool max over time
  * (:112-123) -> per-slot cross-entropy, accuracy and arg-max (:811-821, :839-844) ------------------
