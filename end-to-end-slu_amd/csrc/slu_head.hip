@@ -39,28 +39,30 @@ head_fwd_kernel(const HeadParams p) {
   float* sm = sl + (size_t)p.T * p.V;                  // [V] pooled logits
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = p.T, C = p.C, V = p.V, LD = p.C + 1;
-  for (int idx = tid; idx < T * C; idx += HEAD_THREADS) {
-    const int t = idx / C, c = idx - t * C;
-    sh[t * LD + c] = p.h[((size_t)t * p.B + b) * C + c];
-  }
-  for (int idx = tid; idx < V * C; idx += HEAD_THREADS) {
-    const int v = idx / C, c = idx - v * C;
-    sw[v * LD + c] = p.W[idx];
-  }
+  // stage rows with independent, unrolled loads (one coalesced row segment per iteration)
+#pragma unroll 4
+  for (int t = 0; t < T; ++t)
+    for (int c = tid; c < C; c += HEAD_THREADS) sh[t * LD + c] = p.h[((size_t)t * p.B + b) * C + c];
+#pragma unroll 4
+  for (int v = 0; v < V; ++v)
+    for (int c = tid; c < C; c += HEAD_THREADS) sw[v * LD + c] = p.W[(size_t)v * C + c];
   __syncthreads();
-  {
-    // one wave per (t, v) output: lanes stride over C, then a 6-step butterfly reduction
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int o = wave; o < T * V; o += HEAD_THREADS / 64) {
-      const int t = o / V, v = o - t * V;
-      const float* a = sh + t * LD;
-      const float* w = sw + v * LD;
-      float acc = 0.0f;
-      for (int c = lane; c < C; c += 64) acc = fmaf(a[c], w[c], acc);
-#pragma unroll
-      for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
-      if (lane == 0) sl[o] = acc + p.bias[v];
+  // each thread owns whole (t, v) dot products: a[t][:] is an LDS broadcast within the threads of
+  // one t, w[v][:] rows sit on distinct banks (row stride C+1); no cross-lane reduction
+  for (int o = tid; o < T * V; o += HEAD_THREADS) {
+    const int t = o / V, v = o - t * V;
+    const float* a = sh + t * LD;
+    const float* w = sw + v * LD;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+    int c = 0;
+    for (; c + 3 < C; c += 4) {
+      acc0 = fmaf(a[c], w[c], acc0);
+      acc1 = fmaf(a[c + 1], w[c + 1], acc1);
+      acc2 = fmaf(a[c + 2], w[c + 2], acc2);
+      acc3 = fmaf(a[c + 3], w[c + 3], acc3);
     }
+    for (; c < C; ++c) acc0 = fmaf(a[c], w[c], acc0);
+    sl[o] = ((acc0 + acc1) + (acc2 + acc3)) + p.bias[v];
   }
   __syncthreads();
   if (tid < V) {

@@ -5,9 +5,8 @@ between the 8 GPUs of a node).  The reference has no distributed code at all —
 
 Per step the payload is small (1.2 MB with a frozen encoder, 5.5 MB fully unfrozen), i.e. the
 collective is latency-bound: a single collective over one contiguous buffer is the shape that
-matters, not bandwidth tuning.  Parameter gradients are VIEWS into the bucket (no pack/unpack
-copies); the bucket is rebuilt when the set of parameters that receive gradients changes (the
-gradual-unfreezing schedule changes it once per epoch).
+matters, not bandwidth tuning.  The bucket is rebuilt when the set of parameters that receive
+gradients changes (the gradual-unfreezing schedule changes it once per epoch).
 """
 import os
 
@@ -41,59 +40,68 @@ def init_from_env(backend=None):
 
 
 class GradBucket:
-    """Flat gradient buckets (one per dtype: the Sinc parameters are float64) whose slices ARE the
-    parameters' .grad tensors."""
+    """Flat gradient buckets (one per dtype: the Sinc parameters are float64) for the per-step
+    all-reduce.  After backward the fresh gradients are packed with ONE concatenation kernel per
+    dtype into a persistent flat buffer, which is all-reduced and averaged; the parameters' .grad
+    are then re-pointed at slices of it (a host-side pointer swap, no copy back), so the optimizer
+    reads the reduced values.  Gradients are released (set to None) before every backward, hence
+    autograd assigns instead of accumulating: no zero-fill and no per-parameter add kernels."""
 
     def __init__(self, params):
         self.params = [p for p in params]
         self.live = []
         self.flats = {}
+        self.groups = {}
         self.signature = None
 
     def reset(self):
         """Forget the bucket (call after the trainable set changed, e.g. unfreeze_one_layer)."""
         for p in self.live:
             p.grad = None
-        self.live, self.flats, self.signature = [], {}, None
+        self.live, self.flats, self.groups, self.signature = [], {}, {}, None
 
     @property
     def active(self):
         return self.signature is not None
 
-    def zero(self):
-        for flat in self.flats.values():
-            flat.zero_()
+    def release_grads(self):
+        for p in self.params:
+            p.grad = None
 
     def nbytes(self):
         return sum(f.numel() * f.element_size() for f in self.flats.values())
 
-    def _rebuild(self, live):
-        by_dtype = {}
-        for p in live:
-            by_dtype.setdefault(p.grad.dtype, []).append(p)
-        self.flats = {}
-        for dtype, ps in by_dtype.items():
-            n = sum(p.numel() for p in ps)
-            flat = torch.empty(n, dtype=dtype, device=ps[0].device)
-            off = 0
-            for p in ps:
-                view = flat[off:off + p.numel()].view_as(p)
-                view.copy_(p.grad)
-                p.grad = view
-                off += p.numel()
-            self.flats[dtype] = flat
-        self.live = live
-        self.signature = tuple(id(p) for p in live)
-
-    def allreduce_mean(self):
-        """Average the gradients of all ranks (call after backward)."""
-        rank, ws = world()
+    def observe(self):
+        """Record which parameters received a gradient in the backward that just ran."""
         live = [p for p in self.params if p.grad is not None]
         sig = tuple(id(p) for p in live)
         if sig != self.signature:
-            self._rebuild(live)
+            self.live, self.signature = live, sig
+            self.groups, self.flats = {}, {}
+            for p in live:
+                self.groups.setdefault(p.grad.dtype, []).append(p)
+            for dtype, ps in self.groups.items():
+                self.flats[dtype] = torch.empty(sum(p.numel() for p in ps), dtype=dtype, device=ps[0].device)
+        return live
+
+    def pack(self):
+        """Concatenate the fresh gradients into the flat buffers and point .grad at the slices."""
+        self.observe()
+        for dtype, ps in self.groups.items():
+            flat = self.flats[dtype]
+            torch.cat([p.grad.reshape(-1) for p in ps], out=flat)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def allreduce_mean(self):
+        """Average the gradients of all ranks (call after backward).  One process: bookkeeping only."""
+        rank, ws = world()
         if ws == 1:
+            self.observe()
             return
+        self.pack()
         for flat in self.flats.values():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat.div_(ws)

@@ -86,9 +86,10 @@ class PrefixSlot:
 
 class StepGraph:
     """The trainable remainder of one SLU training step, captured as two hipGraphs around the
-    gradient all-reduce:  G1 = zero the flat gradient bucket, forward from the prefix features, loss,
-    backward;  [RCCL all-reduce of the bucket, eager];  G2 = Adam.  Inputs (features, labels, the
-    dropout step) are static device buffers refreshed before each replay."""
+    gradient all-reduce:  G1 = forward from the prefix features, loss, backward (+ packing the
+    gradients into the flat bucket under data parallelism);  [RCCL all-reduce, eager];  G2 = Adam.
+    Inputs (features, labels, the dropout step) are static device buffers refreshed before each
+    replay."""
 
     def __init__(self, trainer, feats, y, n_prefix, stream):
         model, dev = trainer.model, feats.device
@@ -98,25 +99,34 @@ class StepGraph:
         self.rng = torch.zeros(1, dtype=torch.int64, device=dev)
         self.feats.copy_(feats)
         self.y.copy_(y)
+        from . import dp
         bucket = trainer.bucket
         assert bucket is not None and bucket.active
+        self.world = dp.world()[1]
         torch.cuda.synchronize()
+        bucket.release_grads()
         self.g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g1, stream=stream):
-            bucket.zero()
             self.loss, self.acc = model.forward_from(self.feats, n_prefix, self.y, self.rng)
             self.loss.backward()
+            if self.world > 1:
+                bucket.pack()                       # one concatenation kernel per dtype; .grad -> slices
         self.g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g2, stream=stream):
             trainer.optimizer.step()
+        bucket.observe()
         self.signature = bucket.signature
 
     def run(self, feats, y, step):
+        import torch.distributed as dist
         self.feats.copy_(feats, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
         self.rng.fill_(step * 16)
         self.g1.replay()
-        self.trainer.bucket.allreduce_mean()       # no-op for one process; one RCCL call otherwise
+        if self.world > 1:                          # one RCCL call per gradient dtype
+            for flat in self.trainer.bucket.flats.values():
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(self.world)
         self.g2.replay()
         return self.loss, self.acc
 

@@ -82,10 +82,7 @@ class Trainer:
 
     # -- one optimisation step ---------------------------------------------------------------------
     def _step(self, loss):
-        if self.bucket is not None and self.bucket.active:
-            self.bucket.zero()
-        else:
-            self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         if self.bucket is not None:
             self.bucket.allreduce_mean()

@@ -129,9 +129,10 @@ def _bucket_worker(rank, world, port, out):
     bucket.allreduce_mean()
     assert c.grad is None and bucket.active
     ok = torch.allclose(a.grad, torch.full((4,), 1.5)) and torch.allclose(b.grad, torch.full((2, 3), 15.0, dtype=torch.float64))
-    # grads are views of the flat buckets: zero() clears them in place
-    bucket.zero()
-    ok = ok and float(a.grad.abs().sum()) == 0.0 and a.grad.data_ptr() == bucket.flats[torch.float32].data_ptr()
+    # after the collective the gradients ARE slices of the flat buckets (no copy back)
+    ok = ok and a.grad.data_ptr() == bucket.flats[torch.float32].data_ptr() and bucket.nbytes() == 4 * 4 + 6 * 8
+    bucket.release_grads()
+    ok = ok and a.grad is None and b.grad is None
     sums = dp.allreduce_sums([1.0 + rank, 2.0], torch.device("cpu"))
     ok = ok and sums == [3.0, 4.0]
     bucket.reset()

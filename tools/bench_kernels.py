@@ -45,7 +45,7 @@ def timeit(fn, n=10, warm=2, reps=10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", nargs="*", default=["gemm", "gru", "wconv", "pool"])
+    ap.add_argument("what", nargs="*", default=["gemm", "gru", "wconv", "pool", "head"])
     ap.add_argument("--batch", type=int, default=64)
     a = ap.parse_args()
     B = a.batch
@@ -107,6 +107,24 @@ def main():
             x = torch.randn(T, B, 256, device=dev)
             med, _ = timeit(lambda: ops.dropout_pool_fwd(x, None, 0.5, 1, 2, "avg", 2))
             print("dropout+avgpool %-7s: %6.1f us (%.0f GB/s)" % (name, med, 1.5 * x.numel() * 4 / med / 1e3))
+
+
+    if "head" in a.what:
+        T, C, vps = 19, 256, (6, 14, 4)
+        h = torch.randn(T, B, C, device=dev)
+        W = torch.randn(24, C, device=dev) * 0.06
+        bias = torch.randn(24, device=dev)
+        y = torch.stack([torch.randint(0, n, (B,), device=dev) for n in vps], dim=1)
+        med, mn = timeit(lambda: ops.cls_maxpool_ce_fwd(h, W, bias, y, vps, True))
+        la, lg, pr, am, dl = ops.cls_maxpool_ce_fwd(h, W, bias, y, vps, True)
+        g = torch.ones((), device=dev)
+        from slu_hip import lib as _l
+        L = _l.load()
+        dh, dW, db = torch.empty_like(h), torch.empty_like(W), torch.empty_like(bias)
+        s_ = lambda: torch.cuda.current_stream().cuda_stream
+        medb, _ = timeit(lambda: L.slu_cls_maxpool_ce_bwd(dl.data_ptr(), am.data_ptr(), h.data_ptr(), W.data_ptr(), g.data_ptr(),
+                                                          dh.data_ptr(), dW.data_ptr(), db.data_ptr(), T, B, C, 24, s_()))
+        print("head fwd (+reduce): %6.1f us (min %5.1f) | bwd (dh + dW): %6.1f us" % (med, mn, medb))
 
 
 if __name__ == "__main__":
