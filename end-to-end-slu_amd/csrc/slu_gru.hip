@@ -160,9 +160,9 @@ struct GruBwdParams {
   const float* d_out;     // (T, B, D*H)
   const float* reserve;
   const float* w_hh[2];
-  float* d_gx;            // (T, B, D*3H)
-  float* d_q;             // (T, B, D*H)
-  float* d_bias_part;     // [NBT][D][4H] or null: sums over t and the tile's sequences of d_gx | d_q
+  float* d_gx;            // (T, B, D*3H)  gradient w.r.t. x W_ih^T + b_ih         = [dr_pre, dz_pre, dn_pre]
+  float* d_gh;            // (T, B, D*3H)  gradient w.r.t. h_{t-1} W_hh^T + b_hh   = [dr_pre, dz_pre, dq]
+  float* d_bias_part;     // [NBT][D][6H] or null: sums over t and the tile's sequences of d_gx | d_gh
   int T, B, D;
 };
 
@@ -205,7 +205,7 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
   const size_t gx_ts = (size_t)B * D * 3 * H;
   const float* __restrict__ dod = p.d_out + (size_t)dir * H + j;
   float* __restrict__ dgxd = p.d_gx + (size_t)dir * 3 * H + j;
-  float* __restrict__ dqd = p.d_q + (size_t)dir * H + j;
+  float* __restrict__ dghd = p.d_gh + (size_t)dir * 3 * H + j;
 
   float dcarry[4] = {0.f, 0.f, 0.f, 0.f};
   float sbr = 0.f, sbz = 0.f, sbn = 0.f, sbq = 0.f;
@@ -274,7 +274,8 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
       if (rowok[r]) {
         float* g = dgxd + (size_t)t * gx_ts + grow[r] * D * 3 * H;
         g[0] = dr_pre; g[H] = dz_pre; g[2 * H] = dn_pre;
-        dqd[(size_t)t * out_ts + grow[r] * D * H] = dq;
+        float* gh = dghd + (size_t)t * gx_ts + grow[r] * D * 3 * H;
+        gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dq;
         sbr += dr_pre; sbz += dz_pre; sbn += dn_pre; sbq += dq;
       }
     }
@@ -329,8 +330,9 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
     sbn += __shfl_xor(sbn, 16); sbn += __shfl_xor(sbn, 32);
     sbq += __shfl_xor(sbq, 16); sbq += __shfl_xor(sbq, 32);
     if (kg == 0) {
-      float* o = p.d_bias_part + ((size_t)btile * D + dir) * 4 * H;
-      o[j] = sbr; o[H + j] = sbz; o[2 * H + j] = sbn; o[3 * H + j] = sbq;
+      float* o = p.d_bias_part + ((size_t)btile * D + dir) * 6 * H;
+      o[j] = sbr; o[H + j] = sbz; o[2 * H + j] = sbn;                 // d(b_ih)
+      o[3 * H + j] = sbr; o[4 * H + j] = sbz; o[5 * H + j] = sbq;     // d(b_hh)
     }
   }
 }
@@ -377,15 +379,15 @@ extern "C" int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const flo
 }
 
 extern "C" int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_fwd,
-                               const float* w_hh_rev, float* d_gx, float* d_q, float* d_bias_part,
+                               const float* w_hh_rev, float* d_gx, float* d_gh, float* d_bias_part,
                                int64_t T, int64_t B, int64_t H, int64_t D, void* stream) {
-  SLU_REQUIRE(d_out && reserve && w_hh_fwd && d_gx && d_q, "slu_gru_seq_bwd: null pointer");
+  SLU_REQUIRE(d_out && reserve && w_hh_fwd && d_gx && d_gh, "slu_gru_seq_bwd: null pointer");
   SLU_REQUIRE(D == 1 || w_hh_rev, "slu_gru_seq_bwd: reverse weights missing");
   int rc = gru_check("slu_gru_seq_bwd", T, B, H, D);
   if (rc) return rc;
   GruBwdParams p;
   p.d_out = d_out; p.reserve = reserve; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev;
-  p.d_gx = d_gx; p.d_q = d_q; p.d_bias_part = d_bias_part; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  p.d_gx = d_gx; p.d_gh = d_gh; p.d_bias_part = d_bias_part; p.T = (int)T; p.B = (int)B; p.D = (int)D;
   dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   hipStream_t st = (hipStream_t)stream;
   switch (H) {

@@ -199,26 +199,38 @@ class GRU(torch.nn.Module):
         self.batch_first = True
 
     def _stacked_ih(self):
-        """(W_ih, b_ih) of both directions stacked to (D*3H, I) / (D*3H) so that the input projection
-        is one GEMM.  Frozen weights are stacked once and cached (keyed on the tensors' version
-        counters); trainable ones are concatenated inside the autograd graph every forward."""
+        """(W_ih, b_ih) of both directions as ONE (D*3H, I) / (D*3H) storage that the four parameters
+        are views of, so that the input projection (and its gradients) is a single GEMM with no
+        concatenation.  The link is (re)established lazily — e.g. after .cuda() gave every parameter
+        its own storage — by stacking once and re-pointing the parameters' .data at the slices;
+        optimizers and state_dict keep working on the same Parameter objects."""
         if not self.bidirectional:
             return self.weight_ih_l0, self.bias_ih_l0
-        parts = (self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse)
-        if any(t.requires_grad for t in parts) and torch.is_grad_enabled():
-            return torch.cat(parts[:2]), torch.cat(parts[2:])
-        key = tuple((t.data_ptr(), t._version) for t in parts)
-        if getattr(self, "_ih_cache_key", None) != key:
+        w_f, w_r, b_f, b_r = self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse
+        n = w_f.shape[0]
+        stk = getattr(self, "_ih_storage", None)
+        linked = (stk is not None and stk[0].device == w_f.device
+                  and w_f.data_ptr() == stk[0].data_ptr() and w_r.data_ptr() == stk[0][n:].data_ptr()
+                  and b_f.data_ptr() == stk[1].data_ptr() and b_r.data_ptr() == stk[1][n:].data_ptr())
+        if not linked:
             with torch.no_grad():
-                self._ih_cache = (torch.cat(parts[:2]), torch.cat(parts[2:]))
-            self._ih_cache_key = key
-        return self._ih_cache
+                W = torch.cat([w_f.data, w_r.data])
+                b = torch.cat([b_f.data, b_r.data])
+                w_f.data, w_r.data = W[:n], W[n:]
+                b_f.data, b_r.data = b[:n], b[n:]
+            self._ih_storage = (W, b)
+        return self._ih_storage
 
     def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1):
         w_ih, b_ih = self._stacked_ih()
-        rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse) if self.bidirectional else (None, None)
-        return _ops.GRULayerFn.apply(xt, w_ih, b_ih, self.weight_hh_l0, self.bias_hh_l0, rev[0], rev[1],
-                                     p, mask, seed, offset, method, factor)
+        if self.bidirectional:
+            ih = (self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse)
+            rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse)
+        else:
+            ih = (self.weight_ih_l0, None, self.bias_ih_l0, None)
+            rev = (None, None)
+        return _ops.GRULayerFn.apply(xt, w_ih.detach(), b_ih.detach(), *ih, self.weight_hh_l0, self.bias_hh_l0,
+                                     rev[0], rev[1], p, mask, seed, offset, method, factor)
 
     def forward(self, x):
         _require_device(x)
@@ -418,12 +430,10 @@ class PretrainedModel(torch.nn.Module):
         return n
 
     def warm_weight_caches(self):
-        """Materialise the cached stacked input-projection weights of the frozen GRU layers on the
-        current stream (so that side streams only ever read them)."""
+        """Establish the direction-stacked input-projection storage of every GRU layer on the current
+        stream (so that side streams only ever read it)."""
         for st in self._phone_stages + self._word_stages:
-            if not any(p.requires_grad for p in st.parameters()):
-                with torch.no_grad():
-                    st.gru._stacked_ih()
+            st.gru._stacked_ih()
 
     def _phoneme_features_tm(self, x):
         """x (B,T) on device -> time-major (T', B, C) output of the phoneme module."""

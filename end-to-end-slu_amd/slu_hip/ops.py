@@ -188,13 +188,13 @@ def gru_seq_bwd(d_out, reserve, w_hh_f, w_hh_r, T, B, H, D):
     d_out = _f32c(d_out, "d_out")
     dev = d_out.device
     d_gx = torch.empty(T, B, D * 3 * H, dtype=torch.float32, device=dev)
-    d_q = torch.empty(T, B, D * H, dtype=torch.float32, device=dev)
+    d_gh = torch.empty(T, B, D * 3 * H, dtype=torch.float32, device=dev)
     nbt = -(-B // 16)
-    d_bias_part = torch.empty(nbt, D, 4 * H, dtype=torch.float32, device=dev)
+    d_bias_part = torch.empty(nbt, D, 6 * H, dtype=torch.float32, device=dev)
     _lib.check(L.slu_gru_seq_bwd(d_out.data_ptr(), reserve.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r),
-                                 d_gx.data_ptr(), d_q.data_ptr(), d_bias_part.data_ptr(), T, B, H, D,
+                                 d_gx.data_ptr(), d_gh.data_ptr(), d_bias_part.data_ptr(), T, B, H, D,
                                  _stream()), "slu_gru_seq_bwd")
-    return d_gx, d_q, d_bias_part
+    return d_gx, d_gh, d_bias_part
 
 
 def _mask_args(mask, T, B, C):
@@ -356,17 +356,20 @@ class ConvBlockFn(torch.autograd.Function):
 class GRULayerFn(torch.autograd.Function):
     """nn.GRU (1 layer, h0 = 0) -> RNNSelect -> Dropout -> Downsample  (models.py:232-253).
     x time-major (T, B, I) -> (T_out, B, D*H).
-    w_ih (D*3H, I) / b_ih (D*3H): weight_ih_l0 [; weight_ih_l0_reverse] stacked, so that the input
-    projection of both directions is ONE GEMM launch (N = 768) and so are its two gradients."""
+    w_ih (D*3H, I) / b_ih (D*3H) are the direction-stacked STORAGE the parameters weight_ih_l0[_reverse] /
+    bias_ih_l0[_reverse] are views of (models.GRU links them), so that the input projection of both
+    directions is ONE GEMM launch (N = 768) and so are its two gradients, without any concatenation;
+    the four parameters are passed as well, only to receive their slices of those gradients."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, b_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p, mask, seed, offset, method, factor):
+    def forward(ctx, x, w_ih, b_ih, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r,
+                p, mask, seed, offset, method, factor):
         x = x.contiguous()
         T, B, I = x.shape
         H = w_hh_f.shape[1]
         D = 1 if w_hh_r is None else 2
         gx = gemm(x.view(T * B, I), w_ih.t(), b_ih)                       # (T*B, D*3H)
-        need = any(ctx.needs_input_grad[:7])
+        need = any(ctx.needs_input_grad[:11])
         raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
         offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
         if p == 0.0 and (factor == 1):
@@ -388,35 +391,41 @@ class GRULayerFn(torch.autograd.Function):
             d_raw = dy
         else:
             d_raw = dropout_pool_bwd(dy, raw, mask, p, seed, offset, method, factor, ctx.offset_dev)
-        d_gx, d_q, dbp = gru_seq_bwd(d_raw, reserve, w_hh_f, w_hh_r, T, B, H, D)
+        d_gx, d_gh, dbp = gru_seq_bwd(d_raw, reserve, w_hh_f, w_hh_r, T, B, H, D)
         ng = ctx.needs_input_grad
-        if ng[2] or ng[4] or ng[6]:
-            dbp = dbp.sum(0)                               # (D, 4H): [d_gx sums (3H) | d_q sums (H)]
+        # positions: 0 x | 1 w_ih 2 b_ih (storage, no grad) | 3 w_ih_f 4 w_ih_r 5 b_ih_f 6 b_ih_r |
+        #            7 w_hh_f 8 b_hh_f 9 w_hh_r 10 b_hh_r
+        if ng[5] or ng[6] or ng[8] or ng[10]:
+            dbp = dbp.sum(0)                               # (D, 6H): [d(b_ih) (3H) | d(b_hh) (3H)]
         x2 = x.view(T * B, I)
         g2 = d_gx.view(T * B, D * 3 * H)
-        q2 = d_q.view(T * B, D * H)
+        h2 = d_gh.view(T * B, D * 3 * H)
         r2 = raw.view(T * B, D * H)
-        grads = [None] * 13
+        grads = [None] * 17
         if ng[0]:                                          # dx = d_gx W_ih (both directions, K = D*3H)
             grads[0] = gemm(g2, w_ih).view(T, B, I)
-        if ng[1]:                                          # dW_ih = d_gx^T x
-            grads[1] = gemm(g2.t(), x2)
-        if ng[2]:
-            grads[2] = dbp[:, :3 * H].reshape(-1)
+        if ng[3] or ng[4]:                                 # dW_ih = d_gx^T x, one GEMM for both directions
+            dW = gemm(g2.t(), x2)
+            grads[3] = dW[:3 * H]
+            if D == 2:
+                grads[4] = dW[3 * H:]
+        if ng[5]:
+            grads[5] = dbp[0, :3 * H]
+        if D == 2 and ng[6]:
+            grads[6] = dbp[1, :3 * H]
         for d in range(D):
-            wpos, bpos = 3 + 2 * d, 4 + 2 * d              # (w_hh, b_hh) of direction d
-            if ng[wpos]:                                   # dW_hh = dG_h^T h_{t-1}
-                dW = torch.zeros(3 * H, H, dtype=torch.float32, device=x.device)
+            wpos, bpos = 7 + 2 * d, 8 + 2 * d              # (w_hh, b_hh) of direction d
+            if ng[wpos]:                                   # dW_hh = d_gh^T h_{t-1}
                 if T > 1:
                     n = (T - 1) * B
-                    gd = g2[:, d * 3 * H:(d + 1) * 3 * H]
+                    hd = h2[:, d * 3 * H:(d + 1) * 3 * H]
                     if d == 0:     # h_{t-1} = raw[t-1]: gradient rows t >= 1 against raw rows t-1
-                        ga, qa, hp = gd[B:], q2[B:, :H], r2[:n, :H]
+                        ga, hp = hd[B:], r2[:n, :H]
                     else:          # reverse scan: h_prev(t) = raw[t+1]
-                        ga, qa, hp = gd[:n], q2[:n, H:], r2[B:, H:]
-                    gemm(ga[:, :2 * H].t(), hp, out=dW[:2 * H])
-                    gemm(qa.t(), hp, out=dW[2 * H:])
-                grads[wpos] = dW
+                        ga, hp = hd[:n], r2[B:, H:]
+                    grads[wpos] = gemm(ga.t(), hp)
+                else:
+                    grads[wpos] = torch.zeros(3 * H, H, dtype=torch.float32, device=x.device)
             if ng[bpos]:
-                grads[bpos] = torch.cat([dbp[d, :2 * H], dbp[d, 3 * H:]])
+                grads[bpos] = dbp[d, 3 * H:]
         return tuple(grads)

@@ -118,7 +118,7 @@ class Trainer:
         stage's output does not depend on earlier optimisation steps.  At 64 utterances per step a
         recurrence occupies 8 of 256 CUs, so several batches' encoders run concurrently for free;
         the per-batch dropout streams are step-indexed, so the result is the sequential one."""
-        depth = int(os.environ.get("SLU_LOOKAHEAD", "4"))
+        depth = int(os.environ.get("SLU_LOOKAHEAD", "8"))
         if not train or asr or depth < 2 or not hasattr(self.model, "prefix_features"):
             return 0, 0
         if not all(p.is_cuda for p in self.model.parameters()) or models_masks_injected():
@@ -147,7 +147,7 @@ class Trainer:
         outer = torch.cuda.current_stream()
         dev = next(self.model.parameters()).device
         if getattr(self, "_train_stream", None) is None:
-            self._train_stream = torch.cuda.Stream(dev)
+            self._train_stream = torch.cuda.Stream(dev, priority=-1)      # ahead of the look-ahead streams
         main = self._train_stream
         main.wait_stream(outer)
         if getattr(self, "_slots", None) is None:

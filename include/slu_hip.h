@@ -123,15 +123,15 @@ int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const float* w_hh_re
                     int64_t T, int64_t B, int64_t H, int64_t D, void* stream);
 /* Back-propagation through time.
  *   d_out   (T, B, D*H)  gradient w.r.t. `out`
- *   d_gx    (T, B, D*3H) gradient w.r.t. gx (= w.r.t. the pre-activations incl. b_ih)
- *   d_q     (T, B, D*H)  gradient w.r.t. (W_hn h_{t-1} + b_hn); together with the r,z columns of
- *           d_gx it is the gradient w.r.t. W_hh h_{t-1} + b_hh, from which the caller forms
- *           d(W_hh) with slu_gemm_f32 against the time-shifted `out`.
- *   d_bias_part NULL or (ceil(B/16), D, 4H): per 16-sequence tile, the sums over t and the tile's
- *           sequences of [d_gx (3H) | d_q (H)]; summing over the first axis gives
- *           d(b_ih) = [0:3H) and d(b_hh) = [0:2H) ++ [3H:4H).  (No atomics: deterministic.)       */
+ *   d_gx    (T, B, D*3H) gradient w.r.t. gx = x W_ih^T + b_ih          [dr_pre, dz_pre, dn_pre]
+ *   d_gh    (T, B, D*3H) gradient w.r.t. h_{t-1} W_hh^T + b_hh          [dr_pre, dz_pre, dq],
+ *           dq = dn_pre * r; the caller forms d(W_ih) = d_gx^T x, d(x) = d_gx W_ih and
+ *           d(W_hh) = d_gh^T h_{t-1} with slu_gemm_f32 (h_{t-1} = `out` shifted by one step).
+ *   d_bias_part NULL or (ceil(B/16), D, 6H): per 16-sequence tile, the sums over t and the tile's
+ *           sequences of [d_gx (3H) | d_gh (3H)]; summing over the first axis gives
+ *           d(b_ih) = [0:3H) and d(b_hh) = [3H:6H).  (No atomics: deterministic.)                  */
 int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_fwd,
-                    const float* w_hh_rev, float* d_gx, float* d_q, float* d_bias_part,
+                    const float* w_hh_rev, float* d_gx, float* d_gh, float* d_bias_part,
                     int64_t T, int64_t B, int64_t H, int64_t D, void* stream);
 
 /* -------- Dropout + Downsample: nn.Dropout (models.py:246,276,700) + Downsample (:26-46) -------

@@ -159,12 +159,14 @@ def test_colsum(ops):
 
 
 def _layer_args(xg, gp, bi):
-    """(x, W_ih stacked over directions, b_ih stacked, W_hh, b_hh[, reverse W_hh, b_hh])"""
+    """(x, direction-stacked W_ih / b_ih storage, the four ih parameters, W_hh, b_hh[, reverse W_hh, b_hh])"""
     if bi:
-        return [xg, torch.cat([gp["weight_ih_l0"], gp["weight_ih_l0_reverse"]]),
-                torch.cat([gp["bias_ih_l0"], gp["bias_ih_l0_reverse"]]),
+        W = torch.cat([gp["weight_ih_l0"], gp["weight_ih_l0_reverse"]]).detach()
+        b = torch.cat([gp["bias_ih_l0"], gp["bias_ih_l0_reverse"]]).detach()
+        return [xg, W, b, gp["weight_ih_l0"], gp["weight_ih_l0_reverse"], gp["bias_ih_l0"], gp["bias_ih_l0_reverse"],
                 gp["weight_hh_l0"], gp["bias_hh_l0"], gp["weight_hh_l0_reverse"], gp["bias_hh_l0_reverse"]]
-    return [xg, gp["weight_ih_l0"], gp["bias_ih_l0"], gp["weight_hh_l0"], gp["bias_hh_l0"], None, None]
+    return [xg, gp["weight_ih_l0"].detach(), gp["bias_ih_l0"].detach(), gp["weight_ih_l0"], None, gp["bias_ih_l0"], None,
+            gp["weight_hh_l0"], gp["bias_hh_l0"], None, None]
 
 
 def _gru_case(ops, d, bi, check_grads=True):
