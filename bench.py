@@ -132,6 +132,7 @@ def large_batch_point(rank, samples, batch=2048, steps=3):
     workgroups, one per CU): where the recurrence stops being bound by the 8-workgroup latency chain.
     Reported next to the headline number, never as `value`."""
     from slu_hip import ops
+    os.environ["SLU_LOOKAHEAD"] = "0"          # one big batch per step: nothing to look ahead to
     config, model, trainer, train_ds, work = setup("no_unfreezing", rank, batch, samples, 1)
     dev = next(model.parameters()).device
     batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]
@@ -150,6 +151,7 @@ def large_batch_point(rank, samples, batch=2048, steps=3):
     shutil.rmtree(work, ignore_errors=True)
     del model, trainer, batches
     torch.cuda.empty_cache()
+    os.environ.pop("SLU_LOOKAHEAD", None)
     return {"batch_per_gpu": batch, "utterances_per_s": round(batch * steps / dt, 1),
             "ms_per_step": round(1e3 * dt / steps, 3),
             "gru_seq_fwd_kernel_tflops": round(ach, 2), "gru_seq_fwd_kernel_frac_of_fp32_mfma_peak":
@@ -200,13 +202,20 @@ def main():
     run_steps(model, trainer, batches, args.warmup)
     fence()
     note("timed region")
-    ops.profile_start()
     t0 = time.perf_counter()
     sums = run_steps(model, trainer, batches, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    prof = ops.profile_stop()
     note("timed region done: %.3f s" % elapsed)
+    # Dominant-kernel timing: the same steps once more with the kernels launched eagerly (hipGraph
+    # replays cannot carry per-kernel events) and a HIP event pair around every recurrence launch,
+    # recorded on the stream the kernel is launched on.
+    os.environ["SLU_GRAPHS"] = "0"
+    ops.profile_start()
+    run_steps(model, trainer, batches, min(args.steps, 32))
+    fence()
+    prof = ops.profile_stop()
+    os.environ.pop("SLU_GRAPHS", None)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -241,9 +250,13 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
                          "kernel": "gru_seq_fwd_kernel<128>",
                          "launches": len(prof), "avg_launch_ms": round(kms / max(len(prof), 1), 4),
-                         "note": "fp32 MFMA flops of h(BxH)*W_hh^T(Hx3H) per step, both directions; B=%d gives "
-                                 "%d workgroups (one 16-sequence tile x direction each) on 256 CUs" %
-                                 (args.batch, 2 * -(-args.batch // 16))},
+                         "note": "fp32 MFMA flops of h(BxH)*W_hh^T(Hx3H) per recurrence step, both directions, "
+                                 "summed over the launches of an eager re-run of the timed steps / their HIP-event "
+                                 "durations; a launch covers %d sequences (look-ahead super-batch of the frozen "
+                                 "layers) or %d (trainable intent layer): %d or %d workgroups on 256 CUs" %
+                                 (args.batch * max(1, trainer.lookahead_depth(True, False)[0]), args.batch,
+                                  2 * -(-args.batch * max(1, trainer.lookahead_depth(True, False)[0]) // 16),
+                                  2 * -(-args.batch // 16))},
         }
         if not args.no_large_batch and args.workload == "no_unfreezing":
             note("large-batch point")

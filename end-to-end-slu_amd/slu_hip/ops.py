@@ -170,13 +170,14 @@ def gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, want_reserve):
     reserve = None
     if want_reserve:
         reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=gx.device)
-    if _PROFILE is not None:
+    profiling = _PROFILE is not None and not torch.cuda.is_current_stream_capturing()
+    if profiling:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(L.slu_gru_seq_fwd(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(),
                                  _ptr(b_hh_r), out.data_ptr(), _ptr(reserve), T, B, H, D, _stream()),
                "slu_gru_seq_fwd")
-    if _PROFILE is not None:
+    if profiling:
         ev1.record()
         # h_{t-1} (B x H) times W_hh^T (H x 3H), per direction and step: 2*B*H*3H flops
         _PROFILE.append(("gru_seq_fwd_kernel", ev0, ev1, 2.0 * B * H * 3 * H * D * T))

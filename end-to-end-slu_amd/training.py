@@ -203,7 +203,7 @@ class Trainer:
                     feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
                     y = batch[1]
                     key = (tuple(feats.shape), tuple(y.shape), n_prefix)
-                    sg = self._step_graphs.get(key)
+                    sg = self._step_graphs.get(key) if use_graph else None
                     if sg is not None and sg.signature != self.bucket.signature:
                         sg = None                                   # trainable set changed since capture
                     if sg is None and use_graph and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:

@@ -1,24 +1,42 @@
 #!/usr/bin/env python3
-"""Per-kernel summary (calls, total, average, share) of a rocprofv3 --kernel-trace run.
+"""Per-kernel summary (calls, total, average, share) of a rocprofv3 --kernel-trace run, plus the
+stream-level picture (busy time per HIP stream, concurrency) that matters for the look-ahead pipeline.
 
-rocprofv3 (ROCm 7.2) writes a rocpd SQLite database by default; this prints the same table
-`--stats` would, so that the summary can be committed under profiles/ as plain text.
+Accepts the rocpd SQLite database rocprofv3 (ROCm 7.2) writes by default, or the *_kernel_trace.csv of
+`--output-format csv`; prints the table `--stats` would, so that it can be committed under profiles/.
 
-    python tools/rocprof_summary.py gpurun_out/prof/frozen/r1_results.db > profiles/r01_frozen.txt
+    python tools/rocprof_summary.py gpurun_out/prof/final_frozen/f_kernel_trace.csv > profiles/r01_b_frozen.txt
 """
+import collections
+import csv
 import sqlite3
 import sys
 
 
-def main(path, top=40):
+def load(path):
+    """-> list of (start_ns, end_ns, kernel name, stream id)"""
+    if path.endswith(".csv"):
+        rows = csv.DictReader(open(path))
+        return [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", "0")) for r in rows]
     db = sqlite3.connect(path)
-    rows = list(db.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
-                           "max(end-start)/1e3 from kernels group by name order by 3 desc"))
+    return [(r[0], r[1], r[2], "0") for r in db.execute("select start, end, name from kernels")]
+
+
+def main(path, top=40):
+    ev = load(path)
+    ev.sort()
+    agg = collections.defaultdict(list)
+    for s, e, name, _ in ev:
+        agg[name].append((e - s) / 1e3)
+    rows = sorted(((n, len(v), sum(v), sum(v) / len(v), min(v), max(v)) for n, v in agg.items()), key=lambda r: -r[2])
     total = sum(r[2] for r in rows)
-    span = db.execute("select (max(end)-min(start))/1e3 from kernels").fetchone()[0]
+    span = (max(e for _, e, _, _ in ev) - min(s for s, _, _, _ in ev)) / 1e3
     print("# %s" % path)
-    print("# kernels: %d distinct, %d dispatches, busy %.1f us over a %.1f us span" %
-          (len(rows), sum(r[1] for r in rows), total, span))
+    print("# kernels: %d distinct, %d dispatches, busy %.1f us over a %.1f us span" % (len(rows), len(ev), total, span))
+    streams = collections.defaultdict(float)
+    for s, e, _, st in ev:
+        streams[st] += (e - s) / 1e3
+    print("# busy us per HIP stream: " + ", ".join("%s: %.0f" % kv for kv in sorted(streams.items())))
     print("%-100s %7s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
     for r in rows[:top]:
         print("%-100s %7d %12.1f %10.2f %10.2f %10.2f %6.2f" % (r[0][:100], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / total))
