@@ -47,7 +47,7 @@ class PrefixSlot:
             if use_graph:
                 key = (len(xs), B, T, n_prefix, bool(model.training))
                 entry = self.graphs.get(key)
-                if entry is None and len(self.graphs) < self.MAX_GRAPHS:
+                if entry is None and key not in self.graphs and len(self.graphs) < self.MAX_GRAPHS:
                     entry = self._capture(model, xs, n_prefix, step0, key)
                 if entry is not None:
                     graph, x_static, feats = entry
@@ -77,8 +77,15 @@ class PrefixSlot:
         model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)      # warm-up (lazy initialisation)
         self.stream.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=self.stream):
-            feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)
+        try:
+            # thread-local capture mode: other threads (e.g. the RCCL watchdog) may keep calling the
+            # runtime while this thread captures
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+                feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)
+        except Exception as e:                      # stay eager for this shape
+            print("hipGraph capture of the frozen prefix failed (%s); staying eager" % (e,))
+            self.graphs[key] = None
+            return None
         entry = (graph, x_static, feats)
         self.graphs[key] = entry
         return entry
@@ -106,13 +113,13 @@ class StepGraph:
         torch.cuda.synchronize()
         bucket.release_grads()
         self.g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1, stream=stream):
+        with torch.cuda.graph(self.g1, stream=stream, capture_error_mode="thread_local"):
             self.loss, self.acc = model.forward_from(self.feats, n_prefix, self.y, self.rng)
             self.loss.backward()
             if self.world > 1:
                 bucket.pack()                       # one concatenation kernel per dtype; .grad -> slices
         self.g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g2, stream=stream):
+        with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
             trainer.optimizer.step()
         bucket.observe()
         self.signature = bucket.signature
