@@ -118,7 +118,7 @@ class Trainer:
         stage's output does not depend on earlier optimisation steps.  At 64 utterances per step a
         recurrence occupies 8 of 256 CUs, so several batches' encoders run concurrently for free;
         the per-batch dropout streams are step-indexed, so the result is the sequential one."""
-        depth = int(os.environ.get("SLU_LOOKAHEAD", "8"))
+        depth = int(os.environ.get("SLU_LOOKAHEAD", "16"))
         if not train or asr or depth < 2 or not hasattr(self.model, "prefix_features"):
             return 0, 0
         if not all(p.is_cuda for p in self.model.parameters()) or models_masks_injected():
