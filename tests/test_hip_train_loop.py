@@ -145,3 +145,53 @@ def test_lookahead_pipeline_equals_sequential_training(tmp_path, monkeypatch):
     for k, v in results["0"][1].items():
         assert torch.equal(v, results["3"][1][k]), k
     assert len(set(results["0"][0])) == len(results["0"][0])         # dropout really varied step to step
+
+
+def test_data_parallel_step_graph_logic_with_emulated_second_rank(tmp_path, monkeypatch):
+    """The multi-GPU code path of the captured training step (gradient packing into the flat bucket
+    inside the graph, eager all-reduce between the two graphs, Adam on the bucket slices) exercised on
+    one GPU: the process is told it is rank 0 of 2 and the collective is emulated for an identical
+    second rank (sum = 2x), so the averaged result must equal the single-process run bit for bit."""
+    sys.path.insert(0, PKG)
+    import data
+    import models
+    import training
+    from slu_hip import dp
+    cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                         phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                         intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=2)
+    cfg.folder = str(tmp_path)
+    cfg.training_lr = 0.003
+    cfg.starting_unfreezing_index = 1
+    cfg.unfreezing_type = 0
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    os.makedirs(tmp_path / "pretraining")
+    os.makedirs(tmp_path / "training")
+    torch.manual_seed(1)
+    torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
+    ds = data.SLUDataset(12, 8, 6000, cfg.values_per_slot, seed=5)
+    monkeypatch.setenv("SLU_LOOKAHEAD", "4")
+    results = {}
+    calls = {"n": 0}
+    for world in (1, 2):
+        if world == 2:
+            monkeypatch.setattr(dp, "world", lambda: (0, 2))
+
+            def fake_all_reduce(t, op=None):
+                calls["n"] += 1
+                t.mul_(2)
+            monkeypatch.setattr(torch.distributed, "all_reduce", fake_all_reduce)
+        torch.manual_seed(2)
+        model = models.Model(cfg)
+        models.set_dropout_seed(77)
+        trainer = training.Trainer(model, cfg)
+        assert trainer.world_size == world
+        model.train()
+        losses = [vals[0].item() for vals, _ in trainer._iterate(ds.loader, True, False)]
+        torch.cuda.synchronize()
+        assert len(trainer._step_graphs) == 1                   # the step was captured and replayed
+        results[world] = (losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    assert calls["n"] == 12                                     # one collective per step (one dtype)
+    assert results[1][0] == results[2][0]
+    for k, v in results[1][1].items():
+        assert torch.equal(v, results[2][1][k]), k
