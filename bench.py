@@ -41,7 +41,6 @@ def setup(workload, rank, batch, samples, n_batches):
     import data
     import models
     import training
-    from oracle import slu_oracle as O      # only its reference-format weight initialiser is used here
 
     work = tempfile.mkdtemp(prefix="slu_bench_")
     os.makedirs(os.path.join(work, "experiments"))
@@ -56,7 +55,8 @@ def setup(workload, rank, batch, samples, n_batches):
         config.seed = 1234 + rank                      # per-rank synthetic data
         train_ds, _, _ = data.get_SLU_datasets(config)
         torch.manual_seed(4321)                        # synthetic "pre-trained" encoder (no .pth published)
-        torch.save(O.init_pretrained_state_dict(config), os.path.join(config.folder, "pretraining", "model_state.pth"))
+        torch.save({k: v.cpu() for k, v in models.PretrainedModel(config).state_dict().items()},
+                   os.path.join(config.folder, "pretraining", "model_state.pth"))
         torch.manual_seed(1234)
         model = models.Model(config)
         if workload == "unfreeze_all":
