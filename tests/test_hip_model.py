@@ -306,3 +306,84 @@ def test_layerwise_iteration_matches_fused_path(models_mod, tmp_path):
         out = layer(out)
     fused = pm.compute_features(x)
     assert maxerr(out, fused) <= 1e-6
+
+
+VARIANTS = {
+    # name: overrides of the tiny architecture (every cfg of the reference uses the same hyper-parameters;
+    # these exercise the generality the reference's constructor offers)
+    "conv_frontend_relu_pool22": dict(use_sincnet=False, cnn_act=["relu", "relu", "leaky_relu"], cnn_max_pool_len=[2, 2, 1]),
+    "max_and_none_downsample": dict(phone_downsample_type=["max", "none"], phone_downsample_len=[3, 2],
+                                    word_downsample_type=["avg", "max"], word_downsample_len=[1, 2],
+                                    intent_downsample_type=["max"], intent_downsample_len=[2]),
+    "unidirectional": dict(phone_rnn_bidirectional=False, word_rnn_bidirectional=False, intent_rnn_bidirectional=False),
+    "wide_pool_fallback": dict(cnn_max_pool_len=[3, 1, 1]),
+    "two_intent_layers_three_phone": dict(intent_rnn_num_hidden=[16, 32], intent_rnn_drop=[0.5, 0.25],
+                                          intent_downsample_type=["none", "avg"], intent_downsample_len=[1, 2],
+                                          phone_rnn_num_hidden=[16, 32, 16], phone_downsample_len=[2, 1, 2],
+                                          phone_downsample_type=["avg", "none", "avg"], phone_rnn_drop=[0.5, 0.0, 0.5]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_architecture_variants_vs_oracle(models_mod, tmp_path, name):
+    """Logits, loss and every gradient of reduced-size models built from non-default (but legal)
+    architecture settings, in train mode with injected dropout masks, against the CPU oracle."""
+    cfg = tiny_cfg(tmp_path, **VARIANTS[name])
+    torch.manual_seed(3)
+    model = models_mod.Model(cfg)
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(8)
+    x = 0.1 * torch.randn(5, 2300, generator=g)
+    y = torch.stack([torch.randint(0, n, (5,), generator=g) for n in cfg.values_per_slot], dim=1)
+    masks = O.draw_dropout_masks(cfg, x, seed=21)
+    model.train()
+    models_mod.set_dropout_masks(masks_to_cuda(masks))
+    loss, acc = model(x, y)
+    loss.backward()
+    rloss, racc, rlogits, rpred = O.slu_forward(sd, x, y, cfg, masks)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) <= 1e-5 and acc.item() == racc.item()
+    for k, p in model.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+            continue
+        scale = max(sd[k].grad.abs().max().item(), 1e-6)
+        assert maxerr(p.grad, sd[k].grad) <= 1e-4 * scale, (name, k)
+    model.eval()
+    with torch.no_grad():
+        logits, pred = model.predict_intents(x)
+        _, _, elogits, epred = O.slu_forward({k: v.detach() for k, v in sd.items()}, x, y, cfg, None)
+    assert maxerr(logits, elogits) <= 1e-5 and torch.equal(pred.cpu(), epred)
+
+
+def test_ten_second_utterances_vs_oracle(models_mod, tmp_path):
+    """BASELINE.json configs[4] shape (LibriSpeech-like 10 s utterances, T = 160 000 -> GRU lengths
+    1000/500/250/125/63) in fp32: eval logits and unfrozen train-mode gradients vs the oracle."""
+    meta = {"pretrain_seed": 21, "model_seed": 22}
+    cfg, model = _full_model_from_seeds(models_mod, tmp_path, meta)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(77)
+    x = 0.1 * torch.randn(6, 160000, generator=g)
+    y = torch.stack([torch.randint(0, n, (6,), generator=g) for n in cfg.values_per_slot], dim=1)
+    model.eval()
+    with torch.no_grad():
+        logits, pred = model.predict_intents(x)
+        _, _, ref_logits, ref_pred = O.slu_forward(sd, x, y, cfg, None, explicit_gru=False)
+    err = maxerr(logits, ref_logits)
+    print("10 s eval logits max-abs deviation: %.3e" % err)
+    assert err <= 1e-4 and torch.equal(pred.cpu(), ref_pred)
+    for p in model.parameters():
+        p.requires_grad = True
+    model.train()
+    masks = O.draw_dropout_masks(cfg, x, seed=5)
+    models_mod.set_dropout_masks(masks_to_cuda(masks))
+    loss, _ = model(x, y)
+    loss.backward()
+    sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    rloss, _, _, _ = O.slu_forward(sdg, x, y, cfg, masks, explicit_gru=False)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) <= 1e-4
+    for k, p in model.named_parameters():
+        if sdg[k].grad is not None:
+            scale = max(sdg[k].grad.abs().max().item(), 1e-6)
+            assert maxerr(p.grad, sdg[k].grad) <= 3e-4 * scale, k
