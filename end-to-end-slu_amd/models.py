@@ -624,6 +624,29 @@ class Model(torch.nn.Module):
         x = self.pretrained_model._to_device(x)[0]
         return self.forward_from(x, 0, y_intent, next_rng_step())
 
+    def eval_group(self, xs, ys):
+        """Evaluation (no dropout, no autograd) of several equally-shaped batches in ONE pass through the
+        encoder and the intent GRU (concatenated along the batch axis: 8 x more recurrence workgroups at
+        the same latency), then the per-batch loss/accuracy.  Returns [(loss, acc), ...] — the values
+        forward() gives batch by batch."""
+        assert not self.training
+        pm = self.pretrained_model
+        with torch.no_grad():
+            dev = next(self.parameters()).device
+            B = xs[0].shape[0]
+            x_cat = torch.cat([x.to(dev, non_blocking=True) for x in xs]) if len(xs) > 1 else pm._to_device(xs[0])[0]
+            h = pm.run_stages(x_cat, 0, len(pm._stages()))
+            for st in self._intent_stages:
+                h = st.run(h, False)
+            cls = self.intent_layers[-2]
+            out = []
+            for k, y in enumerate(ys):
+                hk = h[:, k * B:(k + 1) * B].contiguous() if len(xs) > 1 else h.contiguous()
+                la, _, _, _, _ = _ops.cls_maxpool_ce_fwd(hk, cls.weight, cls.bias, y.to(dev).contiguous(),
+                                                         tuple(self.values_per_slot), False)
+                out.append((la[0], la[1]))
+        return out
+
     def predict_intents(self, x):
         """-> (intent_logits (B, num_values_total), predicted_intent (B, num_slots)) (models.py:830-846)"""
         h = self._intent_features_tm(x).contiguous()

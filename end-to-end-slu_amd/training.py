@@ -129,6 +129,27 @@ class Trainer:
     def _iterate(self, loader, train, asr):
         """Yields ([metric tensors], batch_size) per batch, doing the optimisation step when `train`."""
         depth, n_prefix = self.lookahead_depth(train, asr)
+        group_eval = (not train and not asr and hasattr(self.model, "eval_group") and not models_masks_injected()
+                      and all(p.is_cuda for p in self.model.parameters())
+                      and int(os.environ.get("SLU_LOOKAHEAD", "16")) > 1)
+        if group_eval:
+            # evaluation has no step-to-step dependency at all: whole batches are grouped
+            width = int(os.environ.get("SLU_LOOKAHEAD", "16"))
+            group = []
+
+            def flush():
+                res = self.model.eval_group([b[0] for b in group], [b[1] for b in group])
+                out = [([l, a], len(b[0])) for (l, a), b in zip(res, group)]
+                group.clear()
+                return out
+
+            for batch in loader:
+                if group and (tuple(batch[0].shape) != tuple(group[0][0].shape) or len(group) == width):
+                    yield from flush()
+                group.append(batch)
+            if group:
+                yield from flush()
+            return
         if depth == 0:
             for batch in loader:
                 with torch.set_grad_enabled(train):

@@ -195,3 +195,37 @@ def test_data_parallel_step_graph_logic_with_emulated_second_rank(tmp_path, monk
     assert results[1][0] == results[2][0]
     for k, v in results[1][1].items():
         assert torch.equal(v, results[2][1][k]), k
+
+
+def test_grouped_evaluation_equals_batch_by_batch(tmp_path, monkeypatch):
+    """Trainer.test() groups equally-shaped batches into one pass; metrics must equal the batch-by-batch
+    evaluation (ragged last batch and a shape change included)."""
+    sys.path.insert(0, PKG)
+    import data
+    import models
+    import training
+    cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                         phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                         intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=0)
+    cfg.folder = str(tmp_path)
+    cfg.training_lr = 0.003
+    cfg.starting_unfreezing_index = 1
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    os.makedirs(tmp_path / "training")
+    torch.manual_seed(4)
+    model = models.Model(cfg)
+    a = data.SLUDataset(5, 8, 6000, cfg.values_per_slot, seed=1)
+    b = data.SLUDataset(2, 8, 4000, cfg.values_per_slot, seed=2)
+    c = data.SLUDataset(1, 3, 4000, cfg.values_per_slot, seed=3)
+
+    class DS:
+        loader = a.batches + b.batches + c.batches
+    trainer = training.Trainer(model, cfg)
+    monkeypatch.setenv("SLU_LOOKAHEAD", "4")
+    acc_g, loss_g = trainer.test(DS())
+    monkeypatch.setenv("SLU_LOOKAHEAD", "0")
+    acc_s, loss_s = trainer.test(DS())
+    assert acc_g == acc_s and abs(loss_g - loss_s) <= 1e-6
+    model.eval()
+    tot = sum(model(x, y)[0].item() * len(x) for x, y in DS.loader) / sum(len(x) for x, _ in DS.loader)
+    assert abs(tot - loss_s) <= 1e-6
