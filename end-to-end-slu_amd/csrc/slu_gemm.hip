@@ -5,9 +5,11 @@
 //
 // 128 x 128 x 32 workgroup tile, 256 threads = 2 x 2 waves of 64 x 64 (4 x 4 tiles of
 // v_mfma_f32_16x16x4_f32, 128 MFMAs per wave per k-tile = 4096 cycles, enough to cover the global
-// load latency of the next tile even with one workgroup per CU).  Operands are staged k-major in
-// LDS ([k][m], row stride 144 floats, so the four k-groups of a wave hit disjoint banks) through
-// registers with a one-tile prefetch (next tile's global loads are in flight during the MFMAs).  The global->register mapping follows whichever
+// load latency of the next tile even with one workgroup per CU).  Operands are staged through
+// registers (one-tile prefetch: the next tile's global loads are in flight during the MFMAs) into
+// row-major LDS tiles with k contiguous; the MFMA k-index is remapped so that each lane group owns 8
+// CONSECUTIVE k of the tile: a fragment is two ds_read_b128 instead of eight ds_read_b32, and all
+// 16 fragment reads of a k-tile are issued before its 128 back-to-back MFMAs.  The global->register mapping follows whichever
 // operand dimension is contiguous, so A may be row- or column-major (likewise B) without a
 // transposed copy.  Small-output / long-K problems (weight gradients) are split along K into a
 // workspace and reduced in a fixed order (deterministic).
@@ -15,9 +17,11 @@
 
 namespace slu {
 
-constexpr int GM_BM = 128, GM_BN = 128, GM_BK = 32, GM_LD = 144, GM_THREADS = 256;
-constexpr int GM_PASSES = GM_BK / 8;        // float4 loads per thread per operand tile
-constexpr int GM_REGS = 4 * GM_PASSES;
+constexpr int GM_BK = 32, GM_THREADS = 256;
+// WT = 16x16 MFMA tiles per wave per dimension: workgroup tile (32*WT)^2, WT float4 loads per thread
+// per operand k-tile.  WT = 2 (64 x 64) is the default, WT = 4 (128 x 128) for very large problems.
+constexpr int GM_KPV = GM_BK + 4;           // LDS row stride of a k-contiguous operand: float4 stores/reads
+constexpr int GM_KPS = GM_BK + 1;           // LDS row stride of a row-contiguous operand: scalar, conflict-free
 
 struct GemmParams {
   const float* A; long long a_rs, a_cs;
@@ -30,16 +34,17 @@ struct GemmParams {
   int accumulate;
 };
 
-// Loads the GM_REGS elements thread `tid` owns of a (128 x GM_BK) operand tile into r[].
+// Loads the 4*WT elements thread `tid` owns of a (32*WT x GM_BK) operand tile into r[].
 //   X(row, k) = X[row*rs + k*cs], rows [row0, row0+128) limited by nrows, k in [k0, k0+BK) limited by kend.
 //   KFAST: k is the contiguous dimension -> thread owns k-quad tid % (BK/4) of rows tid/(BK/4) + 1024/BK*h.
-//   else : row is contiguous          -> thread owns row-quad tid % 32 of k = tid/32 + 8*h.
-template <bool KFAST>
+//   else : row is contiguous          -> thread owns row-quad tid % (8*WT) of k = tid/(8*WT) + 32/WT*h.
+template <bool KFAST, int WT>
 __device__ __forceinline__ void load_tile(const float* __restrict__ X, long long rs, long long cs,
-                                          int row0, int nrows, int k0, int kend, int tid, float (&r)[GM_REGS]) {
+                                          int row0, int nrows, int k0, int kend, int tid, float (&r)[4 * WT]) {
   constexpr int TPR = GM_BK / 4;              // threads per row (k-fast)
+  constexpr int RQ = 8 * WT;                  // row quads per tile (row-fast)
 #pragma unroll
-  for (int h = 0; h < GM_PASSES; ++h) {
+  for (int h = 0; h < WT; ++h) {
     if (KFAST) {
       const int row = row0 + tid / TPR + (GM_THREADS / TPR) * h;
       const int k = k0 + 4 * (tid % TPR);
@@ -52,8 +57,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, long long
         for (int j = 0; j < 4; ++j) r[4 * h + j] = (row < nrows && k + j < kend) ? p[(long long)j * cs] : 0.0f;
       }
     } else {
-      const int k = k0 + (tid >> 5) + 8 * h;
-      const int row = row0 + 4 * (tid & 31);
+      const int k = k0 + tid / RQ + (GM_THREADS / RQ) * h;
+      const int row = row0 + 4 * (tid % RQ);
       const float* p = X + (long long)row * rs + (long long)k * cs;
       if (k < kend && row + 3 < nrows && rs == 1 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) {
         const float4 v = *reinterpret_cast<const float4*>(p);
@@ -66,30 +71,49 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ X, long long
   }
 }
 
-// Stores r[] into the k-major LDS tile s[k][row] (row stride GM_LD).
-template <bool KFAST>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float (&r)[GM_REGS]) {
+// LDS tiles are ROW-major with k contiguous: s[row][k].  A k-contiguous operand keeps its float4s
+// (row stride 36 floats = 144 B: 16-byte aligned, and the 16 rows of a fragment read land on 16
+// distinct 16-byte slots); a row-contiguous operand is transposed on the way in with scalar stores
+// (row stride 33: conflict-free for both the stores and the scalar fragment reads).
+template <bool KFAST, int WT>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float (&r)[4 * WT]) {
   constexpr int TPR = GM_BK / 4;
+  constexpr int RQ = 8 * WT;
 #pragma unroll
-  for (int h = 0; h < GM_PASSES; ++h) {
+  for (int h = 0; h < WT; ++h) {
     if (KFAST) {
       const int row = tid / TPR + (GM_THREADS / TPR) * h;
       const int k = 4 * (tid % TPR);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) s[(k + j) * GM_LD + row] = r[4 * h + j];
+      *reinterpret_cast<float4*>(&s[row * GM_KPV + k]) = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
     } else {
-      const int k = (tid >> 5) + 8 * h;
-      const int row = 4 * (tid & 31);
-      *reinterpret_cast<float4*>(&s[k * GM_LD + row]) = make_float4(r[4 * h], r[4 * h + 1], r[4 * h + 2], r[4 * h + 3]);
+      const int k = tid / RQ + (GM_THREADS / RQ) * h;
+      const int row = 4 * (tid % RQ);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[(row + j) * GM_KPS + k] = r[4 * h + j];
     }
   }
 }
 
-template <bool A_KFAST, bool B_KFAST>
+// Fragment of one 16-row tile: lane (i = lane & 15, kg = lane >> 4) gets row (base + i), k = kg*8 .. kg*8+7.
+// MFMA step kk of the k-tile consumes element kk from every lane group, i.e. k = kg*8 + kk for A and B alike.
+template <bool KFAST>
+__device__ __forceinline__ void load_frag(const float* __restrict__ s, int row, int kg, float (&f)[8]) {
+  if (KFAST) {
+    const float4 lo = *reinterpret_cast<const float4*>(&s[row * GM_KPV + kg * 8]);
+    const float4 hi = *reinterpret_cast<const float4*>(&s[row * GM_KPV + kg * 8 + 4]);
+    f[0] = lo.x; f[1] = lo.y; f[2] = lo.z; f[3] = lo.w; f[4] = hi.x; f[5] = hi.y; f[6] = hi.z; f[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = s[row * GM_KPS + kg * 8 + k];
+  }
+}
+
+template <bool A_KFAST, bool B_KFAST, int WT>
 __global__ void __launch_bounds__(GM_THREADS)
 gemm_f32_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) float sA[GM_BK * GM_LD];
-  __shared__ __attribute__((aligned(16))) float sB[GM_BK * GM_LD];
+  constexpr int GM_BM = 32 * WT, GM_BN = 32 * WT, WR = 16 * WT;
+  __shared__ __attribute__((aligned(16))) float sA[GM_BM * GM_KPV];
+  __shared__ __attribute__((aligned(16))) float sB[GM_BN * GM_KPV];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -99,42 +123,38 @@ gemm_f32_kernel(const GemmParams p) {
   const int ntiles = (kend - kbeg + GM_BK - 1) / GM_BK;
   const int i = lane & 15, kg = lane >> 4;
 
-  f32x4 acc[4][4];
+  f32x4 acc[WT][WT];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < WT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float ra[GM_REGS], rb[GM_REGS];
+  float ra[4 * WT], rb[4 * WT];
   // B(k,n) = B[k*b_rs + n*b_cs]: as an (n-rows x k) operand its row stride is b_cs, k stride b_rs.
   if (ntiles > 0) {
-    load_tile<A_KFAST>(p.A, p.a_rs, p.a_cs, m0, p.M, kbeg, kend, tid, ra);
-    load_tile<B_KFAST>(p.B, p.b_cs, p.b_rs, n0, p.N, kbeg, kend, tid, rb);
+    load_tile<A_KFAST, WT>(p.A, p.a_rs, p.a_cs, m0, p.M, kbeg, kend, tid, ra);
+    load_tile<B_KFAST, WT>(p.B, p.b_cs, p.b_rs, n0, p.N, kbeg, kend, tid, rb);
   }
-  const float* __restrict__ a_s = sA + wm * 64 + i;
-  const float* __restrict__ b_s = sB + wn * 64 + i;
   for (int t = 0; t < ntiles; ++t) {
-    store_tile<A_KFAST>(sA, tid, ra);
-    store_tile<B_KFAST>(sB, tid, rb);
+    store_tile<A_KFAST, WT>(sA, tid, ra);
+    store_tile<B_KFAST, WT>(sB, tid, rb);
     __syncthreads();
     if (t + 1 < ntiles) {                       // next tile's loads fly during this tile's MFMAs
       const int k0 = kbeg + (t + 1) * GM_BK;
-      load_tile<A_KFAST>(p.A, p.a_rs, p.a_cs, m0, p.M, k0, kend, tid, ra);
-      load_tile<B_KFAST>(p.B, p.b_cs, p.b_rs, n0, p.N, k0, kend, tid, rb);
+      load_tile<A_KFAST, WT>(p.A, p.a_rs, p.a_cs, m0, p.M, k0, kend, tid, ra);
+      load_tile<B_KFAST, WT>(p.B, p.b_cs, p.b_rs, n0, p.N, k0, kend, tid, rb);
     }
+    float af[WT][8], bf[WT][8];
 #pragma unroll
-    for (int kk = 0; kk < GM_BK / 4; ++kk) {
-      const int krow = (kk * 4 + kg) * GM_LD;
-      float af[4], bf[4];
+    for (int a = 0; a < WT; ++a) load_frag<A_KFAST>(sA, wm * WR + a * 16 + i, kg, af[a]);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = a_s[krow + a * 16];
+    for (int b = 0; b < WT; ++b) load_frag<B_KFAST>(sB, wn * WR + b * 16 + i, kg, bf[b]);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = b_s[krow + b * 16];
+    for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(af[a], bf[b], acc[a][b]);
-    }
+        for (int b = 0; b < WT; ++b) acc[a][b] = mfma16(af[a][kk], bf[b][kk], acc[a][b]);
     __syncthreads();
   }
 
@@ -142,28 +162,28 @@ gemm_f32_kernel(const GemmParams p) {
   if (p.ws) {
     float* __restrict__ w = p.ws + (size_t)blockIdx.z * p.M * p.N;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wn * 64 + b * 16 + i;
+      for (int b = 0; b < WT; ++b) {
+        const int n = n0 + wn * WR + b * 16 + i;
         if (n >= p.N) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * 64 + a * 16 + 4 * kg + r;
+          const int m = m0 + wm * WR + a * 16 + 4 * kg + r;
           if (m < p.M) w[(size_t)m * p.N + n] = acc[a][b][r];
         }
       }
   } else {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int n = n0 + wn * 64 + b * 16 + i;
+      for (int b = 0; b < WT; ++b) {
+        const int n = n0 + wn * WR + b * 16 + i;
         if (n >= p.N) continue;
         const float bias = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * 64 + a * 16 + 4 * kg + r;
+          const int m = m0 + wm * WR + a * 16 + 4 * kg + r;
           if (m >= p.M) continue;
           float* c = p.C + (long long)m * p.c_rs + (long long)n * p.c_cs;
           float v = acc[a][b][r] + bias;
@@ -253,8 +273,13 @@ int colsum_two_stage(const float* X, int64_t rs, float* out, int64_t M, int64_t 
   return SLU_OK;
 }
 
-static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper) {
-  const int64_t tiles = cdiv(M, GM_BM) * cdiv(N, GM_BN);
+static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper, int* wt) {
+  // measured on MI355X: the 64-tile wins or ties up to 8192^2 x 1024 (more waves per SIMD hide the
+  // per-k-tile latency chain; L2 absorbs the extra operand re-reads); 128-tiles only pay off when
+  // both the grid and K are large.
+  *wt = (cdiv(M, 128) * cdiv(N, 128) >= 1024 && K >= 2048) ? 4 : 2;
+  const int64_t bm = 32 * *wt;
+  const int64_t tiles = cdiv(M, bm) * cdiv(N, bm);
   int64_t ks = 1;
   if (tiles < 128 && K >= 512) {
     ks = cdiv(256, tiles);
@@ -272,8 +297,8 @@ static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper) {
 using namespace slu;
 
 extern "C" size_t slu_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  int KS, kper;
-  split_plan(M, N, K, &KS, &kper);
+  int KS, kper, wt;
+  split_plan(M, N, K, &KS, &kper, &wt);
   return KS > 1 ? (size_t)KS * M * N * sizeof(float) : 0;
 }
 
@@ -285,8 +310,8 @@ extern "C" int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const fl
   SLU_REQUIRE(M > 0 && N > 0 && K > 0, "slu_gemm_f32: non-positive size");
   SLU_REQUIRE(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "slu_gemm_f32: size overflow");
   hipStream_t st = (hipStream_t)stream;
-  int KS, kper;
-  split_plan(M, N, K, &KS, &kper);
+  int KS, kper, wt;
+  split_plan(M, N, K, &KS, &kper, &wt);
   GemmParams p;
   p.A = A; p.a_rs = a_rs; p.a_cs = a_cs;
   p.B = B; p.b_rs = b_rs; p.b_cs = b_cs;
@@ -300,14 +325,25 @@ extern "C" int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const fl
       SLU_FAIL(SLU_ERR_WORKSPACE, "slu_gemm_f32: workspace too small (%zu < %zu)", workspace_bytes, need);
     p.ws = reinterpret_cast<float*>(workspace);
   }
-  dim3 grid((unsigned)cdiv(N, GM_BN), (unsigned)cdiv(M, GM_BM), (unsigned)KS);
+  const int bm = 32 * wt;
+  dim3 grid((unsigned)cdiv(N, bm), (unsigned)cdiv(M, bm), (unsigned)KS);
   SLU_REQUIRE(grid.y <= 65535, "slu_gemm_f32: M too large for one launch");
   const bool akf = (a_cs == 1) || (a_rs != 1);     // k-fast mapping unless M is the contiguous dim
   const bool bkf = (b_rs == 1) || (b_cs != 1);     // B(k,n): k contiguous when b_rs == 1
-  if (akf && bkf) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(GM_THREADS), 0, st, p);
-  else if (akf && !bkf) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(GM_THREADS), 0, st, p);
-  else if (!akf && bkf) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(GM_THREADS), 0, st, p);
-  else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(GM_THREADS), 0, st, p);
+#define SLU_GEMM_LAUNCH(AK, BK_, W) \
+  hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, W>), grid, dim3(GM_THREADS), 0, st, p)
+  if (wt == 4) {
+    if (akf && bkf) SLU_GEMM_LAUNCH(true, true, 4);
+    else if (akf && !bkf) SLU_GEMM_LAUNCH(true, false, 4);
+    else if (!akf && bkf) SLU_GEMM_LAUNCH(false, true, 4);
+    else SLU_GEMM_LAUNCH(false, false, 4);
+  } else {
+    if (akf && bkf) SLU_GEMM_LAUNCH(true, true, 2);
+    else if (akf && !bkf) SLU_GEMM_LAUNCH(true, false, 2);
+    else if (!akf && bkf) SLU_GEMM_LAUNCH(false, true, 2);
+    else SLU_GEMM_LAUNCH(false, false, 2);
+  }
+#undef SLU_GEMM_LAUNCH
   SLU_CHECK_LAUNCH("gemm_f32_kernel");
   if (KS > 1) {
     const long long total = (long long)M * N;
