@@ -16,6 +16,7 @@
 //     step ahead.
 // The backward kernel mirrors this with W_hh consumed transposed (dh_{t-1} += dG W_hh).
 #include "slu_common.h"
+#include <cstdlib>
 
 namespace slu {
 
@@ -152,6 +153,158 @@ gru_seq_fwd_kernel(const GruFwdParams p) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hprev[r] = hn[r]; gr[r] = ngr[r]; gz[r] = ngz[r]; gn[r] = ngn[r]; }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 4-sequence variant for small batches.  With 16 sequences per workgroup a B = 64 layer is 8
+// workgroups on a 256-CU chip, each paying the full 16-row MFMA chain per step.  Here a workgroup of
+// H/32 waves owns only FOUR sequences and uses v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks
+// per instruction, 8 cycles): lane l = (half = l/32, unit u = l%32) owns hidden unit 32w+u and the
+// k-range [half*H/2, (half+1)*H/2) of the reduction, so each of the three gate tiles is
+// [32 units, k low | the same 32 units, k high] and no MFMA lane is wasted: H/2 * 3 instructions of
+// 8 cycles per wave per step (1536 cycles for H = 128, a quarter of the 16-sequence chain), with the
+// same 3H/4 resident W_hh registers per lane.  The A operand (h_{t-1}, identical for every block of
+// a half) uses the cbsz/abid block broadcast: register q of the four lanes of block a holds
+// h[seq][k(q, a)], so a lane reads H/16 floats of h per step (two ds_read_b128) instead of H/2.
+// v_permlane32_swap folds the two k-halves; the lower half-wave then finishes sequences 0, 1 and the
+// upper one sequences 2, 3 (gates, blend, stores).  Reserve layout and results interoperate with the
+// 16-sequence kernels (summation order differs: not bit-identical between the variants).
+template <int H>
+__global__ void __launch_bounds__(H * 2)
+gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
+  constexpr int NW16 = H / 16;   // waves of the 16-sequence layout (reserve indexing)
+  constexpr int KS = H / 2;      // k range of a half-wave
+  constexpr int NQ = KS / 8;     // A registers per lane (8 blocks x NQ = KS)
+  constexpr int LD = H + 16;     // LDS row stride: rows 16 banks apart -> conflict-free b128 reads
+  static_assert(NQ % 4 == 0, "gru_seq_fwd4_kernel needs H >= 64");
+  __shared__ __attribute__((aligned(16))) float hbuf[2][4 * LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u = lane & 31, half = lane >> 5, blk = (lane >> 2) & 7, si = lane & 3;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 4;
+  const int j = w * 32 + u;
+  const int T = p.T, B = p.B, D = p.D;
+
+  // k index (within the half) consumed by the MFMA that uses A register q with abid = a
+  //   k(q, a) = (q / 4) * 32 + 4 * a + (q % 4):  register group q/4 is one ds_read_b128 at offset 4*blk.
+  float wr[KS], wz[KS], wn[KS];
+  {
+    const float* __restrict__ W = p.w_hh[dir];
+    const float* pr = W + ((size_t)(0 * H + j)) * H + half * KS;
+    const float* pz = W + ((size_t)(1 * H + j)) * H + half * KS;
+    const float* pn = W + ((size_t)(2 * H + j)) * H + half * KS;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { wr[k] = pr[k]; wz[k] = pz[k]; wn[k] = pn[k]; }
+  }
+  const float bhr = p.b_hh[dir][j], bhz = p.b_hh[dir][H + j], bhn = p.b_hh[dir][2 * H + j];
+
+  for (int x = tid; x < 2 * 4 * LD; x += H * 2) (&hbuf[0][0])[x] = 0.0f;   // h0 = 0
+  // this lane finishes sequences b0 + 2*half + {0, 1}
+  float hprev[2] = {0.f, 0.f};
+  bool rowok[2];
+  size_t grow[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int b = b0 + 2 * half + e;
+    rowok[e] = b < B;
+    grow[e] = (size_t)(rowok[e] ? b : 0);
+  }
+  const size_t gx_ts = (size_t)B * D * 3 * H;
+  const size_t out_ts = (size_t)B * D * H;
+  const float* __restrict__ gxd = p.gx + (size_t)dir * 3 * H + j;
+  float* __restrict__ outd = p.out + (size_t)dir * H + j;
+
+  float gr[2], gz[2], gn[2];
+  {
+    const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float* g = gxd + (size_t)t0 * gx_ts + grow[e] * D * 3 * H;
+      gr[e] = g[0]; gz[e] = g[H]; gn[e] = g[2 * H];
+    }
+  }
+  // reserve element (sequence b, unit j, component c) lives where the 16-sequence kernel puts it
+  const size_t rsv_lane = ((size_t)((j & 15) + 16 * ((b0 & 15) >> 2))) * 4 + 2 * half;
+  const size_t rsv_wave = (size_t)(b0 >> 4) * NW16 + (j >> 4);
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int cur = s & 1;
+    float ngr[2], ngz[2], ngn[2];
+    if (s + 1 < T) {
+      const int tn = dir ? t - 1 : t + 1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float* g = gxd + (size_t)tn * gx_ts + grow[e] * D * 3 * H;
+        ngr[e] = g[0]; ngz[e] = g[H]; ngn[e] = g[2 * H];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { ngr[e] = 0.f; ngz[e] = 0.f; ngn[e] = 0.f; }
+    }
+
+    float af[NQ];
+    {
+      const float* __restrict__ hrow = &hbuf[cur][si * LD + half * KS + 4 * blk];
+#pragma unroll
+      for (int v = 0; v < NQ / 4; ++v) {
+        const float4 x = *reinterpret_cast<const float4*>(hrow + 32 * v);
+        af[4 * v + 0] = x.x; af[4 * v + 1] = x.y; af[4 * v + 2] = x.z; af[4 * v + 3] = x.w;
+      }
+    }
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int kb = (q / 4) * 32 + (q % 4);
+#define SLU_GRU4_STEP(a)                                                        \
+      ar = __builtin_amdgcn_mfma_f32_4x4x1f32(af[q], wr[kb + 4 * a], ar, 3, a, 0); \
+      az = __builtin_amdgcn_mfma_f32_4x4x1f32(af[q], wz[kb + 4 * a], az, 3, a, 0); \
+      an = __builtin_amdgcn_mfma_f32_4x4x1f32(af[q], wn[kb + 4 * a], an, 3, a, 0);
+      SLU_GRU4_STEP(0) SLU_GRU4_STEP(1) SLU_GRU4_STEP(2) SLU_GRU4_STEP(3)
+      SLU_GRU4_STEP(4) SLU_GRU4_STEP(5) SLU_GRU4_STEP(6) SLU_GRU4_STEP(7)
+#undef SLU_GRU4_STEP
+    }
+    // fold the k-halves: register pair (seq e, seq e+2) -> lower half-wave gets seq e, upper seq e+2
+    float hr[2], hz[2], hq[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      auto sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(ar[e]), __float_as_uint(ar[e + 2]), false, false);
+      auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(az[e]), __float_as_uint(az[e + 2]), false, false);
+      auto sn = __builtin_amdgcn_permlane32_swap(__float_as_uint(an[e]), __float_as_uint(an[e + 2]), false, false);
+      hr[e] = __uint_as_float(sr[0]) + __uint_as_float(sr[1]);
+      hz[e] = __uint_as_float(sz[0]) + __uint_as_float(sz[1]);
+      hq[e] = __uint_as_float(sn[0]) + __uint_as_float(sn[1]);
+    }
+
+    float rr[2], zz[2], nn[2], qq[2], hn[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      rr[e] = act_sigmoid(gr[e] + (hr[e] + bhr));
+      zz[e] = act_sigmoid(gz[e] + (hz[e] + bhz));
+      qq[e] = hq[e] + bhn;
+      nn[e] = act_tanh(gn[e] + rr[e] * qq[e]);
+      hn[e] = (1.0f - zz[e]) * nn[e] + zz[e] * hprev[e];
+    }
+    float* __restrict__ hnext = &hbuf[cur ^ 1][0];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      hnext[(2 * half + e) * LD + j] = hn[e];
+      if (rowok[e]) outd[(size_t)t * out_ts + grow[e] * D * H] = hn[e];
+    }
+    if (p.reserve) {
+      float* __restrict__ rs = p.reserve + ((((size_t)dir * T + t) * NBT16) * NW16 + rsv_wave) * (5 * 256) + rsv_lane;
+      *reinterpret_cast<float2*>(rs + 0 * 256) = make_float2(rr[0], rr[1]);
+      *reinterpret_cast<float2*>(rs + 1 * 256) = make_float2(zz[0], zz[1]);
+      *reinterpret_cast<float2*>(rs + 2 * 256) = make_float2(nn[0], nn[1]);
+      *reinterpret_cast<float2*>(rs + 3 * 256) = make_float2(qq[0], qq[1]);
+      *reinterpret_cast<float2*>(rs + 4 * 256) = make_float2(hprev[0], hprev[1]);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { hprev[e] = hn[e]; gr[e] = ngr[e]; gz[e] = ngz[e]; gn[e] = ngn[e]; }
     __syncthreads();
   }
 }
@@ -337,6 +490,172 @@ gru_seq_bwd_kernel(const GruBwdParams p) {
   }
 }
 
+// 4-sequence BPTT (see gru_seq_fwd4_kernel): dh_{t-1} += [dr_pre, dz_pre, dq] (4 x 3H) * W_hh (3H x H).
+// Lane (half, u) of wave w owns output unit 32w+u and, for each of the three gate row-blocks of W_hh,
+// the k-range [half*H/2, (half+1)*H/2): 3H/4 resident registers, H/2 * 3 MFMAs per step, three
+// accumulator chains (one per gate block) summed at the end.  Element ownership after the fold is the
+// forward kernel's: lane (half, u) handles sequences 2*half + {0, 1} of unit 32w+u.
+// d_bias_part rows are per 4-sequence tile here: [cdiv(B,4)][D][6H] (slu_gru_bias_tiles).
+template <int H>
+__global__ void __launch_bounds__(H * 2)
+gru_seq_bwd4_kernel(const GruBwdParams p, const int NBT16) {
+  constexpr int NW16 = H / 16;
+  constexpr int KS = H / 2;
+  constexpr int NQ = KS / 8;
+  constexpr int LDB = 3 * H + 16;
+  static_assert(NQ % 4 == 0, "gru_seq_bwd4_kernel needs H >= 64");
+  __shared__ __attribute__((aligned(16))) float gbuf[2][4 * LDB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u = lane & 31, half = lane >> 5, blk = (lane >> 2) & 7, si = lane & 3;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 4;
+  const int j = w * 32 + u;
+  const int T = p.T, B = p.B, D = p.D;
+
+  float wr[KS], wz[KS], wn[KS];   // W_hh[gate*H + half*KS + k][j]
+  {
+    const float* __restrict__ W = p.w_hh[dir] + j;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      wr[k] = W[((size_t)(0 * H + half * KS + k)) * H];
+      wz[k] = W[((size_t)(1 * H + half * KS + k)) * H];
+      wn[k] = W[((size_t)(2 * H + half * KS + k)) * H];
+    }
+  }
+  bool rowok[2];
+  size_t grow[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int b = b0 + 2 * half + e;
+    rowok[e] = b < B;
+    grow[e] = (size_t)(rowok[e] ? b : 0);
+  }
+  const size_t out_ts = (size_t)B * D * H;
+  const size_t gx_ts = (size_t)B * D * 3 * H;
+  const float* __restrict__ dod = p.d_out + (size_t)dir * H + j;
+  float* __restrict__ dgxd = p.d_gx + (size_t)dir * 3 * H + j;
+  float* __restrict__ dghd = p.d_gh + (size_t)dir * 3 * H + j;
+  const size_t rsv_lane = ((size_t)((j & 15) + 16 * ((b0 & 15) >> 2))) * 4 + 2 * half;
+  const size_t rsv_wave = (size_t)(b0 >> 4) * NW16 + (j >> 4);
+
+  float dcarry[2] = {0.f, 0.f};
+  float sbr = 0.f, sbz = 0.f, sbn = 0.f, sbq = 0.f;
+  auto tindex = [&](int s) { return dir ? s : T - 1 - s; };
+  auto rsv = [&](int t) {
+    return p.reserve + ((((size_t)dir * T + t) * NBT16) * NW16 + rsv_wave) * (5 * 256) + rsv_lane;
+  };
+
+  // saved gates / upstream gradient of the current step (prefetched one step ahead)
+  float2 c_r, c_z, c_n, c_q, c_h;
+  float c_do[2];
+  {
+    const int t = tindex(0);
+    const float* rs = rsv(t);
+    c_r = *reinterpret_cast<const float2*>(rs);
+    c_z = *reinterpret_cast<const float2*>(rs + 256);
+    c_n = *reinterpret_cast<const float2*>(rs + 512);
+    c_q = *reinterpret_cast<const float2*>(rs + 768);
+    c_h = *reinterpret_cast<const float2*>(rs + 1024);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float v = dod[(size_t)t * out_ts + grow[e] * D * H];
+      c_do[e] = rowok[e] ? v : 0.f;
+    }
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const int t = tindex(s);
+    const int cur = s & 1;
+    const int tn = tindex(s + 1 < T ? s + 1 : s);
+    const float* rsn = rsv(tn);
+    const float2 n_r = *reinterpret_cast<const float2*>(rsn);
+    const float2 n_z = *reinterpret_cast<const float2*>(rsn + 256);
+    const float2 n_n = *reinterpret_cast<const float2*>(rsn + 512);
+    const float2 n_q = *reinterpret_cast<const float2*>(rsn + 768);
+    const float2 n_h = *reinterpret_cast<const float2*>(rsn + 1024);
+    float n_do[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float v = dod[(size_t)tn * out_ts + grow[e] * D * H];
+      n_do[e] = rowok[e] ? v : 0.f;
+    }
+
+    const float rr[2] = {c_r.x, c_r.y}, zz[2] = {c_z.x, c_z.y}, nn[2] = {c_n.x, c_n.y};
+    const float qq[2] = {c_q.x, c_q.y}, hp[2] = {c_h.x, c_h.y};
+    float ddirect[2];
+    float* __restrict__ gcur = &gbuf[cur][0];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float dh = dcarry[e] + c_do[e];
+      const float omz = 1.0f - zz[e];
+      const float dn_pre = dh * (omz * (1.0f - nn[e] * nn[e]));
+      const float dz_pre = dh * ((hp[e] - nn[e]) * (zz[e] * omz));
+      const float dq = dn_pre * rr[e];
+      const float dr_pre = dn_pre * (qq[e] * (rr[e] * (1.0f - rr[e])));
+      ddirect[e] = dh * zz[e];
+      const int row = 2 * half + e;
+      gcur[row * LDB + 0 * H + j] = dr_pre;
+      gcur[row * LDB + 1 * H + j] = dz_pre;
+      gcur[row * LDB + 2 * H + j] = dq;
+      if (rowok[e]) {
+        float* g = dgxd + (size_t)t * gx_ts + grow[e] * D * 3 * H;
+        g[0] = dr_pre; g[H] = dz_pre; g[2 * H] = dn_pre;
+        float* gh = dghd + (size_t)t * gx_ts + grow[e] * D * 3 * H;
+        gh[0] = dr_pre; gh[H] = dz_pre; gh[2 * H] = dq;
+        sbr += dr_pre; sbz += dz_pre; sbn += dn_pre; sbq += dq;
+      }
+    }
+    __syncthreads();
+
+    float a0[NQ], a1[NQ], a2[NQ];
+    {
+      const float* __restrict__ grow_l = &gbuf[cur][si * LDB + half * KS + 4 * blk];
+#pragma unroll
+      for (int v = 0; v < NQ / 4; ++v) {
+        const float4 x0 = *reinterpret_cast<const float4*>(grow_l + 0 * H + 32 * v);
+        const float4 x1 = *reinterpret_cast<const float4*>(grow_l + 1 * H + 32 * v);
+        const float4 x2 = *reinterpret_cast<const float4*>(grow_l + 2 * H + 32 * v);
+        a0[4 * v] = x0.x; a0[4 * v + 1] = x0.y; a0[4 * v + 2] = x0.z; a0[4 * v + 3] = x0.w;
+        a1[4 * v] = x1.x; a1[4 * v + 1] = x1.y; a1[4 * v + 2] = x1.z; a1[4 * v + 3] = x1.w;
+        a2[4 * v] = x2.x; a2[4 * v + 1] = x2.y; a2[4 * v + 2] = x2.z; a2[4 * v + 3] = x2.w;
+      }
+    }
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int kb = (q / 4) * 32 + (q % 4);
+#define SLU_GRU4_STEP(a)                                                        \
+      ar = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q], wr[kb + 4 * a], ar, 3, a, 0); \
+      az = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q], wz[kb + 4 * a], az, 3, a, 0); \
+      an = __builtin_amdgcn_mfma_f32_4x4x1f32(a2[q], wn[kb + 4 * a], an, 3, a, 0);
+      SLU_GRU4_STEP(0) SLU_GRU4_STEP(1) SLU_GRU4_STEP(2) SLU_GRU4_STEP(3)
+      SLU_GRU4_STEP(4) SLU_GRU4_STEP(5) SLU_GRU4_STEP(6) SLU_GRU4_STEP(7)
+#undef SLU_GRU4_STEP
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float lo = (ar[e] + az[e]) + an[e];
+      const float hi = (ar[e + 2] + az[e + 2]) + an[e + 2];
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+      dcarry[e] = ddirect[e] + (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+      c_do[e] = n_do[e];
+    }
+    c_r = n_r; c_z = n_z; c_n = n_n; c_q = n_q; c_h = n_h;
+    // gbuf[cur] is rewritten two steps from now; the barrier of the next step orders that.
+  }
+
+  if (p.d_bias_part) {
+    sbr += __shfl_xor(sbr, 32); sbz += __shfl_xor(sbz, 32);
+    sbn += __shfl_xor(sbn, 32); sbq += __shfl_xor(sbq, 32);
+    if (half == 0) {
+      float* o = p.d_bias_part + ((size_t)blockIdx.x * D + dir) * 6 * H;
+      o[j] = sbr; o[H + j] = sbz; o[2 * H + j] = sbn;
+      o[3 * H + j] = sbr; o[4 * H + j] = sbz; o[5 * H + j] = sbq;
+    }
+  }
+}
+
 }  // namespace slu
 
 using namespace slu;
@@ -344,6 +663,19 @@ using namespace slu;
 extern "C" size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t D) {
   const int64_t nbt = cdiv(B, 16);
   return (size_t)(D * T * nbt * (H / 16) * 5 * 256) * sizeof(float);
+}
+
+// 4-sequence workgroups while the 16-sequence grid would leave CUs idle (SLU_GRU_TILE=4|16 forces one)
+static bool gru_use_seq4(int64_t B, int64_t H, int64_t D) {
+  static const int forced = getenv("SLU_GRU_TILE") ? atoi(getenv("SLU_GRU_TILE")) : 0;
+  if (H != 64 && H != 128) return false;
+  if (forced == 4) return true;
+  if (forced == 16) return false;
+  return cdiv(B, 16) * D < 256;
+}
+
+extern "C" int64_t slu_gru_bias_tiles(int64_t B, int64_t H, int64_t D) {
+  return gru_use_seq4(B, H, D) ? cdiv(B, 4) : cdiv(B, 16);
 }
 
 static int gru_check(const char* who, int64_t T, int64_t B, int64_t H, int64_t D) {
@@ -366,8 +698,16 @@ extern "C" int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const flo
   GruFwdParams p;
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
   p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
-  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   hipStream_t st = (hipStream_t)stream;
+  if (gru_use_seq4(B, H, D)) {
+    dim3 grid4((unsigned)cdiv(B, 4), (unsigned)D);
+    const int nbt16 = (int)cdiv(B, 16);
+    if (H == 64) hipLaunchKernelGGL(gru_seq_fwd4_kernel<64>, grid4, dim3(128), 0, st, p, nbt16);
+    else hipLaunchKernelGGL(gru_seq_fwd4_kernel<128>, grid4, dim3(256), 0, st, p, nbt16);
+    SLU_CHECK_LAUNCH("gru_seq_fwd4_kernel");
+    return SLU_OK;
+  }
+  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   switch (H) {
     case 16: hipLaunchKernelGGL(gru_seq_fwd_kernel<16>, grid, dim3(64), 0, st, p); break;
     case 32: hipLaunchKernelGGL(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, p); break;
@@ -388,8 +728,16 @@ extern "C" int slu_gru_seq_bwd(const float* d_out, const float* reserve, const f
   GruBwdParams p;
   p.d_out = d_out; p.reserve = reserve; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev;
   p.d_gx = d_gx; p.d_gh = d_gh; p.d_bias_part = d_bias_part; p.T = (int)T; p.B = (int)B; p.D = (int)D;
-  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   hipStream_t st = (hipStream_t)stream;
+  if (gru_use_seq4(B, H, D)) {
+    dim3 grid4((unsigned)cdiv(B, 4), (unsigned)D);
+    const int nbt16 = (int)cdiv(B, 16);
+    if (H == 64) hipLaunchKernelGGL(gru_seq_bwd4_kernel<64>, grid4, dim3(128), 0, st, p, nbt16);
+    else hipLaunchKernelGGL(gru_seq_bwd4_kernel<128>, grid4, dim3(256), 0, st, p, nbt16);
+    SLU_CHECK_LAUNCH("gru_seq_bwd4_kernel");
+    return SLU_OK;
+  }
+  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   switch (H) {
     case 16: hipLaunchKernelGGL(gru_seq_bwd_kernel<16>, grid, dim3(64), 0, st, p); break;
     case 32: hipLaunchKernelGGL(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, p); break;
