@@ -2,8 +2,10 @@
 // followed by Downsample models.py:26-46: "none" = strided slice, "avg"/"max" = pool1d with
 // ceil_mode=True, where a partial last window uses only the frames that exist).
 //
-// Pure HBM-bound elementwise work: one thread per output element, channel index fastest so that
-// every wave access is a contiguous 256-byte row segment.
+// Pure HBM-bound elementwise work.  Main path (C % 4 == 0): one thread per four consecutive channels
+// (float4 accesses, a wave covers a contiguous 1 KB row segment), 2-D grid (time on y) so that all
+// index arithmetic is 32-bit, and ONE Philox4x32-10 evaluation per four elements (its four output
+// words are exactly the four channels).  A scalar kernel covers other channel counts.
 #include "slu_common.h"
 
 namespace slu {
@@ -112,6 +114,112 @@ dropout_pool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ 
   dx[idx] = out;
 }
 
+// ---- vector path: four consecutive channels per thread -----------------------------------------
+__device__ __forceinline__ float4 keep_scale4(const PoolParams& q, uint64_t off_base, int t, int b, int c) {
+  if (q.p <= 0.0f) return make_float4(1.f, 1.f, 1.f, 1.f);
+  if (q.mask) {
+    const float* m = q.mask + (long long)t * q.m_st + (long long)b * q.m_sb + c;
+    return make_float4(m[0] * q.scale, m[1] * q.scale, m[2] * q.scale, m[3] * q.scale);
+  }
+  uint64_t off = off_base;
+  uint64_t idx;
+  if (q.sub_batch > 0) {
+    const int k = b / q.sub_batch, bl = b - k * q.sub_batch;
+    idx = ((uint64_t)t * q.sub_batch + bl) * q.C + c;
+    off += (uint64_t)k * q.sub_stride;
+  } else {
+    idx = ((uint64_t)t * q.B + b) * q.C + c;
+  }
+  // idx % 4 == 0 (C % 4 == 0, c % 4 == 0): the four words of one Philox block are elements idx .. idx+3
+  uint32_t cw[4] = {(uint32_t)(idx >> 2), (uint32_t)(idx >> 34), (uint32_t)off, (uint32_t)(off >> 32)};
+  uint32_t kw[2] = {(uint32_t)q.seed, (uint32_t)(q.seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(cw, kw);
+  const float thr = 1.0f - q.p;
+  float4 o;
+  o.x = ((float)(cw[0] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
+  o.y = ((float)(cw[1] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
+  o.z = ((float)(cw[2] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
+  o.w = ((float)(cw[3] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
+  return o;
+}
+
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// grid: x over B*C/4 quads, y over output frames
+__global__ void __launch_bounds__(256)
+dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, const PoolParams q) {
+  const int C4 = q.C >> 2;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= (unsigned)q.B * C4) return;
+  const int b = e / C4, c = (e - b * C4) * 4;
+  const int to = blockIdx.y;
+  const int t0 = to * q.factor;
+  const size_t row = (size_t)q.B * q.C;
+  const size_t col = (size_t)b * q.C + c;
+  const uint64_t off = q.offset + (q.offset_dev ? *q.offset_dev : 0ull);
+  float4 acc;
+  if (q.method == 0) {
+    acc = mul4(*reinterpret_cast<const float4*>(x + t0 * row + col), keep_scale4(q, off, t0, b, c));
+  } else {
+    const int t1 = min(q.T, t0 + q.factor);
+    acc = (q.method == 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int t = t0; t < t1; ++t) {
+      const float4 v = mul4(*reinterpret_cast<const float4*>(x + t * row + col), keep_scale4(q, off, t, b, c));
+      if (q.method == 1) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      else { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
+    }
+    if (q.method == 1) {
+      const float n = (float)(t1 - t0);
+      acc.x = acc.x / n; acc.y = acc.y / n; acc.z = acc.z / n; acc.w = acc.w / n;
+    }
+  }
+  *reinterpret_cast<float4*>(y + to * row + col) = acc;
+}
+
+// grid: x over B*C/4 quads, y over OUTPUT frames; a thread writes dx for every input frame of its window
+__global__ void __launch_bounds__(256)
+dropout_pool_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                         float* __restrict__ dx, const PoolParams q) {
+  const int C4 = q.C >> 2;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= (unsigned)q.B * C4) return;
+  const int b = e / C4, c = (e - b * C4) * 4;
+  const int to = blockIdx.y;
+  const int t0 = to * q.factor;
+  const int t1 = min(q.T, t0 + q.factor);
+  const size_t row = (size_t)q.B * q.C;
+  const size_t col = (size_t)b * q.C + c;
+  const uint64_t off = q.offset + (q.offset_dev ? *q.offset_dev : 0ull);
+  const float4 g = *reinterpret_cast<const float4*>(dy + to * row + col);
+  if (q.method == 0) {
+    *reinterpret_cast<float4*>(dx + t0 * row + col) = mul4(g, keep_scale4(q, off, t0, b, c));
+    for (int t = t0 + 1; t < t1; ++t) *reinterpret_cast<float4*>(dx + t * row + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else if (q.method == 1) {
+    const float n = (float)(t1 - t0);
+    for (int t = t0; t < t1; ++t) {
+      const float4 k = keep_scale4(q, off, t, b, c);
+      *reinterpret_cast<float4*>(dx + t * row + col) = make_float4(g.x * k.x / n, g.y * k.y / n, g.z * k.z / n, g.w * k.w / n);
+    }
+  } else {
+    // arg-max per channel (first maximum wins, as in the scalar kernel and ATen's max_pool1d)
+    int ax = t0, ay = t0, az = t0, aw = t0;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int t = t0; t < t1; ++t) {
+      const float4 v = mul4(*reinterpret_cast<const float4*>(x + t * row + col), keep_scale4(q, off, t, b, c));
+      if (v.x > best.x) { best.x = v.x; ax = t; }
+      if (v.y > best.y) { best.y = v.y; ay = t; }
+      if (v.z > best.z) { best.z = v.z; az = t; }
+      if (v.w > best.w) { best.w = v.w; aw = t; }
+    }
+    for (int t = t0; t < t1; ++t) {
+      const float4 k = keep_scale4(q, off, t, b, c);
+      *reinterpret_cast<float4*>(dx + t * row + col) =
+          make_float4(ax == t ? g.x * k.x : 0.f, ay == t ? g.y * k.y : 0.f, az == t ? g.z * k.z : 0.f, aw == t ? g.w * k.w : 0.f);
+    }
+  }
+}
+
 static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t m_st, int64_t m_sb,
                      float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                      int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, int64_t T,
@@ -127,6 +235,14 @@ static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t 
   return SLU_OK;
 }
 
+// float4 path: channel count and every row start 16-byte aligned, grid within limits
+static bool pool_vec_ok(const PoolParams& q, const float* a, const float* b, const float* mask) {
+  if (q.C % 4 != 0 || q.T_out > 65535 || (long long)q.B * q.C >= (1LL << 31)) return false;
+  if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15)) return false;
+  (void)mask;   // explicit masks are read with scalar loads (arbitrary strides)
+  return true;
+}
+
 }  // namespace slu
 
 using namespace slu;
@@ -140,6 +256,12 @@ extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m
   PoolParams q;
   int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
+  if (pool_vec_ok(q, x, y, mask)) {
+    hipLaunchKernelGGL(dropout_pool_fwd4_kernel, dim3((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out),
+                       dim3(256), 0, (hipStream_t)stream, x, y, q);
+    SLU_CHECK_LAUNCH("dropout_pool_fwd4_kernel");
+    return SLU_OK;
+  }
   const long long total = (long long)q.T_out * B * C;
   hipLaunchKernelGGL(dropout_pool_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, x, y, q);
@@ -159,6 +281,12 @@ extern "C" int slu_dropout_pool_bwd(const float* dy, const float* x, const float
   PoolParams q;
   int rc = pool_fill(q, "slu_dropout_pool_bwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
+  if (pool_vec_ok(q, dy, dx, mask) && (method != 2 || (reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+    hipLaunchKernelGGL(dropout_pool_bwd4_kernel, dim3((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out),
+                       dim3(256), 0, (hipStream_t)stream, dy, x, dx, q);
+    SLU_CHECK_LAUNCH("dropout_pool_bwd4_kernel");
+    return SLU_OK;
+  }
   const long long total = (long long)T * B * C;
   hipLaunchKernelGGL(dropout_pool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, dy, x, dx, q);
