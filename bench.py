@@ -78,7 +78,10 @@ def run_steps(model, trainer, batches, n):
     sums = torch.zeros(2, dtype=torch.float64, device=dev)
     loader = [batches[i % len(batches)] for i in range(n)]
     for vals, _ in trainer._iterate(loader, True, False):
-        sums += torch.stack([v.detach().double() for v in vals])
+        if torch.is_tensor(vals):
+            sums.add_(vals)
+        else:
+            sums += torch.stack([v.detach().double() for v in vals])
     return sums
 
 
@@ -233,6 +236,10 @@ def main():
     payload = trainer.bucket.nbytes() if trainer.bucket is not None else 0
 
     if rank == 0:
+        look = trainer.lookahead_depth(True, False)[0]
+        if look:
+            import training
+            look = training._lookahead_width(look, args.batch)
         out = {
             "metric": "utterances/sec (train step, 3 s @16 kHz, B=64)",
             "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -249,18 +256,18 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "samples_per_utterance": samples, "parallelism": "dp%d" % world,
                        "allreduce_bytes_per_step": payload, "mean_loss": round(loss_mean, 5),
-                       "encoder_lookahead_batches": trainer.lookahead_depth(True, False)[0]},
+                       "encoder_lookahead_batches": look},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
-                         "kernel": "gru_seq_fwd_kernel<128>",
+                         "kernel": "gru_seq_fwd4_kernel<128> / gru_seq_fwd_kernel<128>",
                          "launches": len(prof), "avg_launch_ms": round(kms / max(len(prof), 1), 4),
                          "note": "fp32 MFMA flops of h(BxH)*W_hh^T(Hx3H) per recurrence step, both directions, "
                                  "summed over the launches of an eager re-run of the timed steps / their HIP-event "
                                  "durations; a launch covers %d sequences (look-ahead super-batch of the frozen "
-                                 "layers) or %d (trainable intent layer): %d or %d workgroups on 256 CUs" %
-                                 (args.batch * max(1, trainer.lookahead_depth(True, False)[0]), args.batch,
-                                  2 * -(-args.batch * max(1, trainer.lookahead_depth(True, False)[0]) // 16),
-                                  2 * -(-args.batch // 16))},
+                                 "layers) or %d (trainable intent layer): %d or %d 4-sequence workgroups "
+                                 "(v_mfma_f32_4x4x1) on 256 CUs" %
+                                 (args.batch * max(1, look), args.batch,
+                                  2 * -(-args.batch * max(1, look) // 4), 2 * -(-args.batch // 4))},
         }
         if not args.no_large_batch and args.workload == "no_unfreezing":
             note("large-batch point")

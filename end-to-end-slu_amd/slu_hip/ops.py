@@ -311,6 +311,7 @@ class IntentHeadFn(torch.autograd.Function):
     """final_classifier Linear -> FinalPool (max over time) -> per-slot cross-entropy / accuracy
     (reference models.py:709, :112-123, :811-821).  h time-major (T,B,C), y (B,S) int64.
     Returns (loss, acc, logits (B,V), pred (B,S)); only `loss` carries a gradient."""
+    last_loss_acc = None
 
     @staticmethod
     def forward(ctx, h, weight, bias, y, values_per_slot):
@@ -320,14 +321,18 @@ class IntentHeadFn(torch.autograd.Function):
         loss_acc, logits, pred, argmax_t, d_logits = cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, need)
         if need:
             ctx.save_for_backward(h, weight, argmax_t, d_logits)
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for acc / logits / pred
         ctx.mark_non_differentiable(logits, pred)
         acc = loss_acc[1]
         ctx.mark_non_differentiable(acc)
+        IntentHeadFn.last_loss_acc = loss_acc  # (2,) float32 [loss, acc]: one-kernel metric accumulation
         return loss_acc[0], acc, logits, pred
 
     @staticmethod
     def backward(ctx, d_loss, _d_acc, _d_logits, _d_pred):
         L = _lib.load()
+        if d_loss is None:
+            return None, None, None, None, None
         h, weight, argmax_t, d_logits = ctx.saved_tensors
         T, B, C = h.shape
         V = weight.shape[0]

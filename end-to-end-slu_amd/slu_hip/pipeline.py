@@ -16,6 +16,8 @@ import os
 
 import torch
 
+from . import ops
+
 
 class PrefixSlot:
     """One in-flight SUPER-BATCH: the frozen prefix of the encoder evaluated for several upcoming
@@ -112,10 +114,12 @@ class StepGraph:
         self.world = dp.world()[1]
         torch.cuda.synchronize()
         bucket.release_grads()
+        self.one = torch.ones((), dtype=torch.float32, device=dev)      # root gradient (no per-step fill)
         self.g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g1, stream=stream, capture_error_mode="thread_local"):
             self.loss, self.acc = model.forward_from(self.feats, n_prefix, self.y, self.rng)
-            self.loss.backward()
+            self.loss_acc = ops.IntentHeadFn.last_loss_acc
+            self.loss.backward(self.one)
             if self.world > 1:
                 bucket.pack()                       # one concatenation kernel per dtype; .grad -> slices
         self.g2 = torch.cuda.CUDAGraph()
@@ -135,7 +139,7 @@ class StepGraph:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
                 flat.div_(self.world)
         self.g2.replay()
-        return self.loss, self.acc
+        return self.loss_acc
 
 
 def graphs_enabled():

@@ -29,6 +29,18 @@ def models_masks_injected():
     return models._DropoutState.masks is not None
 
 
+def _lookahead_env():
+    """SLU_LOOKAHEAD: number of batches per look-ahead super-batch; unset / "auto" -> -1 (by batch size)."""
+    v = os.environ.get("SLU_LOOKAHEAD", "auto")
+    return -1 if v == "auto" else int(v)
+
+
+def _lookahead_width(depth, batch_size):
+    if depth > 0:
+        return depth
+    return max(2, min(32, 512 // max(1, batch_size)))
+
+
 class Trainer:
     def __init__(self, model, config):
         self.model = model
@@ -116,10 +128,12 @@ class Trainer:
         """How many batches ahead the FROZEN prefix of the encoder is evaluated on side HIP streams
         (0 = plain sequential steps).  Only SLU training with a frozen prefix qualifies: a frozen
         stage's output does not depend on earlier optimisation steps.  At 64 utterances per step a
-        recurrence occupies 8 of 256 CUs, so several batches' encoders run concurrently for free;
-        the per-batch dropout streams are step-indexed, so the result is the sequential one."""
-        depth = int(os.environ.get("SLU_LOOKAHEAD", "16"))
-        if not train or asr or depth < 2 or not hasattr(self.model, "prefix_features"):
+        recurrence occupies a fraction of the 256 CUs, so several batches' encoders run as one
+        super-batch; the per-batch dropout streams are step-indexed, so the result is the sequential
+        one.  depth -1 = automatic: as many batches as make a super-batch of ~512 utterances (one
+        4-sequence recurrence workgroup per CU and direction)."""
+        depth = _lookahead_env()
+        if not train or asr or depth in (0, 1) or not hasattr(self.model, "prefix_features"):
             return 0, 0
         if not all(p.is_cuda for p in self.model.parameters()) or models_masks_injected():
             return 0, 0
@@ -131,10 +145,9 @@ class Trainer:
         depth, n_prefix = self.lookahead_depth(train, asr)
         group_eval = (not train and not asr and hasattr(self.model, "eval_group") and not models_masks_injected()
                       and all(p.is_cuda for p in self.model.parameters())
-                      and int(os.environ.get("SLU_LOOKAHEAD", "16")) > 1)
+                      and _lookahead_env() not in (0, 1))
         if group_eval:
             # evaluation has no step-to-step dependency at all: whole batches are grouped
-            width = int(os.environ.get("SLU_LOOKAHEAD", "16"))
             group = []
 
             def flush():
@@ -144,7 +157,8 @@ class Trainer:
                 return out
 
             for batch in loader:
-                if group and (tuple(batch[0].shape) != tuple(group[0][0].shape) or len(group) == width):
+                if group and (tuple(batch[0].shape) != tuple(group[0][0].shape)
+                              or len(group) == _lookahead_width(_lookahead_env(), len(group[0][0]))):
                     yield from flush()
                 group.append(batch)
             if group:
@@ -193,7 +207,7 @@ class Trainer:
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
             nonlocal launched
             group = [carry.pop()] if carry else []
-            while len(group) < depth:
+            while not group or len(group) < _lookahead_width(depth, len(group[0][0])):
                 try:
                     batch = next(it)
                 except StopIteration:
@@ -235,18 +249,19 @@ class Trainer:
                             print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
                             self._eager_steps[key] = -(1 << 30)
                     if sg is not None:
-                        loss, acc = sg.run(feats, y, steps[k])
+                        vals = sg.run(feats, y, steps[k])          # (2,) device tensor [loss, acc]
                     else:
                         self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
                         loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
                         self._step(loss)
+                        vals = [loss, acc]
                     if k == len(group) - 1:
                         slot.consumed = torch.cuda.Event()
                         slot.consumed.record(main)
                 if k == len(group) - 1:
                     launch_next()
                 outer.wait_stream(main)
-                yield [loss, acc], len(batch[0])
+                yield vals, len(batch[0])
                 main.wait_stream(outer)
 
     def _run(self, dataset, train, print_interval):
@@ -265,8 +280,12 @@ class Trainer:
             it = tqdm(it)
         for idx, (vals, batch_size) in enumerate(self._iterate(it, train, asr)):
             num_examples += batch_size
-            step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
-            sums += step_vals * batch_size
+            if torch.is_tensor(vals):                              # captured step: one fused accumulate
+                step_vals = vals
+                sums.add_(vals, alpha=batch_size)
+            else:
+                step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
+                sums += step_vals * batch_size
             if train and idx % print_interval == 0 and self.rank == 0:
                 for n, v in zip(names, step_vals.tolist()):       # one host sync per print interval
                     print(n + ": " + str(v))
