@@ -172,8 +172,8 @@ _T0 = time.perf_counter()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="no_unfreezing", choices=["no_unfreezing", "unfreeze_all"])
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=SECONDS)

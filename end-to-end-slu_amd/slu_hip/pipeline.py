@@ -19,6 +19,35 @@ import torch
 from . import ops
 
 
+def cu_split(device=None):
+    """CUs [0, n) of the device are reserved for the trainable part of the step, the look-ahead
+    super-batches get the rest.  Without the partition the big frozen-prefix kernels keep every CU
+    busy and each of the ~25 small, latency-bound kernels of the trainable part waits for workgroup
+    slots (measured: the two streams then take almost the SUM of their times).  Default: a quarter of
+    the device (64 of 256 CUs, best of a 0..128 sweep on MI355X); SLU_CU_SPLIT=n overrides, 0 = off."""
+    v = os.environ.get("SLU_CU_SPLIT", "auto")
+    if v != "auto":
+        return int(v)
+    if not torch.cuda.is_available():
+        return 0
+    return n_compute_units(torch.cuda.current_device() if device is None else device) // 4
+
+
+def cu_range_stream(device, first, count):
+    """A HIP stream confined to CUs [first, first + count) (slu_stream_create_cu_range), wrapped for torch."""
+    import ctypes
+    from . import lib as _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(L.slu_stream_create_cu_range(first, count, ctypes.byref(h)), "slu_stream_create_cu_range")
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
+def n_compute_units(device):
+    return torch.cuda.get_device_properties(device).multi_processor_count
+
+
 class PrefixSlot:
     """One in-flight SUPER-BATCH: the frozen prefix of the encoder evaluated for several upcoming
     batches at once (concatenated along the batch axis) on this slot's side stream.  The recurrence
@@ -28,7 +57,9 @@ class PrefixSlot:
 
     def __init__(self, device):
         self.device = device
-        self.stream = torch.cuda.Stream(device)
+        n = cu_split()
+        self.stream = (cu_range_stream(device, n, n_compute_units(device) - n) if n > 0
+                       else torch.cuda.Stream(device))
         self.rng = torch.zeros(1, dtype=torch.int64, device=device)      # step0*16, read by the kernels
         self.graphs = {}
         self.consumed = None       # event: the main stream is done with this slot's last output
@@ -37,14 +68,17 @@ class PrefixSlot:
     def invalidate(self):
         self.graphs = {}
 
-    def run(self, model, xs, n_prefix, step0, use_graph):
+    def run(self, model, xs, n_prefix, step0, use_graph, after=None):
         """Enqueue stages [0, n_prefix) for the batches `xs` (equal shapes; consecutive dropout steps
-        step0, step0+1, ...) on this slot's stream.  Returns (features of the concatenated batch,
-        event recorded when they are complete)."""
+        step0, step0+1, ...) on this slot's stream, after the event `after` (the previous super-batch:
+        two super-batches side by side would only delay the one the training step is waiting for).
+        Returns (features of the concatenated batch, event recorded when they are complete)."""
         B, T = xs[0].shape
         with torch.cuda.stream(self.stream):
             if self.consumed is not None:
                 self.stream.wait_event(self.consumed)
+            if after is not None:
+                self.stream.wait_event(after)
             feats = None
             if use_graph:
                 key = (len(xs), B, T, n_prefix, bool(model.training))

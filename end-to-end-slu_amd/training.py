@@ -36,9 +36,15 @@ def _lookahead_env():
 
 
 def _lookahead_width(depth, batch_size):
+    """Batches per look-ahead super-batch: explicit, or as many as give every CU the side streams may use
+    one 4-sequence recurrence workgroup per direction (2 sequences per CU: 512 on a whole MI355X)."""
     if depth > 0:
         return depth
-    return max(2, min(32, 512 // max(1, batch_size)))
+    from slu_hip import pipeline
+    cus = 256
+    if torch.cuda.is_available():
+        cus = pipeline.n_compute_units(torch.cuda.current_device()) - pipeline.cu_split()
+    return max(2, min(32, (2 * cus) // max(1, batch_size)))
 
 
 class Trainer:
@@ -182,7 +188,10 @@ class Trainer:
         outer = torch.cuda.current_stream()
         dev = next(self.model.parameters()).device
         if getattr(self, "_train_stream", None) is None:
-            self._train_stream = torch.cuda.Stream(dev, priority=-1)      # ahead of the look-ahead streams
+            from slu_hip import pipeline as _pl
+            n_cu = _pl.cu_split()
+            self._train_stream = (_pl.cu_range_stream(dev, 0, n_cu) if n_cu > 0
+                                  else torch.cuda.Stream(dev, priority=-1))     # ahead of the look-ahead streams
         main = self._train_stream
         main.wait_stream(outer)
         if getattr(self, "_slots", None) is None:
@@ -202,6 +211,7 @@ class Trainer:
         it = iter(loader)
         carry = []                                    # a batch read ahead that did not fit its group
         launched = 0
+        last_done = [None]
 
         def launch_next():
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
@@ -221,48 +231,53 @@ class Trainer:
             slot = self._slots[launched % 2]
             launched += 1
             steps = [next_rng_step() for _ in group]                        # consecutive by construction
-            feats, done = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph)
+            feats, done = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
+                                   after=last_done[0])
+            last_done[0] = done
             pending.append((group, feats, done, steps, slot))
             return True
 
-        launch_next()
-        launch_next()
-        while pending:
-            group, feats_cat, done, steps, slot = pending.popleft()
-            B = group[0][0].shape[0]
-            for k, batch in enumerate(group):
-                with torch.cuda.stream(main):
-                    if k == 0:
-                        main.wait_event(done)
-                        feats_cat.record_stream(main)
-                    feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
-                    y = batch[1]
-                    key = (tuple(feats.shape), tuple(y.shape), n_prefix)
-                    sg = self._step_graphs.get(key) if use_graph else None
-                    if sg is not None and sg.signature != self.bucket.signature:
-                        sg = None                                   # trainable set changed since capture
-                    if sg is None and use_graph and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:
-                        try:
-                            sg = pipeline.StepGraph(self, feats, y, n_prefix, main)
-                            self._step_graphs[key] = sg
-                        except Exception as e:                      # keep training eagerly if capture fails
-                            print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
-                            self._eager_steps[key] = -(1 << 30)
-                    if sg is not None:
-                        vals = sg.run(feats, y, steps[k])          # (2,) device tensor [loss, acc]
-                    else:
-                        self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
-                        loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
-                        self._step(loss)
-                        vals = [loss, acc]
-                    if k == len(group) - 1:
-                        slot.consumed = torch.cuda.Event()
-                        slot.consumed.record(main)
-                if k == len(group) - 1:
-                    launch_next()
-                outer.wait_stream(main)
-                yield vals, len(batch[0])
-                main.wait_stream(outer)
+        # The consumer's per-step work (metric accumulation in _run) runs with `main` as the current
+        # stream: ordered after the step without touching the default stream, whose legacy
+        # synchronisation with blocking streams (the CU-masked ones) would serialise the pipeline.
+        try:
+            with torch.cuda.stream(main):
+                launch_next()
+                launch_next()
+                while pending:
+                    group, feats_cat, done, steps, slot = pending.popleft()
+                    B = group[0][0].shape[0]
+                    for k, batch in enumerate(group):
+                        if k == 0:
+                            main.wait_event(done)
+                            feats_cat.record_stream(main)
+                        feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
+                        y = batch[1]
+                        key = (tuple(feats.shape), tuple(y.shape), n_prefix)
+                        sg = self._step_graphs.get(key) if use_graph else None
+                        if sg is not None and sg.signature != self.bucket.signature:
+                            sg = None                                   # trainable set changed since capture
+                        if sg is None and use_graph and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:
+                            try:
+                                sg = pipeline.StepGraph(self, feats, y, n_prefix, main)
+                                self._step_graphs[key] = sg
+                            except Exception as e:                      # keep training eagerly if capture fails
+                                print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
+                                self._eager_steps[key] = -(1 << 30)
+                        if sg is not None:
+                            vals = sg.run(feats, y, steps[k])          # (2,) device tensor [loss, acc]
+                        else:
+                            self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
+                            loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
+                            self._step(loss)
+                            vals = [loss, acc]
+                        if k == len(group) - 1:
+                            slot.consumed = torch.cuda.Event()
+                            slot.consumed.record(main)
+                            launch_next()
+                        yield vals, len(batch[0])
+        finally:
+            outer.wait_stream(main)
 
     def _run(self, dataset, train, print_interval):
         asr = self._is_asr(dataset)

@@ -47,6 +47,9 @@ int slu_version(void);                    /* returns SLU_ABI_VERSION            
 const char* slu_last_error(void);         /* thread-local, never NULL                          */
 int slu_device_check(void);               /* 0 iff the current HIP device is gfx950            */
 const char* slu_device_arch(void);        /* gcnArchName of the current device ("" on failure) */
+/* HIP stream restricted to CUs [first_cu, first_cu + n_cus) (mask bit i lands on XCD i mod 8, so a
+ * contiguous range is spread over all XCDs); look-ahead pipeline of training.Trainer. Never freed. */
+int slu_stream_create_cu_range(int64_t first_cu, int64_t n_cus, void** stream_out);
 
 /* -------- Sinc filterbank: models.py:79-106 (SincLayer.forward up to the conv), :7-24 ------- */
 /* filters[n_filt][filt_dim] (float32) from the two float64 parameters, filt_dim odd.            */

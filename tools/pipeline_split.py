@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Where does the pipelined step time go?  Times, on one GPU, (a) the captured trainable suffix of the
+step alone (StepGraph replays back to back), (b) the captured frozen prefix alone (super-batch graph
+replays back to back) and (c) the pipelined loop, so that overlap quality = (a + b/P) vs (c) is visible.
+    python tools/pipeline_split.py [--batch 64] [--lookahead 8]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "end-to-end-slu_amd"))
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--lookahead", type=int, default=8)
+ap.add_argument("--steps", type=int, default=128)
+a = ap.parse_args()
+os.environ["SLU_LOOKAHEAD"] = str(a.lookahead)
+import bench
+
+config, model, trainer, train_ds, work = bench.setup("no_unfreezing", 0, a.batch, 48000, 4)
+dev = next(model.parameters()).device
+batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]
+bench.run_steps(model, trainer, batches, 64)          # warm-up: captures the graphs
+torch.cuda.synchronize()
+
+def wall(fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); fn(n); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+t_pipe = wall(lambda n: bench.run_steps(model, trainer, batches, n), a.steps)
+sg = next(iter(trainer._step_graphs.values()))
+main = trainer._train_stream
+def suffix(n):
+    with torch.cuda.stream(main):
+        for i in range(n):
+            sg.run(sg.feats, sg.y, 1000 + i)
+t_suffix = wall(suffix, a.steps)
+slot = trainer._slots[0]
+(graph, x_static, feats) = next(v for v in slot.graphs.values() if v is not None)
+def prefix(n):
+    with torch.cuda.stream(slot.stream):
+        for i in range(n):
+            graph.replay()
+t_prefix = wall(prefix, 16)
+P = a.lookahead
+print("pipelined step        : %8.1f us" % t_pipe)
+print("suffix alone (graphs) : %8.1f us / step" % t_suffix)
+print("prefix alone (graph)  : %8.1f us / super-batch of %d = %8.1f us / step" % (t_prefix, P, t_prefix / P))
+print("sum                   : %8.1f us   (perfect overlap would approach max = %.1f us)" %
+      (t_suffix + t_prefix / P, max(t_suffix, t_prefix / P)))
+
+# (d) both at once, no dependencies between them: is the hardware running the two streams concurrently?
+def both(n):
+    for _ in range(n):
+        with torch.cuda.stream(slot.stream):
+            graph.replay()
+        with torch.cuda.stream(main):
+            for i in range(P):
+                sg.run(sg.feats, sg.y, 2000 + i)
+t_both = wall(both, 8)
+print("prefix graph + %d suffix steps enqueued together: %8.1f us per group = %6.1f us / step "
+      "(serial would be %.1f, ideal overlap %.1f)" % (P, t_both, t_both / P, t_suffix + t_prefix / P,
+                                                       max(t_suffix, t_prefix / P)))
+
+# (e) CPU cost of enqueueing (no synchronisation inside the timed region; queues drained before)
+def cpu_cost(fn, n):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); fn(n); t1 = time.perf_counter(); torch.cuda.synchronize()
+    return (t1 - t0) / n * 1e6
+print("CPU enqueue cost: suffix step %.1f us, prefix super-batch graph %.1f us" %
+      (cpu_cost(suffix, 12), cpu_cost(prefix, 4)))
+def g1_only(n):
+    with torch.cuda.stream(main):
+        for i in range(n):
+            sg.g1.replay()
+def g2_only(n):
+    with torch.cuda.stream(main):
+        for i in range(n):
+            sg.g2.replay()
+print("CPU enqueue cost: G1 replay %.1f us, G2 replay %.1f us" % (cpu_cost(g1_only, 12), cpu_cost(g2_only, 12)))
