@@ -112,8 +112,9 @@ template <bool A_KFAST, bool B_KFAST, int WT>
 __global__ void __launch_bounds__(GM_THREADS)
 gemm_f32_kernel(const GemmParams p) {
   constexpr int GM_BM = 32 * WT, GM_BN = 32 * WT, WR = 16 * WT;
-  __shared__ __attribute__((aligned(16))) float sA[GM_BM * GM_KPV];
-  __shared__ __attribute__((aligned(16))) float sB[GM_BN * GM_KPV];
+  __shared__ __attribute__((aligned(16))) float smem[(GM_BM + GM_BN) * GM_KPV];
+  float* const sA = smem;
+  float* const sB = smem + GM_BM * GM_KPV;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -159,39 +160,74 @@ gemm_f32_kernel(const GemmParams p) {
   }
 
   // epilogue: lane holds D[row = 4*kg + r][col = i] of each 16x16 tile
-  if (p.ws) {
-    float* __restrict__ w = p.ws + (size_t)blockIdx.z * p.M * p.N;
+  float* __restrict__ outp = p.ws ? p.ws + (size_t)blockIdx.z * p.M * p.N : p.C;
+  const long long o_rs = p.ws ? p.N : p.c_rs, o_cs = p.ws ? 1 : p.c_cs;
+  const bool with_bias = !p.ws && p.bias, with_acc = !p.ws && p.accumulate;
+  if (WT == 2 && o_cs == 1 && (o_rs & 3) == 0 && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0)) {
+    // Row-major output: stage the 64 x 64 tile in LDS (the operand tiles are dead) and write whole
+    // 256-byte rows with float4 stores; a direct store from the MFMA layout is 64-byte pieces.
+    constexpr int LDC = GM_BN + 4;     // 4 k-groups x 4 rows land 16 banks apart: conflict-free
+    static_assert(GM_BM * LDC <= 2 * GM_BM * GM_KPV || WT != 2, "C tile must fit in the operand tiles");
+    float* __restrict__ sC = sA;       // sA and sB are adjacent: 2 * 64 * 36 floats >= 64 * 68
+    __syncthreads();
 #pragma unroll
     for (int a = 0; a < WT; ++a)
 #pragma unroll
-      for (int b = 0; b < WT; ++b) {
-        const int n = n0 + wn * WR + b * 16 + i;
-        if (n >= p.N) continue;
+      for (int b = 0; b < WT; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * WR + a * 16 + 4 * kg + r;
-          if (m < p.M) w[(size_t)m * p.N + n] = acc[a][b][r];
+        for (int r = 0; r < 4; ++r)
+          sC[(wm * WR + a * 16 + 4 * kg + r) * LDC + wn * WR + b * 16 + i] = acc[a][b][r];
+    __syncthreads();
+    const int col = 4 * (tid & 15);
+    const int n = n0 + col;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (with_bias && n + 3 < p.N) {
+      bv.x = p.bias[n]; bv.y = p.bias[n + 1]; bv.z = p.bias[n + 2]; bv.w = p.bias[n + 3];
+    }
+#pragma unroll
+    for (int h = 0; h < GM_BM / 16; ++h) {
+      const int row = (tid >> 4) + 16 * h;
+      const int m = m0 + row;
+      if (m >= p.M) continue;
+      const float4 v = *reinterpret_cast<const float4*>(&sC[row * LDC + col]);
+      float* c = outp + (long long)m * o_rs + n;
+      if (n + 3 < p.N) {
+        float4 o = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+        if (with_acc) {
+          const float4 old = *reinterpret_cast<const float4*>(c);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(c) = o;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (n + j >= p.N) continue;
+          float o = vv[j] + (with_bias ? p.bias[n + j] : 0.0f);
+          if (with_acc) o += c[j];
+          c[j] = o;
         }
       }
-  } else {
-#pragma unroll
-    for (int a = 0; a < WT; ++a)
-#pragma unroll
-      for (int b = 0; b < WT; ++b) {
-        const int n = n0 + wn * WR + b * 16 + i;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * WR + a * 16 + 4 * kg + r;
-          if (m >= p.M) continue;
-          float* c = p.C + (long long)m * p.c_rs + (long long)n * p.c_cs;
-          float v = acc[a][b][r] + bias;
-          if (p.accumulate) v += *c;
-          *c = v;
-        }
-      }
+    }
+    return;
   }
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+      const int n = n0 + wn * WR + b * 16 + i;
+      if (n >= p.N) continue;
+      const float bias = with_bias ? p.bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * WR + a * 16 + 4 * kg + r;
+        if (m >= p.M) continue;
+        float* c = outp + (long long)m * o_rs + (long long)n * o_cs;
+        float v = acc[a][b][r] + bias;
+        if (with_acc) v += *c;
+        *c = v;
+      }
+    }
 }
 
 __global__ void __launch_bounds__(256)

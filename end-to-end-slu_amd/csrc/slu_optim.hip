@@ -1,0 +1,122 @@
+// Adam update for up to SLU_ADAM_MAX_TENSORS parameter tensors in ONE launch (reference:
+// torch.optim.Adam(model.parameters(), lr) at training.py:19, defaults betas (0.9, 0.999), eps 1e-8,
+// no weight decay / amsgrad).  The training step of the frozen-encoder configuration updates ten small
+// tensors (1.2 MB): a launch per tensor, or torch's capturable multi-tensor kernel (45 us of per-element
+// double-precision pow), costs more than the whole intent-GRU recurrence.  Here the tensor list
+// travels by value in the kernel arguments (hipGraph-safe), the step count lives in device memory so a
+// captured graph can be replayed, and the bias corrections are computed once per workgroup.
+//   m <- m + (g - m)(1 - b1);  v <- b2 v + (1 - b2) g^2
+//   p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)        (torch's formulation)
+#include "slu_common.h"
+
+#include <cmath>
+
+namespace slu {
+
+constexpr int ADAM_MAX_TENSORS = 32;
+constexpr int ADAM_CHUNK = 1024;       // elements per workgroup (256 threads x 4)
+
+struct AdamList {
+  void* p[ADAM_MAX_TENSORS];
+  const void* g[ADAM_MAX_TENSORS];
+  void* m[ADAM_MAX_TENSORS];
+  void* v[ADAM_MAX_TENSORS];
+  long long n[ADAM_MAX_TENSORS];
+  int chunk_end[ADAM_MAX_TENSORS];     // exclusive prefix of chunk counts
+  int count;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, const double lr,
+                  const double b1, const double b2, const double eps) {
+  __shared__ float s_coef[2];
+  if (threadIdx.x == 0) {
+    const double t = (double)(*step_dev + 1);
+    s_coef[0] = (float)(lr / (1.0 - pow(b1, t)));          // step size
+    s_coef[1] = (float)sqrt(1.0 - pow(b2, t));             // sqrt of bias correction 2
+  }
+  int k = 0;
+  while (k + 1 < L.count && (int)blockIdx.x >= L.chunk_end[k]) ++k;
+  const int chunk = blockIdx.x - (k ? L.chunk_end[k - 1] : 0);
+  __syncthreads();
+  const float step_size = s_coef[0], bc2_sqrt = s_coef[1];
+  const float fb1 = (float)b1, fb2 = (float)b2, feps = (float)eps;
+  T* __restrict__ p = reinterpret_cast<T*>(L.p[k]);
+  const T* __restrict__ g = reinterpret_cast<const T*>(L.g[k]);
+  T* __restrict__ m = reinterpret_cast<T*>(L.m[k]);
+  T* __restrict__ v = reinterpret_cast<T*>(L.v[k]);
+  const long long n = L.n[k];
+  const long long base = (long long)chunk * ADAM_CHUNK;
+#pragma unroll
+  for (int u = 0; u < ADAM_CHUNK / 256; ++u) {
+    const long long e = base + u * 256 + threadIdx.x;
+    if (e >= n) continue;
+    if (sizeof(T) == 4) {
+      const float gg = (float)g[e];
+      float mm = (float)m[e], vv = (float)v[e];
+      mm = mm + (gg - mm) * (1.0f - fb1);
+      vv = fb2 * vv + (1.0f - fb2) * gg * gg;
+      const float denom = sqrtf(vv) / bc2_sqrt + feps;
+      p[e] = (T)((float)p[e] - step_size * (mm / denom));
+      m[e] = (T)mm; v[e] = (T)vv;
+    } else {                       // float64 parameters (the Sinc band edges): double arithmetic
+      const double gg = (double)g[e];
+      double mm = (double)m[e], vv = (double)v[e];
+      mm = mm + (gg - mm) * (1.0 - b1);
+      vv = b2 * vv + (1.0 - b2) * gg * gg;
+      const double t = (double)(*step_dev + 1);
+      const double denom = sqrt(vv) / sqrt(1.0 - pow(b2, t)) + eps;
+      p[e] = (T)((double)p[e] - (lr / (1.0 - pow(b1, t))) * (mm / denom));
+      m[e] = (T)mm; v[e] = (T)vv;
+    }
+  }
+}
+
+__global__ void adam_step_inc_kernel(long long* step_dev, int count) {
+  if ((int)threadIdx.x < count) step_dev[threadIdx.x] += 1;
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" int slu_adam_max_tensors(void) { return ADAM_MAX_TENSORS; }
+
+// One Adam update of `count` tensors of one dtype (elem_bytes 4 = float32, 8 = float64); the step
+// counter (*step_dev, int64, number of updates done so far) is NOT advanced: call
+// slu_adam_advance_step (which adds 1 to `count` consecutive counters) once per optimisation step
+// after all the tensor lists.
+extern "C" int slu_adam_multi(void* const* params, const void* const* grads, void* const* exp_avg,
+                              void* const* exp_avg_sq, const int64_t* numel, int64_t count,
+                              int elem_bytes, const int64_t* step_dev, double lr, double beta1,
+                              double beta2, double eps, void* stream) {
+  SLU_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && step_dev, "slu_adam_multi: null pointer");
+  SLU_REQUIRE(count > 0 && count <= ADAM_MAX_TENSORS, "slu_adam_multi: 1..%d tensors per call", ADAM_MAX_TENSORS);
+  SLU_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "slu_adam_multi: elem_bytes must be 4 or 8");
+  AdamList L;
+  int chunks = 0;
+  for (int k = 0; k < (int)count; ++k) {
+    SLU_REQUIRE(params[k] && grads[k] && exp_avg[k] && exp_avg_sq[k] && numel[k] > 0, "slu_adam_multi: bad tensor %d", k);
+    L.p[k] = params[k]; L.g[k] = grads[k]; L.m[k] = exp_avg[k]; L.v[k] = exp_avg_sq[k]; L.n[k] = numel[k];
+    chunks += (int)cdiv(numel[k], ADAM_CHUNK);
+    L.chunk_end[k] = chunks;
+  }
+  L.count = (int)count;
+  hipStream_t st = (hipStream_t)stream;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(adam_multi_kernel<float>, dim3((unsigned)chunks), dim3(256), 0, st, L,
+                       (const long long*)step_dev, lr, beta1, beta2, eps);
+  else
+    hipLaunchKernelGGL(adam_multi_kernel<double>, dim3((unsigned)chunks), dim3(256), 0, st, L,
+                       (const long long*)step_dev, lr, beta1, beta2, eps);
+  SLU_CHECK_LAUNCH("adam_multi_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_adam_advance_step(int64_t* step_dev, int64_t count, void* stream) {
+  SLU_REQUIRE(step_dev && count > 0 && count <= 256, "slu_adam_advance_step: bad arguments");
+  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long long*)step_dev, (int)count);
+  SLU_CHECK_LAUNCH("adam_step_inc_kernel");
+  return SLU_OK;
+}

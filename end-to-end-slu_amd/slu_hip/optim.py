@@ -1,0 +1,83 @@
+"""Adam on the HIP kernels: the update rule, defaults and per-parameter step counting of
+torch.optim.Adam (what the reference builds at training.py:19), one launch per (dtype, cohort) instead of
+torch's capturable multi-tensor kernel.  A cohort = the parameters that received their first gradient at
+the same optimisation step (gradual unfreezing adds cohorts); each has its own device-resident step
+counter, so a hipGraph-captured optimiser step can be replayed."""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+
+class HipAdam(torch.optim.Optimizer):
+    MAX_COHORTS = 64
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._steps = None            # int64 device vector: updates done so far, per cohort
+        self._n_cohorts = 0
+        self._plan = None             # cached launch arguments, keyed by the identity of every (param, grad)
+        self._plan_key = None
+
+    def _build(self):
+        L = _lib.load()
+        vmax = L.slu_adam_max_tensors()
+        new_cohort = None
+        lists = {}
+        key = []
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.grad.layout != torch.strided:
+                    raise TypeError("HipAdam needs dense CUDA parameters")
+                st = self.state[p]
+                if not st:
+                    if new_cohort is None:
+                        if self._n_cohorts >= self.MAX_COHORTS:
+                            raise RuntimeError("HipAdam: more than %d parameter cohorts" % self.MAX_COHORTS)
+                        new_cohort = self._n_cohorts
+                        self._n_cohorts += 1
+                    st["cohort"] = new_cohort
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if p.dtype not in (torch.float32, torch.float64) or p.grad.dtype != p.dtype:
+                    raise TypeError("HipAdam supports float32 / float64 parameters")
+                if not (p.is_contiguous() and p.grad.is_contiguous()):
+                    raise TypeError("HipAdam needs contiguous parameters and gradients")
+                lists.setdefault((gi, p.dtype, st["cohort"]), []).append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
+                key.append((p.data_ptr(), p.grad.data_ptr()))
+        if self._steps is None and lists:
+            dev = next(iter(lists.values()))[0][0].device
+            self._steps = torch.zeros(self.MAX_COHORTS, dtype=torch.int64, device=dev)
+        plan = []
+        for (gi, dtype, cohort), items in lists.items():
+            for i in range(0, len(items), vmax):
+                part = items[i:i + vmax]
+                n = len(part)
+                arr = lambda j: (ctypes.c_void_p * n)(*[t[j].data_ptr() for t in part])
+                numel = (ctypes.c_int64 * n)(*[t[0].numel() for t in part])
+                plan.append((gi, arr(0), arr(1), arr(2), arr(3), numel, n, 4 if dtype == torch.float32 else 8, cohort))
+        return plan, tuple(key)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        L = _lib.load()
+        # the launch arguments are rebuilt only when a parameter / gradient address changed
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for g in self.param_groups for p in g["params"]
+                    if p.grad is not None)
+        if key != self._plan_key:
+            self._plan, self._plan_key = self._build()
+        if not self._plan:
+            return loss
+        stream = torch.cuda.current_stream().cuda_stream
+        base = self._steps.data_ptr()
+        for gi, p, g, m, v, numel, n, eb, cohort in self._plan:
+            grp = self.param_groups[gi]
+            b1, b2 = grp["betas"]
+            _lib.check(L.slu_adam_multi(p, g, m, v, numel, n, eb, base + 8 * cohort, float(grp["lr"]), float(b1),
+                                        float(b2), float(grp["eps"]), stream), "slu_adam_multi")
+        _lib.check(L.slu_adam_advance_step(base, self._n_cohorts, stream), "slu_adam_advance_step")
+        return loss

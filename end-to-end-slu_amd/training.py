@@ -57,11 +57,14 @@ class Trainer:
         else:
             self.lr = config.training_lr
             self.checkpoint_path = os.path.join(self.config.folder, "training")
-        # same optimiser and defaults as the reference (training.py:19); on a GPU torch's single-kernel
-        # "fused" implementation is selected (same update rule, one launch instead of ~10 per step)
+        # same optimiser and defaults as the reference (training.py:19); on a GPU the update runs as one
+        # launch per dtype on the HIP kernel (slu_hip/optim.py: same rule and per-parameter step counts)
         on_gpu = all(p.is_cuda for p in model.parameters())
-        self.optimizer = torch.optim.Adam(model.parameters(), lr=self.lr,
-                                          **({"fused": True, "capturable": True} if on_gpu else {}))
+        if on_gpu:
+            from slu_hip.optim import HipAdam
+            self.optimizer = HipAdam(model.parameters(), lr=self.lr)
+        else:
+            self.optimizer = torch.optim.Adam(model.parameters(), lr=self.lr)
         self.epoch = 0
         self.df = None
         self.rank, self.world_size = dp.world()

@@ -184,6 +184,19 @@ int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const
                            float* d_weight, float* d_bias, int64_t T, int64_t B, int64_t C,
                            int64_t V, void* stream);
 
+/* -------- Adam: torch.optim.Adam(model.parameters(), lr) (training.py:19, default betas / eps) ------
+ * One launch updates up to slu_adam_max_tensors() tensors of one dtype (elem_bytes 4 / 8); the pointer
+ * arrays are HOST arrays of device pointers (they travel in the kernel arguments: hipGraph-safe).
+ * *step_dev (int64, device) = number of updates these tensors have received so far; it is read, not
+ * advanced: slu_adam_advance_step adds 1 to `count` consecutive counters once per optimisation step.
+ *   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr/(1 - b1^t) * m / (sqrt(v)/sqrt(1 - b2^t) + eps) */
+int slu_adam_max_tensors(void);
+int slu_adam_multi(void* const* params, const void* const* grads, void* const* exp_avg,
+                   void* const* exp_avg_sq, const int64_t* numel, int64_t count, int elem_bytes,
+                   const int64_t* step_dev, double lr, double beta1, double beta2, double eps,
+                   void* stream);
+int slu_adam_advance_step(int64_t* step_dev, int64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

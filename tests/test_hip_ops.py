@@ -311,3 +311,36 @@ def test_intent_head_fused_vs_torch(ops, T, B, C, vps):
     # inference form: no labels
     _, lg3, p3, _, _ = ops.cls_maxpool_ce_fwd(hg.detach(), Wg.detach(), bg.detach(), None, vps, False)
     assert torch.equal(lg3, lg2) and torch.equal(p3, p2)
+
+
+# ---------------------------------------------------------------------------------------------
+# Adam (slu_optim.hip) against torch.optim.Adam, the optimiser the reference constructs (training.py:19)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_hip_adam_matches_torch_adam():
+    from slu_hip.optim import HipAdam
+    torch.manual_seed(5)
+    shapes = [(384, 256), (384,), (5, 7, 3), (1,), (1030,), (80,)]
+    dtypes = [torch.float32, torch.float32, torch.float32, torch.float32, torch.float32, torch.float64]
+    ref = [torch.randn(s, dtype=d).requires_grad_() for s, d in zip(shapes, dtypes)]
+    late = torch.randn(33, 9).requires_grad_()                    # starts receiving gradients at step 3
+    ours = [r.detach().clone().cuda().requires_grad_() for r in ref + [late]]
+    ref = ref + [late]
+    o_ref = torch.optim.Adam(ref, lr=3e-3)
+    o_hip = HipAdam(ours, lr=3e-3)
+    for step in range(6):
+        for k, (r, o) in enumerate(zip(ref, ours)):
+            if k == len(ref) - 1 and step < 3:
+                r.grad = None
+                o.grad = None
+                continue
+            g = torch.randn(r.shape, dtype=r.dtype) * (10.0 ** (step - 3))
+            r.grad = g.clone()
+            o.grad = g.cuda()
+        o_ref.step()
+        o_hip.step()
+    for r, o in zip(ref, ours):
+        tol = 2e-6 if r.dtype == torch.float32 else 1e-12
+        assert torch.allclose(o.detach().cpu(), r.detach(), rtol=tol, atol=tol * r.detach().abs().max().item()), r.shape
+    # per-parameter step counts: the late tensor is three updates behind
+    assert o_hip._steps[:2].tolist() == [6, 3]
