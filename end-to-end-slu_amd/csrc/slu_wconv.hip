@@ -105,20 +105,35 @@ wconv_fwd_kernel(const WconvParams p) {
   for (int m = 0; m < MT; ++m) abase[m] = (wave * 16 * MT + m * 16 + i) * p.Sp;
   const float* __restrict__ wp = p.wp + lane;
 
-  for (int kk = 0; kk < p.KK; ++kk) {
+  // operands of k-step kk+1 are fetched (LDS window, L1/L2-resident packed filters) before the MFMAs
+  // of k-step kk are issued: the load latency hides under MT*NT*32 MFMA cycles instead of stalling
+  float a_n[MT], b_n[NT];
+  {
     const int off = qd * p.Sp + qm;
-    float a[MT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a[m] = lds[abase[m] + off];
-    float bv[NT];
+    for (int m = 0; m < MT; ++m) a_n[m] = lds[abase[m] + off];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bv[n] = wp[((size_t)kk * NT + n) * 64];
+    for (int n = 0; n < NT; ++n) b_n[n] = wp[(size_t)n * 64];
+  }
+  for (int kk = 0; kk < p.KK; ++kk) {
+    float a[MT], bv[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[m] = a_n[m];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bv[n] = b_n[n];
+    if (kk + 1 < p.KK) {
+      qm += 4;
+      while (qm >= p.S) { qm -= p.S; ++qd; }
+      const int off = qd * p.Sp + qm;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_n[m] = lds[abase[m] + off];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b_n[n] = wp[((size_t)(kk + 1) * NT + n) * 64];
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[m][n] = mfma16(a[m], bv[n], acc[m][n]);
-    qm += 4;
-    while (qm >= p.S) { qm -= p.S; ++qd; }
   }
 
   // ---- epilogue: bias, abs, max-pool over frame pairs, LeakyReLU, strided store ----

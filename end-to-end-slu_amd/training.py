@@ -37,14 +37,15 @@ def _lookahead_env():
 
 def _lookahead_width(depth, batch_size):
     """Batches per look-ahead super-batch: explicit, or as many as give every CU the side streams may use
-    one 4-sequence recurrence workgroup per direction (2 sequences per CU: 512 on a whole MI355X)."""
+    two 4-sequence recurrence workgroups (its register-limited occupancy) per direction, i.e. 4 sequences
+    per CU: 768 on the 192 CUs of the default partition (best of a 4..14 sweep on MI355X)."""
     if depth > 0:
         return depth
     from slu_hip import pipeline
     cus = 256
     if torch.cuda.is_available():
         cus = pipeline.n_compute_units(torch.cuda.current_device()) - pipeline.cu_split()
-    return max(2, min(32, (2 * cus) // max(1, batch_size)))
+    return max(2, min(32, (4 * cus) // max(1, batch_size)))
 
 
 class Trainer:

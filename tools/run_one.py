@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs one kernel shape repeatedly (for rocprofv3 --pmc passes): python tools/run_one.py gemm|gru"""
+"""Runs one kernel shape repeatedly (for rocprofv3 --pmc passes): python tools/run_one.py gemm|gemmbig|gru [B]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "end-to-end-slu_amd"))
@@ -17,7 +17,7 @@ elif what == "gemmbig":
     for _ in range(10):
         ops.gemm(a, w.t(), None, out=out)
 elif what == "gru":
-    T, B, H = 300, 64, 128
+    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 128
     gx = torch.randn(T, B, 6 * H, device="cuda")
     wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
