@@ -8,15 +8,19 @@ legacy cfgs the reference's own parser rejects (they carry `dataset_subset_perce
 the four `*_subset_percentage` keys): the legacy key maps to
 `real_dataset_subset_percentage`, the other three default to 1.0.
 
-The wav/CSV/TextGrid loaders of the reference (data.py:132-545) are IO outside the MI355X hot path
-("next"); this module provides Fluent-Speech-Commands-shaped and
-LibriSpeech-shaped SYNTHETIC datasets with the same duck type (`.loader` yielding the same batch
-tuples; class names `SLUDataset` / `ASRDataset`, which `training.Trainer` dispatches on).
+Datasets: `get_SLU_datasets` / `SLUDataset` / `CollateWavsSLU` read a Fluent-Speech-Commands tree
+(CSV splits + wavs) with the reference's split / subset / label-dictionary logic (data.py:132-376;
+SURVEY.md §8(f) rank 1), feeding pinned, zero-padded (B, T_max) batches to the encoder; with
+`slu_path = synthetic[:NxBxT]` (and always for ASR pre-training, whose LibriSpeech + TextGrid reader is
+not built) FSC- / LibriSpeech-shaped SYNTHETIC datasets with the same duck type are served (`.loader`
+yielding the same batch tuples; `training.Trainer` dispatches on `SLUDataset` / `ASRDataset`).
 """
 import configparser
 import os
 import shutil
+from collections import Counter
 
+import numpy as np
 import torch
 
 
@@ -170,7 +174,101 @@ class _SyntheticLoader:
         return len(self.batches)
 
 
+def read_wav(path):
+    """First channel of a wav file as float32 in [-1, 1) and its sample rate — the array
+    `SoxEffectsChain.sox_build_flow_effects()` hands the reference (data.py:273-293; augmentation is
+    hard-wired off there, so the chain is a plain decode): PCM16 / 32768, PCM32 / 2^31, unsigned 8-bit
+    (v - 128) / 128, float wavs as stored."""
+    from scipy.io import wavfile
+    fs, a = wavfile.read(path)
+    if a.ndim > 1:
+        a = a[:, 0]
+    if a.dtype == np.int16:
+        x = a.astype(np.float32) / 32768.0
+    elif a.dtype == np.int32:
+        x = (a.astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif a.dtype == np.uint8:
+        x = (a.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = a.astype(np.float32)
+    return x, fs
+
+
+class CollateWavsSLU:
+    """list of (waveform, [action, object, location]) -> (x (B, T_max) float32 zero-padded at the end,
+    y_intent (B, 3) int64), as reference data.py:344-376 (non-seq2seq branch).  The batch is assembled
+    directly in ONE buffer (pinned when `pin` and a GPU is present, so the H2D copy of the look-ahead
+    slots is asynchronous) instead of per-row pad + stack."""
+
+    def __init__(self, Sy_intent, seq2seq, pin=False, pad_multiple=None):
+        if seq2seq:
+            raise NotImplementedError("seq2seq collation (reference data.py:363-376) is out of scope")
+        self.Sy_intent = Sy_intent
+        self.num_labels = len(self.Sy_intent)
+        self.seq2seq = seq2seq
+        self.pin = pin
+        # Opt-in (SLU_PAD_TO_MULTIPLE=n samples): round T_max up to a multiple of n so that ragged real
+        # data falls into a few batch shapes (the look-ahead super-batches and hipGraphs are per shape).
+        # Off by default: the extra trailing zeros are seen by the recurrences, i.e. it is not the
+        # reference's batch any more.
+        self.pad_multiple = int(os.environ.get("SLU_PAD_TO_MULTIPLE", "0")) if pad_multiple is None else pad_multiple
+
+    def __call__(self, batch):
+        T = max(len(x) for x, _ in batch)
+        if self.pad_multiple > 1:
+            T = -(-T // self.pad_multiple) * self.pad_multiple
+        x = torch.zeros(len(batch), T, dtype=torch.float32)
+        for i, (xi, _) in enumerate(batch):
+            x[i, :len(xi)] = torch.as_tensor(np.asarray(xi), dtype=torch.float32)
+        y = torch.tensor([list(yi) for _, yi in batch], dtype=torch.int64)
+        if self.pin and torch.cuda.is_available():
+            x, y = x.pin_memory(), y.pin_memory()
+        return x, y
+
+
+def _loader_workers():
+    """The reference starts one DataLoader worker per core (data.py:261); on a 256-thread MI355X host
+    that is all start-up cost, so the default is capped (SLU_DATA_WORKERS overrides, 0 = in-process)."""
+    env = os.environ.get("SLU_DATA_WORKERS")
+    if env is not None:
+        return int(env)
+    return min(16, os.cpu_count() or 1)
+
+
 class SLUDataset(torch.utils.data.Dataset):
+    """Fluent-Speech-Commands-style dataset (reference data.py:246-329): rows of `df` (columns path,
+    action, object, location), wavs under `base_path`; item = (float32 waveform, [3 label indices]);
+    `len` = rows x upsample_factor; `.loader` = shuffling DataLoader with CollateWavsSLU."""
+
+    def __init__(self, df, base_path, Sy_intent, config, upsample_factor=1):
+        self.df = df
+        self.base_path = base_path
+        self.Sy_intent = Sy_intent
+        self.upsample_factor = upsample_factor
+        self.augment = False
+        self.SNRs = [0, 5, 10, 15, 20]
+        self.seq2seq = config.seq2seq
+        if self.seq2seq:
+            raise NotImplementedError("seq2seq datasets (reference data.py:318-326) are out of scope")
+        # label lookup and paths as plain lists: no per-item DataFrame indexing in the workers
+        self._paths = [os.path.join(base_path, p) for p in df["path"].tolist()]
+        self._values = list(zip(df["action"].tolist(), df["object"].tolist(), df["location"].tolist()))
+        self.loader = torch.utils.data.DataLoader(
+            self, batch_size=config.training_batch_size, num_workers=_loader_workers(), shuffle=True,
+            collate_fn=CollateWavsSLU(self.Sy_intent, self.seq2seq, pin=True))
+
+    def __len__(self):
+        return len(self._paths) * self.upsample_factor
+
+    def __getitem__(self, idx):
+        idx = idx % len(self._paths)
+        x, _fs = read_wav(self._paths[idx])
+        # a slot value that never occurs in the training split raises KeyError here, as in the reference
+        y_intent = [self.Sy_intent[slot][v] for slot, v in zip(("action", "object", "location"), self._values[idx])]
+        return x, y_intent
+
+
+class SyntheticSLUDataset(SLUDataset):
     """Synthetic SLU dataset: `.loader` yields (x (B,T) float32, y_intent (B,3) int64) like
     CollateWavsSLU (reference data.py:344-376): zero-mean 0.1-RMS noise waveforms, uniform labels."""
 
@@ -238,28 +336,111 @@ def _synthetic_spec(path):
     return nb, bs, ns
 
 
-def get_SLU_datasets(config):
-    """(train, valid, test) SLU datasets; also sets config.values_per_slot / Sy_intent /
-    num_phonemes like the reference (data.py:132-240).  Only `slu_path = synthetic[:NxBxT]` is
-    served here; reading Fluent Speech Commands wavs is the "next" row of SURVEY.md §8(f)."""
-    spec = _synthetic_spec(config.slu_path)
-    if spec is None:
-        raise NotImplementedError(
-            "real-data SLU loading (CSV + wav decoding, reference data.py:132-391) is outside the "
-            "MI355X hot path of this package; set slu_path=synthetic[:<batches>x<batch>x<samples>]")
-    nb, bs, ns = spec
-    bs = bs or config.training_batch_size
-    config.values_per_slot = list(FSC_VALUES_PER_SLOT)
-    config.Sy_intent = synthetic_Sy_intent(config.values_per_slot)
+def _select_rows(df, count):
+    """`df.loc[np.random.choice(len(df), count, replace=False)]` of the reference (data.py:174,178):
+    label-based, which equals positional selection on a freshly read csv.  After a speaker subset of the
+    same csv the index has gaps and the reference raises KeyError; here the rows are then taken by
+    position (documented superset)."""
+    pick = np.random.choice(len(df), count, replace=False)
+    if df.index.is_unique and set(pick).issubset(set(df.index)):
+        return df.loc[pick]
+    return df.iloc[pick]
+
+
+def _speaker_subset(df, fraction):
+    speakers = np.array(list(Counter(df.speakerId)))
+    np.random.shuffle(speakers)
+    selected = speakers[:round(fraction * len(speakers))]
+    return df[df["speakerId"].isin(selected)]
+
+
+def _read_phoneme_count(config):
     phonemes = os.path.join(config.folder, "pretraining", "phonemes.txt")
     if os.path.isfile(phonemes):
         with open(phonemes) as f:
-            config.num_phonemes = len([ln for ln in f.read().split("\n") if ln != ""])
+            return len([ln for ln in f.read().split("\n") if ln != ""])
+    print("No phoneme file found.")
+    return None
+
+
+def get_SLU_datasets(config):
+    """(train, valid, test) SLU datasets; also sets config.values_per_slot / Sy_intent /
+    num_phonemes (reference data.py:132-240).  `slu_path` is a Fluent-Speech-Commands tree
+    (data/{synthetic,train,valid,test}_data.csv + wavs) or `synthetic[:NxBxT]`.  The numpy global RNG is
+    consumed in the reference's order (speaker shuffles, then row choices), so a seeded run selects the
+    same subsets."""
+    import pandas as pd
+    spec = _synthetic_spec(config.slu_path)
+    if spec is not None:
+        nb, bs, ns = spec
+        bs = bs or config.training_batch_size
+        config.values_per_slot = list(FSC_VALUES_PER_SLOT)
+        config.Sy_intent = synthetic_Sy_intent(config.values_per_slot)
+        n_ph = _read_phoneme_count(config)
+        config.num_phonemes = 42 if n_ph is None else n_ph
+        mk = lambda n, seed: SyntheticSLUDataset(n, bs, ns, config.values_per_slot, seed=seed,
+                                                 Sy_intent=config.Sy_intent)
+        return mk(nb, config.seed), mk(max(1, nb // 4), config.seed + 1), mk(max(1, nb // 4), config.seed + 2)
+    if config.seq2seq:
+        raise NotImplementedError("seq2seq datasets (reference data.py:143-146, 201-208) are out of scope")
+    base_path = config.slu_path
+    csv = lambda name: pd.read_csv(os.path.join(base_path, "data", name))
+    synthetic_train_df = csv("synthetic_data.csv")
+    real_train_df = csv("train_data.csv")
+    have_spk = "speakerId" in list(real_train_df) and "speakerId" in list(synthetic_train_df)
+    if have_spk:
+        if config.real_speaker_subset_percentage < 1:
+            real_train_df = _speaker_subset(real_train_df, config.real_speaker_subset_percentage)
+        if config.synthetic_speaker_subset_percentage < 1:
+            synthetic_train_df = _speaker_subset(synthetic_train_df, config.synthetic_speaker_subset_percentage)
     else:
-        print("No phoneme file found.")
-        config.num_phonemes = 42
-    mk = lambda n, seed: SLUDataset(n, bs, ns, config.values_per_slot, seed=seed, Sy_intent=config.Sy_intent)
-    return mk(nb, config.seed), mk(max(1, nb // 4), config.seed + 1), mk(max(1, nb // 4), config.seed + 2)
+        if "speakerId" in list(real_train_df):
+            real_train_df = real_train_df.drop(columns="speakerId")
+        if "speakerId" in list(synthetic_train_df):
+            synthetic_train_df = synthetic_train_df.drop(columns="speakerId")
+        for frac in (config.real_speaker_subset_percentage, config.synthetic_speaker_subset_percentage):
+            if frac < 1:
+                print("no speaker id listed in dataset .csv; ignoring speaker subset selection")
+    if config.real_dataset_subset_percentage < 1:
+        real_train_df = _select_rows(real_train_df, round(config.real_dataset_subset_percentage * len(real_train_df)))
+    if config.synthetic_dataset_subset_percentage < 1:
+        synthetic_train_df = _select_rows(
+            synthetic_train_df, round(config.synthetic_dataset_subset_percentage * len(synthetic_train_df)))
+    train_df = pd.concat([synthetic_train_df, real_train_df]).reset_index()
+    valid_df = csv("valid_data.csv")
+    test_df = csv("test_data.csv")
+
+    Sy_intent = {"action": {}, "object": {}, "location": {}}
+    values_per_slot = []
+    for slot in ["action", "object", "location"]:
+        slot_values = Counter(train_df[slot])          # first-appearance order, like the reference
+        for idx, value in enumerate(slot_values):
+            Sy_intent[slot][value] = idx
+        values_per_slot.append(len(slot_values))
+    config.values_per_slot = values_per_slot
+    config.Sy_intent = Sy_intent
+
+    def wordings(path):
+        with open(path, "r") as f:
+            return [line.strip() for line in f.readlines()]
+
+    if config.train_wording_path is not None:
+        train_df = train_df.loc[train_df.transcription.isin(wordings(config.train_wording_path))]
+        train_df = train_df.set_index(np.arange(len(train_df)))
+    if config.test_wording_path is not None:
+        keep = wordings(config.test_wording_path)
+        valid_df = valid_df.loc[valid_df.transcription.isin(keep)]
+        valid_df = valid_df.set_index(np.arange(len(valid_df)))
+        test_df = test_df.loc[test_df.transcription.isin(keep)]
+        test_df = test_df.set_index(np.arange(len(test_df)))
+
+    n_ph = _read_phoneme_count(config)
+    if n_ph is not None:
+        config.num_phonemes = n_ph
+    train_dataset = SLUDataset(train_df, base_path, Sy_intent, config, upsample_factor=config.dataset_upsample_factor)
+    valid_dataset = SLUDataset(valid_df, base_path, Sy_intent, config)
+    test_dataset = SLUDataset(test_df, base_path, Sy_intent, config)
+    return train_dataset, valid_dataset, test_dataset
 
 
 def get_ASR_datasets(config):

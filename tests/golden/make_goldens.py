@@ -456,9 +456,87 @@ def g9():
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def g10():
+    """Real-data SLU input pipeline (reference data.py:132-391) on the tiny FSC-shaped tree of
+    tests/slu_data_fixture.py: split/subset/wording logic and label dictionaries of get_SLU_datasets,
+    SLUDataset.__len__/__getitem__ and CollateWavsSLU.  torchaudio/sox is not installed: for this fixture
+    only, the sox effects chain the reference builds in __getitem__ (data.py:273-292, no effects with
+    augment=False: a plain decode) is replaced by a PCM16 -> float32 / 32768 wav read, so the fixture
+    pins path/label/padding logic and the sox sample convention, not sox's decoder."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import slu_data_fixture as fx
+    from scipy.io import wavfile
+
+    class _Chain:
+        def set_input_file(self, path):
+            self.path = path
+
+        def append_effect_to_chain(self, *a):
+            raise AssertionError("augmentation is disabled in the reference")
+
+        def sox_build_flow_effects(self):
+            fs, pcm = wavfile.read(self.path)
+            return torch.from_numpy(pcm.astype(np.float32) / 32768.0).unsqueeze(0), fs
+
+    sys.modules["torchaudio"].sox_effects = types.SimpleNamespace(SoxEffectsChain=_Chain)
+    res = {}
+    for name, (over, np_seed, tree_kw) in fx.VARIANTS.items():
+        root = tempfile.mkdtemp()
+        try:
+            fx.make_fsc_tree(root, seed=11, **tree_kw)
+            cfg = tiny_cfg(folder=root)
+            cfg.slu_path = root
+            cfg.seq2seq = False
+            cfg.training_batch_size = 4
+            cfg.real_speaker_subset_percentage = 1.0
+            cfg.synthetic_speaker_subset_percentage = 1.0
+            cfg.real_dataset_subset_percentage = 1.0
+            cfg.synthetic_dataset_subset_percentage = 1.0
+            cfg.train_wording_path = None
+            cfg.test_wording_path = None
+            cfg.dataset_upsample_factor = 1
+            for k, v in over.items():
+                setattr(cfg, k, os.path.join(root, v) if k.endswith("_path") else v)
+            np.random.seed(np_seed)
+            buf = io.StringIO()
+            stdout = sys.stdout
+            sys.stdout = buf
+            try:
+                tr, va, te = ref_data.get_SLU_datasets(cfg)
+            finally:
+                sys.stdout = stdout
+            entry = {"stdout": buf.getvalue(), "values_per_slot": cfg.values_per_slot, "Sy_intent": cfg.Sy_intent,
+                     "len": [len(tr), len(va), len(te)]}
+            for tag, ds in (("train", tr), ("valid", va), ("test", te)):
+                entry[tag + "_paths"] = [str(v) for v in ds.df.path.tolist()]
+                entry[tag + "_index"] = [int(v) for v in ds.df.index.tolist()]
+            # items: waveform digest + labels for a few indices (incl. one beyond len(df) when upsampled)
+            if name not in ("subsets", "real_subset"):   # items by index need the gap-free index of the other variants
+                idxs = [0, 1, len(tr.df) - 1] + ([len(tr.df) + 2] if len(tr) > len(tr.df) else [])
+                items = []
+                for i in idxs:
+                    x, y = tr[i]
+                    items.append({"idx": i, "n": int(len(x)), "sum": float(np.float64(x).sum()),
+                                  "first": [float(v) for v in x[:4]], "y": [int(v) for v in y], "dtype": str(x.dtype)})
+                entry["items"] = items
+            res[name] = entry
+        finally:
+            shutil.rmtree(root)
+    # collate: ragged float32 waveforms -> zero-padded batch
+    coll = ref_data.CollateWavsSLU({"action": {}, "object": {}, "location": {}}, False)
+    rs = np.random.RandomState(5)
+    batch = [(rs.randn(n).astype(np.float32), [int(rs.randint(6)), int(rs.randint(14)), int(rs.randint(4))])
+             for n in (7, 12, 3, 12, 9)]
+    x, y = coll(batch)
+    res["collate"] = {"lens": [7, 12, 3, 12, 9], "seed": 5, "x": npd(x).tolist(), "y": npd(y).tolist(),
+                      "x_dtype": str(x.dtype), "y_dtype": str(y.dtype)}
+    with open(os.path.join(OUT, "g10_slu_data.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY")
-    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9}
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10}
     for k, fn in fns.items():
         if only is None or k in only.split(","):
             fn()

@@ -1,0 +1,65 @@
+"""Builds a tiny Fluent-Speech-Commands-shaped directory (CSV splits + PCM16 wavs) deterministically.
+Shared by tests/golden/make_goldens.py (which runs the REFERENCE's data.py on it) and
+tests/test_data_real.py (which runs this package's data.py on an identical copy)."""
+import os
+
+import numpy as np
+import pandas as pd
+from scipy.io import wavfile
+
+ACTIONS = ["activate", "deactivate", "increase", "decrease", "change language", "bring"]
+OBJECTS = ["lights", "music", "volume", "heat", "lamp", "none", "newspaper", "shoes"]
+LOCATIONS = ["kitchen", "bedroom", "washroom", "none"]
+PHRASES = ["turn on the lights", "switch off the lamp", "louder please", "bring me my shoes", "make it hotter",
+           "lights off in the kitchen", "play some music"]
+
+
+def _rows(rs, split, n, speakers, with_speaker):
+    rows = []
+    for k in range(n):
+        spk = speakers[rs.randint(len(speakers))]
+        row = {"path": "wavs/speakers/%s/%s_%03d.wav" % (spk, split, k)}
+        if with_speaker:
+            row["speakerId"] = spk
+        row["transcription"] = PHRASES[rs.randint(len(PHRASES))]
+        row["action"] = ACTIONS[rs.randint(len(ACTIONS))]
+        row["object"] = OBJECTS[rs.randint(len(OBJECTS))]
+        row["location"] = LOCATIONS[rs.randint(len(LOCATIONS))]
+        rows.append(row)
+    return pd.DataFrame(rows)
+
+
+def make_fsc_tree(root, seed=0, with_speaker=True, sizes=(23, 11, 7, 5)):
+    """root/data/{train,synthetic,valid,test}_data.csv + root/wavs/... ; returns {split: DataFrame}."""
+    rs = np.random.RandomState(seed)
+    speakers = ["spk%02d" % i for i in range(6)]
+    os.makedirs(os.path.join(root, "data"), exist_ok=True)
+    out = {}
+    for split, n in zip(("train", "synthetic", "valid", "test"), sizes):
+        df = _rows(rs, split, n, speakers, with_speaker)
+        df.to_csv(os.path.join(root, "data", "%s_data.csv" % split))        # FSC csvs carry an unnamed index column
+        for p in df.path:
+            full = os.path.join(root, p)
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            n_samp = int(rs.randint(900, 2400))
+            pcm = (rs.randn(n_samp) * 3000).clip(-32768, 32767).astype(np.int16)
+            wavfile.write(full, 16000, pcm)
+        out[split] = df
+    with open(os.path.join(root, "train_wordings.txt"), "w") as f:
+        f.write("\n".join(PHRASES[:4]) + "\n")
+    with open(os.path.join(root, "test_wordings.txt"), "w") as f:
+        f.write("\n".join(PHRASES[2:6]) + "\n")
+    return out
+
+
+VARIANTS = {
+    # name: (config overrides, numpy seed set right before get_SLU_datasets, tree kwargs)
+    "default": ({}, 0, {}),
+    # (the reference raises KeyError when a speaker subset and a dataset subset hit the SAME csv: the
+    #  second selection is label-based on an index that has gaps by then)
+    "subsets": ({"real_speaker_subset_percentage": 0.5, "synthetic_dataset_subset_percentage": 0.5}, 7, {}),
+    "real_subset": ({"real_dataset_subset_percentage": 0.6}, 9, {}),
+    "wordings": ({"train_wording_path": "train_wordings.txt", "test_wording_path": "test_wordings.txt",
+                  "dataset_upsample_factor": 3}, 0, {}),
+    "no_speaker_column": ({"real_speaker_subset_percentage": 0.5}, 3, {"with_speaker": False}),
+}

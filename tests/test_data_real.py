@@ -1,0 +1,106 @@
+"""Real-data SLU input pipeline against fixture g10: the REFERENCE's
+get_SLU_datasets / SLUDataset / CollateWavsSLU (data.py:132-376) run by tests/golden/make_goldens.py on
+the tiny FSC-shaped tree of tests/slu_data_fixture.py."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import data
+import slu_data_fixture as fx
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g10_slu_data.json")))
+
+
+def _config(root, over):
+    cfg = types.SimpleNamespace(
+        slu_path=root, folder=root, seq2seq=False, training_batch_size=4, seed=1,
+        real_speaker_subset_percentage=1.0, synthetic_speaker_subset_percentage=1.0,
+        real_dataset_subset_percentage=1.0, synthetic_dataset_subset_percentage=1.0,
+        train_wording_path=None, test_wording_path=None, dataset_upsample_factor=1)
+    for k, v in over.items():
+        setattr(cfg, k, os.path.join(root, v) if k.endswith("_path") else v)
+    return cfg
+
+
+@pytest.mark.parametrize("name", sorted(fx.VARIANTS))
+def test_get_slu_datasets_matches_reference(name, tmp_path, capsys, monkeypatch):
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    over, np_seed, tree_kw = fx.VARIANTS[name]
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=11, **tree_kw)
+    cfg = _config(root, over)
+    np.random.seed(np_seed)
+    tr, va, te = data.get_SLU_datasets(cfg)
+    g = GOLD[name]
+    assert capsys.readouterr().out == g["stdout"]
+    assert cfg.values_per_slot == g["values_per_slot"]
+    assert cfg.Sy_intent == g["Sy_intent"]
+    assert [len(tr), len(va), len(te)] == g["len"]
+    for tag, ds in (("train", tr), ("valid", va), ("test", te)):
+        assert [str(p) for p in ds.df.path.tolist()] == g[tag + "_paths"]
+        assert [int(i) for i in ds.df.index.tolist()] == g[tag + "_index"]
+    for it in g.get("items", []):
+        x, y = tr[it["idx"]]
+        assert x.dtype == np.float32 and str(x.dtype) == it["dtype"]
+        assert len(x) == it["n"] and [int(v) for v in y] == it["y"]
+        assert [float(v) for v in x[:4]] == it["first"]
+        assert float(np.float64(x).sum()) == it["sum"]
+
+
+def test_collate_matches_reference():
+    g = GOLD["collate"]
+    rs = np.random.RandomState(g["seed"])
+    batch = [(rs.randn(n).astype(np.float32), [int(rs.randint(6)), int(rs.randint(14)), int(rs.randint(4))])
+             for n in g["lens"]]
+    x, y = data.CollateWavsSLU({"action": {}, "object": {}, "location": {}}, False)(batch)
+    assert str(x.dtype) == g["x_dtype"] and str(y.dtype) == g["y_dtype"]
+    assert torch.equal(x, torch.tensor(g["x"], dtype=torch.float32))
+    assert torch.equal(y, torch.tensor(g["y"], dtype=torch.int64))
+
+
+def test_loader_batches_and_wav_formats(tmp_path, monkeypatch):
+    from scipy.io import wavfile
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=3)
+    cfg = _config(root, {})
+    tr, va, te = data.get_SLU_datasets(cfg)
+    seen = 0
+    for x, y in va.loader:
+        assert x.dtype == torch.float32 and y.dtype == torch.int64 and y.shape == (x.shape[0], 3)
+        assert x.shape[0] <= cfg.training_batch_size
+        assert (x[:, -1] != 0).any()                      # padded to the longest item of the batch, not beyond
+        seen += x.shape[0]
+    assert seen == len(va)
+    # other sample formats: first channel, full-scale conventions
+    p = os.path.join(root, "fmt.wav")
+    wavfile.write(p, 16000, np.array([[16384, 1], [-32768, 2]], dtype=np.int16))
+    assert data.read_wav(p)[0].tolist() == [0.5, -1.0]
+    wavfile.write(p, 16000, np.array([2 ** 30, -2 ** 31], dtype=np.int32))
+    assert data.read_wav(p)[0].tolist() == [0.5, -1.0]
+    wavfile.write(p, 16000, np.array([192, 0], dtype=np.uint8))
+    assert data.read_wav(p)[0].tolist() == [0.5, -1.0]
+    wavfile.write(p, 8000, np.array([0.25, -0.75], dtype=np.float32))
+    x, fs = data.read_wav(p)
+    assert x.tolist() == [0.25, -0.75] and fs == 8000
+    # a slot value unseen in training fails at item access, as in the reference
+    te._values[0] = ("unseen action",) + te._values[0][1:]
+    with pytest.raises(KeyError):
+        te[0]
+
+
+def test_trainer_consumes_real_loader_shapes(tmp_path, monkeypatch):
+    """The batch tuples of the real loader are what Trainer._forward_losses expects (x (B,T), y (B,3))."""
+    monkeypatch.setenv("SLU_DATA_WORKERS", "2")          # worker processes + collate in the workers
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=4)
+    tr, _, _ = data.get_SLU_datasets(_config(root, {"dataset_upsample_factor": 2}))
+    n = 0
+    for x, y in tr.loader:
+        assert x.ndim == 2 and y.shape[1] == 3
+        n += len(x)
+    assert n == len(tr) == 2 * len(tr.df)

@@ -121,7 +121,7 @@ def test_lookahead_pipeline_equals_sequential_training(tmp_path, monkeypatch):
     os.makedirs(tmp_path / "training")
     torch.manual_seed(1)
     torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
-    ds = data.SLUDataset(7, 8, 6000, cfg.values_per_slot, seed=5)
+    ds = data.SyntheticSLUDataset(7, 8, 6000, cfg.values_per_slot, seed=5)
     results = {}
     for depth in ("0", "3"):
         monkeypatch.setenv("SLU_LOOKAHEAD", depth)
@@ -169,7 +169,7 @@ def test_data_parallel_step_graph_logic_with_emulated_second_rank(tmp_path, monk
     os.makedirs(tmp_path / "training")
     torch.manual_seed(1)
     torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
-    ds = data.SLUDataset(12, 8, 6000, cfg.values_per_slot, seed=5)
+    ds = data.SyntheticSLUDataset(12, 8, 6000, cfg.values_per_slot, seed=5)
     monkeypatch.setenv("SLU_LOOKAHEAD", "4")
     results = {}
     calls = {"n": 0}
@@ -214,9 +214,9 @@ def test_grouped_evaluation_equals_batch_by_batch(tmp_path, monkeypatch):
     os.makedirs(tmp_path / "training")
     torch.manual_seed(4)
     model = models.Model(cfg)
-    a = data.SLUDataset(5, 8, 6000, cfg.values_per_slot, seed=1)
-    b = data.SLUDataset(2, 8, 4000, cfg.values_per_slot, seed=2)
-    c = data.SLUDataset(1, 3, 4000, cfg.values_per_slot, seed=3)
+    a = data.SyntheticSLUDataset(5, 8, 6000, cfg.values_per_slot, seed=1)
+    b = data.SyntheticSLUDataset(2, 8, 4000, cfg.values_per_slot, seed=2)
+    c = data.SyntheticSLUDataset(1, 3, 4000, cfg.values_per_slot, seed=3)
 
     class DS:
         loader = a.batches + b.batches + c.batches
@@ -229,3 +229,63 @@ def test_grouped_evaluation_equals_batch_by_batch(tmp_path, monkeypatch):
     model.eval()
     tot = sum(model(x, y)[0].item() * len(x) for x, y in DS.loader) / sum(len(x) for x, _ in DS.loader)
     assert abs(tot - loss_s) <= 1e-6
+
+
+def test_real_data_loader_trains_on_ragged_batches(tmp_path, monkeypatch):
+    """get_SLU_datasets on an FSC-shaped tree (CSV + wavs, ragged lengths) -> Trainer.train/test on the
+    HIP path; the pipelined run equals the sequential one, and padding to a multiple only changes the
+    batch shapes."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import data
+    import models
+    import training
+    import slu_data_fixture as fx
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    root = str(tmp_path / "fsc")
+    fx.make_fsc_tree(root, seed=21, sizes=(40, 24, 9, 9))
+    results = {}
+    for mode in ("0", "auto", "pad"):
+        monkeypatch.setenv("SLU_LOOKAHEAD", "0" if mode == "0" else "3")
+        if mode == "pad":
+            monkeypatch.setenv("SLU_PAD_TO_MULTIPLE", "4000")
+        cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                             phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                             intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=2)
+        work = tmp_path / ("run_" + mode)
+        os.makedirs(work / "pretraining")
+        os.makedirs(work / "training")
+        cfg.folder = str(work)
+        cfg.slu_path = root
+        cfg.seq2seq = False
+        cfg.training_lr = 0.003
+        cfg.training_batch_size = 8
+        cfg.unfreezing_type = 0
+        cfg.starting_unfreezing_index = 1
+        cfg.seed = 1
+        for k in ("real_speaker_subset_percentage", "synthetic_speaker_subset_percentage",
+                  "real_dataset_subset_percentage", "synthetic_dataset_subset_percentage"):
+            setattr(cfg, k, 1.0)
+        cfg.train_wording_path = cfg.test_wording_path = None
+        cfg.dataset_upsample_factor = 1
+        torch.manual_seed(4)
+        tr, va, te = data.get_SLU_datasets(cfg)
+        assert cfg.values_per_slot == [6, 8, 4]
+        torch.save(models.PretrainedModel(cfg).state_dict(), work / "pretraining" / "model_state.pth")
+        model = models.Model(cfg)
+        models.set_dropout_seed(5)
+        trainer = training.Trainer(model, cfg)
+        torch.manual_seed(6)                      # DataLoader shuffle order
+        acc, loss = trainer.train(tr)
+        vacc, vloss = trainer.test(va)
+        torch.cuda.synchronize()
+        assert np.isfinite([acc, loss, vacc, vloss]).all()
+        results[mode] = (acc, loss, vacc, vloss, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        shapes = {tuple(x.shape) for x, _ in va.loader}
+        if mode == "pad":
+            assert all(s[1] % 4000 == 0 for s in shapes)
+    a, b = results["0"], results["auto"]
+    assert a[:4] == b[:4]
+    for k, v in a[4].items():
+        assert torch.equal(v, b[4][k]), k
+    assert results["pad"][1] != a[1]              # longer zero tails are a different batch
