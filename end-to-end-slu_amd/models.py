@@ -453,21 +453,14 @@ class PretrainedModel(torch.nn.Module):
         x, y_phoneme, y_word = self._to_device(x, y_phoneme, y_word)
         _DropoutState.current = next_rng_step()
         ph_tm = self._phoneme_features_tm(x)                         # (T',B,C)
-        logits = self.phoneme_linear(ph_tm.transpose(0, 1))          # (B,T',P)
-        logits = logits.reshape(logits.shape[0] * logits.shape[1], -1)
-        yp = y_phoneme.reshape(-1)
-        phoneme_loss = torch.nn.functional.cross_entropy(logits, yp, ignore_index=-1)
-        keep = yp != -1
-        phoneme_acc = (logits.max(1)[1][keep] == yp[keep]).float().mean()
+        # Linear + cross-entropy(ignore_index=-1) + frame accuracy: slu_gemm_f32 + slu_frame_ce_fwd
+        pl = self.phoneme_linear
+        phoneme_loss, phoneme_acc = _ops.FrameHeadFn.apply(ph_tm, pl.weight, pl.bias, y_phoneme)
         if self.pretraining_type == 1:
             return phoneme_loss, torch.tensor([0.]), phoneme_acc, torch.tensor([0.])
         wd_tm = self._word_features_tm(ph_tm)
-        wlogits = self.word_linear(wd_tm.transpose(0, 1))
-        wlogits = wlogits.reshape(wlogits.shape[0] * wlogits.shape[1], -1)
-        yw = y_word.reshape(-1)
-        word_loss = torch.nn.functional.cross_entropy(wlogits, yw, ignore_index=-1)
-        keepw = yw != -1
-        word_acc = (wlogits.max(1)[1][keepw] == yw[keepw]).float().mean()
+        wl = self.word_linear
+        word_loss, word_acc = _ops.FrameHeadFn.apply(wd_tm, wl.weight, wl.bias, y_word)
         return phoneme_loss, word_loss, phoneme_acc, word_acc
 
     def compute_posteriors(self, x):

@@ -348,6 +348,52 @@ class IntentHeadFn(torch.autograd.Function):
 
 
 
+class FrameHeadFn(torch.autograd.Function):
+    """Linear -> F.cross_entropy(ignore_index=-1) + frame accuracy of the ASR pre-training heads
+    (reference models.py:291-331: phoneme_linear / word_linear on every frame).  h time-major (T,B,C),
+    y (B,T) int64 with -1 = unlabelled frame.  Returns (loss, acc); only `loss` carries a gradient.
+    The (N, V) logits buffer (N = T*B, V up to 10 000) is overwritten in place with d loss / d logits."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, y):
+        L = _lib.load()
+        T, B, C = h.shape
+        V = weight.shape[0]
+        hn = _f32c(h, "h").reshape(T * B, C)
+        y_tm = y.t().contiguous().reshape(-1)                       # row t*B + b, like hn
+        if y_tm.dtype != torch.int64 or y_tm.numel() != T * B:
+            raise TypeError("FrameHeadFn: y must be int64 of shape (B, T)")
+        need = any(ctx.needs_input_grad[:3])
+        logits = gemm(hn, weight.t(), bias)
+        row_stats = torch.empty(2 * T * B, dtype=torch.float32, device=h.device)
+        out3 = torch.empty(3, dtype=torch.float32, device=h.device)
+        _lib.check(L.slu_frame_ce_fwd(logits.data_ptr(), y_tm.data_ptr(), T * B, V, -1, int(need),
+                                      row_stats.data_ptr(), out3.data_ptr(), _stream()), "slu_frame_ce_fwd")
+        if need:
+            ctx.save_for_backward(hn, weight, logits)
+        ctx.set_materialize_grads(False)
+        ctx.shape = (T, B, C)
+        acc = out3[1]
+        ctx.mark_non_differentiable(acc)
+        return out3[0], acc
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_acc):
+        if d_loss is None:
+            return None, None, None, None
+        hn, weight, d_logits = ctx.saved_tensors
+        T, B, C = ctx.shape
+        g = d_loss.float()
+        dh = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dh = gemm(d_logits, weight).mul_(g).view(T, B, C)
+        if ctx.needs_input_grad[1]:
+            dW = gemm(d_logits.t(), hn).mul_(g)
+        if ctx.needs_input_grad[2]:
+            db = colsum(d_logits).mul_(g)
+        return dh, dW, db, None
+
+
 class SincBlockFn(torch.autograd.Function):
     """SincLayer -> Abs -> MaxPool1d(ceil) -> LeakyReLU  (models.py:77-110, :163-168, :205, :211).
     x (B,T) -> (B, L_out, N_filt) channels-last, or (L_out, B, N_filt) when time_major."""

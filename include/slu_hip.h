@@ -184,6 +184,15 @@ int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const
                            float* d_weight, float* d_bias, int64_t T, int64_t B, int64_t C,
                            int64_t V, void* stream);
 
+/* -------- ASR pre-training heads: F.cross_entropy(logits, y, ignore_index) + frame accuracy ----------
+ * (PretrainedModel.forward, models.py:291-331; the Linear layers are slu_gemm_f32 calls).
+ *   logits (N, V) row-major; y (N) int64, rows with y == ignore_index carry no label
+ *   out3 = [mean CE over labelled rows, accuracy over labelled rows (first arg-max == y), #labelled]
+ *   write_grad != 0: logits is overwritten IN PLACE with d(out3[0]) / d(logits)
+ *   row_stats: workspace of 2 N floats.  Targets must lie in [0, V) or equal ignore_index.            */
+int slu_frame_ce_fwd(float* logits, const int64_t* y, int64_t N, int64_t V, int64_t ignore_index,
+                     int write_grad, float* row_stats, float* out3, void* stream);
+
 /* -------- Adam: torch.optim.Adam(model.parameters(), lr) (training.py:19, default betas / eps) ------
  * One launch updates up to slu_adam_max_tensors() tensors of one dtype (elem_bytes 4 / 8); the pointer
  * arrays are HOST arrays of device pointers (they travel in the kernel arguments: hipGraph-safe).

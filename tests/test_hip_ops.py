@@ -344,3 +344,44 @@ def test_hip_adam_matches_torch_adam():
         assert torch.allclose(o.detach().cpu(), r.detach(), rtol=tol, atol=tol * r.detach().abs().max().item()), r.shape
     # per-parameter step counts: the late tensor is three updates behind
     assert o_hip._steps[:2].tolist() == [6, 3]
+
+
+# ---------------------------------------------------------------------------------------------
+# ASR pre-training heads: Linear + cross-entropy(ignore_index=-1) + frame accuracy (slu_framece.hip)
+# against torch (reference models.py:291-331)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B,C,V", [(19, 8, 256, 10000), (75, 4, 64, 42), (3, 2, 16, 5), (1, 1, 8, 300)])
+def test_frame_head_vs_torch(ops, T, B, C, V):
+    torch.manual_seed(T * 31 + V)
+    h = torch.randn(T, B, C) * 0.5
+    W = torch.randn(V, C) * 0.2
+    b = torch.randn(V) * 0.1
+    y = torch.randint(0, V, (B, T))
+    y[torch.rand(B, T) < 0.25] = -1
+    y[0, 0] = V - 1                                                  # at least one labelled frame
+    # torch reference in the reference's own layout: (B,T,C) -> (B*T, V)
+    hr, Wr, br = h.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+    logits = torch.nn.functional.linear(hr.transpose(0, 1), Wr, br).reshape(B * T, V)
+    yy = y.reshape(-1)
+    loss_ref = torch.nn.functional.cross_entropy(logits, yy, ignore_index=-1)
+    keep = yy != -1
+    acc_ref = (logits.max(1)[1][keep] == yy[keep]).float().mean()
+    (loss_ref * 1.7).backward()
+    hd, Wd, bd = (t.clone().cuda().requires_grad_() for t in (h, W, b))
+    loss, acc = ops.FrameHeadFn.apply(hd, Wd, bd, y.cuda())
+    (loss * 1.7).backward()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-6 * max(1.0, abs(loss_ref.item()))
+    assert acc.item() == pytest.approx(acc_ref.item(), abs=1e-7)
+    for got, ref, name in ((hd.grad, hr.grad, "dh"), (Wd.grad, Wr.grad, "dW"), (bd.grad, br.grad, "db")):
+        scale = ref.abs().max().item() + 1e-12
+        assert (got.cpu() - ref).abs().max().item() <= 2e-6 * scale + 1e-9, name
+
+
+@pytest.mark.gpu
+def test_frame_head_all_frames_unlabelled_is_nan_like_torch(ops):
+    h = torch.randn(2, 2, 8).cuda()
+    W = torch.randn(5, 8).cuda().requires_grad_()
+    y = torch.full((2, 2), -1, dtype=torch.int64).cuda()
+    loss, acc = ops.FrameHeadFn.apply(h, W, torch.zeros(5).cuda(), y)
+    assert torch.isnan(loss).item()                                  # F.cross_entropy gives nan as well
