@@ -281,13 +281,23 @@ colsum_partial_kernel(const float* __restrict__ X, long long rs, float* __restri
     part[(size_t)blockIdx.y * N + n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// 64 columns x 4 row groups per workgroup: the (up to 256) partial rows are summed by four waves in
+// parallel (fixed order: deterministic), not by one serial loop per column.
 __global__ void __launch_bounds__(256)
 colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int RS) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.0f;
-  for (int r = 0; r < RS; ++r) s += part[(size_t)r * N + n];
-  out[n] = s;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (n < N) {
+    int r = w;
+#pragma unroll 4
+    for (; r + 4 < RS; r += 8) { s0 += part[(size_t)r * N + n]; s1 += part[(size_t)(r + 4) * N + n]; }
+    if (r < RS) s0 += part[(size_t)r * N + n];
+  }
+  red[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && n < N) out[n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 int colsum_splits(int64_t M) {
@@ -303,7 +313,7 @@ int colsum_two_stage(const float* X, int64_t rs, float* out, int64_t M, int64_t 
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)RS), dim3(256), 0, st,
                      X, (long long)rs, ws, (int)M, (int)N, rows);
   SLU_CHECK_LAUNCH("colsum_partial_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, st,
                      (const float*)ws, out, (int)N, RS);
   SLU_CHECK_LAUNCH("colsum_final_kernel");
   return SLU_OK;

@@ -667,7 +667,8 @@ extern "C" size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t
 
 // 4-sequence workgroups while the 16-sequence grid would leave CUs idle (SLU_GRU_TILE=4|16 forces one)
 static bool gru_use_seq4(int64_t B, int64_t H, int64_t D) {
-  static const int forced = getenv("SLU_GRU_TILE") ? atoi(getenv("SLU_GRU_TILE")) : 0;
+  const char* env = getenv("SLU_GRU_TILE");          // read per call: tests switch it at run time
+  const int forced = env ? atoi(env) : 0;
   if (H != 64 && H != 128) return false;
   if (forced == 4) return true;
   if (forced == 16) return false;

@@ -192,8 +192,12 @@ def test_gru_vs_golden(ops, name):
     _gru_case(ops, load(name), name.endswith("_bi.npz"))
 
 
+@pytest.mark.parametrize("tile", ["auto", "4", "16"])
 @pytest.mark.parametrize("B,T,I,H", [(64, 40, 60, 128), (17, 23, 256, 128), (5, 9, 33, 64), (70, 3, 20, 32)])
-def test_gru_vs_oracle_ragged_batches(ops, B, T, I, H):
+def test_gru_vs_oracle_ragged_batches(ops, monkeypatch, tile, B, T, I, H):
+    """Both recurrence geometries (4- and 16-sequence workgroups; H = 32 always takes the 16-sequence one)."""
+    if tile != "auto":
+        monkeypatch.setenv("SLU_GRU_TILE", tile)
     torch.manual_seed(B + T)
     m = torch.nn.GRU(I, H, batch_first=True, bidirectional=True)
     x = torch.randn(B, T, I, requires_grad=True)
@@ -206,6 +210,29 @@ def test_gru_vs_oracle_ragged_batches(ops, B, T, I, H):
         d[k] = v.detach().numpy()
         d["grad_" + k] = v.grad.numpy()
     _gru_case(ops, d, True)
+
+
+def test_gru_reserve_layout_is_shared_by_both_geometries(ops, monkeypatch):
+    """Forward with 4-sequence workgroups, BPTT with 16-sequence ones (and vice versa): the saved gates
+    have ONE layout, so the pairs must agree with the homogeneous runs to rounding."""
+    torch.manual_seed(3)
+    T, B, H, D = 21, 37, 128, 2
+    gx = cu(torch.randn(T, B, D * 3 * H))
+    wf, wr = cu(torch.randn(3 * H, H) * 0.1), cu(torch.randn(3 * H, H) * 0.1)
+    bf, br = cu(torch.randn(3 * H) * 0.1), cu(torch.randn(3 * H) * 0.1)
+    d_out = cu(torch.randn(T, B, D * H))
+    res = {}
+    for f_tile in ("4", "16"):
+        monkeypatch.setenv("SLU_GRU_TILE", f_tile)
+        out, rsv = ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, True)
+        for b_tile in ("4", "16"):
+            monkeypatch.setenv("SLU_GRU_TILE", b_tile)
+            d_gx, d_gh, dbp = ops.gru_seq_bwd(d_out, rsv, wf, wr, T, B, H, D)
+            res[(f_tile, b_tile)] = (out, d_gx, d_gh, dbp.sum(0))
+    ref = res[("16", "16")]
+    for key, val in res.items():
+        for a, b, name in zip(val, ref, ("out", "d_gx", "d_gh", "d_bias")):
+            assert_close(a, b, 2e-5 * max(1.0, b.abs().max().item()), "%s %s" % (key, name))
 
 
 @pytest.mark.parametrize("method", ["none", "avg", "max"])
