@@ -269,11 +269,13 @@ def main():
                                  (args.batch * max(1, look), args.batch,
                                   2 * -(-args.batch * max(1, look) // 4), 2 * -(-args.batch // 4))},
         }
-        if not args.no_large_batch and args.workload == "no_unfreezing":
+        # The two side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
+        # one rank alone would issue gradient all-reduces the other ranks never join.
+        if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing":
             note("large-batch point")
             out["large_batch_point"] = large_batch_point(rank, samples)
         note("cpu baseline")
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)
         print(json.dumps(out), flush=True)
     if world > 1:

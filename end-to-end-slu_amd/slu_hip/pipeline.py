@@ -33,15 +33,26 @@ def cu_split(device=None):
     return n_compute_units(torch.cuda.current_device() if device is None else device) // 4
 
 
-def cu_range_stream(device, first, count):
-    """A HIP stream confined to CUs [first, first + count) (slu_stream_create_cu_range), wrapped for torch."""
+_CU_MASK_BROKEN = [False]
+
+
+def cu_range_stream(device, first, count, **stream_kw):
+    """A HIP stream confined to CUs [first, first + count) (slu_stream_create_cu_range), wrapped for torch.
+    The partition is a scheduling aid, not a correctness requirement: if the runtime refuses the mask
+    (e.g. a driver without CU-mask support) an ordinary stream is used and a warning printed once."""
     import ctypes
     from . import lib as _lib
-    L = _lib.load()
-    h = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        _lib.check(L.slu_stream_create_cu_range(first, count, ctypes.byref(h)), "slu_stream_create_cu_range")
-    return torch.cuda.ExternalStream(h.value, device=device)
+    if not _CU_MASK_BROKEN[0]:
+        L = _lib.load()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = L.slu_stream_create_cu_range(first, count, ctypes.byref(h))
+        if rc == 0 and h.value:
+            return torch.cuda.ExternalStream(h.value, device=device)
+        _CU_MASK_BROKEN[0] = True
+        print("warning: CU-masked streams unavailable (%s); the look-ahead pipeline shares all CUs"
+              % L.slu_last_error().decode(errors="replace"))
+    return torch.cuda.Stream(device, **stream_kw)
 
 
 def n_compute_units(device):

@@ -194,7 +194,7 @@ class Trainer:
         if getattr(self, "_train_stream", None) is None:
             from slu_hip import pipeline as _pl
             n_cu = _pl.cu_split()
-            self._train_stream = (_pl.cu_range_stream(dev, 0, n_cu) if n_cu > 0
+            self._train_stream = (_pl.cu_range_stream(dev, 0, n_cu, priority=-1) if n_cu > 0
                                   else torch.cuda.Stream(dev, priority=-1))     # ahead of the look-ahead streams
         main = self._train_stream
         main.wait_stream(outer)
