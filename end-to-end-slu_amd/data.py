@@ -11,9 +11,10 @@ the four `*_subset_percentage` keys): the legacy key maps to
 Datasets: `get_SLU_datasets` / `SLUDataset` / `CollateWavsSLU` read a Fluent-Speech-Commands tree
 (CSV splits + wavs) with the reference's split / subset / label-dictionary logic (data.py:132-376;
 SURVEY.md §8(f) rank 1), feeding pinned, zero-padded (B, T_max) batches to the encoder; with
-`slu_path = synthetic[:NxBxT]` (and always for ASR pre-training, whose LibriSpeech + TextGrid reader is
-not built) FSC- / LibriSpeech-shaped SYNTHETIC datasets with the same duck type are served (`.loader`
-yielding the same batch tuples; `training.Trainer` dispatches on `SLUDataset` / `ASRDataset`).
+`get_ASR_datasets` / `ASRDataset` / `CollateWavsASR` read a LibriSpeech + TextGrid alignment tree
+(data.py:393-545).  With `slu_path` / `asr_path = synthetic[:NxBxT]` FSC- / LibriSpeech-shaped SYNTHETIC
+datasets with the same duck type are served (`.loader` yielding the same batch tuples;
+`training.Trainer` dispatches on `SLUDataset` / `ASRDataset`).
 """
 import configparser
 import os
@@ -296,7 +297,123 @@ class SyntheticSLUDataset(SLUDataset):
         return x[idx % bs], y[idx % bs]
 
 
+def read_textgrid(path):
+    """Interval tiers of a Praat TextGrid (the long "ooTextFile" format the Montreal Forced Aligner writes
+    for LibriSpeech): {tier name: [(minTime, maxTime, mark), ...]}; the first tier of a name wins, like
+    `textgrid.TextGrid().getList(name)[0]` in the reference (data.py:478-497).  Point tiers are skipped."""
+    import re
+    tiers, cur, t0, t1, is_interval = {}, None, None, None, False
+    num = r"([-+0-9.eE]+)"
+    with open(path, "r", encoding="utf-8", errors="replace") as f:
+        for raw in f:
+            ln = raw.strip()
+            m = re.match(r'class = "(\w+)"', ln)
+            if m:
+                is_interval = m.group(1) == "IntervalTier"
+                cur = None
+                continue
+            m = re.match(r'name = "(.*)"$', ln)
+            if m and is_interval:
+                name = m.group(1)
+                cur = tiers.setdefault(name, []) if name not in tiers else []    # later duplicates are ignored
+                continue
+            if cur is None:
+                continue
+            m = re.match(r"xmin = " + num, ln)
+            if m:
+                t0 = float(m.group(1))
+                continue
+            m = re.match(r"xmax = " + num, ln)
+            if m:
+                t1 = float(m.group(1))
+                continue
+            m = re.match(r'text = "(.*)"$', ln)
+            if m:
+                cur.append((t0, t1, m.group(1).replace('""', '"')))
+    return tiers
+
+
+def _strip_stress(mark):
+    return mark.rstrip("0123456789")
+
+
+class CollateWavsASR:
+    """list of (waveform, phoneme labels, word labels) -> (x (B,T_max) float32 zero-padded, y_phoneme
+    (B,U_p) int64, y_word (B,U_w) int64, both padded with the ignore index -1) — reference data.py:511-545.
+    Assembled in one (optionally pinned) buffer per tensor."""
+
+    def __init__(self, pin=False):
+        self.pin = pin
+
+    def __call__(self, batch):
+        n = len(batch)
+        T = max(len(b[0]) for b in batch)
+        Up = max(len(b[1]) for b in batch)
+        Uw = max(len(b[2]) for b in batch)
+        x = torch.zeros(n, T, dtype=torch.float32)
+        yp = torch.full((n, Up), -1, dtype=torch.int64)
+        yw = torch.full((n, Uw), -1, dtype=torch.int64)
+        for i, (xi, pi, wi) in enumerate(batch):
+            x[i, :len(xi)] = torch.as_tensor(np.asarray(xi)).float()
+            yp[i, :len(pi)] = torch.as_tensor(np.asarray(pi, dtype=np.int64))
+            yw[i, :len(wi)] = torch.as_tensor(np.asarray(wi, dtype=np.int64))
+        if self.pin and torch.cuda.is_available():
+            x, yp, yw = x.pin_memory(), yp.pin_memory(), yw.pin_memory()
+        return x, yp, yw
+
+
 class ASRDataset(torch.utils.data.Dataset):
+    """LibriSpeech + forced-alignment dataset of ASR pre-training (reference data.py:453-509): item =
+    a random snippet of the utterance (length ~ N(mean, var) seconds, at least 0.5 s; torch's global RNG,
+    consumed in the reference's order) with one phoneme label per `phone_downsample_factor` samples and
+    one word label per `word_downsample_factor` samples; -1 = no label (silence / out-of-vocabulary).
+    Label lookup is a dictionary (first index wins, like list.index) and the per-sample label tracks are
+    numpy repeats instead of Python lists."""
+
+    def __init__(self, wav_paths, textgrid_paths, Sy_phoneme, Sy_word, config):
+        self.wav_paths = wav_paths
+        self.textgrid_paths = textgrid_paths
+        self.length_mean = config.pretraining_length_mean
+        self.length_var = config.pretraining_length_var
+        self.Sy_phoneme = Sy_phoneme
+        self.Sy_word = Sy_word
+        self.phone_downsample_factor = config.phone_downsample_factor
+        self.word_downsample_factor = config.word_downsample_factor
+        self._phone_idx, self._word_idx = {}, {}
+        for i, v in enumerate(Sy_phoneme):
+            self._phone_idx.setdefault(v, i)
+        for i, v in enumerate(Sy_word):
+            self._word_idx.setdefault(v, i)
+        self.loader = torch.utils.data.DataLoader(
+            self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), shuffle=True,
+            collate_fn=CollateWavsASR(pin=True))
+
+    def __len__(self):
+        return len(self.wav_paths)
+
+    @staticmethod
+    def _track(intervals, index_of, fs):
+        idx = np.array([index_of(mark) for _, _, mark in intervals], dtype=np.int64)
+        reps = np.array([max(0, round((t1 - t0) * fs)) for t0, t1, _ in intervals], dtype=np.int64)
+        return np.repeat(idx, reps)
+
+    def __getitem__(self, idx):
+        x32, fs = read_wav(self.wav_paths[idx])
+        x = x32.astype(np.float64)                     # soundfile.read hands the reference float64
+        tg = read_textgrid(self.textgrid_paths[idx])
+        y_phoneme = self._track(tg["phones"], lambda m: -1 if m == "" else self._phone_idx.get(_strip_stress(m), -1), fs)
+        y_word = self._track(tg["words"], lambda m: self._word_idx.get(m, -1), fs)
+        random_length = round(fs * max(self.length_mean + self.length_var * torch.randn(1).item(), 0.5))
+        if len(x) <= random_length:
+            start = 0
+        else:
+            start = torch.randint(low=0, high=len(x) - random_length, size=(1,)).item()
+        end = start + random_length
+        return (x[start:end], y_phoneme[start:end:self.phone_downsample_factor].tolist(),
+                y_word[start:end:self.word_downsample_factor].tolist())
+
+
+class SyntheticASRDataset(ASRDataset):
     """Synthetic ASR pre-training dataset: `.loader` yields (x (B,T), y_phoneme (B,ceil(T/640)),
     y_word (B,ceil(T/2560))) like CollateWavsASR (reference data.py:511-545); 10 % of the frame
     labels are the ignore index -1."""
@@ -444,14 +561,48 @@ def get_SLU_datasets(config):
 
 
 def get_ASR_datasets(config):
-    """(train, valid, test) ASR datasets; `asr_path = synthetic[:NxBxT]` only (see get_SLU_datasets)."""
+    """(train, valid, test) ASR pre-training datasets (reference data.py:393-451).  `asr_path` holds
+    `text/<split>*/<speaker>/<chapter>/<utt>.TextGrid` alignments and the matching `audio/...wav` files
+    (splits train* / dev* / test*), or is `synthetic[:NxBxT]`.  The phoneme / word vocabularies are read
+    from <folder>/pretraining/{phonemes,words}.txt or built from the dev split (phonemes in first-seen
+    order with stress digits stripped, the `vocabulary_size` most common words) and written there."""
     spec = _synthetic_spec(config.asr_path)
-    if spec is None:
-        raise NotImplementedError(
-            "LibriSpeech + TextGrid loading (reference data.py:393-545) is outside the MI355X hot "
-            "path of this package; set asr_path=synthetic[:<batches>x<batch>x<samples>]")
-    nb, bs, ns = spec
-    bs = bs or config.pretraining_batch_size
-    config.num_phonemes = 42
-    mk = lambda n, seed: ASRDataset(n, bs, ns, config, seed=seed)
-    return mk(nb, config.seed), mk(max(1, nb // 4), config.seed + 1), mk(max(1, nb // 4), config.seed + 2)
+    if spec is not None:
+        nb, bs, ns = spec
+        bs = bs or config.pretraining_batch_size
+        config.num_phonemes = 42
+        mk = lambda n, seed: SyntheticASRDataset(n, bs, ns, config, seed=seed)
+        return mk(nb, config.seed), mk(max(1, nb // 4), config.seed + 1), mk(max(1, nb // 4), config.seed + 2)
+    import glob
+    base_path = config.asr_path
+    wavs = lambda tgs: [p.replace("text", "audio").replace(".TextGrid", ".wav") for p in tgs]
+    train_tg = glob.glob(base_path + "/text/train*/*/*/*.TextGrid")
+    valid_tg = glob.glob(base_path + "/text/dev*/*/*/*.TextGrid")
+    test_tg = glob.glob(base_path + "/text/test*/*/*/*.TextGrid")
+    ph_file = os.path.join(config.folder, "pretraining", "phonemes.txt")
+    wd_file = os.path.join(config.folder, "pretraining", "words.txt")
+    if os.path.isfile(ph_file) and os.path.isfile(wd_file):
+        with open(ph_file, "r") as f:
+            Sy_phoneme = [ln.rstrip("\n") for ln in f.readlines() if ln.rstrip("\n") != ""]
+        with open(wd_file, "r") as f:
+            Sy_word = [ln.rstrip("\n") for ln in f.readlines()]
+        config.num_phonemes = len(Sy_phoneme)
+    else:
+        print("Getting vocabulary...")
+        phoneme_counter, word_counter = Counter(), Counter()
+        for path in valid_tg:
+            tg = read_textgrid(path)
+            phoneme_counter.update([_strip_stress(m) for _, _, m in tg["phones"] if m != ""])
+            word_counter.update([m for _, _, m in tg["words"]])
+        Sy_phoneme = list(phoneme_counter)
+        Sy_word = [w[0] for w in word_counter.most_common(config.vocabulary_size)]
+        config.num_phonemes = len(Sy_phoneme)
+        with open(ph_file, "w") as f:
+            for phoneme in Sy_phoneme:
+                f.write(phoneme + "\n")
+        with open(wd_file, "w") as f:
+            for word in Sy_word:
+                f.write(word + "\n")
+    print("Done.")
+    mk = lambda tgs: ASRDataset(wavs(tgs), tgs, Sy_phoneme, Sy_word, config)
+    return mk(train_tg), mk(valid_tg), mk(test_tg)

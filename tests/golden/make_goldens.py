@@ -534,9 +534,108 @@ def g10():
         json.dump(res, f, indent=1, sort_keys=True)
 
 
+def g11():
+    """ASR pre-training input pipeline (reference data.py:393-545) on the LibriSpeech-shaped tree of
+    tests/slu_data_fixture.py: vocabulary construction, ASRDataset.__getitem__ (label tracks, random
+    snippet with torch's RNG, strided labels) and CollateWavsASR.  `soundfile` and `textgrid` are not
+    installed: for this fixture only they are replaced by a PCM16 -> float64 / 32768 wav read and by a
+    small regex TextGrid reader written here (independent of the package's parser), so the fixture pins the
+    reference's label / cropping / padding logic, not those libraries."""
+    import re
+    sys.path.insert(0, os.path.dirname(OUT))
+    import slu_data_fixture as fx
+    from scipy.io import wavfile
+
+    def sf_read(path):
+        fs, pcm = wavfile.read(path)
+        return pcm.astype(np.float64) / 32768.0, fs
+
+    class _Interval:
+        def __init__(self, a, b, m):
+            self.minTime, self.maxTime, self.mark = a, b, m
+
+    class _TextGrid:
+        def read(self, path):
+            text = open(path).read()
+            self.tiers = {}
+            for block in re.split(r"item \[\d+\]:", text)[1:]:
+                name = re.search(r'name = "(.*?)"', block).group(1)
+                ivs = re.findall(r'intervals \[\d+\]:\s*xmin = (\S+)\s*xmax = (\S+)\s*text = "(.*?)"', block)
+                self.tiers.setdefault(name, []).append([_Interval(float(a), float(b), m) for a, b, m in ivs])
+
+        def getList(self, name):
+            return self.tiers[name]
+
+    sys.modules["soundfile"].read = sf_read
+    sys.modules["textgrid"].TextGrid = _TextGrid
+    ref_data.sf.read = sf_read
+    ref_data.textgrid.TextGrid = _TextGrid
+    root = tempfile.mkdtemp()
+    res = {}
+    try:
+        base = fx.make_asr_tree(root, seed=5)
+        cfg = tiny_cfg(folder=os.path.join(root, "exp"))
+        os.makedirs(os.path.join(cfg.folder, "pretraining"))
+        cfg.asr_path = base
+        cfg.vocabulary_size = 5
+        cfg.pretraining_batch_size = 3
+        cfg.pretraining_length_mean = 1.0
+        cfg.pretraining_length_var = 0.4
+        cfg.phone_downsample_factor = 40
+        cfg.word_downsample_factor = 160
+        rel = lambda p: os.path.relpath(p, base)
+
+        def call():
+            buf = io.StringIO()
+            stdout = sys.stdout
+            sys.stdout = buf
+            try:
+                out = ref_data.get_ASR_datasets(cfg)
+            finally:
+                sys.stdout = stdout
+            return out, buf.getvalue()
+
+        (tr, va, te), out1 = call()
+        res["stdout_first"] = out1
+        res["num_phonemes"] = cfg.num_phonemes
+        res["Sy_phoneme_sorted"] = sorted(tr.Sy_phoneme)        # first-seen order depends on glob order
+        res["Sy_word_set"] = sorted(tr.Sy_word)
+        res["len"] = [len(tr), len(va), len(te)]
+        for tag, ds in (("train", tr), ("valid", va), ("test", te)):
+            res[tag + "_wavs"] = sorted(rel(p) for p in ds.wav_paths)
+        # fix the vocabularies (independent of directory listing order) and re-read them
+        with open(os.path.join(cfg.folder, "pretraining", "phonemes.txt"), "w") as f:
+            f.write("\n".join(sorted(tr.Sy_phoneme)) + "\n")
+        with open(os.path.join(cfg.folder, "pretraining", "words.txt"), "w") as f:
+            f.write("\n".join(sorted(tr.Sy_word)) + "\n")
+        (tr, va, te), out2 = call()
+        res["stdout_second"] = out2
+        res["Sy_phoneme"] = tr.Sy_phoneme
+        res["Sy_word"] = tr.Sy_word
+        items = {}
+        for i in range(len(tr)):
+            torch.manual_seed(100 + len(rel(tr.wav_paths[i])) + i * 0)
+            key = rel(tr.wav_paths[i])
+            torch.manual_seed(int(hashlib.sha256(key.encode()).hexdigest()[:6], 16))
+            x, yp, yw = tr[i]
+            items[key] = {"n": int(len(x)), "dtype": str(np.asarray(x).dtype), "sum": float(np.sum(x)),
+                          "first": [float(v) for v in x[:3]], "y_phoneme": [int(v) for v in yp], "y_word": [int(v) for v in yw]}
+        res["items"] = items
+    finally:
+        shutil.rmtree(root)
+    rs = np.random.RandomState(8)
+    batch = [(rs.randn(n), [int(v) for v in rs.randint(-1, 9, size=-(-n // 4))], [int(v) for v in rs.randint(-1, 5, size=-(-n // 16))])
+             for n in (33, 50, 17)]
+    x, yp, yw = ref_data.CollateWavsASR()(batch)
+    res["collate"] = {"lens": [33, 50, 17], "seed": 8, "x": npd(x).tolist(), "yp": npd(yp).tolist(), "yw": npd(yw).tolist(),
+                      "dtypes": [str(x.dtype), str(yp.dtype), str(yw.dtype)]}
+    with open(os.path.join(OUT, "g11_asr_data.json"), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY")
-    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10}
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
     for k, fn in fns.items():
         if only is None or k in only.split(","):
             fn()

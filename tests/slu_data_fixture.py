@@ -63,3 +63,55 @@ VARIANTS = {
                   "dataset_upsample_factor": 3}, 0, {}),
     "no_speaker_column": ({"real_speaker_subset_percentage": 0.5}, 3, {"with_speaker": False}),
 }
+
+
+# ------------------------------------------------------------------------------------------------
+# LibriSpeech-shaped tree with Montreal-Forced-Aligner style TextGrids (long format)
+# ------------------------------------------------------------------------------------------------
+WORDS = ["the", "cat", "sat", "on", "mat", "a", "dog", "ran", "fast", "slow", "", "blue", "sky"]
+PHONES = ["DH", "AH0", "K", "AE1", "T", "S", "AA1", "N", "M", "EY1", "D", "AO1", "G", "R", "F", "L", "OW1", "", "sil"]
+
+
+def _tier(name, total, marks_and_ends):
+    out = ['    item [%d]:' % (1 if name == "words" else 2), '        class = "IntervalTier" ',
+           '        name = "%s" ' % name, '        xmin = 0 ', '        xmax = %s ' % repr(total),
+           '        intervals: size = %d ' % len(marks_and_ends)]
+    t0 = 0.0
+    for k, (mark, t1) in enumerate(marks_and_ends):
+        out += ['        intervals [%d]:' % (k + 1), '            xmin = %s ' % repr(t0),
+                '            xmax = %s ' % repr(t1), '            text = "%s" ' % mark]
+        t0 = t1
+    return out
+
+
+def write_textgrid(path, total, words, phones):
+    lines = ['File type = "ooTextFile"', 'Object class = "TextGrid"', '', 'xmin = 0 ', 'xmax = %s ' % repr(total),
+             'tiers? <exists> ', 'size = 2 ', 'item []: '] + _tier("words", total, words) + _tier("phones", total, phones)
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def _segments(rs, total, marks, n):
+    cuts = np.sort(rs.uniform(0.02, total - 0.02, size=n - 1)).round(2).tolist() + [total]
+    return [(marks[rs.randint(len(marks))], float(c)) for c in cuts]
+
+
+def make_asr_tree(root, seed=0, counts=(5, 4, 3)):
+    """root/asr/{text,audio}/{train-clean,dev-clean,test-clean}/<spk>/<chapter>/<utt>.{TextGrid,wav}"""
+    rs = np.random.RandomState(seed)
+    base = os.path.join(root, "asr")
+    for split, n in zip(("train-clean", "dev-clean", "test-clean"), counts):
+        for k in range(n):
+            spk, chap = "%d" % (100 + rs.randint(3)), "%d" % (7 + rs.randint(2))
+            utt = "%s-%s-%04d" % (spk, chap, k)
+            tdir = os.path.join(base, "text", split, spk, chap)
+            adir = os.path.join(base, "audio", split, spk, chap)
+            os.makedirs(tdir, exist_ok=True)
+            os.makedirs(adir, exist_ok=True)
+            total = float(np.round(rs.uniform(0.9, 2.2), 2))
+            n_samp = int(round(total * 16000))
+            pcm = (rs.randn(n_samp) * 2500).clip(-32768, 32767).astype(np.int16)
+            wavfile.write(os.path.join(adir, utt + ".wav"), 16000, pcm)
+            write_textgrid(os.path.join(tdir, utt + ".TextGrid"), total,
+                           _segments(rs, total, WORDS, 2 + rs.randint(4)), _segments(rs, total, PHONES, 5 + rs.randint(8)))
+    return base

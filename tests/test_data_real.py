@@ -104,3 +104,78 @@ def test_trainer_consumes_real_loader_shapes(tmp_path, monkeypatch):
         assert x.ndim == 2 and y.shape[1] == 3
         n += len(x)
     assert n == len(tr) == 2 * len(tr.df)
+
+
+# ------------------------------------------------------------------------------------------------
+# ASR pre-training input pipeline (reference data.py:393-545) against fixture g11
+# ------------------------------------------------------------------------------------------------
+GOLD_ASR = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g11_asr_data.json")))
+
+
+def _asr_config(root, base):
+    folder = os.path.join(root, "exp")
+    os.makedirs(os.path.join(folder, "pretraining"), exist_ok=True)
+    return types.SimpleNamespace(asr_path=base, folder=folder, vocabulary_size=5, pretraining_batch_size=3,
+                                 pretraining_length_mean=1.0, pretraining_length_var=0.4,
+                                 phone_downsample_factor=40, word_downsample_factor=160, seed=1)
+
+
+def test_get_asr_datasets_matches_reference(tmp_path, capsys, monkeypatch):
+    import hashlib
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    root = str(tmp_path)
+    base = fx.make_asr_tree(root, seed=5)
+    cfg = _asr_config(root, base)
+    g = GOLD_ASR
+    tr, va, te = data.get_ASR_datasets(cfg)
+    assert capsys.readouterr().out == g["stdout_first"]
+    assert cfg.num_phonemes == g["num_phonemes"]
+    assert sorted(tr.Sy_phoneme) == g["Sy_phoneme_sorted"] and sorted(tr.Sy_word) == g["Sy_word_set"]
+    assert [len(tr), len(va), len(te)] == g["len"]
+    rel = lambda p: os.path.relpath(p, base)
+    for tag, ds in (("train", tr), ("valid", va), ("test", te)):
+        assert sorted(rel(p) for p in ds.wav_paths) == g[tag + "_wavs"]
+    # the vocabulary files written by the first call are what a second call reads back
+    assert open(os.path.join(cfg.folder, "pretraining", "phonemes.txt")).read().split("\n")[:-1] == tr.Sy_phoneme
+    with open(os.path.join(cfg.folder, "pretraining", "phonemes.txt"), "w") as f:
+        f.write("\n".join(g["Sy_phoneme"]) + "\n")
+    with open(os.path.join(cfg.folder, "pretraining", "words.txt"), "w") as f:
+        f.write("\n".join(g["Sy_word"]) + "\n")
+    tr, va, te = data.get_ASR_datasets(cfg)
+    assert capsys.readouterr().out == g["stdout_second"]
+    assert tr.Sy_phoneme == g["Sy_phoneme"] and tr.Sy_word == g["Sy_word"]
+    for i in range(len(tr)):
+        key = rel(tr.wav_paths[i])
+        it = g["items"][key]
+        torch.manual_seed(int(hashlib.sha256(key.encode()).hexdigest()[:6], 16))
+        x, yp, yw = tr[i]
+        assert str(np.asarray(x).dtype) == it["dtype"] and len(x) == it["n"]
+        assert [float(v) for v in x[:3]] == it["first"] and float(np.sum(x)) == it["sum"]
+        assert [int(v) for v in yp] == it["y_phoneme"] and [int(v) for v in yw] == it["y_word"]
+    # loader: shapes and the ignore index as padding value
+    seen = 0
+    for x, yp, yw in tr.loader:
+        assert x.dtype == torch.float32 and yp.dtype == torch.int64 and yw.dtype == torch.int64
+        assert x.shape[0] == yp.shape[0] == yw.shape[0] <= 3
+        seen += len(x)
+    assert seen == len(tr)
+
+
+def test_collate_asr_matches_reference():
+    g = GOLD_ASR["collate"]
+    rs = np.random.RandomState(g["seed"])
+    batch = [(rs.randn(n), [int(v) for v in rs.randint(-1, 9, size=-(-n // 4))],
+              [int(v) for v in rs.randint(-1, 5, size=-(-n // 16))]) for n in g["lens"]]
+    x, yp, yw = data.CollateWavsASR()(batch)
+    assert [str(x.dtype), str(yp.dtype), str(yw.dtype)] == g["dtypes"]
+    assert torch.equal(x, torch.tensor(g["x"], dtype=torch.float32))
+    assert torch.equal(yp, torch.tensor(g["yp"])) and torch.equal(yw, torch.tensor(g["yw"]))
+
+
+def test_textgrid_reader_edge_cases(tmp_path):
+    p = str(tmp_path / "a.TextGrid")
+    fx.write_textgrid(p, 1.5, [("he said ""hi""", 0.5), ("", 1.5)], [("HH", 0.2), ("IY1", 0.5), ("sil", 1.5)])
+    tg = data.read_textgrid(p)
+    assert [m for _, _, m in tg["phones"]] == ["HH", "IY1", "sil"]
+    assert tg["words"][0][:2] == (0.0, 0.5) and tg["words"][1] == (0.5, 1.5, "")
+    assert tg["phones"][1][:2] == (0.2, 0.5)

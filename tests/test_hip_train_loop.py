@@ -64,7 +64,7 @@ def test_trainer_asr_step_matches_oracle(tmp_path):
     torch.manual_seed(9)
     pm = models.PretrainedModel(cfg)
     sd0 = {k: v.detach().cpu().clone() for k, v in pm.state_dict().items()}
-    ds = data.ASRDataset(2, 4, 3200, cfg, seed=3)
+    ds = data.SyntheticASRDataset(2, 4, 3200, cfg, seed=3)
     trainer = training.Trainer(pm, cfg)
     masks = [O.draw_dropout_masks(cfg, ds.batches[i][0], seed=50 + i, include_intent=False) for i in range(2)]
 
@@ -289,3 +289,40 @@ def test_real_data_loader_trains_on_ragged_batches(tmp_path, monkeypatch):
     for k, v in a[4].items():
         assert torch.equal(v, b[4][k]), k
     assert results["pad"][1] != a[1]              # longer zero tails are a different batch
+
+
+def test_real_asr_loader_pretrains(tmp_path, monkeypatch):
+    """get_ASR_datasets on a LibriSpeech-shaped tree (wav + TextGrid alignments) -> Trainer.train/test of the
+    PretrainedModel on the HIP path: ragged snippets, label rows padded with the ignore index."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import data
+    import models
+    import training
+    import slu_data_fixture as fx
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    base = fx.make_asr_tree(str(tmp_path), seed=9, counts=(10, 5, 4))
+    cfg = O.OracleConfig(cnn_N_filt=[8, 6, 6], cnn_len_filt=[41, 5, 3], cnn_stride=[10, 1, 1],
+                         phone_rnn_num_hidden=[16, 16], word_rnn_num_hidden=[16, 16],
+                         intent_rnn_num_hidden=[16], vocabulary_size=6, num_phonemes=11, pretraining_type=2)
+    cfg.folder = str(tmp_path / "exp")
+    os.makedirs(tmp_path / "exp" / "pretraining")
+    cfg.asr_path = base
+    cfg.pretraining_lr = 0.002
+    cfg.pretraining_batch_size = 4
+    cfg.pretraining_length_mean, cfg.pretraining_length_var = 1.0, 0.3
+    cfg.phone_downsample_factor, cfg.word_downsample_factor = 10 * 2 * 4, 10 * 2 * 16
+    torch.manual_seed(2)
+    tr, va, te = data.get_ASR_datasets(cfg)
+    assert cfg.num_phonemes == len(tr.Sy_phoneme) > 5
+    pm = models.PretrainedModel(cfg)
+    trainer = training.Trainer(pm, cfg)
+    first = trainer.train(tr)
+    for _ in range(3):
+        last = trainer.train(tr)
+    valid = trainer.test(va)
+    torch.cuda.synchronize()
+    assert np.isfinite(list(first) + list(last) + list(valid)).all()
+    assert last[1] < first[1]                         # phoneme loss goes down on the training snippets
+    log = open(tmp_path / "exp" / "pretraining" / "log.csv").read().splitlines()
+    assert len(log) == 1 + 4 + 1
