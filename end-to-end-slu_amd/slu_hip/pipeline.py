@@ -2,15 +2,17 @@
 go (a "super-batch") on a side HIP stream, optionally replayed from a captured hipGraph, while the
 trainable remainder of each step runs on the training stream.
 
-Why: with 64 utterances per step a GRU recurrence is 8 persistent workgroups on a 256-CU chip and
-the step is a chain of ~580 dependent recurrence steps — latency-bound, 3 % of the machine.  The
-outputs of frozen stages do not depend on earlier optimisation steps, so P upcoming batches can
-share one pass: the recurrences launch 8P workgroups at the latency of 8, the GEMMs and convolutions
-see P times larger (more efficient) problems, and two slots alternate so that the next super-batch
-is computed while the current one is consumed step by step.  A prefix forward is ~60 kernel launches with fixed shapes and no autograd, i.e. an
-ideal hipGraph: replaying it costs the host a few microseconds instead of ~1 ms of Python dispatch,
-which is what keeps several slots busy at once.  Dropout inside a captured prefix reads its Philox
-offset (step*16) from device memory, so every replay draws the masks of its own step.
+Why: with 64 utterances per step a GRU recurrence is a few dozen persistent workgroups on a 256-CU
+chip and the step is a chain of ~580 dependent recurrence steps — latency-bound, a few per cent of the
+machine.  The outputs of frozen stages do not depend on earlier optimisation steps, so P upcoming
+batches can share one pass: the recurrences launch P times as many workgroups at the same latency, the
+GEMMs and convolutions see P times larger (more efficient) problems, and two slots alternate so that
+the next super-batch is computed while the current one is consumed step by step.  The two halves run
+on CU-partitioned streams (cu_split / cu_range_stream): without the partition the super-batch kernels
+occupy every CU and each small kernel of the training step queues behind them.  A prefix forward is
+~60 kernel launches with fixed shapes and no autograd, i.e. an ideal hipGraph: replaying it costs the
+host a few microseconds instead of ~1 ms of Python dispatch.  Dropout inside a captured prefix reads
+its Philox offset (step*16) from device memory, so every replay draws the masks of its own step.
 """
 import os
 
@@ -62,7 +64,7 @@ def n_compute_units(device):
 class PrefixSlot:
     """One in-flight SUPER-BATCH: the frozen prefix of the encoder evaluated for several upcoming
     batches at once (concatenated along the batch axis) on this slot's side stream.  The recurrence
-    kernels then launch (#batches x 8) workgroups instead of 8 and every other kernel sees a
+    kernels then launch #batches times as many workgroups (two per CU) and every other kernel sees a
     proportionally larger problem, at (nearly) the latency of a single batch."""
     MAX_GRAPHS = 4          # distinct (super-batch shape, prefix length, mode) keys kept per slot
 
