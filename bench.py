@@ -201,10 +201,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # one-off initialisation (hipGraph capture of the look-ahead and step graphs needs a few dozen
-    # eager steps per shape); not part of the W warm-up steps the contract asks for, which follow
+    # one-off initialisation (the look-ahead slots capture a super-batch shape as a hipGraph on its second
+    # appearance, the step graph after three eager steps: a few dozen steps per shape); not part of the W
+    # warm-up steps the contract asks for, which follow
     note("initialisation")
-    run_steps(model, trainer, batches, max(0, 48 - args.warmup))
+    import training as _training
+    width = _training._lookahead_width(trainer.lookahead_depth(True, False)[0] or 1, args.batch)
+    run_steps(model, trainer, batches, max(0, max(48, 8 * width) - args.warmup))
     note("warmup")
     run_steps(model, trainer, batches, args.warmup)
     fence()

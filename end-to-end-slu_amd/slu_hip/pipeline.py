@@ -75,11 +75,13 @@ class PrefixSlot:
                        else torch.cuda.Stream(device))
         self.rng = torch.zeros(1, dtype=torch.int64, device=device)      # step0*16, read by the kernels
         self.graphs = {}
+        self.seen = {}             # how often each super-batch shape was requested
         self.consumed = None       # event: the main stream is done with this slot's last output
         self.signature = None      # versions of the frozen parameters the graphs were captured with
 
     def invalidate(self):
         self.graphs = {}
+        self.seen = {}
 
     def run(self, model, xs, n_prefix, step0, use_graph, after=None):
         """Enqueue stages [0, n_prefix) for the batches `xs` (equal shapes; consecutive dropout steps
@@ -96,7 +98,11 @@ class PrefixSlot:
             if use_graph:
                 key = (len(xs), B, T, n_prefix, bool(model.training))
                 entry = self.graphs.get(key)
-                if entry is None and key not in self.graphs and len(self.graphs) < self.MAX_GRAPHS:
+                # capture a shape on its second appearance in this slot: a one-off shape (the ragged last
+                # group of an epoch, a short run) is cheaper launched eagerly than captured (~10 ms)
+                self.seen[key] = self.seen.get(key, 0) + 1
+                if (entry is None and key not in self.graphs and self.seen[key] >= 2
+                        and len(self.graphs) < self.MAX_GRAPHS):
                     entry = self._capture(model, xs, n_prefix, step0, key)
                 if entry is not None:
                     graph, x_static, feats = entry
