@@ -26,11 +26,14 @@ def init_from_env(backend=None):
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test aid: SLU_DIST_BACKEND=gloo SLU_LOCAL_DEVICE=0 runs several ranks on ONE GPU (RCCL refuses
+    # duplicate devices), which exercises the whole multi-process step path on a single-GPU box.
+    local = int(os.environ.get("SLU_LOCAL_DEVICE", local))
     if ws > 1 and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SLU_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
