@@ -115,7 +115,7 @@ head_reduce_kernel(const float* __restrict__ row_stats, float* __restrict__ loss
   r0[threadIdx.x] = a; r1[threadIdx.x] = c;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+    if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
     __syncthreads();
   }
   if (threadIdx.x == 0) { loss_acc[0] = r0[0] / (float)B; loss_acc[1] = r1[0] / (float)B; }

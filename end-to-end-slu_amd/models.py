@@ -22,7 +22,6 @@ and `predict_intents` run the fused stage plan.  There is no CPU path: without a
 the forward methods raise.  The seq2seq head (models.py:381-651) is outside the hot path and is
 not provided.
 """
-import math
 import os
 import sys
 
