@@ -236,6 +236,48 @@ def _loader_workers():
     return min(16, os.cpu_count() or 1)
 
 
+def wav_num_samples(path):
+    """Number of frames of a wav file from its header (falls back to decoding for non-PCM files)."""
+    import wave
+    try:
+        with wave.open(path, "rb") as w:
+            return w.getnframes()
+    except (wave.Error, EOFError):
+        return len(read_wav(path)[0])
+
+
+class LengthBucketBatchSampler(torch.utils.data.Sampler):
+    """Opt-in batch sampler for ragged real data (SLU_BUCKET_BATCHES=1 together with
+    SLU_PAD_TO_MULTIPLE=n): utterances are bucketed by ceil(length / n), batches are drawn inside a bucket
+    (shuffled every epoch) and the batches of one bucket are emitted consecutively, buckets in random
+    order.  With the collate function padding to the same multiple, every batch of a bucket has the SAME
+    shape and equal shapes are adjacent — which is what lets the look-ahead pipeline form super-batches
+    and replay its hipGraphs on real data (it groups consecutive equally-shaped batches).  The price is
+    less length mixing inside an epoch than the reference's plain shuffle; off by default."""
+
+    def __init__(self, lengths, batch_size, multiple, shuffle=True, generator=None):
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.generator = generator
+        buckets = {}
+        for i, n in enumerate(lengths):
+            buckets.setdefault(-(-int(n) // int(multiple)), []).append(i)
+        self.buckets = [buckets[k] for k in sorted(buckets)]
+
+    def __len__(self):
+        return sum(-(-len(b) // self.batch_size) for b in self.buckets)
+
+    def __iter__(self):
+        g = self.generator
+        order = torch.randperm(len(self.buckets), generator=g).tolist() if self.shuffle else range(len(self.buckets))
+        for k in order:
+            idx = self.buckets[k]
+            if self.shuffle:
+                idx = [idx[j] for j in torch.randperm(len(idx), generator=g).tolist()]
+            for s0 in range(0, len(idx), self.batch_size):
+                yield idx[s0:s0 + self.batch_size]
+
+
 class SLUDataset(torch.utils.data.Dataset):
     """Fluent-Speech-Commands-style dataset (reference data.py:246-329): rows of `df` (columns path,
     action, object, location), wavs under `base_path`; item = (float32 waveform, [3 label indices]);
@@ -254,9 +296,16 @@ class SLUDataset(torch.utils.data.Dataset):
         # label lookup and paths as plain lists: no per-item DataFrame indexing in the workers
         self._paths = [os.path.join(base_path, p) for p in df["path"].tolist()]
         self._values = list(zip(df["action"].tolist(), df["object"].tolist(), df["location"].tolist()))
-        self.loader = torch.utils.data.DataLoader(
-            self, batch_size=config.training_batch_size, num_workers=_loader_workers(), shuffle=True,
-            collate_fn=CollateWavsSLU(self.Sy_intent, self.seq2seq, pin=True))
+        collate = CollateWavsSLU(self.Sy_intent, self.seq2seq, pin=True)
+        if os.environ.get("SLU_BUCKET_BATCHES", "0") == "1" and collate.pad_multiple > 1:
+            lengths = [wav_num_samples(p) for p in self._paths] * self.upsample_factor
+            self.loader = torch.utils.data.DataLoader(
+                self, num_workers=_loader_workers(), collate_fn=collate,
+                batch_sampler=LengthBucketBatchSampler(lengths, config.training_batch_size, collate.pad_multiple))
+        else:
+            self.loader = torch.utils.data.DataLoader(
+                self, batch_size=config.training_batch_size, num_workers=_loader_workers(), shuffle=True,
+                collate_fn=collate)
 
     def __len__(self):
         return len(self._paths) * self.upsample_factor

@@ -179,3 +179,37 @@ def test_textgrid_reader_edge_cases(tmp_path):
     assert [m for _, _, m in tg["phones"]] == ["HH", "IY1", "sil"]
     assert tg["words"][0][:2] == (0.0, 0.5) and tg["words"][1] == (0.5, 1.5, "")
     assert tg["phones"][1][:2] == (0.2, 0.5)
+
+
+def test_length_bucketed_batches(tmp_path, monkeypatch):
+    """SLU_BUCKET_BATCHES=1 + SLU_PAD_TO_MULTIPLE: every utterance once per epoch, one shape per bucket,
+    equal shapes adjacent (what the look-ahead pipeline groups on), a new order every epoch."""
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    monkeypatch.setenv("SLU_PAD_TO_MULTIPLE", "500")
+    monkeypatch.setenv("SLU_BUCKET_BATCHES", "1")
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=8, sizes=(60, 30, 9, 9))
+    torch.manual_seed(0)
+    tr, va, te = data.get_SLU_datasets(_config(root, {"dataset_upsample_factor": 2}))
+    assert isinstance(tr.loader.batch_sampler, data.LengthBucketBatchSampler)
+    lengths = [data.wav_num_samples(p) for p in tr._paths]
+    epochs = []
+    for _ in range(2):
+        order, shapes = [], []
+        for batch in tr.loader.batch_sampler:
+            order.append(list(batch))
+        seen = sorted(i for b in order for i in b)
+        assert seen == list(range(len(tr)))                       # every (upsampled) index exactly once
+        for b in order:
+            ts = {-(-lengths[i % len(lengths)] // 500) for i in b}
+            assert len(ts) == 1 and len(b) <= 4
+            shapes.append(ts.pop())
+        changes = sum(1 for a, b in zip(shapes, shapes[1:]) if a != b)
+        assert changes == len(set(shapes)) - 1                    # the batches of a bucket are consecutive
+        epochs.append(order)
+    assert epochs[0] != epochs[1]
+    n = 0
+    for x, y in tr.loader:                                        # collate pads to the bucket's multiple
+        assert x.shape[1] % 500 == 0 and x.shape[1] - 500 < max(1, int((x != 0).any(0).nonzero().max()) + 1)
+        n += len(x)
+    assert n == len(tr)

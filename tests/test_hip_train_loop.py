@@ -326,3 +326,53 @@ def test_real_asr_loader_pretrains(tmp_path, monkeypatch):
     assert last[1] < first[1]                         # phoneme loss goes down on the training snippets
     log = open(tmp_path / "exp" / "pretraining" / "log.csv").read().splitlines()
     assert len(log) == 1 + 4 + 1
+
+
+def test_bucketed_real_data_forms_super_batches(tmp_path, monkeypatch):
+    """With the length-bucketed sampler the ragged FSC-shaped data reaches the look-ahead pipeline as runs of
+    equally-shaped batches: super-batches of several batches are formed and the result is still the
+    sequential one, bit for bit."""
+    sys.path.insert(0, PKG)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import data
+    import models
+    import training
+    import slu_data_fixture as fx
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    monkeypatch.setenv("SLU_PAD_TO_MULTIPLE", "800")
+    monkeypatch.setenv("SLU_BUCKET_BATCHES", "1")
+    root = str(tmp_path / "fsc")
+    fx.make_fsc_tree(root, seed=22, sizes=(70, 50, 9, 9))
+    results = {}
+    for mode in ("0", "3"):
+        monkeypatch.setenv("SLU_LOOKAHEAD", mode)
+        cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                             phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                             intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=2)
+        work = tmp_path / ("run_" + mode)
+        os.makedirs(work / "pretraining")
+        os.makedirs(work / "training")
+        cfg.folder, cfg.slu_path, cfg.seq2seq = str(work), root, False
+        cfg.training_lr, cfg.training_batch_size, cfg.unfreezing_type, cfg.starting_unfreezing_index = 0.003, 8, 0, 1
+        cfg.seed = 1
+        for k in ("real_speaker_subset_percentage", "synthetic_speaker_subset_percentage",
+                  "real_dataset_subset_percentage", "synthetic_dataset_subset_percentage"):
+            setattr(cfg, k, 1.0)
+        cfg.train_wording_path = cfg.test_wording_path = None
+        cfg.dataset_upsample_factor = 1
+        torch.manual_seed(4)
+        tr, va, te = data.get_SLU_datasets(cfg)
+        torch.save(models.PretrainedModel(cfg).state_dict(), work / "pretraining" / "model_state.pth")
+        model = models.Model(cfg)
+        models.set_dropout_seed(5)
+        trainer = training.Trainer(model, cfg)
+        torch.manual_seed(6)
+        res = trainer.train(tr)
+        torch.cuda.synchronize()
+        results[mode] = (res, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        if mode == "3":
+            widths = [key[0] for slot in trainer._slots for key in slot.seen]
+            assert max(widths) == 3                   # several equally-shaped batches per super-batch
+    assert results["0"][0] == results["3"][0]
+    for k, v in results["0"][1].items():
+        assert torch.equal(v, results["3"][1][k]), k
