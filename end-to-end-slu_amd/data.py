@@ -227,6 +227,14 @@ class CollateWavsSLU:
         return x, y
 
 
+def _world():
+    """(rank, world size) of the data-parallel job (one process per GPU), (0, 1) outside one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def _loader_workers():
     """The reference starts one DataLoader worker per core (data.py:261); on a 256-thread MI355X host
     that is all start-up cost, so the default is capped (SLU_DATA_WORKERS overrides, 0 = in-process)."""
@@ -253,22 +261,30 @@ class LengthBucketBatchSampler(torch.utils.data.Sampler):
     order.  With the collate function padding to the same multiple, every batch of a bucket has the SAME
     shape and equal shapes are adjacent — which is what lets the look-ahead pipeline form super-batches
     and replay its hipGraphs on real data (it groups consecutive equally-shaped batches).  The price is
-    less length mixing inside an epoch than the reference's plain shuffle; off by default."""
+    less length mixing inside an epoch than the reference's plain shuffle; off by default.
+    Under data parallelism every rank draws the same batch list (seed + epoch) and keeps every
+    world-th batch, wrapping around so that all ranks run the same number of steps."""
 
-    def __init__(self, lengths, batch_size, multiple, shuffle=True, generator=None):
+    def __init__(self, lengths, batch_size, multiple, shuffle=True, generator=None, rank=0, world=1, seed=0):
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
         self.generator = generator
+        self.rank, self.world, self.seed, self.epoch = rank, world, seed, 0
         buckets = {}
         for i, n in enumerate(lengths):
             buckets.setdefault(-(-int(n) // int(multiple)), []).append(i)
         self.buckets = [buckets[k] for k in sorted(buckets)]
 
-    def __len__(self):
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _total(self):
         return sum(-(-len(b) // self.batch_size) for b in self.buckets)
 
-    def __iter__(self):
-        g = self.generator
+    def __len__(self):
+        return -(-self._total() // self.world)
+
+    def _batches(self, g):
         order = torch.randperm(len(self.buckets), generator=g).tolist() if self.shuffle else range(len(self.buckets))
         for k in order:
             idx = self.buckets[k]
@@ -277,13 +293,22 @@ class LengthBucketBatchSampler(torch.utils.data.Sampler):
             for s0 in range(0, len(idx), self.batch_size):
                 yield idx[s0:s0 + self.batch_size]
 
+    def __iter__(self):
+        if self.world == 1:
+            yield from self._batches(self.generator)
+            return
+        g = torch.Generator().manual_seed(self.seed + self.epoch)       # the same list on every rank
+        batches = list(self._batches(g))
+        for k in range(len(self)):
+            yield batches[(self.rank + k * self.world) % len(batches)]
+
 
 class SLUDataset(torch.utils.data.Dataset):
     """Fluent-Speech-Commands-style dataset (reference data.py:246-329): rows of `df` (columns path,
     action, object, location), wavs under `base_path`; item = (float32 waveform, [3 label indices]);
     `len` = rows x upsample_factor; `.loader` = shuffling DataLoader with CollateWavsSLU."""
 
-    def __init__(self, df, base_path, Sy_intent, config, upsample_factor=1):
+    def __init__(self, df, base_path, Sy_intent, config, upsample_factor=1, shard=False):
         self.df = df
         self.base_path = base_path
         self.Sy_intent = Sy_intent
@@ -297,11 +322,23 @@ class SLUDataset(torch.utils.data.Dataset):
         self._paths = [os.path.join(base_path, p) for p in df["path"].tolist()]
         self._values = list(zip(df["action"].tolist(), df["object"].tolist(), df["location"].tolist()))
         collate = CollateWavsSLU(self.Sy_intent, self.seq2seq, pin=True)
+        # Data parallelism (`shard`: the training split only): every rank draws a disjoint 1/world of the
+        # epoch (DistributedSampler pads by repetition so that all ranks run the same number of steps);
+        # validation / test stay whole on every rank, so their metrics are the single-process ones.
+        rank, world = _world() if shard else (0, 1)
+        seed = getattr(config, "seed", 0)
         if os.environ.get("SLU_BUCKET_BATCHES", "0") == "1" and collate.pad_multiple > 1:
             lengths = [wav_num_samples(p) for p in self._paths] * self.upsample_factor
             self.loader = torch.utils.data.DataLoader(
                 self, num_workers=_loader_workers(), collate_fn=collate,
-                batch_sampler=LengthBucketBatchSampler(lengths, config.training_batch_size, collate.pad_multiple))
+                batch_sampler=LengthBucketBatchSampler(lengths, config.training_batch_size, collate.pad_multiple,
+                                                       rank=rank, world=world, seed=seed))
+        elif world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(self, num_replicas=world, rank=rank,
+                                                                      shuffle=True, seed=seed)
+            self.loader = torch.utils.data.DataLoader(
+                self, batch_size=config.training_batch_size, num_workers=_loader_workers(), sampler=sampler,
+                collate_fn=collate)
         else:
             self.loader = torch.utils.data.DataLoader(
                 self, batch_size=config.training_batch_size, num_workers=_loader_workers(), shuffle=True,
@@ -419,7 +456,7 @@ class ASRDataset(torch.utils.data.Dataset):
     Label lookup is a dictionary (first index wins, like list.index) and the per-sample label tracks are
     numpy repeats instead of Python lists."""
 
-    def __init__(self, wav_paths, textgrid_paths, Sy_phoneme, Sy_word, config):
+    def __init__(self, wav_paths, textgrid_paths, Sy_phoneme, Sy_word, config, shard=False):
         self.wav_paths = wav_paths
         self.textgrid_paths = textgrid_paths
         self.length_mean = config.pretraining_length_mean
@@ -433,9 +470,17 @@ class ASRDataset(torch.utils.data.Dataset):
             self._phone_idx.setdefault(v, i)
         for i, v in enumerate(Sy_word):
             self._word_idx.setdefault(v, i)
-        self.loader = torch.utils.data.DataLoader(
-            self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), shuffle=True,
-            collate_fn=CollateWavsASR(pin=True))
+        rank, world = _world() if shard else (0, 1)          # training split under data parallelism
+        if world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(self, num_replicas=world, rank=rank,
+                                                                      shuffle=True, seed=getattr(config, "seed", 0))
+            self.loader = torch.utils.data.DataLoader(
+                self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), sampler=sampler,
+                collate_fn=CollateWavsASR(pin=True))
+        else:
+            self.loader = torch.utils.data.DataLoader(
+                self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), shuffle=True,
+                collate_fn=CollateWavsASR(pin=True))
 
     def __len__(self):
         return len(self.wav_paths)
@@ -546,7 +591,9 @@ def get_SLU_datasets(config):
         config.num_phonemes = 42 if n_ph is None else n_ph
         mk = lambda n, seed: SyntheticSLUDataset(n, bs, ns, config.values_per_slot, seed=seed,
                                                  Sy_intent=config.Sy_intent)
-        return mk(nb, config.seed), mk(max(1, nb // 4), config.seed + 1), mk(max(1, nb // 4), config.seed + 2)
+        rank = _world()[0]                                  # every rank its own training batches
+        return (mk(nb, config.seed + 1000003 * rank), mk(max(1, nb // 4), config.seed + 1),
+                mk(max(1, nb // 4), config.seed + 2))
     if config.seq2seq:
         raise NotImplementedError("seq2seq datasets (reference data.py:143-146, 201-208) are out of scope")
     base_path = config.slu_path
@@ -603,7 +650,8 @@ def get_SLU_datasets(config):
     n_ph = _read_phoneme_count(config)
     if n_ph is not None:
         config.num_phonemes = n_ph
-    train_dataset = SLUDataset(train_df, base_path, Sy_intent, config, upsample_factor=config.dataset_upsample_factor)
+    train_dataset = SLUDataset(train_df, base_path, Sy_intent, config, upsample_factor=config.dataset_upsample_factor,
+                               shard=True)
     valid_dataset = SLUDataset(valid_df, base_path, Sy_intent, config)
     test_dataset = SLUDataset(test_df, base_path, Sy_intent, config)
     return train_dataset, valid_dataset, test_dataset
@@ -621,7 +669,9 @@ def get_ASR_datasets(config):
         bs = bs or config.pretraining_batch_size
         config.num_phonemes = 42
         mk = lambda n, seed: SyntheticASRDataset(n, bs, ns, config, seed=seed)
-        return mk(nb, config.seed), mk(max(1, nb // 4), config.seed + 1), mk(max(1, nb // 4), config.seed + 2)
+        rank = _world()[0]
+        return (mk(nb, config.seed + 1000003 * rank), mk(max(1, nb // 4), config.seed + 1),
+                mk(max(1, nb // 4), config.seed + 2))
     import glob
     base_path = config.asr_path
     wavs = lambda tgs: [p.replace("text", "audio").replace(".TextGrid", ".wav") for p in tgs]
@@ -630,6 +680,14 @@ def get_ASR_datasets(config):
     test_tg = glob.glob(base_path + "/text/test*/*/*/*.TextGrid")
     ph_file = os.path.join(config.folder, "pretraining", "phonemes.txt")
     wd_file = os.path.join(config.folder, "pretraining", "words.txt")
+    rank, world = _world()
+    if world > 1:
+        # identical file order on every rank (DistributedSampler indexes into it); one rank builds the
+        # vocabulary files, the others read them
+        train_tg, valid_tg, test_tg = sorted(train_tg), sorted(valid_tg), sorted(test_tg)
+        import torch.distributed as dist
+        if rank != 0:
+            dist.barrier()
     if os.path.isfile(ph_file) and os.path.isfile(wd_file):
         with open(ph_file, "r") as f:
             Sy_phoneme = [ln.rstrip("\n") for ln in f.readlines() if ln.rstrip("\n") != ""]
@@ -652,6 +710,8 @@ def get_ASR_datasets(config):
         with open(wd_file, "w") as f:
             for word in Sy_word:
                 f.write(word + "\n")
+    if world > 1 and rank == 0:
+        dist.barrier()
     print("Done.")
-    mk = lambda tgs: ASRDataset(wavs(tgs), tgs, Sy_phoneme, Sy_word, config)
-    return mk(train_tg), mk(valid_tg), mk(test_tg)
+    mk = lambda tgs, shard=False: ASRDataset(wavs(tgs), tgs, Sy_phoneme, Sy_word, config, shard=shard)
+    return mk(train_tg, True), mk(valid_tg), mk(test_tg)

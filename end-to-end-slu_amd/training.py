@@ -295,6 +295,11 @@ class Trainer:
             if self.rank == 0:
                 self.model.print_frozen()
         it = dataset.loader
+        if train:
+            # data-parallel / bucketed samplers reshuffle per epoch from (seed, epoch)
+            for smp in (getattr(it, "sampler", None), getattr(it, "batch_sampler", None)):
+                if hasattr(smp, "set_epoch"):
+                    smp.set_epoch(self.epoch)
         if train and self.rank == 0:
             it = tqdm(it)
         for idx, (vals, batch_size) in enumerate(self._iterate(it, train, asr)):

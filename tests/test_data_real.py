@@ -213,3 +213,40 @@ def test_length_bucketed_batches(tmp_path, monkeypatch):
         assert x.shape[1] % 500 == 0 and x.shape[1] - 500 < max(1, int((x != 0).any(0).nonzero().max()) + 1)
         n += len(x)
     assert n == len(tr)
+
+
+@pytest.mark.parametrize("bucketed", [False, True])
+def test_training_split_is_sharded_across_ranks(tmp_path, monkeypatch, bucketed):
+    """Under data parallelism the ranks draw disjoint parts of each training epoch (same number of steps
+    on every rank, a new partition per epoch); validation stays whole on every rank."""
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    if bucketed:
+        monkeypatch.setenv("SLU_PAD_TO_MULTIPLE", "500")
+        monkeypatch.setenv("SLU_BUCKET_BATCHES", "1")
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=12, sizes=(41, 20, 9, 9))
+    per_rank = {}
+    for rank in (0, 1):
+        monkeypatch.setattr(data, "_world", lambda r=rank: (r, 2))
+        np.random.seed(0)
+        tr, va, te = data.get_SLU_datasets(_config(root, {}))
+        assert sum(len(x) for x, _ in va.loader) == len(va)                  # whole validation set
+        epochs = []
+        for epoch in (0, 1):
+            smp = tr.loader.batch_sampler if bucketed else tr.loader.sampler
+            smp.set_epoch(epoch)
+            if bucketed:
+                idx = [list(b) for b in tr.loader.batch_sampler]
+            else:
+                idx = [list(tr.loader.sampler)]
+            epochs.append(idx)
+        per_rank[rank] = epochs
+    for epoch in (0, 1):
+        a = [i for b in per_rank[0][epoch] for i in b]
+        b = [i for b in per_rank[1][epoch] for i in b]
+        assert len(per_rank[0][epoch]) == len(per_rank[1][epoch])            # same number of steps
+        if bucketed:
+            assert set(a) | set(b) == set(range(61))
+        else:
+            assert len(a) == len(b) == 31 and set(a) | set(b) == set(range(61))   # 61 items -> 31 + 31 (one repeated)
+    assert per_rank[0][0] != per_rank[0][1]
