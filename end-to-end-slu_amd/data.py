@@ -198,16 +198,16 @@ def read_wav(path):
 class CollateWavsSLU:
     """list of (waveform, [action, object, location]) -> (x (B, T_max) float32 zero-padded at the end,
     y_intent (B, 3) int64), as reference data.py:344-376 (non-seq2seq branch).  The batch is assembled
-    directly in ONE buffer (pinned when `pin` and a GPU is present, so the H2D copy of the look-ahead
-    slots is asynchronous) instead of per-row pad + stack."""
+    directly in ONE buffer instead of per-row pad + stack; the DataLoader pins it (pin_memory=True, in
+    the parent process — never in a forked worker) so that the H2D copy of the look-ahead slots is
+    asynchronous."""
 
-    def __init__(self, Sy_intent, seq2seq, pin=False, pad_multiple=None):
+    def __init__(self, Sy_intent, seq2seq, pad_multiple=None):
         if seq2seq:
             raise NotImplementedError("seq2seq collation (reference data.py:363-376) is out of scope")
         self.Sy_intent = Sy_intent
         self.num_labels = len(self.Sy_intent)
         self.seq2seq = seq2seq
-        self.pin = pin
         # Opt-in (SLU_PAD_TO_MULTIPLE=n samples): round T_max up to a multiple of n so that ragged real
         # data falls into a few batch shapes (the look-ahead super-batches and hipGraphs are per shape).
         # Off by default: the extra trailing zeros are seen by the recurrences, i.e. it is not the
@@ -222,8 +222,6 @@ class CollateWavsSLU:
         for i, (xi, _) in enumerate(batch):
             x[i, :len(xi)] = torch.as_tensor(np.asarray(xi), dtype=torch.float32)
         y = torch.tensor([list(yi) for _, yi in batch], dtype=torch.int64)
-        if self.pin and torch.cuda.is_available():
-            x, y = x.pin_memory(), y.pin_memory()
         return x, y
 
 
@@ -321,7 +319,8 @@ class SLUDataset(torch.utils.data.Dataset):
         # label lookup and paths as plain lists: no per-item DataFrame indexing in the workers
         self._paths = [os.path.join(base_path, p) for p in df["path"].tolist()]
         self._values = list(zip(df["action"].tolist(), df["object"].tolist(), df["location"].tolist()))
-        collate = CollateWavsSLU(self.Sy_intent, self.seq2seq, pin=True)
+        collate = CollateWavsSLU(self.Sy_intent, self.seq2seq)
+        pin = torch.cuda.is_available()
         # Data parallelism (`shard`: the training split only): every rank draws a disjoint 1/world of the
         # epoch (DistributedSampler pads by repetition so that all ranks run the same number of steps);
         # validation / test stay whole on every rank, so their metrics are the single-process ones.
@@ -330,7 +329,7 @@ class SLUDataset(torch.utils.data.Dataset):
         if os.environ.get("SLU_BUCKET_BATCHES", "0") == "1" and collate.pad_multiple > 1:
             lengths = [wav_num_samples(p) for p in self._paths] * self.upsample_factor
             self.loader = torch.utils.data.DataLoader(
-                self, num_workers=_loader_workers(), collate_fn=collate,
+                self, num_workers=_loader_workers(), collate_fn=collate, pin_memory=pin,
                 batch_sampler=LengthBucketBatchSampler(lengths, config.training_batch_size, collate.pad_multiple,
                                                        rank=rank, world=world, seed=seed))
         elif world > 1:
@@ -338,11 +337,11 @@ class SLUDataset(torch.utils.data.Dataset):
                                                                       shuffle=True, seed=seed)
             self.loader = torch.utils.data.DataLoader(
                 self, batch_size=config.training_batch_size, num_workers=_loader_workers(), sampler=sampler,
-                collate_fn=collate)
+                collate_fn=collate, pin_memory=pin)
         else:
             self.loader = torch.utils.data.DataLoader(
                 self, batch_size=config.training_batch_size, num_workers=_loader_workers(), shuffle=True,
-                collate_fn=collate)
+                collate_fn=collate, pin_memory=pin)
 
     def __len__(self):
         return len(self._paths) * self.upsample_factor
@@ -426,10 +425,7 @@ def _strip_stress(mark):
 class CollateWavsASR:
     """list of (waveform, phoneme labels, word labels) -> (x (B,T_max) float32 zero-padded, y_phoneme
     (B,U_p) int64, y_word (B,U_w) int64, both padded with the ignore index -1) — reference data.py:511-545.
-    Assembled in one (optionally pinned) buffer per tensor."""
-
-    def __init__(self, pin=False):
-        self.pin = pin
+    Assembled in one buffer per tensor (pinned by the DataLoader)."""
 
     def __call__(self, batch):
         n = len(batch)
@@ -443,8 +439,6 @@ class CollateWavsASR:
             x[i, :len(xi)] = torch.as_tensor(np.asarray(xi)).float()
             yp[i, :len(pi)] = torch.as_tensor(np.asarray(pi, dtype=np.int64))
             yw[i, :len(wi)] = torch.as_tensor(np.asarray(wi, dtype=np.int64))
-        if self.pin and torch.cuda.is_available():
-            x, yp, yw = x.pin_memory(), yp.pin_memory(), yw.pin_memory()
         return x, yp, yw
 
 
@@ -476,11 +470,11 @@ class ASRDataset(torch.utils.data.Dataset):
                                                                       shuffle=True, seed=getattr(config, "seed", 0))
             self.loader = torch.utils.data.DataLoader(
                 self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), sampler=sampler,
-                collate_fn=CollateWavsASR(pin=True))
+                collate_fn=CollateWavsASR(), pin_memory=torch.cuda.is_available())
         else:
             self.loader = torch.utils.data.DataLoader(
                 self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), shuffle=True,
-                collate_fn=CollateWavsASR(pin=True))
+                collate_fn=CollateWavsASR(), pin_memory=torch.cuda.is_available())
 
     def __len__(self):
         return len(self.wav_paths)

@@ -300,7 +300,7 @@ def test_real_asr_loader_pretrains(tmp_path, monkeypatch):
     import models
     import training
     import slu_data_fixture as fx
-    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    monkeypatch.setenv("SLU_DATA_WORKERS", "2")      # forked workers decode, the parent pins and trains
     base = fx.make_asr_tree(str(tmp_path), seed=9, counts=(10, 5, 4))
     cfg = O.OracleConfig(cnn_N_filt=[8, 6, 6], cnn_len_filt=[41, 5, 3], cnn_stride=[10, 1, 1],
                          phone_rnn_num_hidden=[16, 16], word_rnn_num_hidden=[16, 16],
