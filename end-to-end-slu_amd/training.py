@@ -199,7 +199,8 @@ class Trainer:
         main = self._train_stream
         main.wait_stream(outer)
         if getattr(self, "_slots", None) is None:
-            self._slots = [pipeline.PrefixSlot(dev) for _ in range(2)]      # double-buffered super-batches
+            n_slots = max(2, int(os.environ.get("SLU_LOOKAHEAD_SLOTS", "2")))
+            self._slots = [pipeline.PrefixSlot(dev) for _ in range(n_slots)]   # in-flight super-batches
         pm = self.model.pretrained_model
         with torch.cuda.stream(main):
             pm.warm_weight_caches()
@@ -232,7 +233,7 @@ class Trainer:
                 group.append(batch)
             if not group:
                 return False
-            slot = self._slots[launched % 2]
+            slot = self._slots[launched % len(self._slots)]
             launched += 1
             steps = [next_rng_step() for _ in group]                        # consecutive by construction
             feats, done = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
@@ -246,8 +247,8 @@ class Trainer:
         # synchronisation with blocking streams (the CU-masked ones) would serialise the pipeline.
         try:
             with torch.cuda.stream(main):
-                launch_next()
-                launch_next()
+                for _ in self._slots:
+                    launch_next()
                 while pending:
                     group, feats_cat, done, steps, slot = pending.popleft()
                     B = group[0][0].shape[0]
