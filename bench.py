@@ -4,20 +4,30 @@ B = 64 per GPU — BASELINE.json `metric`, workload = configs[3] (no_unfreezing:
 SincNet/conv/biGRU encoder in train mode + intent GRU trained; forward, loss, backward, gradient
 all-reduce, Adam) — through models.Model / training.Trainer on the HIP kernels.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload no_unfreezing|unfreeze_all]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload no_unfreezing|unfreeze_all|asr_pretrain]
+
+`--gpus N` with N > 1 launches the N ranks itself (one process per GPU, RCCL over xGMI) unless the
+process was already started by torch.distributed.run (WORLD_SIZE set), which works as well:
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One JSON line on rank 0.  `value` = utterances all ranks processed / max-over-ranks wall time of the
-K timed steps (inputs resident in HBM, barrier + synchronize on both sides).  `roofline` is for the
-dominant kernel (the persistent GRU recurrence, fp32 MFMA bound): algorithmic flops of its launches
-in the timed region / their HIP-event durations.  `cpu_baseline` times the CPU oracle (torch-CPU
-restatement of the reference path) on a bounded sample of the same workload on this host's cores.
+K timed steps (inputs resident in HBM, barrier + synchronize on both sides).
+`roofline` describes the kernel with the largest share of the step's GPU time and lists the top
+three (`kernels`): algorithmic flops of each distinct launch shape of the timed steps / its average
+duration, measured with HIP events on the CU-masked stream the kernel runs on, the launches enqueued
+back to back (a hipGraph of 20) so that no host dispatch gap is counted.  `cpu_baseline` times the CPU
+oracle (torch-CPU restatement of the reference path) on a bounded sample of the same workload on this
+host's cores.  `parity` = the golden batch of BASELINE configs[0] (tests/golden/g6, generated from the
+reference) through this very process' kernels: max-abs logit deviation and predicted-intent equality.
 """
 import argparse
 import json
 import os
 import shutil
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -34,8 +44,20 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 BATCH = 64
 SECONDS = 3
 FS = 16000
+CFG = {"no_unfreezing": "no_unfreezing_synthetic.cfg", "unfreeze_all": "unfreeze_all_layers_synthetic.cfg",
+       "asr_pretrain": "unfreeze_all_layers_synthetic.cfg"}
+WORKLOAD_TEXT = {
+    "no_unfreezing": "experiments/no_unfreezing.cfg SLU train step (frozen SincNet/conv/biGRU encoder in train "
+                     "mode + intent biGRU trained): fwd + 3-slot CE + bwd + grad all-reduce + Adam",
+    "unfreeze_all": "SLU train step with every encoder layer unfrozen (unfreeze_all_layers end state): fwd + CE "
+                    "+ full bwd + grad all-reduce + Adam",
+    "asr_pretrain": "ASR pre-training step of the full PretrainedModel (BASELINE configs[2]): fwd + phoneme/word "
+                    "CE heads (vocabulary 10 000) + full bwd + grad all-reduce + Adam"}
 
 
+# ------------------------------------------------------------------------------------------------------
+# setup
+# ------------------------------------------------------------------------------------------------------
 def setup(workload, rank, batch, samples, n_batches):
     """read_config on the package's synthetic cfg, synthetic pre-training checkpoint, Model, Trainer."""
     import data
@@ -44,26 +66,34 @@ def setup(workload, rank, batch, samples, n_batches):
 
     work = tempfile.mkdtemp(prefix="slu_bench_")
     os.makedirs(os.path.join(work, "experiments"))
-    name = "no_unfreezing_synthetic.cfg" if workload == "no_unfreezing" else "unfreeze_all_layers_synthetic.cfg"
+    name = CFG[workload]
     shutil.copy(os.path.join(PKG, "experiments", name), os.path.join(work, "experiments", name))
     cwd = os.getcwd()
     os.chdir(work)
     try:
         config = data.read_config(os.path.join("experiments", name))
         config.folder = os.path.join(work, config.folder)
-        config.slu_path = "synthetic:%dx%dx%d" % (n_batches, batch, samples)
+        for sub in ("", "pretraining", "training"):
+            os.makedirs(os.path.join(config.folder, sub), exist_ok=True)
         config.seed = 1234 + rank                      # per-rank synthetic data
-        train_ds, _, _ = data.get_SLU_datasets(config)
-        torch.manual_seed(4321)                        # synthetic "pre-trained" encoder (no .pth published)
-        torch.save({k: v.cpu() for k, v in models.PretrainedModel(config).state_dict().items()},
-                   os.path.join(config.folder, "pretraining", "model_state.pth"))
-        torch.manual_seed(1234)
-        model = models.Model(config)
-        if workload == "unfreeze_all":
-            for p in model.pretrained_model.phoneme_layers.parameters():
-                p.requires_grad = True
-            for p in model.pretrained_model.word_layers.parameters():
-                p.requires_grad = True
+        if workload == "asr_pretrain":
+            config.asr_path = "synthetic:%dx%dx%d" % (n_batches, batch, samples)
+            train_ds, _, _ = data.get_ASR_datasets(config)
+            torch.manual_seed(1234)
+            model = models.PretrainedModel(config)
+        else:
+            config.slu_path = "synthetic:%dx%dx%d" % (n_batches, batch, samples)
+            train_ds, _, _ = data.get_SLU_datasets(config)
+            torch.manual_seed(4321)                    # synthetic "pre-trained" encoder (no .pth published)
+            torch.save({k: v.cpu() for k, v in models.PretrainedModel(config).state_dict().items()},
+                       os.path.join(config.folder, "pretraining", "model_state.pth"))
+            torch.manual_seed(1234)
+            model = models.Model(config)
+            if workload == "unfreeze_all":
+                for p in model.pretrained_model.phoneme_layers.parameters():
+                    p.requires_grad = True
+                for p in model.pretrained_model.word_layers.parameters():
+                    p.requires_grad = True
         models.set_dropout_seed(1234 + 7919 * rank)
         trainer = training.Trainer(model=model, config=config)
     finally:
@@ -71,28 +101,56 @@ def setup(workload, rank, batch, samples, n_batches):
     return config, model, trainer, train_ds, work
 
 
-def run_steps(model, trainer, batches, n):
+def run_steps(model, trainer, batches, n, asr=False, first_done=None):
     """n optimisation steps through Trainer's own step loop (forward, loss, backward, gradient
-    all-reduce, Adam; with the frozen-encoder look-ahead pipeline when it applies)."""
+    all-reduce, Adam; with the frozen-encoder look-ahead pipeline when it applies).
+    first_done: optional timing event recorded when the first step has been enqueued completely."""
+    import contextlib
     dev = next(model.parameters()).device
-    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    sums = None
     loader = [batches[i % len(batches)] for i in range(n)]
-    for vals, _ in trainer._iterate(loader, True, False):
-        if torch.is_tensor(vals):
+    with contextlib.closing(trainer._iterate(loader, True, asr)) as steps:
+        for i, (vals, _) in enumerate(steps):
+            if not torch.is_tensor(vals):
+                vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
+            if sums is None:
+                sums = torch.zeros(vals.numel(), dtype=torch.float64, device=dev)
             sums.add_(vals)
-        else:
-            sums += torch.stack([v.detach().double() for v in vals])
+            if i == 0 and first_done is not None:
+                first_done.record()
     return sums
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = torch-CPU restatement of the reference path); the ONLY user of oracle/ here
+# ------------------------------------------------------------------------------------------------------
+def host_topology():
+    """lscpu model / sockets / cores / threads of the box the baseline runs on."""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        want = {"Model name": "model", "Socket(s)": "sockets", "Core(s) per socket": "cores_per_socket",
+                "Thread(s) per core": "threads_per_core", "CPU(s)": "logical_cpus"}
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in want:
+                v = v.strip()
+                info[want[k.strip()]] = int(v) if v.isdigit() else v
+        if "sockets" in info and "cores_per_socket" in info:
+            info["physical_cores"] = info["sockets"] * info["cores_per_socket"]
+    except Exception as e:                           # lscpu missing: keep os.cpu_count()
+        info["lscpu_error"] = str(e)
+    return info
 
 
 def cpu_baseline(config, batch, samples, budget_s=20.0):
     """The CPU oracle (torch-CPU restatement of the reference path, ATen GRU like the reference) on
-    the same workload: train-mode forward + backward of the trainable part + Adam, all host cores."""
+    the same workload: train-mode forward + backward of the trainable part + Adam, on the host's cores."""
     from oracle import slu_oracle as O
     # torch's default intra-op pool (what the reference would run with on this host), capped: with
     # one thread per SMT sibling (256 on the MI355X host) ATen's small per-step GRU matmuls thrash.
-    cores = max(1, min(torch.get_num_threads(), 64))
-    torch.set_num_threads(cores)
+    threads = max(1, min(torch.get_num_threads(), 64))
+    torch.set_num_threads(threads)
     torch.manual_seed(1234)
     sd = O.init_model_state_dict(config)
     trainable = [k for k in sd if k.startswith("intent_layers")]
@@ -113,52 +171,215 @@ def cpu_baseline(config, batch, samples, budget_s=20.0):
         opt.step()
 
     t0 = time.perf_counter()
-    step(False)                                                # warm-up
+    step(False)                                                # warm-up (thread pool, allocator, mkldnn primitives)
     first = time.perf_counter() - t0
+    warm = 1
+    while warm < 3 and first * (warm + 1) < budget_s * 0.25:
+        step(False)
+        warm += 1
     t0 = time.perf_counter()
     n = 0
-    while n < 1 or (n < 3 and first < budget_s / 4) or (time.perf_counter() - t0 + first < budget_s * 0.6 and n < 50):
+    while n < 3 or (time.perf_counter() - t0 < budget_s * 0.5 and n < 50):
         step(False)
         n += 1
     dedup = n * batch / (time.perf_counter() - t0)
+    step(True)                                                 # warm-up of the 80-convolution variant
     t0 = time.perf_counter()
-    step(True)                                                 # one step with the 80 in-loop convolutions
-    faithful = batch / (time.perf_counter() - t0)
-    return {"value": round(dedup, 2), "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps of B=%d x %d s on %d torch-CPU threads (oracle, ATen GRU, one conv per "
-                      "Sinc forward); reference-faithful variant with the 80 redundant in-loop convolutions "
-                      "(models.py:98-108): %.2f utterances/s" % (n, batch, samples // FS, cores, faithful)}
+    nf = 0
+    while nf < 2 or (time.perf_counter() - t0 < budget_s * 0.2 and nf < 10):
+        step(True)
+        nf += 1
+    faithful = nf * batch / (time.perf_counter() - t0)
+    return {"value": round(dedup, 2), "unit": "utterances/s", "cores": threads, "kind": "port",
+            "host": host_topology(),
+            "sample": "%d train steps (after %d warm-up) of B=%d x %d s on %d torch-CPU threads (oracle, ATen GRU, "
+                      "one conv per Sinc forward); reference-faithful variant with the 80 redundant in-loop "
+                      "convolutions (models.py:98-108), %d steps after 1 warm-up: %.2f utterances/s"
+                      % (n, warm, batch, samples // FS, threads, nf, faithful),
+            "faithful_sinc_value": round(faithful, 2)}
+
+
+# ------------------------------------------------------------------------------------------------------
+# parity of this process' kernels on the reference's golden batch (BASELINE configs[0], fixture g6)
+# ------------------------------------------------------------------------------------------------------
+def parity_check(dev):
+    """no_unfreezing architecture under the reference's seeds (state_dict SHA-256 pinned by the fixture),
+    x = 0.1 randn(16, 16000) by seed: eval-mode logits vs the REFERENCE's (stored in
+    tests/golden/g6_full_model.npz by tests/golden/make_goldens.py), predicted intents bit-identical."""
+    import hashlib
+    import numpy as np
+    import data
+    import models
+    path = os.path.join(ROOT, "tests", "golden", "g6_full_model.npz")
+    d = dict(np.load(path))
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    work = tempfile.mkdtemp(prefix="slu_parity_")
+    cwd = os.getcwd()
+    try:
+        os.makedirs(os.path.join(work, "experiments"))
+        name = CFG["no_unfreezing"]
+        shutil.copy(os.path.join(PKG, "experiments", name), os.path.join(work, "experiments", name))
+        os.chdir(work)
+        config = data.read_config(os.path.join("experiments", name))
+        config.folder = os.path.join(work, config.folder)
+        config.values_per_slot = [6, 14, 4]
+        config.Sy_intent = data.synthetic_Sy_intent(config.values_per_slot)
+        torch.manual_seed(meta["pretrain_seed"])
+        torch.save({k: v.cpu() for k, v in models.PretrainedModel(config).state_dict().items()},
+                   os.path.join(config.folder, "pretraining", "model_state.pth"))
+        torch.manual_seed(meta["model_seed"])
+        model = models.Model(config)
+    finally:
+        os.chdir(cwd)
+    sha = {k: hashlib.sha256(v.cpu().contiguous().numpy().tobytes()).hexdigest() for k, v in model.state_dict().items()}
+    weights_ok = sha == meta["model_sha256"]
+    g = torch.Generator().manual_seed(1234)
+    x = 0.1 * torch.randn(16, 16000, generator=g)
+    model.eval()
+    with torch.no_grad():
+        logits, pred = model.predict_intents(x)
+    dev_max = float((logits.cpu().double() - torch.from_numpy(d["eval.logits"]).double()).abs().max())
+    same = bool(np.array_equal(pred.cpu().numpy(), d["eval.pred"]))
+    shutil.rmtree(work, ignore_errors=True)
+    del model
+    return {"max_abs_logit_dev": dev_max, "intents_equal": same, "weights_sha256_match": weights_ok,
+            "tolerance": 1e-4, "golden": "tests/golden/g6_full_model.npz (reference outputs, BASELINE configs[0])"}
+
+
+# ------------------------------------------------------------------------------------------------------
+# per-kernel roofline: each distinct launch shape of the step, back to back on the stream it runs on
+# ------------------------------------------------------------------------------------------------------
+def _timed_graph(fn, stream, reps=20):
+    """Average duration (ms) of one fn() launch: `reps` launches captured as one hipGraph on `stream`
+    (the CU-masked stream the kernel runs on in the timed steps), replayed between two HIP events on that
+    stream — kernels run back to back, no host dispatch gap is counted."""
+    with torch.cuda.stream(stream):
+        fn()
+        fn()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            for _ in range(reps):
+                fn()
+        graph.replay()                              # warm replay
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        graph.replay()
+        e1.record(stream)
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del graph
+    return ms
+
+
+def kernel_table(model, trainer, batch, samples, width, asr=False):
+    """Top kernels of the step by GPU time with the algorithmic flops and the measured average duration of
+    every distinct launch shape (frozen stages at `width` x batch sequences on the look-ahead stream,
+    trainable stages at `batch` sequences on the training stream)."""
+    from slu_hip import ops
+    dev = next(model.parameters()).device
+    pm = model.pretrained_model if hasattr(model, "pretrained_model") else model
+    n_prefix = pm.frozen_prefix_len() if width > 1 else 0
+    slots = getattr(trainer, "_slots", None)
+    side = slots[0].stream if slots else torch.cuda.Stream(dev)
+    main = getattr(trainer, "_train_stream", None) if width > 1 else getattr(trainer, "_full_stream", None)
+    main = main or torch.cuda.Stream(dev)
+    rows = {"wconv_fwd_kernel": [], "gemm_f32_kernel<true,true,2>": [], "gru_seq_fwd4_kernel<128>": []}
+    stages = pm._stages() + list(getattr(model, "_intent_stages", []))
+    L, C = samples, 1
+    for si, st in enumerate(stages):
+        frozen = si < n_prefix
+        B = batch * (width if frozen else 1)
+        stream = side if frozen else main
+        where = "%d sequences, look-ahead stream" % B if frozen else "%d sequences, training stream" % B
+        if hasattr(st, "conv"):                                         # CNN block
+            conv = st.conv
+            if st.is_sinc:
+                w = conv.filters().view(conv.N_filt, 1, conv.Filt_dim)
+                bias, c_out, k, stride = None, conv.N_filt, conv.Filt_dim, conv.stride
+            else:
+                w, bias, c_out, k, stride = conv.weight.detach(), conv.bias.detach(), conv.out_channels, conv.kernel_size, conv.stride
+            x = torch.randn(B, L, C, device=dev) * 0.1
+            l_conv = ops.conv_out_len(L, k, stride)
+            pool = st.pool if st.pool in (1, 2) else 1
+            tm = si == len(pm._cnn_stages) - 1
+            ms = _timed_graph(lambda: ops.wconv_fwd(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, False), stream)
+            rows["wconv_fwd_kernel"].append({"shape": "B=%d L=%d Cin=%d Cout=%d k=%d stride=%d (%s)" % (B, L, C, c_out, k, stride, where),
+                                             "flops": 2.0 * B * l_conv * c_out * k * C, "ms": ms})
+            L, C = -(-l_conv // pool), c_out
+            del x
+        else:                                                           # GRU layer
+            gru = st.gru
+            H, D, I = gru.hidden_size, 2 if gru.bidirectional else 1, gru.input_size
+            T = L
+            w_ih, b_ih = gru._stacked_ih()
+            x = torch.randn(T * B, I, device=dev)
+            ms = _timed_graph(lambda: ops.gemm(x, w_ih.detach().t(), b_ih.detach()), stream)
+            rows["gemm_f32_kernel<true,true,2>"].append({"shape": "M=%d N=%d K=%d input projection (%s)" % (T * B, D * 3 * H, I, where),
+                                                         "flops": 2.0 * T * B * D * 3 * H * I, "ms": ms,
+                                                         "bytes": 4.0 * (T * B * I + D * 3 * H * I + T * B * D * 3 * H)})
+            gx = torch.randn(T, B, D * 3 * H, device=dev)
+            wr = gru.weight_hh_l0_reverse.detach() if D == 2 else None
+            br = gru.bias_hh_l0_reverse.detach() if D == 2 else None
+            ms = _timed_graph(lambda: ops.gru_seq_fwd(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                      T, B, H, D, not frozen), stream)
+            rows["gru_seq_fwd4_kernel<128>"].append({"shape": "T=%d B=%d H=%d D=%d (%s)" % (T, B, H, D, where),
+                                                     "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
+                                                     "bytes": 4.0 * (T * B * D * 3 * H + T * B * D * H + D * 3 * H * H)})
+            L, C = -(-T // st.factor), D * H
+            del x, gx
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    out = []
+    for name, shapes in rows.items():
+        if not shapes:
+            continue
+        # per optimisation step: a frozen-stage launch serves `width` steps
+        t_step = sum(s["ms"] / (width if "look-ahead" in s["shape"] else 1) for s in shapes)
+        flops = sum(s["flops"] for s in shapes)
+        ms = sum(s["ms"] for s in shapes)
+        tf = flops / (ms * 1e-3) / 1e12
+        out.append({"kernel": name, "launches_per_cycle": len(shapes), "flops": flops, "avg_us": round(1e3 * ms / len(shapes), 2),
+                    "tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "gpu_ms_per_step": round(t_step, 4),
+                    "shapes": [{"shape": s["shape"], "gflop": round(s["flops"] / 1e9, 3), "us": round(1e3 * s["ms"], 2),
+                                "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
+                                "algorithmic_MB": round(s["bytes"] / 1e6, 2) if "bytes" in s else None} for s in shapes]})
+    out.sort(key=lambda r: -r["gpu_ms_per_step"])
+    return out
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (separate run,
+    FETCH_SIZE x 2 correction of MI355X_MICROARCH.md): profiles/pmc_traffic.json, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
 
 
 def large_batch_point(rank, samples, batch=2048, steps=3):
     """The same train step at B = 2048 per GPU (128 sequence tiles x 2 directions = 256 recurrence
     workgroups, one per CU): where the recurrence stops being bound by the 8-workgroup latency chain.
     Reported next to the headline number, never as `value`."""
-    from slu_hip import ops
     os.environ["SLU_LOOKAHEAD"] = "0"          # one big batch per step: nothing to look ahead to
     config, model, trainer, train_ds, work = setup("no_unfreezing", rank, batch, samples, 1)
     dev = next(model.parameters()).device
     batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]
     model.train()
-    run_steps(model, trainer, batches, 1)
+    run_steps(model, trainer, batches, 4)      # three eager steps, then the captured step
     torch.cuda.synchronize()
-    ops.profile_start()
     t0 = time.perf_counter()
     run_steps(model, trainer, batches, steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = ops.profile_stop()
-    kflops = sum(p[3] for p in prof)
-    kms = sum(p[1].elapsed_time(p[2]) for p in prof)
-    ach = kflops / (kms * 1e-3) / 1e12
     shutil.rmtree(work, ignore_errors=True)
     del model, trainer, batches
     torch.cuda.empty_cache()
     os.environ.pop("SLU_LOOKAHEAD", None)
     return {"batch_per_gpu": batch, "utterances_per_s": round(batch * steps / dt, 1),
-            "ms_per_step": round(1e3 * dt / steps, 3),
-            "gru_seq_fwd_kernel_tflops": round(ach, 2), "gru_seq_fwd_kernel_frac_of_fp32_mfma_peak":
-            round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
+            "ms_per_step": round(1e3 * dt / steps, 3)}
 
 
 def note(msg):
@@ -169,31 +390,95 @@ def note(msg):
 _T0 = time.perf_counter()
 
 
+# ------------------------------------------------------------------------------------------------------
+# multi-GPU self-launch
+# ------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start one rank per GPU (rank 0 owns stdout)."""
+    n = args.gpus
+    visible = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if visible < n:
+        if not args.share_gpu:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (--share-gpu runs all ranks on the "
+                             "visible GPUs over gloo: a functional check of the multi-process path, not a measurement)"
+                             % (n, visible))
+        env["SLU_DIST_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        if visible < n:
+            e["SLU_LOCAL_DEVICE"] = str(r % max(visible, 1))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                r = p.poll()
+                if r is None:
+                    continue
+                live.remove(p)
+                if r != 0:
+                    rc = rc or r
+                    for q in live:                 # a rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
+
+
+def rccl_info(world):
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    info = {"ranks": world, "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else ""),
+            "algo": os.environ.get("NCCL_ALGO", "default"), "proto": os.environ.get("NCCL_PROTO", "default")}
+    try:
+        info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:
+        info["version"] = "unknown (%s)" % (e,)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="no_unfreezing", choices=["no_unfreezing", "unfreeze_all"])
+    ap.add_argument("--workload", default="no_unfreezing", choices=sorted(CFG))
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=SECONDS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-batch", action="store_true",
                     help="skip the extra large-batch point (B=2048/GPU, forward-dominant kernels throughput-bound)")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline measurement")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="with --gpus N > visible GPUs: run the N ranks on the visible GPUs over gloo (functional check)")
     args = ap.parse_args()
 
-    from slu_hip import dp, lib, ops
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+        return
+
+    from slu_hip import dp, lib
     rank, world, local = dp.init_from_env()
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     lib.require_gfx950()
     samples = int(args.seconds * FS)
-    note("setup")
-    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4)
+    asr = args.workload == "asr_pretrain"
     dev = torch.device("cuda", local)
-    batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]       # inputs resident in HBM
-    model.train()
 
     def fence():
         torch.cuda.synchronize()
@@ -201,48 +486,63 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # one-off initialisation (the look-ahead slots capture a super-batch shape as a hipGraph on its second
-    # appearance, the step graph after three eager steps: a few dozen steps per shape); not part of the W
-    # warm-up steps the contract asks for, which follow
+    parity = None
+    if rank == 0:
+        note("parity on the golden batch")
+        parity = parity_check(dev)
+    note("setup")
+    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4)
+    batches = [tuple(t.to(dev) for t in b) for b in train_ds.loader]       # inputs resident in HBM
+    model.train()
+
+    # One-off initialisation, not part of the W warm-up steps the contract asks for (which follow): every
+    # super-batch shape a K-step and a W-step run produce (incl. the tail K mod width) is captured as a
+    # hipGraph on its second appearance in its look-ahead slot, the optimisation step after three eager steps.
     note("initialisation")
     import training as _training
-    width = _training._lookahead_width(trainer.lookahead_depth(True, False)[0] or 1, args.batch)
-    run_steps(model, trainer, batches, max(0, max(48, 8 * width) - args.warmup))
+    depth = trainer.lookahead_depth(True, asr)[0]
+    width = _training._lookahead_width(depth, args.batch) if depth else 1
+    for _ in range(3):
+        run_steps(model, trainer, batches, args.steps, asr)
+        if args.warmup:
+            run_steps(model, trainer, batches, args.warmup, asr)
     note("warmup")
-    run_steps(model, trainer, batches, args.warmup)
+    if args.warmup:
+        run_steps(model, trainer, batches, args.warmup, asr)
     fence()
     note("timed region")
+    ev0, ev_first = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    sums = run_steps(model, trainer, batches, args.steps)
+    ev0.record()
+    sums = run_steps(model, trainer, batches, args.steps, asr, first_done=ev_first)
     fence()
     elapsed = time.perf_counter() - t0
+    fill_ms = ev0.elapsed_time(ev_first)
     note("timed region done: %.3f s" % elapsed)
-    # Dominant-kernel timing: the same steps once more with the kernels launched eagerly (hipGraph
-    # replays cannot carry per-kernel events) and a HIP event pair around every recurrence launch,
-    # recorded on the stream the kernel is launched on.
-    os.environ["SLU_GRAPHS"] = "0"
-    ops.profile_start()
-    run_steps(model, trainer, batches, min(args.steps, 32))
-    fence()
-    prof = ops.profile_stop()
-    os.environ.pop("SLU_GRAPHS", None)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed = tmax.item()
     loss_mean = (sums[0] / args.steps).item()
+    graphs = trainer.graph_stats()
 
-    # dominant kernel: the persistent GRU recurrence (5 launches per step)
-    kflops = sum(p[3] for p in prof)
-    kms = sum(p[1].elapsed_time(p[2]) for p in prof)
-    achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+    # steady state of the same loop (long run), reported beside `value` when K is short: the first
+    # super-batch of a run has to be computed before its first step can start (pipeline fill)
+    steady = None
+    if args.steps < 256 and world == 1:
+        n_long = 512
+        run_steps(model, trainer, batches, n_long, asr)
+        run_steps(model, trainer, batches, n_long, asr)
+        fence()
+        t1 = time.perf_counter()
+        run_steps(model, trainer, batches, n_long, asr)
+        fence()
+        dt = time.perf_counter() - t1
+        steady = {"steps": n_long, "ms_per_step": round(1e3 * dt / n_long, 4),
+                  "utterances_per_s": round(args.batch * n_long / dt, 2)}
+
     payload = trainer.bucket.nbytes() if trainer.bucket is not None else 0
-
     if rank == 0:
-        look = trainer.lookahead_depth(True, False)[0]
-        if look:
-            import training
-            look = training._lookahead_width(look, args.batch)
         out = {
             "metric": "utterances/sec (train step, 3 s @16 kHz, B=64)",
             "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -251,34 +551,45 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("experiments/no_unfreezing.cfg SLU train step (frozen SincNet/conv/biGRU "
-                                    "encoder in train mode + intent biGRU trained): fwd + 3-slot CE + bwd + "
-                                    "grad all-reduce + Adam" if args.workload == "no_unfreezing" else
-                                    "SLU train step with every encoder layer unfrozen (unfreeze_all_layers "
-                                    "end state): fwd + CE + full bwd + grad all-reduce + Adam"),
+            "config": {"workload": WORKLOAD_TEXT[args.workload],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "samples_per_utterance": samples, "parallelism": "dp%d" % world,
                        "allreduce_bytes_per_step": payload, "mean_loss": round(loss_mean, 5),
-                       "encoder_lookahead_batches": look},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), "traffic": None,
-                         "kernel": "gru_seq_fwd4_kernel<128> / gru_seq_fwd_kernel<128>",
-                         "launches": len(prof), "avg_launch_ms": round(kms / max(len(prof), 1), 4),
-                         "note": "fp32 MFMA flops of h(BxH)*W_hh^T(Hx3H) per recurrence step, both directions, "
-                                 "summed over the launches of an eager re-run of the timed steps / their HIP-event "
-                                 "durations; a launch covers %d sequences (look-ahead super-batch of the frozen "
-                                 "layers) or %d (trainable intent layer): %d or %d 4-sequence workgroups "
-                                 "(v_mfma_f32_4x4x1) on 256 CUs" %
-                                 (args.batch * max(1, look), args.batch,
-                                  2 * -(-args.batch * max(1, look) // 4), 2 * -(-args.batch // 4))},
+                       "encoder_lookahead_batches": width if depth else 0},
+            "pipeline_fill_ms": round(fill_ms, 3),
+            "graphs_captured": graphs,
+            "parity": parity,
         }
-        # The two side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
+        if steady:
+            out["steady_state"] = steady
+        if world > 1:
+            out["rccl"] = rccl_info(world)
+            if os.environ.get("SLU_DIST_BACKEND") == "gloo":
+                out["config"]["parallelism"] += " (ranks share the visible GPU(s) over gloo: functional check only)"
+        if world == 1 and not args.no_kernel_table:
+            note("kernel table")
+            table = kernel_table(model, trainer, args.batch, samples, width, asr)
+            top = table[0]
+            algo_bytes = sum(s["algorithmic_MB"] or 0 for s in top["shapes"]) * 1e6 / max(1, len(top["shapes"]))
+            out["roofline"] = {
+                "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": top["frac"], "traffic": pmc_traffic(top["kernel"]),
+                "algorithmic_bytes_per_launch": round(algo_bytes) if algo_bytes else None,
+                "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
+                "kernels": table[:3],
+                "note": "per kernel: sum of the algorithmic fp32 flops of its distinct launch shapes in one "
+                        "look-ahead cycle (%d steps) / sum of their average durations; each shape is launched "
+                        "20x back to back (one hipGraph) on the CU-masked stream it runs on during the timed "
+                        "steps (frozen stages: %d sequences on CUs [64,256); trainable stages: %d sequences on "
+                        "CUs [0,64)) between two HIP events on that stream.  Peak = whole-chip fp32 MFMA."
+                        % (width, args.batch * width, args.batch)}
+        # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
         if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing":
             note("large-batch point")
             out["large_batch_point"] = large_batch_point(rank, samples)
-        note("cpu baseline")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not asr:
+            note("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -29,7 +29,7 @@ struct AdamList {
 template <typename T>
 __global__ void __launch_bounds__(256)
 adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, const double lr,
-                  const double b1, const double b2, const double eps) {
+                  const double b1, const double b2, const double eps, const double grad_div) {
   __shared__ float s_coef[2];
   if (threadIdx.x == 0) {
     const double t = (double)(*step_dev + 1);
@@ -41,7 +41,7 @@ adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, cons
   const int chunk = blockIdx.x - (k ? L.chunk_end[k - 1] : 0);
   __syncthreads();
   const float step_size = s_coef[0], bc2_sqrt = s_coef[1];
-  const float fb1 = (float)b1, fb2 = (float)b2, feps = (float)eps;
+  const float fb1 = (float)b1, fb2 = (float)b2, feps = (float)eps, fdiv = (float)grad_div;
   T* __restrict__ p = reinterpret_cast<T*>(L.p[k]);
   const T* __restrict__ g = reinterpret_cast<const T*>(L.g[k]);
   T* __restrict__ m = reinterpret_cast<T*>(L.m[k]);
@@ -53,7 +53,8 @@ adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, cons
     const long long e = base + u * 256 + threadIdx.x;
     if (e >= n) continue;
     if (sizeof(T) == 4) {
-      const float gg = (float)g[e];
+      float gg = (float)g[e];
+      if (fdiv != 1.0f) gg = gg / fdiv;            // data-parallel mean of the all-reduced sum
       float mm = (float)m[e], vv = (float)v[e];
       mm = mm + (gg - mm) * (1.0f - fb1);
       vv = fb2 * vv + (1.0f - fb2) * gg * gg;
@@ -61,7 +62,8 @@ adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, cons
       p[e] = (T)((float)p[e] - step_size * (mm / denom));
       m[e] = (T)mm; v[e] = (T)vv;
     } else {                       // float64 parameters (the Sinc band edges): double arithmetic
-      const double gg = (double)g[e];
+      double gg = (double)g[e];
+      if (grad_div != 1.0) gg = gg / grad_div;
       double mm = (double)m[e], vv = (double)v[e];
       mm = mm + (gg - mm) * (1.0 - b1);
       vv = b2 * vv + (1.0 - b2) * gg * gg;
@@ -73,8 +75,8 @@ adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, cons
   }
 }
 
-__global__ void adam_step_inc_kernel(long long* step_dev, int count) {
-  if ((int)threadIdx.x < count) step_dev[threadIdx.x] += 1;
+__global__ void adam_step_inc_kernel(long long* step_dev, unsigned long long mask) {
+  if ((mask >> threadIdx.x) & 1ull) step_dev[threadIdx.x] += 1;
 }
 
 }  // namespace slu
@@ -85,15 +87,17 @@ extern "C" int slu_adam_max_tensors(void) { return ADAM_MAX_TENSORS; }
 
 // One Adam update of `count` tensors of one dtype (elem_bytes 4 = float32, 8 = float64); the step
 // counter (*step_dev, int64, number of updates done so far) is NOT advanced: call
-// slu_adam_advance_step (which adds 1 to `count` consecutive counters) once per optimisation step
-// after all the tensor lists.
+// slu_adam_advance_step (which adds 1 to the counters selected by a bit mask) once per optimisation
+// step after all the tensor lists.  Gradients are divided by grad_div first (the world size under data
+// parallelism: the all-reduce delivers the sum), 1.0 = as they are.
 extern "C" int slu_adam_multi(void* const* params, const void* const* grads, void* const* exp_avg,
                               void* const* exp_avg_sq, const int64_t* numel, int64_t count,
                               int elem_bytes, const int64_t* step_dev, double lr, double beta1,
-                              double beta2, double eps, void* stream) {
+                              double beta2, double eps, double grad_div, void* stream) {
   SLU_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && step_dev, "slu_adam_multi: null pointer");
   SLU_REQUIRE(count > 0 && count <= ADAM_MAX_TENSORS, "slu_adam_multi: 1..%d tensors per call", ADAM_MAX_TENSORS);
   SLU_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "slu_adam_multi: elem_bytes must be 4 or 8");
+  SLU_REQUIRE(grad_div > 0.0, "slu_adam_multi: grad_div must be positive");
   AdamList L;
   int chunks = 0;
   for (int k = 0; k < (int)count; ++k) {
@@ -106,17 +110,21 @@ extern "C" int slu_adam_multi(void* const* params, const void* const* grads, voi
   hipStream_t st = (hipStream_t)stream;
   if (elem_bytes == 4)
     hipLaunchKernelGGL(adam_multi_kernel<float>, dim3((unsigned)chunks), dim3(256), 0, st, L,
-                       (const long long*)step_dev, lr, beta1, beta2, eps);
+                       (const long long*)step_dev, lr, beta1, beta2, eps, grad_div);
   else
     hipLaunchKernelGGL(adam_multi_kernel<double>, dim3((unsigned)chunks), dim3(256), 0, st, L,
-                       (const long long*)step_dev, lr, beta1, beta2, eps);
+                       (const long long*)step_dev, lr, beta1, beta2, eps, grad_div);
   SLU_CHECK_LAUNCH("adam_multi_kernel");
   return SLU_OK;
 }
 
-extern "C" int slu_adam_advance_step(int64_t* step_dev, int64_t count, void* stream) {
-  SLU_REQUIRE(step_dev && count > 0 && count <= 256, "slu_adam_advance_step: bad arguments");
-  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long long*)step_dev, (int)count);
+// step_dev[i] += 1 for every bit i set in cohort_mask (i < 64): only the cohorts that were updated in
+// this optimisation step advance, like torch.optim.Adam's per-parameter step counts.
+extern "C" int slu_adam_advance_step(int64_t* step_dev, uint64_t cohort_mask, void* stream) {
+  SLU_REQUIRE(step_dev, "slu_adam_advance_step: null pointer");
+  if (cohort_mask == 0) return SLU_OK;
+  hipLaunchKernelGGL(adam_step_inc_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)step_dev,
+                     (unsigned long long)cohort_mask);
   SLU_CHECK_LAUNCH("adam_step_inc_kernel");
   return SLU_OK;
 }

@@ -86,14 +86,14 @@ def read_config(config_file):
     config.folder = parser.get("experiment", "folder")
 
     # side effects of the reference (data.py:29-33): experiment folder + a copy of the cfg
-    if not os.path.isdir(config.folder):
-        os.mkdir(config.folder)
-        os.mkdir(os.path.join(config.folder, "pretraining"))
-        os.mkdir(os.path.join(config.folder, "training"))
-    try:
-        shutil.copyfile(config_file, os.path.join(config.folder, "experiment.cfg"))
-    except (shutil.SameFileError, OSError):
-        pass
+    # (race-free: under torch.distributed every rank calls read_config; only rank 0 copies the cfg)
+    for sub in ("", "pretraining", "training"):
+        os.makedirs(os.path.join(config.folder, sub), exist_ok=True)
+    if int(os.environ.get("RANK", "0")) == 0:
+        try:
+            shutil.copyfile(config_file, os.path.join(config.folder, "experiment.cfg"))
+        except (shutil.SameFileError, OSError):
+            pass
 
     for section, key, conv in _REQUIRED:
         setattr(config, key, conv(parser.get(section, key)))

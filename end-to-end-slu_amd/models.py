@@ -65,12 +65,14 @@ def next_rng_step():
     return _DropoutState.step
 
 
-def _dropout_args(name, site, p, training):
+def _dropout_args(name, site, p, training, cnn=False):
     """-> (p_eff, mask_time_major_or_None, seed, offset)"""
     if not training or p == 0.0:
         return 0.0, None, 0, 0
     if _DropoutState.masks is not None:
         m = _DropoutState.masks[name]
+        if cnn:                                    # reference shape (B,C,L) -> channels-last (B,L,C)
+            return p, m.transpose(1, 2).contiguous(), 0, 0
         return p, m.transpose(0, 1), 0, 0          # (T,B,C) view; kernel takes its strides
     seed = _DropoutState.seed if _DropoutState.seed is not None else torch.initial_seed()
     if _DropoutState.current_dev is not None:
@@ -78,6 +80,17 @@ def _dropout_args(name, site, p, training):
     if _DropoutState.sub_batch:
         return p, None, seed & 0xFFFFFFFFFFFFFFFF, (_DropoutState.current * 16 + site, None, _DropoutState.sub_batch)
     return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.current * 16 + site
+
+
+_SITE_BASE = {"phone": 0, "word": 4, "intent": 8, "cnn": 12}     # 16 dropout sites per step (Philox offset)
+
+
+def _site(module, idx):
+    """Dropout-site number of layer `idx` of a module: the Philox offset of a step is step*16 + site."""
+    if not 0 <= idx < 4:
+        raise NotImplementedError("at most 4 layers per module (%s layer %d): a step owns 16 dropout-stream "
+                                  "offsets, 4 per module" % (module, idx))
+    return _SITE_BASE[module] + idx
 
 
 def _require_device(t):
@@ -122,6 +135,27 @@ class _PoolOnlyFn(torch.autograd.Function):
         method, factor = ctx.cfg
         (xt,) = ctx.saved_tensors
         return _ops.dropout_pool_bwd(dy, xt, None, 0.0, 0, 0, method, factor), None, None
+
+
+class _DropOnlyFn(torch.autograd.Function):
+    """Dropout alone on a contiguous 3-D activation (the CNN blocks' nn.Dropout): slu_dropout_pool with
+    factor 1.  The kernel's (T,B,C) indexing is applied to the tensor as it lies in memory."""
+
+    @staticmethod
+    def forward(ctx, x, p, mask, seed, offset):
+        offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
+        if sub_batch:
+            raise NotImplementedError("CNN dropout inside a look-ahead super-batch")
+        ctx.cfg = (p, seed, offset)
+        ctx.offset_dev = offset_dev
+        ctx.save_for_backward(x, mask)
+        return _ops.dropout_pool_fwd(x, mask, p, seed, offset, "none", 1, offset_dev, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, offset = ctx.cfg
+        x, mask = ctx.saved_tensors
+        return _ops.dropout_pool_bwd(dy, x, mask, p, seed, offset, "none", 1, ctx.offset_dev), None, None, None, None
 
 
 class SincLayer(torch.nn.Module):
@@ -278,8 +312,9 @@ def _named(layer, name):
 class _ConvStage:
     """[conv|sinc, (abs), pool, act, dropout] of one CNN block (reference models.py:182-220)."""
 
-    def __init__(self, conv, is_sinc, do_abs, pool, act, drop):
+    def __init__(self, conv, is_sinc, do_abs, pool, act, drop, idx=0):
         self.conv, self.is_sinc, self.do_abs, self.pool, self.drop = conv, is_sinc, do_abs, pool, drop
+        self.drop_name, self.site = "dropout%d" % idx, (_site("cnn", idx) if drop > 0.0 else -1)
         self.slope = 0.2 if act == "leaky_relu" else 0.0
         self.time_major = False       # set on the last CNN stage: its output feeds the RNN stack
 
@@ -308,8 +343,11 @@ class _ConvStage:
                 h = h.abs()
             h = torch.nn.functional.max_pool1d(h, self.pool, ceil_mode=True)
             h = torch.nn.functional.leaky_relu(h, self.slope).transpose(1, 2)
-        if self.drop > 0.0:
-            h = torch.nn.functional.dropout(h, self.drop, training)
+        if self.drop > 0.0 and training:
+            # nn.Dropout of the CNN block (models.py:217-220) on the same step-indexed Philox stream as
+            # the RNN sites (or the injected mask, given in the reference's (B,C,L) shape)
+            p, mask, seed, offset = _dropout_args(self.drop_name, self.site, self.drop, training, cnn=True)
+            h = _DropOnlyFn.apply(h.contiguous(), p, mask, seed, offset)
         if time_major and not tm:
             h = h.transpose(0, 1).contiguous()
         return h
@@ -318,12 +356,10 @@ class _ConvStage:
 class _RnnStage:
     """[gru, select, dropout, downsample] (reference models.py:230-253, 260-283, 684-707)."""
 
-    SITES = {"phone": 0, "word": 4, "intent": 8}      # dropout-site numbering (<= 4 layers per module)
-
     def __init__(self, gru, drop_name, p, method, factor):
         self.gru, self.drop_name, self.p, self.method, self.factor = gru, drop_name, p, method, factor
         module, idx = drop_name.split("_dropout")
-        self.site = self.SITES[module] + int(idx)
+        self.site = _site(module, int(idx)) if p > 0.0 else -1
 
     def parameters(self):
         return list(self.gru.parameters())
@@ -376,7 +412,7 @@ class PretrainedModel(torch.nn.Module):
             phoneme_layers.append(_named(act, "act%d" % idx))
             phoneme_layers.append(_named(torch.nn.Dropout(p=config.cnn_drop[idx]), "dropout%d" % idx))
             self._cnn_stages.append(_ConvStage(conv, is_sinc, idx == 0, config.cnn_max_pool_len[idx],
-                                               config.cnn_act[idx], config.cnn_drop[idx]))
+                                               config.cnn_act[idx], config.cnn_drop[idx], idx))
         phoneme_layers.append(_named(NCL2NLC(), "ncl2nlc"))
         out_dim = _build_rnn_stack(phoneme_layers, self._phone_stages, "phone", config.cnn_N_filt[-1],
                                    config.phone_rnn_num_hidden, config.phone_rnn_bidirectional,
@@ -446,21 +482,29 @@ class PretrainedModel(torch.nn.Module):
         return self.run_stages(x, 0, len(self._stages()))
 
     # -- reference API --------------------------------------------------------------------------
-    def forward(self, x, y_phoneme, y_word):
+    def forward(self, x, y_phoneme, y_word, rng_step=None):
         """x (B,T), y_phoneme (B,T'), y_word (B,T'') -> (phoneme_loss, word_loss, phoneme_acc,
-        word_acc); cross-entropy ignores label -1 (reference models.py:291-331)."""
+        word_acc); cross-entropy ignores label -1 (reference models.py:291-331).
+        rng_step (not in the reference): the dropout stream index of this forward — None = the next
+        one, or a 1-element int64 CUDA tensor holding step*16 (hipGraph-captured steps)."""
         x, y_phoneme, y_word = self._to_device(x, y_phoneme, y_word)
-        _DropoutState.current = next_rng_step()
-        ph_tm = self._phoneme_features_tm(x)                         # (T',B,C)
-        # Linear + cross-entropy(ignore_index=-1) + frame accuracy: slu_gemm_f32 + slu_frame_ce_fwd
-        pl = self.phoneme_linear
-        phoneme_loss, phoneme_acc = _ops.FrameHeadFn.apply(ph_tm, pl.weight, pl.bias, y_phoneme)
-        if self.pretraining_type == 1:
-            return phoneme_loss, torch.tensor([0.]), phoneme_acc, torch.tensor([0.])
-        wd_tm = self._word_features_tm(ph_tm)
-        wl = self.word_linear
-        word_loss, word_acc = _ops.FrameHeadFn.apply(wd_tm, wl.weight, wl.bias, y_word)
-        return phoneme_loss, word_loss, phoneme_acc, word_acc
+        if torch.is_tensor(rng_step):
+            _DropoutState.current_dev = rng_step
+        else:
+            _DropoutState.current = next_rng_step() if rng_step is None else rng_step
+        try:
+            ph_tm = self._phoneme_features_tm(x)                         # (T',B,C)
+            # Linear + cross-entropy(ignore_index=-1) + frame accuracy: slu_gemm_f32 + slu_frame_ce_fwd
+            pl = self.phoneme_linear
+            phoneme_loss, phoneme_acc = _ops.FrameHeadFn.apply(ph_tm, pl.weight, pl.bias, y_phoneme)
+            if self.pretraining_type == 1:
+                return phoneme_loss, torch.tensor([0.]), phoneme_acc, torch.tensor([0.])
+            wd_tm = self._word_features_tm(ph_tm)
+            wl = self.word_linear
+            word_loss, word_acc = _ops.FrameHeadFn.apply(wd_tm, wl.weight, wl.bias, y_word)
+            return phoneme_loss, word_loss, phoneme_acc, word_acc
+        finally:
+            _DropoutState.current_dev = None
 
     def compute_posteriors(self, x):
         (x,) = self._to_device(x)
@@ -506,7 +550,9 @@ class Model(torch.nn.Module):
         pretrained_model = PretrainedModel(config)
         if config.pretraining_type != 0:
             path = os.path.join(config.folder, "pretraining", "model_state.pth")
-            pretrained_model.load_state_dict(torch.load(path, map_location=None if self.is_cuda else "cpu"))
+            # the file was written by rank 0 from cuda:0: deserialise onto the host, copy into this rank's
+            # parameters (no allocation on a device the rank does not own)
+            pretrained_model.load_state_dict(torch.load(path, map_location="cpu"))
         self.pretrained_model = pretrained_model
         self.unfreezing_type = config.unfreezing_type
         self.unfreezing_index = config.starting_unfreezing_index

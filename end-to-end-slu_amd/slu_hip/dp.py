@@ -56,6 +56,7 @@ class GradBucket:
         self.flats = {}
         self.groups = {}
         self.signature = None
+        self.divide = True        # False: the optimiser divides by the world size itself (HipAdam.grad_div)
 
     def reset(self):
         """Forget the bucket (call after the trainable set changed, e.g. unfreeze_one_layer)."""
@@ -98,6 +99,15 @@ class GradBucket:
                 p.grad = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
 
+    def allreduce_flats(self):
+        """ONE collective per gradient dtype over the packed flat buffers: the sum over ranks, and the
+        division by the world size unless the optimiser folds it into its update (`divide` False)."""
+        ws = world()[1]
+        for flat in self.flats.values():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if self.divide:
+                flat.div_(ws)
+
     def allreduce_mean(self):
         """Average the gradients of all ranks (call after backward).  One process: bookkeeping only."""
         rank, ws = world()
@@ -105,9 +115,7 @@ class GradBucket:
             self.observe()
             return
         self.pack()
-        for flat in self.flats.values():
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(ws)
+        self.allreduce_flats()
 
 
 def allreduce_sums(values, device):

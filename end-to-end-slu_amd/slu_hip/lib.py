@@ -43,8 +43,8 @@ SIGNATURES = {
     "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64]),
     "slu_frame_ce_fwd": (c_int, [vp, vp, c_i64, c_i64, c_i64, c_int, vp, vp, vp]),
     "slu_adam_max_tensors": (c_int, []),
-    "slu_adam_multi": (c_int, [vp, vp, vp, vp, vp, c_i64, c_int, vp, c_f64, c_f64, c_f64, c_f64, vp]),
-    "slu_adam_advance_step": (c_int, [vp, c_i64, vp]),
+    "slu_adam_multi": (c_int, [vp, vp, vp, vp, vp, c_i64, c_int, vp, c_f64, c_f64, c_f64, c_f64, c_f64, vp]),
+    "slu_adam_advance_step": (c_int, [vp, c_u64, vp]),
     "slu_gru_seq_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
     "slu_gru_seq_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
     "slu_dropout_pool_fwd": (c_int, [vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_int,
@@ -57,6 +57,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):
@@ -80,8 +81,9 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the ABI and this table disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.slu_version() != 1:
-        raise SluHipError("libslu_hip.so ABI version %d, expected 1" % lib.slu_version())
+    if lib.slu_version() != ABI_VERSION:
+        raise SluHipError("libslu_hip.so ABI version %d, expected %d (rebuild with csrc/build.sh)"
+                          % (lib.slu_version(), ABI_VERSION))
     _lib = lib
     return lib
 

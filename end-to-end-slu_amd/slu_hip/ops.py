@@ -28,22 +28,6 @@ def _f32c(t, what):
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Optional per-launch timing of the recurrence kernels (bench.py): a list of
-# (kernel name, start event, end event, algorithmic flops) recorded on the launch stream.
-_PROFILE = None
-
-
-def profile_start():
-    global _PROFILE
-    _PROFILE = []
-
-
-def profile_stop():
-    global _PROFILE
-    out, _PROFILE = _PROFILE, None
-    return out
-
-
 # Auxiliary streams for independent work inside one backward stage (the weight-gradient GEMMs of a GRU
 # layer do not depend on each other nor on the data-gradient GEMM): forked from and joined back into
 # the current stream.
@@ -219,17 +203,9 @@ def gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, want_reserve):
     reserve = None
     if want_reserve:
         reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=gx.device)
-    profiling = _PROFILE is not None and not torch.cuda.is_current_stream_capturing()
-    if profiling:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
     _lib.check(L.slu_gru_seq_fwd(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(),
                                  _ptr(b_hh_r), out.data_ptr(), _ptr(reserve), T, B, H, D, _stream()),
                "slu_gru_seq_fwd")
-    if profiling:
-        ev1.record()
-        # h_{t-1} (B x H) times W_hh^T (H x 3H), per direction and step: 2*B*H*3H flops
-        _PROFILE.append(("gru_seq_fwd_kernel", ev0, ev1, 2.0 * B * H * 3 * H * D * T))
     return out, reserve
 
 

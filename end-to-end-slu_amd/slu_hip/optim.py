@@ -19,6 +19,8 @@ class HipAdam(torch.optim.Optimizer):
         self._n_cohorts = 0
         self._plan = None             # cached launch arguments, keyed by the identity of every (param, grad)
         self._plan_key = None
+        self._plan_mask = 0           # bit c set: cohort c has a parameter with a gradient in this plan
+        self.grad_div = 1.0           # gradients are divided by it inside the kernel (DP: the world size)
 
     def _build(self):
         L = _lib.load()
@@ -59,6 +61,9 @@ class HipAdam(torch.optim.Optimizer):
                 arr = lambda j: (ctypes.c_void_p * n)(*[t[j].data_ptr() for t in part])
                 numel = (ctypes.c_int64 * n)(*[t[0].numel() for t in part])
                 plan.append((gi, arr(0), arr(1), arr(2), arr(3), numel, n, 4 if dtype == torch.float32 else 8, cohort))
+        self._plan_mask = 0
+        for (_, _, cohort) in lists:
+            self._plan_mask |= 1 << cohort
         return plan, tuple(key)
 
     @torch.no_grad()
@@ -78,6 +83,37 @@ class HipAdam(torch.optim.Optimizer):
             grp = self.param_groups[gi]
             b1, b2 = grp["betas"]
             _lib.check(L.slu_adam_multi(p, g, m, v, numel, n, eb, base + 8 * cohort, float(grp["lr"]), float(b1),
-                                        float(b2), float(grp["eps"]), stream), "slu_adam_multi")
-        _lib.check(L.slu_adam_advance_step(base, self._n_cohorts, stream), "slu_adam_advance_step")
+                                        float(b2), float(grp["eps"]), float(self.grad_div), stream),
+                       "slu_adam_multi")
+        # only the cohorts updated in this step advance (torch.optim.Adam counts steps per parameter and
+        # skips parameters without a gradient)
+        _lib.check(L.slu_adam_advance_step(base, self._plan_mask, stream), "slu_adam_advance_step")
         return loss
+
+    # -- checkpointing: the per-parameter `step` of torch.optim.Adam's state_dict ----------------------
+    def state_dict(self):
+        if self._steps is not None:
+            steps = self._steps.tolist()
+            for st in self.state.values():
+                if "cohort" in st:
+                    st["step"] = torch.tensor(float(steps[st["cohort"]]))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Accepts a state_dict of this class or of torch.optim.Adam (exp_avg, exp_avg_sq, step): cohorts
+        are rebuilt from the distinct step counts."""
+        super().load_state_dict(state_dict)
+        values = sorted({int(st["step"]) for st in self.state.values() if "step" in st})
+        if len(values) > self.MAX_COHORTS:
+            raise RuntimeError("HipAdam: more than %d distinct step counts" % self.MAX_COHORTS)
+        dev = None
+        for p, st in self.state.items():
+            if "step" in st:
+                st["cohort"] = values.index(int(st["step"]))
+                dev = p.device
+        self._n_cohorts = len(values)
+        if dev is not None:
+            self._steps = torch.zeros(self.MAX_COHORTS, dtype=torch.int64, device=dev)
+            if values:
+                self._steps[:len(values)] = torch.tensor(values, dtype=torch.int64)
+        self._plan = self._plan_key = None

@@ -78,6 +78,7 @@ class PrefixSlot:
         self.seen = {}             # how often each super-batch shape was requested
         self.consumed = None       # event: the main stream is done with this slot's last output
         self.signature = None      # versions of the frozen parameters the graphs were captured with
+        self.capture_failures = 0
 
     def invalidate(self):
         self.graphs = {}
@@ -137,9 +138,10 @@ class PrefixSlot:
             # runtime while this thread captures
             with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
                 feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)
-        except Exception as e:                      # stay eager for this shape
+        except RuntimeError as e:                   # stay eager for this shape
             print("hipGraph capture of the frozen prefix failed (%s); staying eager" % (e,))
             self.graphs[key] = None
+            self.capture_failures += 1
             return None
         entry = (graph, x_static, feats)
         self.graphs[key] = entry
@@ -147,20 +149,24 @@ class PrefixSlot:
 
 
 class StepGraph:
-    """The trainable remainder of one SLU training step, captured as two hipGraphs around the
-    gradient all-reduce:  G1 = forward from the prefix features, loss, backward (+ packing the
-    gradients into the flat bucket under data parallelism);  [RCCL all-reduce, eager];  G2 = Adam.
-    Inputs (features, labels, the dropout step) are static device buffers refreshed before each
-    replay."""
+    """One optimisation step captured as two hipGraphs around the gradient all-reduce:
+    G1 = forward, loss, backward (+ packing the gradients into the flat bucket under data
+    parallelism);  [RCCL all-reduce, eager];  G2 = Adam.  Used for the trainable remainder of an SLU
+    step (inputs = prefix features + labels), for a fully trainable SLU step (waveforms + labels) and
+    for an ASR pre-training step (waveforms + phoneme / word labels): a B = 64 step is ~100 short
+    kernels, i.e. host-bound when launched one by one.  Inputs and the dropout step are static device
+    buffers refreshed before each replay.
 
-    def __init__(self, trainer, feats, y, n_prefix, stream):
-        model, dev = trainer.model, feats.device
+    forward(static_inputs, rng_dev) -> (metrics, loss): `metrics` a 1-D device tensor (what the epoch
+    statistics accumulate), `loss` the 0-d tensor to back-propagate."""
+
+    def __init__(self, trainer, inputs, forward, stream):
+        dev = next(trainer.model.parameters()).device
         self.trainer = trainer
-        self.feats = torch.empty_like(feats)
-        self.y = torch.empty(tuple(y.shape), dtype=torch.int64, device=dev)
+        self.inputs = [torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for t in inputs]
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src)
         self.rng = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.feats.copy_(feats)
-        self.y.copy_(y)
         from . import dp
         bucket = trainer.bucket
         assert bucket is not None and bucket.active
@@ -170,8 +176,7 @@ class StepGraph:
         self.one = torch.ones((), dtype=torch.float32, device=dev)      # root gradient (no per-step fill)
         self.g1 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g1, stream=stream, capture_error_mode="thread_local"):
-            self.loss, self.acc = model.forward_from(self.feats, n_prefix, self.y, self.rng)
-            self.loss_acc = ops.IntentHeadFn.last_loss_acc
+            self.metrics, self.loss = forward(self.inputs, self.rng)
             self.loss.backward(self.one)
             if self.world > 1:
                 bucket.pack()                       # one concatenation kernel per dtype; .grad -> slices
@@ -181,18 +186,15 @@ class StepGraph:
         bucket.observe()
         self.signature = bucket.signature
 
-    def run(self, feats, y, step):
-        import torch.distributed as dist
-        self.feats.copy_(feats, non_blocking=True)
-        self.y.copy_(y, non_blocking=True)
+    def run(self, inputs, step):
+        for dst, src in zip(self.inputs, inputs):
+            dst.copy_(src, non_blocking=True)
         self.rng.fill_(step * 16)
         self.g1.replay()
-        if self.world > 1:                          # one RCCL call per gradient dtype
-            for flat in self.trainer.bucket.flats.values():
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat.div_(self.world)
+        if self.world > 1:                          # one collective per gradient dtype; the mean's 1/N is
+            self.trainer.bucket.allreduce_flats()   # folded into the Adam kernel (HipAdam.grad_div)
         self.g2.replay()
-        return self.loss_acc
+        return self.metrics
 
 
 def graphs_enabled():

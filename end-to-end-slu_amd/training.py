@@ -13,6 +13,7 @@ back once per print interval / epoch instead of four `.cpu()` round trips per st
 moves the model to the CPU for its seq2seq beam search, training.py:150,166, and crashes on a
 CPU-only host); under torch.distributed only rank 0 prints, logs and writes checkpoints.
 """
+import contextlib
 import os
 
 import pandas as pd
@@ -33,6 +34,11 @@ def _lookahead_env():
     """SLU_LOOKAHEAD: number of batches per look-ahead super-batch; unset / "auto" -> -1 (by batch size)."""
     v = os.environ.get("SLU_LOOKAHEAD", "auto")
     return -1 if v == "auto" else int(v)
+
+
+def _max_step_graphs():
+    """Distinct step shapes kept as captured hipGraphs (each owns its activations: ~0.2 GB at B = 64)."""
+    return int(os.environ.get("SLU_MAX_STEP_GRAPHS", "8"))
 
 
 def _lookahead_width(depth, batch_size):
@@ -73,6 +79,12 @@ class Trainer:
         # GPU) what gives the gradients fixed addresses for hipGraph-captured steps
         self.bucket = dp.GradBucket(model.parameters()) if (self.world_size > 1 or on_gpu) else None
         self._step_graphs, self._eager_steps = {}, {}
+        self.capture_failures = 0
+        self._hip_adam = on_gpu
+        if on_gpu and self.world_size > 1:
+            # data-parallel mean: the all-reduce delivers the SUM, Adam divides by the world size in-kernel
+            self.optimizer.grad_div = float(self.world_size)
+            self.bucket.divide = False
 
     # -- checkpoints / log (reference training.py:23-45) -------------------------------------------
     def load_checkpoint(self):
@@ -121,17 +133,26 @@ class Trainer:
         tot = dp.allreduce_sums([float(s) for s in sums] + [float(num_examples)], device)
         return [v / tot[-1] for v in tot[:-1]]
 
-    def _forward_losses(self, batch, asr):
+    def _forward_losses(self, batch, asr, rng_step=None):
+        """-> ([metric tensors in log order], loss to back-propagate).  rng_step: None = the model draws the
+        next dropout-stream index itself (the plain reference-style call), else the index to use."""
         if asr:
             x, y_phoneme, y_word = batch
-            phoneme_loss, word_loss, phoneme_acc, word_acc = self.model(x, y_phoneme, y_word)
+            if rng_step is None:
+                phoneme_loss, word_loss, phoneme_acc, word_acc = self.model(x, y_phoneme, y_word)
+            else:
+                phoneme_loss, word_loss, phoneme_acc, word_acc = self.model(x, y_phoneme, y_word, rng_step=rng_step)
             ptype = self.config.pretraining_type
             loss = {1: phoneme_loss, 3: word_loss}.get(ptype)
             if ptype == 2:
                 loss = phoneme_loss + word_loss
             return [phoneme_loss, word_loss, phoneme_acc, word_acc], loss
         x, y_intent = batch
-        intent_loss, intent_acc = self.model(x, y_intent)
+        if rng_step is None:
+            intent_loss, intent_acc = self.model(x, y_intent)
+        else:
+            intent_loss, intent_acc = self.model.forward_from(self.model.pretrained_model._to_device(x)[0], 0,
+                                                              y_intent, rng_step)
         return [intent_loss, intent_acc], intent_loss
 
     def lookahead_depth(self, train, asr):
@@ -148,7 +169,95 @@ class Trainer:
         if not all(p.is_cuda for p in self.model.parameters()) or models_masks_injected():
             return 0, 0
         n = self.model.frozen_prefix_len()
+        # a CNN-block dropout inside the frozen prefix has no per-sub-batch stream (all shipped cfgs have
+        # cnn_drop = 0): stay sequential there, so that the step-indexed masks remain those of the plain loop
+        pm = self.model.pretrained_model
+        if any(st.drop > 0.0 for st in pm._cnn_stages[:n]):
+            return 0, 0
         return (depth, n) if n > 0 else (0, 0)
+
+    # -- hipGraph-captured optimisation steps -------------------------------------------------------------
+    def _graphable(self):
+        """Captured steps need the HIP optimiser (device-resident step counters), fixed gradient addresses
+        (the bucket) and the in-kernel Philox dropout (injected masks change per call)."""
+        from slu_hip import pipeline
+        return (pipeline.graphs_enabled() and self.bucket is not None and self._hip_adam
+                and not models_masks_injected() and all(p.is_cuda for p in self.model.parameters()))
+
+    def graph_stats(self):
+        """{"step_graphs": captured optimisation steps, "prefix_graphs": captured look-ahead super-batch
+        shapes, "capture_failures": shapes that fell back to eager launches} — reported by bench.py."""
+        slots = getattr(self, "_slots", None) or []
+        return {"step_graphs": len(self._step_graphs),
+                "prefix_graphs": sum(1 for sl in slots for g in sl.graphs.values() if g is not None),
+                "capture_failures": self.capture_failures + sum(sl.capture_failures for sl in slots)}
+
+    def _graph_step(self, key, inputs, step, forward, stream):
+        """One optimisation step on `inputs` (device tensors): replay of the hipGraph captured for `key`
+        (captured after three eager steps of that key), else eagerly.  -> metrics (tensor or list)."""
+        from slu_hip import pipeline
+        sg = self._step_graphs.get(key)
+        if sg is not None and sg.signature != self.bucket.signature:
+            sg = None                                   # trainable set changed since capture
+        if (sg is None and self._eager_steps.get(key, 0) >= 3 and self.bucket.active
+                and (key in self._step_graphs or len(self._step_graphs) < _max_step_graphs())):
+            try:
+                sg = pipeline.StepGraph(self, inputs, forward, stream)
+                self._step_graphs[key] = sg
+            except RuntimeError as e:                   # keep training eagerly if capture fails
+                print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
+                self._eager_steps[key] = -(1 << 30)
+                self._step_graphs.pop(key, None)
+                self.capture_failures += 1
+        if sg is not None:
+            return sg.run(inputs, step)
+        self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
+        metrics, loss = forward(inputs, step)
+        self._step(loss)
+        return metrics
+
+    def _slu_forward(self, n_prefix):
+        from slu_hip import ops
+
+        def forward(ins, rng):
+            loss, _ = self.model.forward_from(ins[0], n_prefix, ins[1], rng)
+            return ops.IntentHeadFn.last_loss_acc, loss          # (2,) float32 [loss, acc]
+        return forward
+
+    def _asr_forward(self, ins, rng):
+        vals, loss = self._forward_losses(ins, True, rng)
+        dev = ins[0].device
+        # pretraining_type 1 returns host zeros for the word head (reference models.py:317-319)
+        vals = torch.stack([v.detach().float().reshape(()) if v.is_cuda else torch.zeros((), device=dev)
+                            for v in vals])
+        return vals, loss
+
+    def _iterate_full_steps(self, loader, asr):
+        """Training with nothing to look ahead to (ASR pre-training, SLU with an unfrozen first layer or
+        SLU_LOOKAHEAD=0): each step is ~100 short launches, so fixed-shape steps are captured as hipGraphs
+        (StepGraph) on a dedicated stream; the losses and parameters are those of the eager loop."""
+        from models import next_rng_step
+        dev = next(self.model.parameters()).device
+        outer = torch.cuda.current_stream()
+        if getattr(self, "_full_stream", None) is None:
+            self._full_stream = torch.cuda.Stream(dev)
+        main = self._full_stream
+        main.wait_stream(outer)
+        if hasattr(self.model, "pretrained_model"):
+            pm, forward = self.model.pretrained_model, self._slu_forward(0)
+        else:
+            pm, forward = self.model, self._asr_forward
+        try:
+            with torch.cuda.stream(main):
+                pm.warm_weight_caches()
+                for batch in loader:
+                    ins = [t.to(dev, non_blocking=True) for t in batch]
+                    ins[0] = ins[0].float()
+                    key = ("full", asr) + tuple(tuple(t.shape) for t in ins)
+                    vals = self._graph_step(key, ins, next_rng_step(), forward, main)
+                    yield vals, len(batch[0])
+        finally:
+            outer.wait_stream(main)
 
     def _iterate(self, loader, train, asr):
         """Yields ([metric tensors], batch_size) per batch, doing the optimisation step when `train`."""
@@ -175,6 +284,9 @@ class Trainer:
                 yield from flush()
             return
         if depth == 0:
+            if train and self._graphable():
+                yield from self._iterate_full_steps(loader, asr)
+                return
             for batch in loader:
                 with torch.set_grad_enabled(train):
                     vals, loss = self._forward_losses(batch, asr)
@@ -212,6 +324,8 @@ class Trainer:
                 slot.signature = signature
             slot.stream.wait_stream(main)
         use_graph = pipeline.graphs_enabled()
+        step_graphs = use_graph and self._graphable()
+        forward = self._slu_forward(n_prefix)
         pending = collections.deque()
         it = iter(loader)
         carry = []                                    # a batch read ahead that did not fit its group
@@ -257,22 +371,11 @@ class Trainer:
                             main.wait_event(done)
                             feats_cat.record_stream(main)
                         feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
-                        y = batch[1]
-                        key = (tuple(feats.shape), tuple(y.shape), n_prefix)
-                        sg = self._step_graphs.get(key) if use_graph else None
-                        if sg is not None and sg.signature != self.bucket.signature:
-                            sg = None                                   # trainable set changed since capture
-                        if sg is None and use_graph and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:
-                            try:
-                                sg = pipeline.StepGraph(self, feats, y, n_prefix, main)
-                                self._step_graphs[key] = sg
-                            except Exception as e:                      # keep training eagerly if capture fails
-                                print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
-                                self._eager_steps[key] = -(1 << 30)
-                        if sg is not None:
-                            vals = sg.run(feats, y, steps[k])          # (2,) device tensor [loss, acc]
+                        y = batch[1].to(dev, non_blocking=True)
+                        if step_graphs:
+                            key = (tuple(feats.shape), tuple(y.shape), n_prefix)
+                            vals = self._graph_step(key, [feats, y], steps[k], forward, main)
                         else:
-                            self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
                             loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
                             self._step(loss)
                             vals = [loss, acc]
@@ -303,17 +406,20 @@ class Trainer:
                     smp.set_epoch(self.epoch)
         if train and self.rank == 0:
             it = tqdm(it)
-        for idx, (vals, batch_size) in enumerate(self._iterate(it, train, asr)):
-            num_examples += batch_size
-            if torch.is_tensor(vals):                              # captured step: one fused accumulate
-                step_vals = vals
-                sums.add_(vals, alpha=batch_size)
-            else:
-                step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
-                sums += step_vals * batch_size
-            if train and idx % print_interval == 0 and self.rank == 0:
-                for n, v in zip(names, step_vals.tolist()):       # one host sync per print interval
-                    print(n + ": " + str(v))
+        # closing(): if the loop is left early (exception, KeyboardInterrupt) the generator's finally clause
+        # runs NOW — the current stream returns to the caller's and it waits for the training stream
+        with contextlib.closing(self._iterate(it, train, asr)) as steps:
+            for idx, (vals, batch_size) in enumerate(steps):
+                num_examples += batch_size
+                if torch.is_tensor(vals):                              # captured step: one fused accumulate
+                    step_vals = vals
+                    sums.add_(vals, alpha=batch_size)
+                else:
+                    step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
+                    sums += step_vals * batch_size
+                if train and idx % print_interval == 0 and self.rank == 0:
+                    for n, v in zip(names, step_vals.tolist()):       # one host sync per print interval
+                        print(n + ": " + str(v))
         return self._epoch_means(sums.tolist(), num_examples, dev)
 
     # -- reference API -----------------------------------------------------------------------------

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 1
+#define SLU_ABI_VERSION 2
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -197,14 +197,18 @@ int slu_frame_ce_fwd(float* logits, const int64_t* y, int64_t N, int64_t V, int6
  * One launch updates up to slu_adam_max_tensors() tensors of one dtype (elem_bytes 4 / 8); the pointer
  * arrays are HOST arrays of device pointers (they travel in the kernel arguments: hipGraph-safe).
  * *step_dev (int64, device) = number of updates these tensors have received so far; it is read, not
- * advanced: slu_adam_advance_step adds 1 to `count` consecutive counters once per optimisation step.
- *   m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;  p -= lr/(1 - b1^t) * m / (sqrt(v)/sqrt(1 - b2^t) + eps) */
+ * advanced: slu_adam_advance_step adds 1 to the counters step_dev[i] whose bit i is set in cohort_mask,
+ * once per optimisation step (only tensors that received a gradient advance, as in torch.optim.Adam).
+ * grad_div: the gradients are divided by it before use (the world size under data parallelism, where
+ * the RCCL all-reduce delivers the SUM over ranks; 1.0 otherwise).
+ *   g /= grad_div;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;
+ *   p -= lr/(1 - b1^t) * m / (sqrt(v)/sqrt(1 - b2^t) + eps) */
 int slu_adam_max_tensors(void);
 int slu_adam_multi(void* const* params, const void* const* grads, void* const* exp_avg,
                    void* const* exp_avg_sq, const int64_t* numel, int64_t count, int elem_bytes,
                    const int64_t* step_dev, double lr, double beta1, double beta2, double eps,
-                   void* stream);
-int slu_adam_advance_step(int64_t* step_dev, int64_t count, void* stream);
+                   double grad_div, void* stream);
+int slu_adam_advance_step(int64_t* step_dev, uint64_t cohort_mask, void* stream);
 
 #ifdef __cplusplus
 }

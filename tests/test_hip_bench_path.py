@@ -1,0 +1,195 @@
+"""GPU parity of the EXACT path bench.py times (BASELINE.json configs[3] at full size: no_unfreezing
+architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 12 batches (768 sequences, 4-sequence
+recurrence kernels, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
+step, against (1) the plain sequential eager loop, bit for bit, and (2) the CPU oracle (<= 1e-4).
+
+Chain proven here:  oracle == HIP kernels at super-batch size (mask-in)  and  sequential eager ==
+sequential captured == pipelined + captured (Philox), so the benchmarked path computes what the
+reference computes (reference models.py:797-823, training.py:84-119)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import slu_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "end-to-end-slu_amd")
+sys.path.insert(0, PKG)
+
+
+def _full_cfg(tmp_path, **kw):
+    import data
+    cfg = O.OracleConfig(pretraining_type=2, **kw)           # defaults = experiments/no_unfreezing.cfg
+    cfg.folder = str(tmp_path)
+    cfg.training_lr = 0.001
+    cfg.starting_unfreezing_index = 1
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    os.makedirs(tmp_path / "pretraining", exist_ok=True)
+    os.makedirs(tmp_path / "training", exist_ok=True)
+    return cfg
+
+
+def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps):
+    import models
+    import training
+    monkeypatch.setenv("SLU_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("SLU_GRAPHS", graphs)
+    torch.manual_seed(2)
+    model = models.Model(cfg)
+    models.set_dropout_seed(1234)
+    trainer = training.Trainer(model, cfg)
+    model.train()
+    vals = []
+    import contextlib
+    with contextlib.closing(trainer._iterate(loader, True, False)) as it:
+        for v, _ in it:
+            # captured steps return their static (2,) metrics buffer: snapshot it on the current stream
+            vals.append(v.clone() if torch.is_tensor(v) else torch.stack([v[0].detach(), v[1].detach()]))
+    torch.cuda.synchronize()
+    losses = [float(v[0]) for v in vals]
+    assert len(losses) == n_steps
+    return trainer, losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, monkeypatch):
+    """72 steps of B = 64 x 3 s: five 12-batch super-batches per ... each slot captures its shape on the
+    second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
+    Per-step losses and final parameters must be bit-equal to the eager sequential loop."""
+    import data
+    cfg = _full_cfg(tmp_path)
+    torch.manual_seed(1)
+    torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
+    ds = data.SyntheticSLUDataset(4, 64, 48000, cfg.values_per_slot, seed=1234)
+    n_steps = 72
+    loader = [ds.batches[i % 4] for i in range(n_steps)]
+    ref_tr, ref_losses, ref_sd = _run_training(cfg, loader, monkeypatch, "0", "0", n_steps)
+    assert ref_tr.graph_stats() == {"step_graphs": 0, "prefix_graphs": 0, "capture_failures": 0}
+    assert len(set(ref_losses)) == n_steps                      # dropout and the optimiser really moved
+
+    # sequential steps, each captured as a hipGraph (what --workload unfreeze_all / SLU_LOOKAHEAD=0 run)
+    tr, losses, sd = _run_training(cfg, loader, monkeypatch, "0", "1", n_steps)
+    assert tr.graph_stats() == {"step_graphs": 1, "prefix_graphs": 0, "capture_failures": 0}
+    assert losses == ref_losses
+    for k, v in ref_sd.items():
+        assert torch.equal(v, sd[k]), k
+
+    # the bench.py default: automatic look-ahead width (12 batches = 768 sequences) + graphs
+    tr, losses, sd = _run_training(cfg, loader, monkeypatch, "auto", "1", n_steps)
+    import training
+    assert training._lookahead_width(-1, 64) == 12
+    stats = tr.graph_stats()
+    assert stats["step_graphs"] == 1 and stats["capture_failures"] == 0
+    assert all(len([g for g in slot.graphs.values() if g is not None]) >= 1 for slot in tr._slots)
+    assert stats["prefix_graphs"] == 2
+    # every slot replayed its captured graph at least once (seen >= 3 for the 12-batch key)
+    assert all(max(slot.seen.values()) >= 3 for slot in tr._slots)
+    assert losses == ref_losses
+    for k, v in ref_sd.items():
+        assert torch.equal(v, sd[k]), k
+
+
+def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path):
+    """One look-ahead super-batch (12 x 64 = 768 utterances of 3 s: 4-sequence recurrence kernels at the size
+    the bench launches them) through the frozen encoder with the oracle's dropout masks, against the CPU
+    oracle's encoder (models.py:349-361): features within 1e-4."""
+    import models
+    cfg = _full_cfg(tmp_path)
+    torch.manual_seed(1)
+    pre = O.init_pretrained_state_dict(cfg)
+    torch.save(pre, tmp_path / "pretraining" / "model_state.pth")
+    torch.manual_seed(2)
+    model = models.Model(cfg)
+    model.train()
+    g = torch.Generator().manual_seed(7)
+    x = 0.1 * torch.randn(768, 48000, generator=g)
+    masks = O.draw_dropout_masks(cfg, x, seed=11, include_intent=False)
+    models.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
+    try:
+        n = model.frozen_prefix_len()
+        assert n == 7
+        feats = model.prefix_features(x.cuda(), n, 1)              # (19, 768, 256) time-major
+        torch.cuda.synchronize()
+    finally:
+        models.set_dropout_masks(None)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref = O.encoder_stages(pre, x, cfg, masks, explicit_gru=False)["features"]       # (768, 19, 256)
+    err = (feats.transpose(0, 1).cpu() - ref).abs().max().item()
+    print("super-batch (768 x 3 s) encoder features max-abs deviation vs oracle: %.3e" % err)
+    assert err <= 1e-4
+
+
+@pytest.mark.parametrize("tile", ["4", "16"])
+def test_recurrence_at_super_batch_size_vs_oracle(tile, monkeypatch):
+    """slu_gru_seq_fwd at B = 768, T = 300, I = 60, H = 128, both directions (phone_rnn0 of a super-batch),
+    forced onto the 4-sequence (the bench's) and the 16-sequence kernels, against the oracle's GRU
+    (torch.nn.GRU semantics, models.py:232)."""
+    from slu_hip import ops
+    monkeypatch.setenv("SLU_GRU_TILE", tile)
+    T, B, I, H = 300, 768, 60, 128
+    torch.manual_seed(3)
+    p = {}
+    for sfx in ("", "_reverse"):
+        p["weight_ih_l0" + sfx] = (torch.rand(3 * H, I) * 2 - 1) / H ** 0.5
+        p["weight_hh_l0" + sfx] = (torch.rand(3 * H, H) * 2 - 1) / H ** 0.5
+        p["bias_ih_l0" + sfx] = (torch.rand(3 * H) * 2 - 1) / H ** 0.5
+        p["bias_hh_l0" + sfx] = (torch.rand(3 * H) * 2 - 1) / H ** 0.5
+    x = torch.randn(B, T, I)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    with torch.no_grad():
+        ref = O.gru_layer(x, p, bidirectional=True, explicit=False)                 # (B, T, 2H)
+    d = {k: v.cuda() for k, v in p.items()}
+    xt = x.transpose(0, 1).contiguous().cuda()
+    w_ih = torch.cat([d["weight_ih_l0"], d["weight_ih_l0_reverse"]])
+    b_ih = torch.cat([d["bias_ih_l0"], d["bias_ih_l0_reverse"]])
+    gx = ops.gemm(xt.view(T * B, I), w_ih.t(), b_ih)
+    out, _ = ops.gru_seq_fwd(gx, d["weight_hh_l0"], d["weight_hh_l0_reverse"], d["bias_hh_l0"],
+                             d["bias_hh_l0_reverse"], T, B, H, 2, False)
+    torch.cuda.synchronize()
+    err = (out.transpose(0, 1).cpu() - ref).abs().max().item()
+    print("GRU B=768 T=300 tile %s: max-abs deviation vs oracle %.3e" % (tile, err))
+    assert err <= 1e-4
+
+
+def test_captured_asr_pretraining_step_equals_eager(tmp_path, monkeypatch):
+    """ASR pre-training (BASELINE configs[2] shape family: every layer trainable, both CE heads): the
+    hipGraph-captured step loop gives bit-identical losses and parameters to the eager loop."""
+    import contextlib
+    import data
+    import models
+    import training
+    cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                         phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                         intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=2)
+    cfg.folder = str(tmp_path)
+    cfg.pretraining_lr = 0.002
+    cfg.phone_downsample_factor, cfg.word_downsample_factor = 20 * 2 * 4, 20 * 2 * 16
+    os.makedirs(tmp_path / "pretraining", exist_ok=True)
+    ds = data.SyntheticASRDataset(3, 8, 8000, cfg, seed=3)
+    loader = [ds.batches[i % 3] for i in range(10)]
+    results = {}
+    for graphs in ("0", "1"):
+        monkeypatch.setenv("SLU_GRAPHS", graphs)
+        torch.manual_seed(9)
+        pm = models.PretrainedModel(cfg)
+        models.set_dropout_seed(5)
+        trainer = training.Trainer(pm, cfg)
+        pm.train()
+        vals = []
+        with contextlib.closing(trainer._iterate(loader, True, True)) as it:
+            for v, _ in it:
+                vals.append(v.clone() if torch.is_tensor(v) else
+                            torch.stack([t.detach().float().reshape(()).cuda() for t in v]))
+        torch.cuda.synchronize()
+        assert trainer.graph_stats()["step_graphs"] == (1 if graphs == "1" else 0)
+        assert trainer.graph_stats()["capture_failures"] == 0
+        results[graphs] = (torch.stack(vals).cpu(), {k: v.detach().cpu().clone() for k, v in pm.state_dict().items()})
+    assert torch.equal(results["0"][0], results["1"][0])
+    assert len(set(results["0"][0][:, 0].tolist())) == 10
+    for k, v in results["0"][1].items():
+        assert torch.equal(v, results["1"][1][k]), k

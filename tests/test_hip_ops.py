@@ -373,6 +373,46 @@ def test_hip_adam_matches_torch_adam():
     assert o_hip._steps[:2].tolist() == [6, 3]
 
 
+@pytest.mark.gpu
+def test_hip_adam_skipped_steps_grad_div_and_state_dict():
+    """A parameter without a gradient in some steps keeps its own step count (torch.optim.Adam skips it:
+    bias correction must not advance); grad_div divides the gradients in-kernel (data-parallel mean);
+    state_dict carries torch.optim.Adam's per-parameter `step` and round-trips."""
+    from slu_hip.optim import HipAdam
+    torch.manual_seed(6)
+    a, b = torch.randn(40, 12).requires_grad_(), torch.randn(77).requires_grad_()
+    ours = [t.detach().clone().cuda().requires_grad_() for t in (a, b)]
+    o_ref, o_hip = torch.optim.Adam([a, b], lr=2e-3), HipAdam(ours, lr=2e-3)
+    o_hip.grad_div = 2.0
+    # b (its own cohort: first gradient at step 1) sits out steps 2 and 3
+    for step in range(6):
+        for k, (r, o) in enumerate(zip((a, b), ours)):
+            if (k == 0 and step == 0) or (k == 1 and step in (2, 3)):
+                r.grad = o.grad = None
+                continue
+            g = torch.randn(r.shape)
+            r.grad = g.clone()
+            o.grad = (2.0 * g).cuda()              # "sum over two identical ranks"
+        o_ref.step()
+        o_hip.step()
+    for r, o in zip((a, b), ours):
+        assert torch.allclose(o.detach().cpu(), r.detach(), rtol=2e-6, atol=2e-6 * r.detach().abs().max().item())
+    sd = o_hip.state_dict()
+    steps = sorted(int(v["step"]) for v in sd["state"].values())
+    assert steps == sorted(int(o_ref.state[p]["step"]) for p in (a, b)) == [4, 5]
+    # round trip into a fresh optimiser, one more step on both
+    ours2 = [o.detach().clone().requires_grad_() for o in ours]
+    o_hip2 = HipAdam(ours2, lr=2e-3)
+    o_hip2.load_state_dict(sd)
+    for r, o in zip((a, b), ours2):
+        g = torch.randn(r.shape)
+        r.grad, o.grad = g.clone(), g.cuda()
+    o_ref.step()
+    o_hip2.step()
+    for r, o in zip((a, b), ours2):
+        assert torch.allclose(o.detach().cpu(), r.detach(), rtol=3e-6, atol=3e-6 * r.detach().abs().max().item())
+
+
 # ---------------------------------------------------------------------------------------------
 # ASR pre-training heads: Linear + cross-entropy(ignore_index=-1) + frame accuracy (slu_framece.hip)
 # against torch (reference models.py:291-331)
