@@ -224,6 +224,7 @@ def parity_check(dev):
         config.folder = os.path.join(work, config.folder)
         config.values_per_slot = [6, 14, 4]
         config.Sy_intent = data.synthetic_Sy_intent(config.values_per_slot)
+        config.num_phonemes = 42                                   # no_unfreezing.cfg's phoneme inventory
         torch.manual_seed(meta["pretrain_seed"])
         torch.save({k: v.cpu() for k, v in models.PretrainedModel(config).state_dict().items()},
                    os.path.join(config.folder, "pretraining", "model_state.pth"))

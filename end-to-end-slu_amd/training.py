@@ -199,8 +199,9 @@ class Trainer:
         sg = self._step_graphs.get(key)
         if sg is not None and sg.signature != self.bucket.signature:
             sg = None                                   # trainable set changed since capture
-        if (sg is None and self._eager_steps.get(key, 0) >= 3 and self.bucket.active
-                and (key in self._step_graphs or len(self._step_graphs) < _max_step_graphs())):
+        if sg is None and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:
+            if key not in self._step_graphs and len(self._step_graphs) >= _max_step_graphs():
+                self._step_graphs.pop(next(iter(self._step_graphs)))     # evict the oldest capture
             try:
                 sg = pipeline.StepGraph(self, inputs, forward, stream)
                 self._step_graphs[key] = sg
@@ -247,13 +248,15 @@ class Trainer:
             pm, forward = self.model.pretrained_model, self._slu_forward(0)
         else:
             pm, forward = self.model, self._asr_forward
+        # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it)
+        trainable = tuple(p.requires_grad for p in self.model.parameters())
         try:
             with torch.cuda.stream(main):
                 pm.warm_weight_caches()
                 for batch in loader:
                     ins = [t.to(dev, non_blocking=True) for t in batch]
                     ins[0] = ins[0].float()
-                    key = ("full", asr) + tuple(tuple(t.shape) for t in ins)
+                    key = ("full", asr, trainable) + tuple(tuple(t.shape) for t in ins)
                     vals = self._graph_step(key, ins, next_rng_step(), forward, main)
                     yield vals, len(batch[0])
         finally:
@@ -326,6 +329,7 @@ class Trainer:
         use_graph = pipeline.graphs_enabled()
         step_graphs = use_graph and self._graphable()
         forward = self._slu_forward(n_prefix)
+        trainable = tuple(p.requires_grad for p in self.model.parameters())
         pending = collections.deque()
         it = iter(loader)
         carry = []                                    # a batch read ahead that did not fit its group
@@ -373,7 +377,7 @@ class Trainer:
                         feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
                         y = batch[1].to(dev, non_blocking=True)
                         if step_graphs:
-                            key = (tuple(feats.shape), tuple(y.shape), n_prefix)
+                            key = (tuple(feats.shape), tuple(y.shape), n_prefix, trainable)
                             vals = self._graph_step(key, [feats, y], steps[k], forward, main)
                         else:
                             loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])

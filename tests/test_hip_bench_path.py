@@ -57,7 +57,7 @@ def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps):
 
 
 def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, monkeypatch):
-    """72 steps of B = 64 x 3 s: five 12-batch super-batches per ... each slot captures its shape on the
+    """72 steps of B = 64 x 3 s: six 12-batch super-batches, three per look-ahead slot: each slot captures its shape on the
     second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
     Per-step losses and final parameters must be bit-equal to the eager sequential loop."""
     import data

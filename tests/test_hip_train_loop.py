@@ -75,9 +75,9 @@ def test_trainer_asr_step_matches_oracle(tmp_path):
     it = iter(range(2))
     orig = pm.forward
 
-    def fwd(x, yp, yw):
+    def fwd(x, yp, yw, **kw):
         models.set_dropout_masks({k: v.cuda() for k, v in masks[next(it)].items()})
-        return orig(x, yp, yw)
+        return orig(x, yp, yw, **kw)
     pm.forward = fwd
     try:
         res = trainer.train(ds)
