@@ -79,15 +79,26 @@ wconv_fwd_kernel(const WconvParams p) {
     const long long u0 = (long long)l0 * p.S - p.pad;
     const int total = p.nrows * p.S;
     const float invS = 1.0f / (float)p.S;
-    for (int idx = tid; idx < total; idx += WC_THREADS) {
-      int row = (int)((float)idx * invS);
-      int col = idx - row * p.S;
-      if (col < 0) { col += p.S; --row; }
-      if (col >= p.S) { col -= p.S; ++row; }
-      const long long u = u0 + idx;
-      float v = 0.0f;
-      if (u >= 0 && u < p.in_row) v = inb[u];
-      lds[row * p.Sp + col] = v;
+    // eight independent global loads in flight per thread, then their LDS stores (a load -> store chain per
+    // element would expose the full memory latency once per element)
+    constexpr int U = 8;
+    for (int base = 0; base < total; base += WC_THREADS * U) {
+      float v[U];
+      int off[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int idx = base + j * WC_THREADS + tid;
+        int row = (int)((float)idx * invS);
+        int col = idx - row * p.S;
+        if (col < 0) { col += p.S; --row; }
+        if (col >= p.S) { col -= p.S; ++row; }
+        const long long u = u0 + idx;
+        off[j] = idx < total ? row * p.Sp + col : -1;
+        v[j] = (idx < total && u >= 0 && u < p.in_row) ? inb[u] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+        if (off[j] >= 0) lds[off[j]] = v[j];
     }
   }
   __syncthreads();
@@ -211,88 +222,124 @@ wconv_bwd_act_kernel(const float* __restrict__ dy, const float* __restrict__ y,
 
 // ---- weight gradient:  dW(c, q) = sum_{b,l} d_conv[b][l][c] * in_flat[b][l*S + q - pad] ----
 // MFMA with M = channels, N = taps q, K = frames.  Workgroup (qg, ks): taps [qg*128, qg*128+128),
-// K-split ks = a contiguous range of 64-frame chunks.  Per chunk the d_conv slab (64 x c_out) and
-// the input window are staged in LDS.  Partial sums go to ws[ks][c_out][Kw]; wconv_dw_reduce sums
-// the splits in fixed order (deterministic) and scatters to the torch (c_out, c_in, k_t) layout.
+// K-split ks = a contiguous range of 64-frame chunks.  Both operands of a chunk are CONTIGUOUS pieces
+// of global memory — the d_conv slab (64 frames x c_out) and the flat input window
+// [l0*S + q0 - pad, + 64*S + 128) — so they are copied to LDS as they lie (float4 where aligned, zero
+// outside the row), and tap q of frame f is simply window[f*S + q].  The next chunk's pieces are
+// fetched into registers while the current chunk's MFMAs run (one-chunk prefetch: without it every
+// chunk paid a full global-load round trip between two barriers, 0.04-0.13 of the MFMA peak).
+// The bias gradient rides along as the virtual tap q = Kw whose input is the constant 1.
+// Partial sums go to ws[ks][c_out][Kw1]; wconv_dw_reduce sums the splits in fixed order
+// (deterministic) and scatters to the torch (c_out, c_in, k_t) layout (+ d_bias).
 constexpr int DW_FC = 64;     // frames per chunk
 constexpr int DW_QG = 128;    // taps per workgroup (4 waves x 2 N-tiles x 16)
+constexpr int DW_NIN = 9;     // float4 of the input window per thread: 64*S + 128 <= 9216 floats (S <= 142)
 
 struct WconvDwParams {
   const float* d_conv;  // (B, l_conv, c_out)
   const float* in;      // (B, in_row)
-  float* ws;            // [KS][c_out][Kw]
+  float* ws;            // [KS][c_out][Kw1]
   long long in_row;
-  int S, Sp, Kw, pad, l_conv, c_out;
+  int S, Kw, Kw1, pad, l_conv, c_out;
   int chunks_per_row, chunks_total, chunks_per_split;
-  int nrows;            // LDS rows of the input window
+  int win;              // floats of the input window per chunk (multiple of 4)
+  int bias_tap;         // Kw when the bias gradient is wanted, else -1
 };
+
+// 4 consecutive floats base[idx .. idx+3] with zero outside [0, n)
+__device__ __forceinline__ float4 load4_bounded(const float* __restrict__ base, long long idx, long long n) {
+  const float* p = base + idx;
+  if (idx >= 0 && idx + 3 < n && ((reinterpret_cast<uintptr_t>(p) & 15) == 0))
+    return *reinterpret_cast<const float4*>(p);
+  float4 v;
+  v.x = (idx >= 0 && idx < n) ? p[0] : 0.0f;
+  v.y = (idx + 1 >= 0 && idx + 1 < n) ? p[1] : 0.0f;
+  v.z = (idx + 2 >= 0 && idx + 2 < n) ? p[2] : 0.0f;
+  v.w = (idx + 3 >= 0 && idx + 3 < n) ? p[3] : 0.0f;
+  return v;
+}
 
 template <int MTC>
 __global__ void __launch_bounds__(WC_THREADS)
 wconv_dw_kernel(const WconvDwParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* lds_in = reinterpret_cast<float*>(smem);
-  float* lds_d = lds_in + (size_t)p.nrows * p.Sp;            // [DW_FC][MTC*16 + 1]
-  constexpr int DLD = MTC * 16 + 1;
+  float* lds_in = reinterpret_cast<float*>(smem);            // [win]
+  float* lds_d = lds_in + p.win;                             // [DW_FC * c_out] (+ MTC*16 slack), as in memory
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q0 = blockIdx.x * DW_QG;
   const int ks = blockIdx.y;
   const int i = lane & 15, kg = lane >> 4;
+  const int c_out = p.c_out;
+  const int dsz = DW_FC * c_out;                             // floats of a d_conv slab
 
   f32x4 acc[MTC][2];
 #pragma unroll
   for (int m = 0; m < MTC; ++m) { acc[m][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  // per-lane B-operand offsets inside the window for its two N-tiles
+  // per-lane tap offsets inside the window for its two N-tiles; the bias tap reads the constant 1
   int boff[2];
+  bool is_bias[2];
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int qq = wave * 32 + n * 16 + i;
-    const int qd = qq / p.S, qm = qq - qd * p.S;
-    boff[n] = qd * p.Sp + qm;
+    boff[n] = wave * 32 + n * 16 + i;
+    is_bias[n] = (q0 + boff[n]) == p.bias_tap;
   }
 
   const int c_first = ks * p.chunks_per_split;
   const int c_last = min(c_first + p.chunks_per_split, p.chunks_total);
-  const float invS = 1.0f / (float)p.S;
-  for (int ch = c_first; ch < c_last; ++ch) {
+
+  float4 rin[DW_NIN], rd[MTC];
+  auto fetch = [&](int ch) {
     const int b = ch / p.chunks_per_row;
     const int l0 = (ch - b * p.chunks_per_row) * DW_FC;
-    __syncthreads();
-    {  // input window: u in [l0*S + q0 - pad, ...)
-      const float* __restrict__ inb = p.in + (size_t)b * p.in_row;
-      const long long u0 = (long long)l0 * p.S + q0 - p.pad;
-      const int total = p.nrows * p.S;
-      for (int idx = tid; idx < total; idx += WC_THREADS) {
-        int row = (int)((float)idx * invS);
-        int col = idx - row * p.S;
-        if (col < 0) { col += p.S; --row; }
-        if (col >= p.S) { col -= p.S; ++row; }
-        const long long u = u0 + idx;
-        float v = 0.0f;
-        if (u >= 0 && u < p.in_row) v = inb[u];
-        lds_in[row * p.Sp + col] = v;
-      }
-      // d_conv slab: frames l0 .. l0+63, channels 0 .. c_out (zero padded to MTC*16)
-      const float* __restrict__ db = p.d_conv + ((size_t)b * p.l_conv + l0) * p.c_out;
-      const int nfr = min(DW_FC, p.l_conv - l0);
-      for (int idx = tid; idx < DW_FC * MTC * 16; idx += WC_THREADS) {
-        const int f = idx / (MTC * 16), c = idx - f * (MTC * 16);
-        float v = 0.0f;
-        if (f < nfr && c < p.c_out) v = db[(size_t)f * p.c_out + c];
-        lds_d[f * DLD + c] = v;
-      }
+    const float* __restrict__ inb = p.in + (size_t)b * p.in_row;
+    const long long u0 = (long long)l0 * p.S + q0 - p.pad;
+#pragma unroll
+    for (int v = 0; v < DW_NIN; ++v) {
+      const int idx = 4 * (tid + v * WC_THREADS);
+      if (idx < p.win) rin[v] = load4_bounded(inb, u0 + idx, p.in_row);
     }
+    // slab: frames l0 .. l0+63 of row b are contiguous; frames beyond the row end contribute zero
+    const float* __restrict__ db = p.d_conv + ((size_t)b * p.l_conv + l0) * c_out;
+    const long long nvalid = (long long)min(DW_FC, p.l_conv - l0) * c_out;
+#pragma unroll
+    for (int v = 0; v < MTC; ++v) {
+      const int idx = 4 * (tid + v * WC_THREADS);
+      if (idx < dsz) rd[v] = load4_bounded(db, idx, nvalid);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int v = 0; v < DW_NIN; ++v) {
+      const int idx = 4 * (tid + v * WC_THREADS);
+      if (idx < p.win) *reinterpret_cast<float4*>(lds_in + idx) = rin[v];
+    }
+#pragma unroll
+    for (int v = 0; v < MTC; ++v) {
+      const int idx = 4 * (tid + v * WC_THREADS);
+      if (idx < dsz) *reinterpret_cast<float4*>(lds_d + idx) = rd[v];
+    }
+  };
+
+  // slack behind the slab (rows c >= c_out of the last frame read it; those accumulator rows are dropped)
+  for (int x = tid; x < MTC * 16; x += WC_THREADS) lds_d[dsz + x] = 0.0f;
+  if (c_first < c_last) fetch(c_first);
+  for (int ch = c_first; ch < c_last; ++ch) {
+    __syncthreads();                     // the previous chunk's MFMAs are done with the LDS tiles
+    stash();
     __syncthreads();
+    if (ch + 1 < c_last) fetch(ch + 1);  // in flight during this chunk's MFMAs
 #pragma unroll 4
     for (int kk = 0; kk < DW_FC / 4; ++kk) {
       const int fr = 4 * kk + kg;
       float a[MTC];
 #pragma unroll
-      for (int m = 0; m < MTC; ++m) a[m] = lds_d[fr * DLD + m * 16 + i];
-      const float b0 = lds_in[fr * p.Sp + boff[0]];
-      const float b1 = lds_in[fr * p.Sp + boff[1]];
+      for (int m = 0; m < MTC; ++m) a[m] = lds_d[fr * c_out + m * 16 + i];
+      float b0 = lds_in[fr * p.S + boff[0]];
+      float b1 = lds_in[fr * p.S + boff[1]];
+      b0 = is_bias[0] ? 1.0f : b0;
+      b1 = is_bias[1] ? 1.0f : b1;
 #pragma unroll
       for (int m = 0; m < MTC; ++m) {
         acc[m][0] = mfma16(a[m], b0, acc[m][0]);
@@ -300,30 +347,40 @@ wconv_dw_kernel(const WconvDwParams p) {
       }
     }
   }
-  float* __restrict__ ws = p.ws + (size_t)ks * p.c_out * p.Kw;
+  float* __restrict__ ws = p.ws + (size_t)ks * c_out * p.Kw1;
 #pragma unroll
   for (int m = 0; m < MTC; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int q = q0 + wave * 32 + n * 16 + i;
-      if (q >= p.Kw) continue;
+      if (q >= p.Kw1) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = m * 16 + 4 * kg + r;
-        if (c < p.c_out) ws[(size_t)c * p.Kw + q] = acc[m][n][r];
+        if (c < c_out) ws[(size_t)c * p.Kw1 + q] = acc[m][n][r];
       }
     }
 }
 
 __global__ void __launch_bounds__(256)
-wconv_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int KS, int c_out,
-                       int c_in, int k_t) {
+wconv_dw_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ dbias,
+                       int KS, int c_out, int c_in, int k_t, int Kw1) {
   const int Kw = c_in * k_t;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= c_out * Kw) return;
-  float s = 0.0f;
-  for (int k = 0; k < KS; ++k) s += ws[(size_t)k * c_out * Kw + idx];
-  const int c = idx / Kw, q = idx - c * Kw;
+  if (idx >= c_out * Kw1) return;
+  float s0 = 0.0f, s1 = 0.0f;
+  int k = 0;
+  for (; k + 1 < KS; k += 2) {
+    s0 += ws[(size_t)k * c_out * Kw1 + idx];
+    s1 += ws[(size_t)(k + 1) * c_out * Kw1 + idx];
+  }
+  if (k < KS) s0 += ws[(size_t)k * c_out * Kw1 + idx];
+  const float s = s0 + s1;
+  const int c = idx / Kw1, q = idx - c * Kw1;
+  if (q == Kw) {
+    if (dbias) dbias[c] = s;
+    return;
+  }
   const int kt = q / c_in, ci = q - kt * c_in;
   dw[((size_t)c * c_in + ci) * k_t + kt] = s;
 }
@@ -477,8 +534,8 @@ extern "C" int slu_wconv_bwd_data(const float* d_conv, const float* weight, floa
 static void dw_geometry(int64_t B, int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t,
                         int64_t stride_t, int64_t* l_conv, int* QGn, int* KS, int* cps, int* cpr) {
   *l_conv = (l_in + 2 * (k_t / 2) - k_t) / stride_t + 1;
-  const int64_t Kw = k_t * c_in;
-  *QGn = (int)cdiv(Kw, DW_QG);
+  const int64_t Kw1 = k_t * c_in + 1;                 // + the bias tap
+  *QGn = (int)cdiv(Kw1, DW_QG);
   *cpr = (int)cdiv(*l_conv, DW_FC);
   const int64_t chunks = B * *cpr;
   int64_t ks = 512 / *QGn;
@@ -493,7 +550,7 @@ extern "C" size_t slu_wconv_bwd_weight_workspace_bytes(int64_t B, int64_t l_in, 
                                                        int64_t c_out, int64_t k_t, int64_t stride_t) {
   int64_t l_conv; int QGn, KS, cps, cpr;
   dw_geometry(B, l_in, c_in, c_out, k_t, stride_t, &l_conv, &QGn, &KS, &cps, &cpr);
-  return ((size_t)KS * c_out * k_t * c_in + (size_t)colsum_splits(B * l_conv) * c_out) * sizeof(float);
+  return ((size_t)KS * c_out * (k_t * c_in + 1)) * sizeof(float);
 }
 
 extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float* d_weight,
@@ -504,8 +561,8 @@ extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float*
   hipStream_t st = (hipStream_t)stream;
   int64_t l_conv; int QGn, KS, cps, cpr;
   dw_geometry(B, l_in, c_in, c_out, k_t, stride_t, &l_conv, &QGn, &KS, &cps, &cpr);
-  const size_t dw_floats = (size_t)KS * c_out * k_t * c_in;
-  const size_t need = (dw_floats + (size_t)colsum_splits(B * l_conv) * c_out) * sizeof(float);
+  const int64_t Kw = k_t * c_in, Kw1 = Kw + 1;
+  const size_t need = (size_t)KS * c_out * Kw1 * sizeof(float);
   if (!workspace || workspace_bytes < need)
     SLU_FAIL(SLU_ERR_WORKSPACE, "slu_wconv_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes, need);
   const int MTC = (int)cdiv(c_out, 16);
@@ -513,14 +570,32 @@ extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float*
   WconvDwParams p;
   p.d_conv = d_conv; p.in = in; p.ws = reinterpret_cast<float*>(workspace);
   p.in_row = l_in * c_in;
-  p.S = (int)(stride_t * c_in); p.Sp = p.S | 1;
-  p.Kw = (int)(k_t * c_in); p.pad = (int)((k_t / 2) * c_in);
+  p.S = (int)(stride_t * c_in);
+  p.Kw = (int)Kw; p.Kw1 = (int)Kw1; p.pad = (int)((k_t / 2) * c_in);
   p.l_conv = (int)l_conv; p.c_out = (int)c_out;
   p.chunks_per_row = cpr; p.chunks_total = (int)(B * cpr); p.chunks_per_split = cps;
-  p.nrows = DW_FC + (int)cdiv(DW_QG, p.S) + 1;
+  p.win = (int)(cdiv((int64_t)(DW_FC - 1) * p.S + DW_QG, 4) * 4);
+  p.bias_tap = d_bias ? (int)Kw : -1;
+  if (p.win > DW_NIN * WC_THREADS * 4)
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_bwd_weight: stride*c_in = %d too large (window of %d floats)", p.S, p.win);
   dim3 grid((unsigned)QGn, (unsigned)KS);
-  size_t lds = ((size_t)p.nrows * p.Sp + (size_t)DW_FC * (MTC * 16 + 1)) * sizeof(float);
-  if (lds > 64 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_bwd_weight: LDS need %zu exceeds 64 KiB", lds);
+  const size_t lds = ((size_t)p.win + (size_t)DW_FC * c_out + (size_t)MTC * 16) * sizeof(float);
+  if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_bwd_weight: LDS need %zu exceeds 160 KiB", lds);
+  if (lds > 64 * 1024) {
+    const void* fn = nullptr;
+    switch (MTC) {
+      case 1: fn = (const void*)wconv_dw_kernel<1>; break;
+      case 2: fn = (const void*)wconv_dw_kernel<2>; break;
+      case 3: fn = (const void*)wconv_dw_kernel<3>; break;
+      case 4: fn = (const void*)wconv_dw_kernel<4>; break;
+      case 5: fn = (const void*)wconv_dw_kernel<5>; break;
+      case 6: fn = (const void*)wconv_dw_kernel<6>; break;
+      case 7: fn = (const void*)wconv_dw_kernel<7>; break;
+      default: fn = (const void*)wconv_dw_kernel<8>; break;
+    }
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_wconv_bwd_weight: cannot raise the dynamic LDS cap to %zu: %s", lds, hipGetErrorString(e));
+  }
   switch (MTC) {
     case 1: hipLaunchKernelGGL(wconv_dw_kernel<1>, grid, dim3(WC_THREADS), lds, st, p); break;
     case 2: hipLaunchKernelGGL(wconv_dw_kernel<2>, grid, dim3(WC_THREADS), lds, st, p); break;
@@ -532,12 +607,9 @@ extern "C" int slu_wconv_bwd_weight(const float* d_conv, const float* in, float*
     default: hipLaunchKernelGGL(wconv_dw_kernel<8>, grid, dim3(WC_THREADS), lds, st, p); break;
   }
   SLU_CHECK_LAUNCH("wconv_dw_kernel");
-  const int total = (int)(c_out * k_t * c_in);
+  const int total = (int)(c_out * Kw1);
   hipLaunchKernelGGL(wconv_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st,
-                     (const float*)p.ws, d_weight, KS, (int)c_out, (int)c_in, (int)k_t);
+                     (const float*)p.ws, d_weight, d_bias, KS, (int)c_out, (int)c_in, (int)k_t, (int)Kw1);
   SLU_CHECK_LAUNCH("wconv_dw_reduce_kernel");
-  if (d_bias)
-    return colsum_two_stage(d_conv, c_out, d_bias, B * l_conv, c_out,
-                            reinterpret_cast<float*>(workspace) + dw_floats, st);
   return SLU_OK;
 }

@@ -47,10 +47,14 @@ class _Fork:
     _Fork.join(device) makes the current stream wait for every auxiliary stream used since."""
     _used = {}
 
+    capture_forks = False     # set by pipeline.StepGraph while it captures a step with nothing running beside it
+
     def __init__(self, device, i):
-        # Inside a captured step the branches land on extra hardware queues that compete with the
-        # look-ahead streams (measured: -17 % on the pipelined step), so forking is eager-mode only.
-        self.active = not torch.cuda.is_current_stream_capturing()
+        # Inside a captured step of the look-ahead pipeline the branches land on extra hardware queues that
+        # compete with the look-ahead streams (measured: -17 % on the pipelined step): there forking is
+        # eager-mode only.  A fully trainable step has the chip to itself: its captured graph keeps the
+        # branches (weight-gradient GEMMs beside the next layer's BPTT, which fills 32 of 256 CUs).
+        self.active = _Fork.capture_forks or not torch.cuda.is_current_stream_capturing()
         if self.active:
             self.cur = torch.cuda.current_stream(device)
             self.side = _aux_streams(device, i + 1)[i]

@@ -192,7 +192,7 @@ class Trainer:
                 "prefix_graphs": sum(1 for sl in slots for g in sl.graphs.values() if g is not None),
                 "capture_failures": self.capture_failures + sum(sl.capture_failures for sl in slots)}
 
-    def _graph_step(self, key, inputs, step, forward, stream):
+    def _graph_step(self, key, inputs, step, forward, stream, forks=False):
         """One optimisation step on `inputs` (device tensors): replay of the hipGraph captured for `key`
         (captured after three eager steps of that key), else eagerly.  -> metrics (tensor or list)."""
         from slu_hip import pipeline
@@ -203,7 +203,7 @@ class Trainer:
             if key not in self._step_graphs and len(self._step_graphs) >= _max_step_graphs():
                 self._step_graphs.pop(next(iter(self._step_graphs)))     # evict the oldest capture
             try:
-                sg = pipeline.StepGraph(self, inputs, forward, stream)
+                sg = pipeline.StepGraph(self, inputs, forward, stream, forks)
                 self._step_graphs[key] = sg
             except RuntimeError as e:                   # keep training eagerly if capture fails
                 print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
@@ -257,7 +257,8 @@ class Trainer:
                     ins = [t.to(dev, non_blocking=True) for t in batch]
                     ins[0] = ins[0].float()
                     key = ("full", asr, trainable) + tuple(tuple(t.shape) for t in ins)
-                    vals = self._graph_step(key, ins, next_rng_step(), forward, main)
+                    vals = self._graph_step(key, ins, next_rng_step(), forward, main,
+                                            forks=os.environ.get("SLU_GRAPH_FORKS", "1") != "0")
                     yield vals, len(batch[0])
         finally:
             outer.wait_stream(main)

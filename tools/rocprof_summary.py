@@ -13,11 +13,21 @@ import sqlite3
 import sys
 
 
+BY_SHAPE = False      # --by-shape: one row per (kernel, grid size) = per distinct launch shape
+
+
 def load(path):
     """-> list of (start_ns, end_ns, kernel name, stream id)"""
     if path.endswith(".csv"):
         rows = csv.DictReader(open(path))
-        return [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", "0")) for r in rows]
+        out = []
+        for r in rows:
+            name = r["Kernel_Name"]
+            if BY_SHAPE:
+                name = "%s  grid=%sx%sx%s wg=%s" % (name[:70], r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"),
+                                                     r.get("Grid_Size_Z", "?"), r.get("Workgroup_Size_X", "?"))
+            out.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Stream_Id", "0")))
+        return out
     db = sqlite3.connect(path)
     return [(r[0], r[1], r[2], "0") for r in db.execute("select start, end, name from kernels")]
 
@@ -43,4 +53,6 @@ def main(path, top=40):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    args = [a for a in sys.argv[1:] if a != "--by-shape"]
+    BY_SHAPE = "--by-shape" in sys.argv
+    main(args[0], int(args[1]) if len(args) > 1 else 40)

@@ -1,0 +1,36 @@
+#!/bin/bash
+# rocprofv3 passes of round 2 (run on the GPU box through gpurun): kernel trace of the bench.py command lines and
+# separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ set) on the dominant kernel's headline launch shapes.
+TAG=${1:-r02_prof}
+O=/root/repo/gpurun_out/$TAG; mkdir -p $O
+R=/root/repo
+cd /tmp && export TMPDIR=/tmp
+B="--no-kernel-table --no-cpu-baseline --no-large-batch"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o d -- python $R/bench.py $B > $O/bench_default_prof.json 2> $O/bench_default_prof.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_unfrozen -o u -- python $R/bench.py $B --workload unfreeze_all --steps 100 --warmup 10 > $O/bench_unfrozen_prof.json 2> $O/bench_unfrozen_prof.err
+for W in gemm_ip0 gemm_ip1; do
+  timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$W -o p -- python $R/tools/run_one.py $W > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$W -o p -- python $R/tools/run_one.py $W > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_sq_$W -o p -- python $R/tools/run_one.py $W > /dev/null 2>&1
+done
+cd $R
+for t in default unfrozen; do
+  f=$(find $O/trace_$t -name "*kernel_trace.csv" | head -1)
+  python tools/rocprof_summary.py $f 30 > $O/${t}_kernel_stats.txt
+  python tools/rocprof_summary.py $f 40 --by-shape > $O/${t}_kernel_stats_by_shape.txt
+done
+for W in gemm_ip0 gemm_ip1; do for c in fetch write sq; do
+  f=$(find $O/pmc_${c}_$W -name "*counter_collection.csv" | head -1)
+  echo "== $W $c"; python - <<PY
+import csv, collections
+rows = list(csv.DictReader(open("$f")))
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in rows:
+    if "gemm_f32_kernel" in r["Kernel_Name"]:
+        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, cs in agg.items():
+    for c, v in cs.items():
+        print(k, c, "launches", len(v), "mean", sum(v) / len(v))
+PY
+done; done > $O/pmc_gemm_summary.txt 2>&1
+head -12 $O/default_kernel_stats.txt; cat $O/pmc_gemm_summary.txt; cat $O/bench_default_prof.json | head -c 600

@@ -16,6 +16,13 @@ elif what == "gemmbig":
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); out = torch.empty(M, N, device="cuda")
     for _ in range(10):
         ops.gemm(a, w.t(), None, out=out)
+elif what in ("gemm_ip0", "gemm_ip1"):
+    # input projections of a 12-batch look-ahead super-batch (768 sequences): phone_rnn0 (T=300, K=60), phone_rnn1 (T=150, K=256)
+    M, N, K = (300 * 768, 768, 60) if what == "gemm_ip0" else (150 * 768, 768, 256)
+    a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); bias = torch.randn(N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    for _ in range(5):
+        ops.gemm(a, w.t(), bias, out=out)
 elif what == "gru":
     T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 128
     gx = torch.randn(T, B, 6 * H, device="cuda")
