@@ -118,7 +118,23 @@ gemm_f32_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+  // XCD-aware tile order.  Workgroup L = (y * gridDim.x + x) is dispatched to XCD L % 8 (MI355X_MICROARCH.md),
+  // each XCD has its own L2: the gridDim.x column tiles that re-read one A row-tile must run on ONE XCD, or
+  // that tile is fetched through eight L2s (measured with rocprofv3 FETCH_SIZE on the input projections:
+  // 7.8x the algorithmic A bytes).  Renumber so that each XCD walks a contiguous range of (row-tile, column-
+  // tile) pairs: V = (L % 8) * ceil(total / 8) + L / 8.  Tiles past the end (total not a multiple of 8) are
+  // taken by the workgroups whose V falls outside: they fetch the leftover ids instead.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int total = gridDim.x * gridDim.y;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((total & 7) == 0) {
+      const int V = (L & 7) * (total >> 3) + (L >> 3);
+      by = V / gridDim.x;
+      bx = V - by * gridDim.x;
+    }
+  }
+  const int m0 = by * GM_BM, n0 = bx * GM_BN;
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int ntiles = (kend - kbeg + GM_BK - 1) / GM_BK;
@@ -328,7 +344,9 @@ static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper, int*
   const int64_t tiles = cdiv(M, bm) * cdiv(N, bm);
   int64_t ks = 1;
   if (tiles < 128 && K >= 512) {
-    ks = cdiv(256, tiles);
+    // two co-resident workgroups per CU (each is four waves with a barrier per k-tile: the second one fills
+    // the first one's staging phases) and never a partial second round: at most 512 workgroups
+    ks = 512 / tiles;
     const int64_t max_ks = K / 128;            // keep >= 128 k per split
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;
