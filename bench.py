@@ -58,8 +58,9 @@ WORKLOAD_TEXT = {
 # ------------------------------------------------------------------------------------------------------
 # setup
 # ------------------------------------------------------------------------------------------------------
-def setup(workload, rank, batch, samples, n_batches):
-    """read_config on the package's synthetic cfg, synthetic pre-training checkpoint, Model, Trainer."""
+def setup(workload, rank, batch, samples, n_batches, hidden=0):
+    """read_config on the package's synthetic cfg, synthetic pre-training checkpoint, Model, Trainer.
+    hidden > 0: every GRU layer gets that hidden size (a synthetic variant, not a reference cfg)."""
     import data
     import models
     import training
@@ -76,6 +77,10 @@ def setup(workload, rank, batch, samples, n_batches):
         for sub in ("", "pretraining", "training"):
             os.makedirs(os.path.join(config.folder, sub), exist_ok=True)
         config.seed = 1234 + rank                      # per-rank synthetic data
+        if hidden:
+            config.phone_rnn_num_hidden = [hidden] * len(config.phone_rnn_num_hidden)
+            config.word_rnn_num_hidden = [hidden] * len(config.word_rnn_num_hidden)
+            config.intent_rnn_num_hidden = [hidden] * len(config.intent_rnn_num_hidden)
         if workload == "asr_pretrain":
             config.asr_path = "synthetic:%dx%dx%d" % (n_batches, batch, samples)
             train_ds, _, _ = data.get_ASR_datasets(config)
@@ -459,6 +464,9 @@ def main():
     ap.add_argument("--workload", default="no_unfreezing", choices=sorted(CFG))
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=SECONDS)
+    ap.add_argument("--hidden", type=int, default=0,
+                    help="GRU hidden size of every layer (default: the cfg's 128); any other value is a labelled "
+                         "synthetic variant (SURVEY 8.0-A: H = 512 extra point), never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-batch", action="store_true",
                     help="skip the extra large-batch point (B=2048/GPU, forward-dominant kernels throughput-bound)")
@@ -492,7 +500,7 @@ def main():
         note("parity on the golden batch")
         parity = parity_check(dev)
     note("setup")
-    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4)
+    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4, args.hidden)
     batches = [tuple(t.to(dev) for t in b) for b in train_ds.loader]       # inputs resident in HBM
     model.train()
 
@@ -552,7 +560,9 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD_TEXT[args.workload],
+            "config": {"workload": WORKLOAD_TEXT[args.workload] + (
+                           " -- SYNTHETIC VARIANT: GRU hidden size %d in every layer (reference cfgs use 128)" % args.hidden
+                           if args.hidden else ""),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "samples_per_utterance": samples, "parallelism": "dp%d" % world,
                        "allreduce_bytes_per_step": payload, "mean_loss": round(loss_mean, 5),
@@ -586,7 +596,7 @@ def main():
                         % (width, args.batch * width, args.batch)}
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
-        if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing":
+        if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing" and not args.hidden:
             note("large-batch point")
             out["large_batch_point"] = large_batch_point(rank, samples)
         if world == 1 and not args.no_cpu_baseline and not asr:

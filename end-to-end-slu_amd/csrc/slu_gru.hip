@@ -658,9 +658,23 @@ gru_seq_bwd4_kernel(const GruBwdParams p, const int NBT16) {
 
 }  // namespace slu
 
+// H-generic path (slu_gru_step.hip): one launch per time step
+namespace slu {
+int gru_step_bias_splits(int64_t T, int64_t B);
+size_t gru_step_reserve_floats(int64_t T, int64_t B, int64_t H, int64_t D);
+int gru_step_fwd(const float* gx, const float* const w_hh[2], const float* const b_hh[2], float* out,
+                 float* reserve, int64_t T, int64_t B, int64_t H, int64_t D, hipStream_t st);
+int gru_step_bwd(const float* d_out, const float* reserve, const float* const w_hh[2], float* d_gx,
+                 float* d_gh, float* d_bias_part, int64_t T, int64_t B, int64_t H, int64_t D, hipStream_t st);
+}  // namespace slu
+
 using namespace slu;
 
+// hidden sizes with a persistent (W_hh resident in VGPRs) instantiation; every other H runs step by step
+static bool gru_persistent(int64_t H) { return H == 16 || H == 32 || H == 64 || H == 128; }
+
 extern "C" size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t D) {
+  if (!gru_persistent(H)) return gru_step_reserve_floats(T, B, H, D) * sizeof(float);
   const int64_t nbt = cdiv(B, 16);
   return (size_t)(D * T * nbt * (H / 16) * 5 * 256) * sizeof(float);
 }
@@ -675,15 +689,15 @@ static bool gru_use_seq4(int64_t B, int64_t H, int64_t D) {
   return cdiv(B, 16) * D < 256;
 }
 
-extern "C" int64_t slu_gru_bias_tiles(int64_t B, int64_t H, int64_t D) {
+extern "C" int64_t slu_gru_bias_tiles(int64_t T, int64_t B, int64_t H, int64_t D) {
+  if (!gru_persistent(H)) return gru_step_bias_splits(T, B);
   return gru_use_seq4(B, H, D) ? cdiv(B, 4) : cdiv(B, 16);
 }
 
 static int gru_check(const char* who, int64_t T, int64_t B, int64_t H, int64_t D) {
   SLU_REQUIRE(T > 0 && B > 0, "%s: non-positive T or B", who);
   SLU_REQUIRE(D == 1 || D == 2, "%s: D must be 1 or 2", who);
-  if (!(H == 16 || H == 32 || H == 64 || H == 128))
-    SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: hidden size %lld not instantiated (16, 32, 64, 128)", who, (long long)H);
+  SLU_REQUIRE(H > 0 && H <= 8192, "%s: hidden size %lld outside [1, 8192]", who, (long long)H);
   SLU_REQUIRE(cdiv(B, 16) <= 65535, "%s: B too large", who);
   return SLU_OK;
 }
@@ -700,6 +714,7 @@ extern "C" int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const flo
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
   p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
   hipStream_t st = (hipStream_t)stream;
+  if (!gru_persistent(H)) return gru_step_fwd(gx, p.w_hh, p.b_hh, out, reserve, T, B, H, D, st);
   if (gru_use_seq4(B, H, D)) {
     dim3 grid4((unsigned)cdiv(B, 4), (unsigned)D);
     const int nbt16 = (int)cdiv(B, 16);
@@ -730,6 +745,7 @@ extern "C" int slu_gru_seq_bwd(const float* d_out, const float* reserve, const f
   p.d_out = d_out; p.reserve = reserve; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev;
   p.d_gx = d_gx; p.d_gh = d_gh; p.d_bias_part = d_bias_part; p.T = (int)T; p.B = (int)B; p.D = (int)D;
   hipStream_t st = (hipStream_t)stream;
+  if (!gru_persistent(H)) return gru_step_bwd(d_out, reserve, p.w_hh, d_gx, d_gh, d_bias_part, T, B, H, D, st);
   if (gru_use_seq4(B, H, D)) {
     dim3 grid4((unsigned)cdiv(B, 4), (unsigned)D);
     const int nbt16 = (int)cdiv(B, 16);

@@ -40,7 +40,7 @@ SIGNATURES = {
                              c_i64, c_int, vp, c_sz, vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
-    "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64]),
+    "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "slu_frame_ce_fwd": (c_int, [vp, vp, c_i64, c_i64, c_i64, c_int, vp, vp, vp]),
     "slu_adam_max_tensors": (c_int, []),
     "slu_adam_multi": (c_int, [vp, vp, vp, vp, vp, c_i64, c_int, vp, c_f64, c_f64, c_f64, c_f64, c_f64, vp]),

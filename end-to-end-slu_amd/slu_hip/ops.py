@@ -219,7 +219,7 @@ def gru_seq_bwd(d_out, reserve, w_hh_f, w_hh_r, T, B, H, D):
     dev = d_out.device
     d_gx = torch.empty(T, B, D * 3 * H, dtype=torch.float32, device=dev)
     d_gh = torch.empty(T, B, D * 3 * H, dtype=torch.float32, device=dev)
-    nbt = int(L.slu_gru_bias_tiles(B, H, D))
+    nbt = int(L.slu_gru_bias_tiles(T, B, H, D))
     d_bias_part = torch.empty(nbt, D, 6 * H, dtype=torch.float32, device=dev)
     _lib.check(L.slu_gru_seq_bwd(d_out.data_ptr(), reserve.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r),
                                  d_gx.data_ptr(), d_gh.data_ptr(), d_bias_part.data_ptr(), T, B, H, D,

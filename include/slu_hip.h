@@ -118,10 +118,12 @@ int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t 
  *           direction 1 scans t = T-1 .. 0 (bidirectional GRU output, RNNSelect models.py:138-149)
  *   reserve NULL (inference / frozen layer) or slu_gru_reserve_bytes(): per step r, z, n,
  *           W_hn h + b_hn and h_{t-1}, in the lane order of the backward kernel
- * One persistent workgroup per (direction, sequence tile) runs the whole time loop with its slice
- * of W_hh resident in VGPRs; tiles hold 16 sequences (v_mfma_f32_16x16x4_f32), or 4 sequences
- * (v_mfma_f32_4x4x1_16b_f32, H = 64 / 128) while the 16-sequence grid would leave CUs idle.
- * H is 16, 32, 64 or 128; D is 1 or 2.                                                            */
+ * H = 16 / 32 / 64 / 128: one persistent workgroup per (direction, sequence tile) runs the whole time
+ * loop with its slice of W_hh resident in VGPRs; tiles hold 16 sequences (v_mfma_f32_16x16x4_f32), or
+ * 4 sequences (v_mfma_f32_4x4x1_16b_f32, H = 64 / 128) while the 16-sequence grid would leave CUs idle.
+ * Any other H in [1, 8192] (W_hh no longer fits a CU's registers): one launch per time step enqueued by
+ * this call, (16 units) x (16 sequences) x D workgroups each, W_hh from L2 (the reserve then has a
+ * different, private layout: always pair slu_gru_seq_fwd / _bwd of the same H).  D is 1 or 2.        */
 size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t D);
 int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
                     const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
@@ -132,10 +134,10 @@ int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const float* w_hh_re
  *   d_gh    (T, B, D*3H) gradient w.r.t. h_{t-1} W_hh^T + b_hh          [dr_pre, dz_pre, dq],
  *           dq = dn_pre * r; the caller forms d(W_ih) = d_gx^T x, d(x) = d_gx W_ih and
  *           d(W_hh) = d_gh^T h_{t-1} with slu_gemm_f32 (h_{t-1} = `out` shifted by one step).
- *   d_bias_part NULL or (slu_gru_bias_tiles(B,H,D), D, 6H): per sequence tile, the sums over t and
- *           the tile's sequences of [d_gx (3H) | d_gh (3H)]; summing over the first axis gives
+ *   d_bias_part NULL or (slu_gru_bias_tiles(T,B,H,D), D, 6H): partial sums (per sequence tile, or per
+ *           block of (t, b) rows on the step-wise path) of [d_gx (3H) | d_gh (3H)]; summing over the first axis gives
  *           d(b_ih) = [0:3H) and d(b_hh) = [3H:6H).  (No atomics: deterministic.)                  */
-int64_t slu_gru_bias_tiles(int64_t B, int64_t H, int64_t D);
+int64_t slu_gru_bias_tiles(int64_t T, int64_t B, int64_t H, int64_t D);
 int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_fwd,
                     const float* w_hh_rev, float* d_gx, float* d_gh, float* d_bias_part,
                     int64_t T, int64_t B, int64_t H, int64_t D, void* stream);

@@ -212,6 +212,24 @@ def test_gru_vs_oracle_ragged_batches(ops, monkeypatch, tile, B, T, I, H):
     _gru_case(ops, d, True)
 
 
+@pytest.mark.parametrize("B,T,I,H", [(20, 11, 48, 256), (64, 6, 60, 512), (7, 5, 10, 24), (5, 4, 7, 10), (33, 3, 12, 200)])
+def test_gru_generic_hidden_sizes_vs_oracle(ops, B, T, I, H):
+    """Hidden sizes without a persistent instantiation (torch.nn.GRU takes any; SURVEY 8.0-A asks for 512)
+    run on the step-wise kernels (slu_gru_step.hip): output and every gradient against the oracle."""
+    torch.manual_seed(B + T + H)
+    m = torch.nn.GRU(I, H, batch_first=True, bidirectional=True)
+    x = torch.randn(B, T, I, requires_grad=True)
+    p = {k: v.detach().clone().requires_grad_() for k, v in m.named_parameters()}
+    out = O.gru_layer(x, p, True, explicit=False)
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    d = {"x": x.detach().numpy(), "out": out.detach().numpy(), "g": g.numpy(), "dx": x.grad.numpy()}
+    for k, v in p.items():
+        d[k] = v.detach().numpy()
+        d["grad_" + k] = v.grad.numpy()
+    _gru_case(ops, d, True)
+
+
 def test_gru_reserve_layout_is_shared_by_both_geometries(ops, monkeypatch):
     """Forward with 4-sequence workgroups, BPTT with 16-sequence ones (and vice versa): the saved gates
     have ONE layout, so the pairs must agree with the homogeneous runs to rounding."""
