@@ -1,0 +1,277 @@
+// Split-precision (bf16 MFMA) GEMM for the input projections of the FROZEN GRU layers:
+//   C(m, n) = sum_k A(m, k) W(n, k) + bias(n)          (x W_ih^T + b_ih of torch.nn.GRU, models.py:232/:262)
+// A: NS bf16 planes (M x Kp, Kp = K rounded up to 32, zero padded) written by the producing stage;
+// W: (N x K) fp32 weights, split and re-laid in MFMA B-fragment order once per launch by gemm_bf_pack;
+// C: fp32 (the recurrence's gx).  NS = 3: fp32-class result from six bf16 products (slu_bf16.h), NS = 1: bf16.
+//
+// Workgroup tile 128 x 128, 4 waves as 2 x 2 (64 x 64 each = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16), one
+// 32-wide k-chunk per stage:
+//   * A goes through LDS (double buffered, swizzled 64-byte rows -> conflict-free ds_read_b128 fragments),
+//     staged with 16-byte global loads that are in flight during the previous chunk's MFMAs;
+//   * W fragments are read straight from L2 in fragment order (1 KiB coalesced per wave-load, one chunk ahead):
+//     the packed weights are <= 1.2 MB and shared by every workgroup;
+//   * the workgroup -> tile map is XCD-aware (the N/128 column tiles of one row tile run on one XCD, whose L2
+//     then serves five of the six reads of that A tile);
+//   * the epilogue adds the bias and writes full 256-byte row segments (per-wave LDS transpose).
+// fp32 output makes the K = 60 projection HBM-write bound (708 MB per 768-sequence super-batch) and the
+// K = 256 ones MFMA bound at 6/16 of the fp32-MFMA cycle count.
+#include "slu_bf16.h"
+
+namespace slu {
+
+constexpr int GB_BM = 128, GB_BN = 128, GB_THREADS = 256;
+
+struct GemmBfParams {
+  const unsigned short* A;    // planes: A + p * a_plane, rows of lda bf16
+  long long a_plane, lda;
+  const uint4* wp;            // packed W: [plane][kc][nt][lane] uint4 (8 bf16)
+  const float* bias;          // (N) or null
+  float* C; long long ldc;
+  int M, N, KC;               // KC = number of 32-wide k-chunks
+};
+
+// W (N x K, row stride ldw) fp32 -> packed bf16 planes in B-fragment order, zero beyond N / K
+template <int NS>
+__global__ void __launch_bounds__(256)
+gemm_bf_pack_kernel(const float* __restrict__ W, long long ldw, uint4* __restrict__ wp, int N, int K, int KC, int NT) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (kc, nt, lane)
+  if (idx >= KC * NT * 64) return;
+  const int lane = idx & 63, nt = (idx >> 6) % NT, kc = (idx >> 6) / NT;
+  const int n = nt * 16 + (lane & 15), k0 = kc * 32 + (lane >> 4) * 8;
+  unsigned short h[NS][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (n < N && k0 + e < K) ? W[(long long)n * ldw + k0 + e] : 0.0f;
+    unsigned short s[NS];
+    split_bf16<NS>(v, s);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) h[p][e] = s[p];
+  }
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    uint4 o;
+    o.x = h[p][0] | ((unsigned)h[p][1] << 16); o.y = h[p][2] | ((unsigned)h[p][3] << 16);
+    o.z = h[p][4] | ((unsigned)h[p][5] << 16); o.w = h[p][6] | ((unsigned)h[p][7] << 16);
+    wp[(size_t)p * KC * NT * 64 + idx] = o;
+  }
+}
+
+// fp32 (rows x K, row stride ldx) -> NS bf16 planes (rows x Kp), zero padded: the entry into the split format
+// for tensors that were not produced by a split-writing epilogue
+template <int NS>
+__global__ void __launch_bounds__(256)
+split_planes_kernel(const float* __restrict__ x, long long ldx, unsigned short* __restrict__ out, long long plane,
+                    long long rows, int K, int Kp) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (row, 8-column group)
+  const int groups = Kp / 8;
+  if (idx >= rows * groups) return;
+  const long long r = idx / groups;
+  const int c0 = (int)(idx - r * groups) * 8;
+  unsigned short h[NS][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = (c0 + e < K) ? x[r * ldx + c0 + e] : 0.0f;
+    unsigned short s[NS];
+    split_bf16<NS>(v, s);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) h[p][e] = s[p];
+  }
+#pragma unroll
+  for (int p = 0; p < NS; ++p) {
+    uint4 o;
+    o.x = h[p][0] | ((unsigned)h[p][1] << 16); o.y = h[p][2] | ((unsigned)h[p][3] << 16);
+    o.z = h[p][4] | ((unsigned)h[p][5] << 16); o.w = h[p][6] | ((unsigned)h[p][7] << 16);
+    *reinterpret_cast<uint4*>(out + (size_t)p * plane + (size_t)r * Kp + c0) = o;
+  }
+}
+
+template <int NS>
+__global__ void __launch_bounds__(GB_THREADS, 2)
+gemm_bf_kernel(const GemmBfParams p) {
+  // A stage: NS planes x 128 rows x 64 B; two stages.  The epilogue reuses the memory (4 waves x 32 x 68 floats).
+  constexpr int STAGE_U4 = NS * GB_BM * 4;
+  constexpr int EPI_FLOATS = 4 * 32 * 68;
+  constexpr int SMEM_BYTES = (2 * STAGE_U4 * 16 > EPI_FLOATS * 4) ? 2 * STAGE_U4 * 16 : EPI_FLOATS * 4;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  uint4* const sA = reinterpret_cast<uint4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 15, kg = lane >> 4;
+  const int NT = p.N / 16;
+
+  // XCD-aware tile order (see gemm_f32_kernel): workgroup L runs on XCD L % 8
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int total = gridDim.x * gridDim.y;
+    const int L = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((total & 7) == 0) {
+      const int V = (L & 7) * (total >> 3) + (L >> 3);
+      by = V / gridDim.x;
+      bx = V - by * gridDim.x;
+    }
+  }
+  const int m0 = by * GB_BM, n0 = bx * GB_BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging map: thread -> (row = tid / 4 + 64 h, 16-byte slot tid % 4) of each plane
+  const int srow = tid >> 2, sslot = tid & 3;
+  uint4 ra[NS][2];
+  auto fetchA = [&](int kc) {
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = m0 + srow + 64 * h;
+        const unsigned short* src = p.A + (size_t)pl * p.a_plane + (size_t)(m < p.M ? m : 0) * p.lda + kc * 32 + sslot * 8;
+        uint4 v = *reinterpret_cast<const uint4*>(src);
+        if (m >= p.M) v = make_uint4(0u, 0u, 0u, 0u);
+        ra[pl][h] = v;
+      }
+  };
+  auto stashA = [&](int buf) {
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = srow + 64 * h;
+        sA[buf * STAGE_U4 + (pl * GB_BM + r) * 4 + swz_slot(r, sslot)] = ra[pl][h];
+      }
+  };
+  uint4 rb[NS][4];
+  auto fetchB = [&](int kc, uint4 (&dst)[NS][4]) {
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        dst[pl][b] = p.wp[((size_t)(pl * p.KC + kc) * NT + (n0 / 16 + wn * 4 + b)) * 64 + lane];
+  };
+
+  fetchA(0);
+  fetchB(0, rb);
+  stashA(0);
+  __syncthreads();
+  for (int kc = 0; kc < p.KC; ++kc) {
+    const int buf = kc & 1;
+    uint4 rbn[NS][4];
+    const bool more = kc + 1 < p.KC;
+    if (more) { fetchA(kc + 1); fetchB(kc + 1, rbn); }      // in flight during this chunk's MFMAs
+    uint4 fa[NS][4];
+#pragma unroll
+    for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int r = wm * 64 + a * 16 + i;
+        fa[pl][a] = sA[buf * STAGE_U4 + (pl * GB_BM + r) * 4 + swz_slot(r, kg)];
+      }
+#pragma unroll
+    for (int q = 0; q < SplitPairs<NS>::N; ++q) {
+      const int pa = SplitPairs<NS>::A[q], pb = SplitPairs<NS>::B[q];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[pa][a], rb[pb][b], acc[a][b]);
+    }
+    if (more) {
+      stashA(buf ^ 1);                                      // the other buffer: read last in chunk kc - 1
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) rb[pl][b] = rbn[pl][b];
+    }
+    __syncthreads();
+  }
+
+  // epilogue: two passes of 32 rows per wave through LDS, float4 row-contiguous stores (+ bias)
+  float* const sC = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  const int col4 = (lane & 15) * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ncol = n0 + wn * 64 + col4;
+  if (p.bias) { bv.x = p.bias[ncol]; bv.y = p.bias[ncol + 1]; bv.z = p.bias[ncol + 2]; bv.w = p.bias[ncol + 3]; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sC[(a2 * 16 + 4 * kg + r) * 68 + b * 16 + i] = acc[2 * h + a2][b][r];
+    // a wave only reads what it wrote itself: no workgroup barrier needed, LDS ops of a wave are ordered
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int rl = (lane >> 4) + 4 * it;
+      const int m = m0 + wm * 64 + h * 32 + rl;
+      const float4 v = *reinterpret_cast<const float4*>(&sC[rl * 68 + col4]);
+      if (m < p.M)
+        *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + ncol) = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
+    }
+  }
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" size_t slu_gemm_bf16_pack_bytes(int64_t N, int64_t K, int nsplit) {
+  return (size_t)nsplit * cdiv(K, 32) * cdiv(N, 16) * 64 * sizeof(uint4);
+}
+
+extern "C" int slu_gemm_bf16_pack(const float* W, int64_t ldw, void* packed, int64_t N, int64_t K, int nsplit,
+                                  void* stream) {
+  SLU_REQUIRE(W && packed && N > 0 && K > 0, "slu_gemm_bf16_pack: bad argument");
+  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_gemm_bf16_pack: nsplit must be 1 or 3");
+  const int KC = (int)cdiv(K, 32), NT = (int)cdiv(N, 16);
+  const int total = KC * NT * 64;
+  if (nsplit == 3)
+    hipLaunchKernelGGL(gemm_bf_pack_kernel<3>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W,
+                       (long long)ldw, (uint4*)packed, (int)N, (int)K, KC, NT);
+  else
+    hipLaunchKernelGGL(gemm_bf_pack_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W,
+                       (long long)ldw, (uint4*)packed, (int)N, (int)K, KC, NT);
+  SLU_CHECK_LAUNCH("gemm_bf_pack_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_split_bf16(const float* x, int64_t ldx, void* planes, int64_t plane_stride, int64_t rows,
+                              int64_t K, int nsplit, void* stream) {
+  SLU_REQUIRE(x && planes && rows > 0 && K > 0, "slu_split_bf16: bad argument");
+  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_split_bf16: nsplit must be 1 or 3");
+  const int Kp = (int)(cdiv(K, 32) * 32);
+  SLU_REQUIRE(plane_stride >= rows * Kp, "slu_split_bf16: plane stride smaller than rows * round_up(K, 32)");
+  const long long total = rows * (Kp / 8);
+  if (nsplit == 3)
+    hipLaunchKernelGGL(split_planes_kernel<3>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)ldx, (unsigned short*)planes, (long long)plane_stride, (long long)rows, (int)K, Kp);
+  else
+    hipLaunchKernelGGL(split_planes_kernel<1>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)ldx, (unsigned short*)planes, (long long)plane_stride, (long long)rows, (int)K, Kp);
+  SLU_CHECK_LAUNCH("split_planes_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, const void* w_packed,
+                             const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                             int nsplit, void* stream) {
+  SLU_REQUIRE(A_planes && w_packed && C, "slu_gemm_bf16: null pointer");
+  SLU_REQUIRE(M > 0 && N > 0 && K > 0, "slu_gemm_bf16: non-positive size");
+  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_gemm_bf16: nsplit must be 1 or 3");
+  if (N % GB_BN != 0) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_bf16: N = %lld is not a multiple of %d", (long long)N, GB_BN);
+  const int64_t Kp = cdiv(K, 32) * 32;
+  SLU_REQUIRE(lda >= Kp && (lda % 8) == 0, "slu_gemm_bf16: lda must be >= round_up(K, 32) and a multiple of 8");
+  SLU_REQUIRE((ldc % 4) == 0, "slu_gemm_bf16: ldc must be a multiple of 4");
+  GemmBfParams p;
+  p.A = (const unsigned short*)A_planes; p.a_plane = a_plane_stride; p.lda = lda;
+  p.wp = (const uint4*)w_packed; p.bias = bias; p.C = C; p.ldc = ldc;
+  p.M = (int)M; p.N = (int)N; p.KC = (int)(Kp / 32);
+  dim3 grid((unsigned)(N / GB_BN), (unsigned)cdiv(M, GB_BM));
+  SLU_REQUIRE(grid.y <= 65535, "slu_gemm_bf16: M too large for one launch");
+  if (nsplit == 3) hipLaunchKernelGGL(gemm_bf_kernel<3>, grid, dim3(GB_THREADS), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gemm_bf_kernel<1>, grid, dim3(GB_THREADS), 0, (hipStream_t)stream, p);
+  SLU_CHECK_LAUNCH("gemm_bf_kernel");
+  return SLU_OK;
+}

@@ -27,6 +27,7 @@ struct HeadParams {
   float* d_logits;         // (B, V) or null: d loss / d logits
   float* row_stats;        // (B, 2): per-utterance loss and all-slots-correct flag
   int T, B, C, V, S;
+  int w_in_lds;            // 0: the classifier rows are read from L2 (T x C + V x C does not fit the LDS)
   int slot_begin[HEAD_MAX_SLOTS + 1];
 };
 
@@ -35,7 +36,7 @@ head_fwd_kernel(const HeadParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sh = reinterpret_cast<float*>(smem);          // [T][C+1]
   float* sw = sh + (size_t)p.T * (p.C + 1);            // [V][C+1]
-  float* sl = sw + (size_t)p.V * (p.C + 1);            // [T][V] logits_t
+  float* sl = sw + (p.w_in_lds ? (size_t)p.V * (p.C + 1) : 0);   // [T][V] logits_t
   float* sm = sl + (size_t)p.T * p.V;                  // [V] pooled logits
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = p.T, C = p.C, V = p.V, LD = p.C + 1;
@@ -43,16 +44,18 @@ head_fwd_kernel(const HeadParams p) {
 #pragma unroll 4
   for (int t = 0; t < T; ++t)
     for (int c = tid; c < C; c += HEAD_THREADS) sh[t * LD + c] = p.h[((size_t)t * p.B + b) * C + c];
+  if (p.w_in_lds) {
 #pragma unroll 4
-  for (int v = 0; v < V; ++v)
-    for (int c = tid; c < C; c += HEAD_THREADS) sw[v * LD + c] = p.W[(size_t)v * C + c];
+    for (int v = 0; v < V; ++v)
+      for (int c = tid; c < C; c += HEAD_THREADS) sw[v * LD + c] = p.W[(size_t)v * C + c];
+  }
   __syncthreads();
   // each thread owns whole (t, v) dot products: a[t][:] is an LDS broadcast within the threads of
   // one t, w[v][:] rows sit on distinct banks (row stride C+1); no cross-lane reduction
   for (int o = tid; o < T * V; o += HEAD_THREADS) {
     const int t = o / V, v = o - t * V;
     const float* a = sh + t * LD;
-    const float* w = sw + v * LD;
+    const float* w = p.w_in_lds ? sw + v * LD : p.W + (size_t)v * C;
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
     int c = 0;
     for (; c + 3 < C; c += 4) {
@@ -209,7 +212,12 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
   p.slot_begin[num_slots] = V;
   p.V = V;
   SLU_REQUIRE(V >= 1 && V <= HEAD_THREADS, "slu_cls_maxpool_ce_fwd: 1..%d classifier outputs supported", HEAD_THREADS);
-  const size_t lds = ((size_t)(T + V) * (C + 1) + (size_t)T * V + V) * sizeof(float);
+  size_t lds = ((size_t)(T + V) * (C + 1) + (size_t)T * V + V) * sizeof(float);
+  p.w_in_lds = 1;
+  if (lds > 160 * 1024) {                      // wide features (H > 128): keep only the T x C rows in LDS
+    p.w_in_lds = 0;
+    lds = ((size_t)T * (C + 1) + (size_t)T * V + V) * sizeof(float);
+  }
   if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_cls_maxpool_ce_fwd: T=%lld x C=%lld does not fit the LDS", (long long)T, (long long)C);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

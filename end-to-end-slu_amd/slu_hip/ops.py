@@ -190,6 +190,44 @@ def gemm(a, b, bias=None, out=None, accumulate=False):
     return out
 
 
+# -- split-precision (bf16 MFMA) path of the frozen stages: see csrc/slu_bf16.h --------------------------
+def round_up(n, m):
+    return -(-n // m) * m
+
+
+def split_bf16(x2d, nsplit):
+    """fp32 (rows, K) with unit column stride -> (nsplit, rows, round_up(K, 32)) bf16 planes, zero padded."""
+    L = _lib.load()
+    rows, K = x2d.shape
+    assert x2d.dtype == torch.float32 and x2d.stride(1) == 1
+    planes = torch.empty(nsplit, rows, round_up(K, 32), dtype=torch.bfloat16, device=x2d.device)
+    _lib.check(L.slu_split_bf16(x2d.data_ptr(), x2d.stride(0), planes.data_ptr(), planes.stride(0), rows, K,
+                                nsplit, _stream()), "slu_split_bf16")
+    return planes
+
+
+def gemm_bf16_pack(w, nsplit):
+    """(N, K) fp32 weights -> bf16 planes in MFMA B-fragment order (opaque byte tensor)."""
+    L = _lib.load()
+    N, K = w.shape
+    assert w.dtype == torch.float32 and w.stride(1) == 1
+    packed = torch.empty(L.slu_gemm_bf16_pack_bytes(N, K, nsplit), dtype=torch.uint8, device=w.device)
+    _lib.check(L.slu_gemm_bf16_pack(w.data_ptr(), w.stride(0), packed.data_ptr(), N, K, nsplit, _stream()),
+               "slu_gemm_bf16_pack")
+    return packed
+
+
+def gemm_bf16(planes, packed, bias, N, K, out=None):
+    """out (M, N) fp32 = A W^T + bias; planes (nsplit, M, ld) from split_bf16 / a split-writing stage."""
+    L = _lib.load()
+    nsplit, M, ld = planes.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=planes.device)
+    _lib.check(L.slu_gemm_bf16(planes.data_ptr(), planes.stride(0), ld, packed.data_ptr(), _ptr(bias), out.data_ptr(),
+                               out.stride(0), M, N, K, nsplit, _stream()), "slu_gemm_bf16")
+    return out
+
+
 def colsum(x2d, out=None, accumulate=False):
     L = _lib.load()
     M, N = x2d.shape

@@ -111,6 +111,24 @@ int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
 int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,
                    int accumulate, void* stream);
 
+/* -------- split-precision (bf16 MFMA) path of the FROZEN encoder stages ---------------------------------
+ * An fp32 value x = x1 + x2 + x3 (three bf16 terms, exact); a product keeps the six bf16 x bf16 terms above
+ * 2^-24 |a b| (v_mfma_f32_16x16x32_bf16, fp32 accumulation): fp32-class results at 6/16 of the fp32-MFMA
+ * cycle count.  nsplit = 3 selects that, nsplit = 1 plain bf16 (BASELINE configs[4]).  Activations between
+ * the stages are `nsplit` planes of bf16 (rows x ld, ld = round_up(K, 32), zero padded), plane p at
+ * planes + p * plane_stride (in bf16 elements).
+ *   slu_split_bf16     fp32 (rows x K, row stride ldx) -> planes (entry into the format)
+ *   slu_gemm_bf16_pack W (N x K) fp32 -> packed bf16 planes in MFMA B-fragment order (once per weight)
+ *   slu_gemm_bf16      C (M x N fp32, row stride ldc) = A W^T + bias: the input projection x W_ih^T + b_ih of
+ *                      nn.GRU (models.py:232/:262) for frozen layers; N must be a multiple of 128          */
+int slu_split_bf16(const float* x, int64_t ldx, void* planes, int64_t plane_stride, int64_t rows, int64_t K,
+                   int nsplit, void* stream);
+size_t slu_gemm_bf16_pack_bytes(int64_t N, int64_t K, int nsplit);
+int slu_gemm_bf16_pack(const float* W, int64_t ldw, void* packed, int64_t N, int64_t K, int nsplit, void* stream);
+int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, const void* w_packed,
+                  const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int nsplit,
+                  void* stream);
+
 /* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
  *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)
  *   w_hh[d] (3H, H), b_hh[d] (3H): weight_hh_l0 / bias_hh_l0 (d = 0) and *_reverse (d = 1)

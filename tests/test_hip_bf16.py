@@ -1,0 +1,49 @@
+"""GPU: the split-precision (bf16 MFMA) kernels of the frozen encoder stages (csrc/slu_bf16.h) against
+float64 references.  nsplit = 3 must be fp32-class (the error of an exact fp32 fmaf chain is ~1e-7 of
+sum |a b|; a few 2^-24 per product here), nsplit = 1 is plain bf16 (2^-9 per operand)."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "end-to-end-slu_amd"))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from slu_hip import lib, ops as _ops
+    lib.require_gfx950()
+    return _ops
+
+
+def test_split_planes_are_exact(ops):
+    torch.manual_seed(0)
+    x = (torch.randn(37, 60) * torch.logspace(-3, 3, 60)).cuda()
+    pl = ops.split_bf16(x, 3)
+    assert pl.shape == (3, 37, 64) and pl.dtype == torch.bfloat16
+    assert torch.equal(pl[:, :, 60:].float(), torch.zeros(3, 37, 4, device="cuda"))
+    back = (pl[0, :, :60].double() + pl[1, :, :60].double() + pl[2, :, :60].double())
+    assert torch.equal(back.float(), x)                      # three bf16 terms carry all 24 bits
+    one = ops.split_bf16(x, 1)
+    assert torch.equal(one[0, :, :60], x.to(torch.bfloat16))  # round to nearest even
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 60), (4097, 768, 256), (130, 384, 256), (64, 128, 33)])
+@pytest.mark.parametrize("nsplit", [3, 1])
+def test_gemm_bf16_vs_float64(ops, M, N, K, nsplit):
+    torch.manual_seed(M + K)
+    a = torch.randn(M, K)
+    w = torch.randn(N, K) * 0.2
+    bias = torch.randn(N)
+    ref = a.double() @ w.double().t() + bias.double()
+    scale = (a.abs().double() @ w.abs().double().t()).max().item()
+    out = ops.gemm_bf16(ops.split_bf16(a.cuda(), nsplit), ops.gemm_bf16_pack(w.cuda(), nsplit), bias.cuda(), N, K)
+    err = (out.cpu().double() - ref).abs().max().item() / scale
+    exact = (a.cuda() @ w.cuda().t() + bias.cuda()).cpu().double()
+    err_f32 = (exact - ref).abs().max().item() / scale
+    print("gemm_bf16 nsplit=%d M=%d N=%d K=%d: rel err %.2e (torch fp32 GEMM: %.2e)" % (nsplit, M, N, K, err, err_f32))
+    assert err <= (4e-7 if nsplit == 3 else 2e-2)

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Times the split-precision kernels against their exact-fp32 counterparts at the launch shapes of a
+12-batch look-ahead super-batch (768 sequences):  python tools/bf16_bench.py [gemm] [gru] [wconv]"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "end-to-end-slu_amd"))
+import torch
+from bench import _timed_graph
+from slu_hip import ops
+
+what = sys.argv[1:] or ["gemm", "gru", "wconv"]
+st = torch.cuda.Stream()
+B = int(os.environ.get("SEQS", "768"))
+if "gemm" in what:
+    for T, K in ((300, 60), (150, 256), (75, 256), (38, 256)):
+        M, N = T * B, 768
+        a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.1; bias = torch.randn(N, device="cuda")
+        out = torch.empty(M, N, device="cuda")
+        ms32 = _timed_graph(lambda: ops.gemm(a, w.t(), bias, out=out), st)
+        line = "gemm M=%d N=%d K=%d: fp32 %.1f us (%.1f TF)" % (M, N, K, 1e3 * ms32, 2.0 * M * N * K / ms32 / 1e9)
+        for ns in (3, 1):
+            pl = ops.split_bf16(a, ns); pk = ops.gemm_bf16_pack(w, ns)
+            ms = _timed_graph(lambda: ops.gemm_bf16(pl, pk, bias, N, K, out=out), st)
+            byt = pl.numel() * 2 + out.numel() * 4
+            line += " | nsplit=%d %.1f us (%.1f TF-equivalent, %.2f TB/s)" % (ns, 1e3 * ms, 2.0 * M * N * K / ms / 1e9, byt / ms / 1e9)
+        print(line, flush=True)
