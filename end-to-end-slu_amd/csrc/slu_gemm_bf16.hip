@@ -4,10 +4,10 @@
 // W: (N x K) fp32 weights, split and re-laid in MFMA B-fragment order once per launch by gemm_bf_pack;
 // C: fp32 (the recurrence's gx).  NS = 3: fp32-class result from six bf16 products (slu_bf16.h), NS = 1: bf16.
 //
-// Workgroup tile 128 x 128, 4 waves as 2 x 2 (64 x 64 each = 4 x 4 tiles of v_mfma_f32_16x16x32_bf16), one
-// 32-wide k-chunk per stage:
+// Workgroup tile 128 x 64, 4 waves as 2 x 2 (64 x 32 each = 4 x 2 tiles of v_mfma_f32_16x16x32_bf16), one
+// 32-wide k-chunk per stage, three workgroups per CU:
 //   * A goes through LDS (double buffered, swizzled 64-byte rows -> conflict-free ds_read_b128 fragments),
-//     staged with 16-byte global loads that are in flight during the previous chunk's MFMAs;
+//     filled by LDS-DMA (global_load_lds_dwordx4, swizzle on the source address) during the previous chunk's MFMAs;
 //   * W fragments are read straight from L2 in fragment order (1 KiB coalesced per wave-load, one chunk ahead):
 //     the packed weights are <= 1.2 MB and shared by every workgroup;
 //   * the workgroup -> tile map is XCD-aware (the N/128 column tiles of one row tile run on one XCD, whose L2
@@ -19,7 +19,7 @@
 
 namespace slu {
 
-constexpr int GB_BM = 128, GB_BN = 128, GB_THREADS = 256;
+constexpr int GB_BM = 128, GB_BN = 64, GB_THREADS = 256;     // wave tile 64 x 32: 152 live VGPRs -> 3 waves / SIMD
 
 struct GemmBfParams {
   const unsigned short* A;    // planes: A + p * a_plane, rows of lda bf16
@@ -86,11 +86,11 @@ split_planes_kernel(const float* __restrict__ x, long long ldx, unsigned short* 
 }
 
 template <int NS>
-__global__ void __launch_bounds__(GB_THREADS, 2)
+__global__ void __launch_bounds__(GB_THREADS, 3)
 gemm_bf_kernel(const GemmBfParams p) {
   // A stage: NS planes x 128 rows x 64 B; two stages.  The epilogue reuses the memory (4 waves x 32 x 68 floats).
   constexpr int STAGE_U4 = NS * GB_BM * 4;
-  constexpr int EPI_FLOATS = 4 * 32 * 68;
+  constexpr int EPI_FLOATS = 4 * 32 * 36;
   constexpr int SMEM_BYTES = (2 * STAGE_U4 * 16 > EPI_FLOATS * 4) ? 2 * STAGE_U4 * 16 : EPI_FLOATS * 4;
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   uint4* const sA = reinterpret_cast<uint4*>(smem);
@@ -113,100 +113,98 @@ gemm_bf_kernel(const GemmBfParams p) {
   }
   const int m0 = by * GB_BM, n0 = bx * GB_BN;
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging map: thread -> (row = tid / 4 + 64 h, 16-byte slot tid % 4) of each plane
+  // A staging by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): a wave-load fills
+  // 1 KiB of LDS linearly (lane l -> bytes [16 l, 16 l + 16) = row l / 4, slot l % 4 of a 16-row group), so the
+  // swizzle is applied to the SOURCE address: the lane fetches the k-slot that belongs in its LDS slot.
+  // Rows past M read row 0: rows of C are independent and those are never stored.
   const int srow = tid >> 2, sslot = tid & 3;
-  uint4 ra[NS][2];
-  auto fetchA = [&](int kc) {
+  const unsigned short* a_src[2];
 #pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int m = m0 + srow + 64 * h;
-        const unsigned short* src = p.A + (size_t)pl * p.a_plane + (size_t)(m < p.M ? m : 0) * p.lda + kc * 32 + sslot * 8;
-        uint4 v = *reinterpret_cast<const uint4*>(src);
-        if (m >= p.M) v = make_uint4(0u, 0u, 0u, 0u);
-        ra[pl][h] = v;
-      }
-  };
-  auto stashA = [&](int buf) {
-#pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int r = srow + 64 * h;
-        sA[buf * STAGE_U4 + (pl * GB_BM + r) * 4 + swz_slot(r, sslot)] = ra[pl][h];
-      }
-  };
-  uint4 rb[NS][4];
-  auto fetchB = [&](int kc, uint4 (&dst)[NS][4]) {
-#pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        dst[pl][b] = p.wp[((size_t)(pl * p.KC + kc) * NT + (n0 / 16 + wn * 4 + b)) * 64 + lane];
-  };
-
-  fetchA(0);
-  fetchB(0, rb);
-  stashA(0);
-  __syncthreads();
-  for (int kc = 0; kc < p.KC; ++kc) {
-    const int buf = kc & 1;
-    uint4 rbn[NS][4];
-    const bool more = kc + 1 < p.KC;
-    if (more) { fetchA(kc + 1); fetchB(kc + 1, rbn); }      // in flight during this chunk's MFMAs
-    uint4 fa[NS][4];
-#pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int r = wm * 64 + a * 16 + i;
-        fa[pl][a] = sA[buf * STAGE_U4 + (pl * GB_BM + r) * 4 + swz_slot(r, kg)];
-      }
-#pragma unroll
-    for (int q = 0; q < SplitPairs<NS>::N; ++q) {
-      const int pa = SplitPairs<NS>::A[q], pb = SplitPairs<NS>::B[q];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma_bf16(fa[pa][a], rb[pb][b], acc[a][b]);
-    }
-    if (more) {
-      stashA(buf ^ 1);                                      // the other buffer: read last in chunk kc - 1
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) rb[pl][b] = rbn[pl][b];
-    }
-    __syncthreads();
+  for (int h = 0; h < 2; ++h) {
+    const int r = srow + 64 * h, m = m0 + r;
+    a_src[h] = p.A + (size_t)(m < p.M ? m : 0) * p.lda + swz_slot(r, sslot) * 8;
   }
+  const uint4* b_src = p.wp + (size_t)(n0 / 16 + wn * 2) * 64 + lane;
+  const size_t b_plane = (size_t)p.KC * NT * 64, b_chunk = (size_t)NT * 64;
+  int a_frag[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = wm * 64 + a * 16 + i;
+    a_frag[a] = r * 4 + swz_slot(r, kg);
+  }
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  uint4 rb0[NS][2], rb1[NS][2];
+#define GB_DMA_A(kc_, buf_)                                                                          \
+  _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int h = 0; h < 2; ++h)    \
+    __builtin_amdgcn_global_load_lds((gptr_t)(a_src[h] + (size_t)pl * p.a_plane + (kc_) * 32),       \
+                                     (lptr_t)(sA + (buf_) * STAGE_U4 + (pl * GB_BM + 64 * h + 16 * wave) * 4), 16, 0, 0);
+#define GB_FETCH_B(kc_, dst)                                                                         \
+  _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int b = 0; b < 2; ++b)    \
+    dst[pl][b] = b_src[(size_t)pl * b_plane + (size_t)(kc_) * b_chunk + b * 64];
+  // one k-chunk: W fragments `cur` were fetched a chunk ago; the next chunk's A tile (DMA into the other LDS
+  // buffer, last read before the previous barrier) and W fragments (`nxt`) are in flight during this chunk's
+  // MFMAs.  Two alternating fragment sets: no register copies.  Unconditional (the last chunk re-fetches
+  // itself into the idle buffer): no control flow around the register arrays.
+#define GB_STEP(kc_, buf, cur, nxt)   /* buf: literal 0 / 1 = (kc_) & 1 */                           \
+  {                                                                                                  \
+    const int kn = min((kc_) + 1, p.KC - 1);                                                         \
+    /* fragment reads first: the compiler orders every LDS read behind a pending LDS-DMA (vmcnt(0)), \
+       so the DMA of the next tile is issued after them and then flies during the MFMAs */           \
+    uint4 fa[NS][4];                                                                                 \
+    _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int a = 0; a < 4; ++a)  \
+      fa[pl][a] = sA[buf * STAGE_U4 + pl * GB_BM * 4 + a_frag[a]];                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    GB_DMA_A(kn, 1 - buf) GB_FETCH_B(kn, nxt)                                                        \
+    __builtin_amdgcn_sched_barrier(0);   /* the loads are issued HERE, ahead of the MFMAs */          \
+    _Pragma("unroll") for (int q = 0; q < NPAIR; ++q) {                                              \
+      const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15; \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)    \
+        acc[a][b] = mfma_bf16(fa[pa][a], cur[pb][b], acc[a][b]);                                     \
+    }                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);   /* ... and the MFMAs stay on this side of the barrier */     \
+    __syncthreads();   /* (drains the DMA and the W loads: both are needed right after) */           \
+  }
+  constexpr int NPAIR = NS == 1 ? 1 : 6;       // pairs (pa, pb) = (1,1) (2,0) (0,2) (1,0) (0,1) (0,0): small terms first
+
+  GB_DMA_A(0, 0)
+  GB_FETCH_B(0, rb0)
+  __syncthreads();
+  for (int kc = 0; kc < p.KC; kc += 2) {
+    GB_STEP(kc, 0, rb0, rb1)
+    if (kc + 1 < p.KC) GB_STEP(kc + 1, 1, rb1, rb0)
+  }
+#undef GB_STEP
+#undef GB_FETCH_B
+#undef GB_DMA_A
 
   // epilogue: two passes of 32 rows per wave through LDS, float4 row-contiguous stores (+ bias)
-  float* const sC = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  const int col4 = (lane & 15) * 4;
+  float* const sC = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+  const int col4 = (lane & 7) * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int ncol = n0 + wn * 64 + col4;
+  const int ncol = n0 + wn * 32 + col4;
   if (p.bias) { bv.x = p.bias[ncol]; bv.y = p.bias[ncol + 1]; bv.z = p.bias[ncol + 2]; bv.w = p.bias[ncol + 3]; }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
     for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sC[(a2 * 16 + 4 * kg + r) * 68 + b * 16 + i] = acc[2 * h + a2][b][r];
+        for (int r = 0; r < 4; ++r) sC[(a2 * 16 + 4 * kg + r) * 36 + b * 16 + i] = acc[2 * h + a2][b][r];
     // a wave only reads what it wrote itself: no workgroup barrier needed, LDS ops of a wave are ordered
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rl = (lane >> 4) + 4 * it;
+    for (int it = 0; it < 4; ++it) {
+      const int rl = (lane >> 3) + 8 * it;
       const int m = m0 + wm * 64 + h * 32 + rl;
-      const float4 v = *reinterpret_cast<const float4*>(&sC[rl * 68 + col4]);
+      const float4 v = *reinterpret_cast<const float4*>(&sC[rl * 36 + col4]);
       if (m < p.M)
         *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + ncol) = make_float4(v.x + bv.x, v.y + bv.y, v.z + bv.z, v.w + bv.w);
     }

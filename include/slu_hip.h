@@ -120,7 +120,7 @@ int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t 
  *   slu_split_bf16     fp32 (rows x K, row stride ldx) -> planes (entry into the format)
  *   slu_gemm_bf16_pack W (N x K) fp32 -> packed bf16 planes in MFMA B-fragment order (once per weight)
  *   slu_gemm_bf16      C (M x N fp32, row stride ldc) = A W^T + bias: the input projection x W_ih^T + b_ih of
- *                      nn.GRU (models.py:232/:262) for frozen layers; N must be a multiple of 128          */
+ *                      nn.GRU (models.py:232/:262) for frozen layers; N must be a multiple of 64           */
 int slu_split_bf16(const float* x, int64_t ldx, void* planes, int64_t plane_stride, int64_t rows, int64_t K,
                    int nsplit, void* stream);
 size_t slu_gemm_bf16_pack_bytes(int64_t N, int64_t K, int nsplit);
