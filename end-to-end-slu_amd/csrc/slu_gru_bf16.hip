@@ -1,0 +1,195 @@
+// Split-precision persistent GRU recurrence (forward only, no saved gates) for FROZEN layers:
+// torch.nn.GRU semantics (models.py:232/:262: h0 = 0, gates [r; z; n], optional reverse direction), the
+// hidden x hidden contraction on v_mfma_f32_16x16x32_bf16 with W_hh and h_{t-1} each split into NS bf16
+// terms (slu_bf16.h): NS = 3 keeps six products (fp32-class result at 6/16 of the fp32-MFMA cycles),
+// NS = 1 is plain bf16 (BASELINE configs[4]).
+//
+// Geometry = gru_seq_fwd_kernel's: grid (16-sequence tile) x (direction), H/16 waves, wave w owns hidden
+// units [16w, 16w+16) of all three gates, so each lane ends up with r, z, n of the same (sequence, unit) and
+// the gate math is fused in registers.
+//   * the wave's W_hh slice — 3 gates x H/32 k-chunks x NS planes of 8 bf16 per lane — is split once at
+//     kernel start and stays RESIDENT in VGPRs (144 registers for H = 128, NS = 3) for all T steps;
+//   * h_{t-1} lives in LDS as NS bf16 planes (double buffered, 16-byte slots XOR-swizzled by the row: the
+//     ds_read_b128 fragments and the 2-byte stores are conflict-free), in fp32 in the owning lane for the blend;
+//   * per step and wave 3 x H/32 x (6 | 1) MFMAs of 16 cycles on six accumulator chains:
+//     72 x 16 = 1152 cycles per wave, 2304 per SIMD (two waves) for SIXTEEN sequences, against 1536 cycles for
+//     FOUR sequences on the fp32 4x4x1 kernel: 2.7x the sequences per CU-cycle.
+#include "slu_bf16.h"
+
+namespace slu {
+
+__device__ __forceinline__ float bf_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float bf_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+struct GruBfParams {
+  const float* gx;        // (T, B, D*3H)
+  const float* w_hh[2];   // (3H, H) fp32
+  const float* b_hh[2];   // (3H)
+  float* out;             // (T, B, D*H)
+  int T, B, D;
+};
+
+template <int H, int NS>
+__global__ void __launch_bounds__(H * 4)
+gru_bf_fwd_kernel(const GruBfParams p) {
+  constexpr int NW = H / 16;          // waves
+  constexpr int KC = H / 32;          // 32-wide k-chunks
+  constexpr int ROWB = H * 2;         // bytes per LDS row (one sequence, one plane)
+  constexpr int SLOTS = H / 8;        // 16-byte slots per row
+  constexpr int NPAIR = NS == 1 ? 1 : 6;
+  __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][NS][16 * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kg = lane >> 4;
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const int j = w * 16 + i;           // hidden unit of this lane's outputs
+  const int T = p.T, B = p.B, D = p.D;
+
+  // resident W_hh fragments: wb[g][c][pl] = 8 bf16 of W_hh[g*H + j][c*32 + kg*8 .. +7], plane pl
+  uint4 wb[3][KC][NS];
+  {
+    const float* __restrict__ W = p.w_hh[dir];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float* src = W + (size_t)(g * H + j) * H + c * 32 + kg * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned short s[8][NS];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split_bf16<NS>(v[e], s[e]);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+          uint4 o;
+          o.x = s[0][pl] | ((unsigned)s[1][pl] << 16); o.y = s[2][pl] | ((unsigned)s[3][pl] << 16);
+          o.z = s[4][pl] | ((unsigned)s[5][pl] << 16); o.w = s[6][pl] | ((unsigned)s[7][pl] << 16);
+          wb[g][c][pl] = o;
+        }
+      }
+  }
+  const float bhr = p.b_hh[dir][j], bhz = p.b_hh[dir][H + j], bhn = p.b_hh[dir][2 * H + j];
+
+  for (int x = tid; x < 2 * NS * 16 * ROWB / 4; x += H * 4) reinterpret_cast<unsigned*>(&hbuf[0][0][0])[x] = 0u;   // h0 = 0
+  float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+  // rows b0 + 4 kg + r of this lane: 32-bit offsets inside one time step (B * D * 3H < 2^31 is checked by the
+  // launcher); rows past B read row 0 and are never stored (oob row offset -1)
+  int g_off[4], o_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * kg + r;
+    g_off[r] = (b < B ? b : 0) * D * 3 * H;
+    o_off[r] = b < B ? b * D * H : -1;
+  }
+  const size_t gx_ts = (size_t)B * D * 3 * H, out_ts = (size_t)B * D * H;
+  const float* __restrict__ gxd = p.gx + (size_t)dir * 3 * H + j;
+  float* __restrict__ outd = p.out + (size_t)dir * H + j;
+  // A-fragment read: row i (sequence), slot (c*4 + kg) ^ i;  h store: row 4*kg + r, slot (j/8) ^ row, element j%8
+  int a_off[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) a_off[c] = i * ROWB + (((c * 4 + kg) ^ i) & (SLOTS - 1)) * 16;
+  int h_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * kg + r;
+    h_off[r] = row * ROWB + ((((j >> 3) ^ row) & (SLOTS - 1)) * 16) + (j & 7) * 2;
+  }
+
+  float gr[4], gz[4], gn[4];
+  {
+    const int t0 = dir ? T - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* g = gxd + (size_t)t0 * gx_ts + g_off[r];
+      gr[r] = g[0]; gz[r] = g[H]; gn[r] = g[2 * H];
+    }
+  }
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int cur = s & 1;
+    float ngr[4], ngz[4], ngn[4];
+    {
+      const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* g = gxd + (size_t)tn * gx_ts + g_off[r];
+        ngr[r] = g[0]; ngz[r] = g[H]; ngn[r] = g[2 * H];
+      }
+    }
+    // one accumulator chain per gate: three independent chains per wave, two waves per SIMD
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      uint4 fa[NS];                     // (W_hh takes 144 of the 256 registers: one fragment set at a time)
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
+#pragma unroll
+      for (int q = 0; q < NPAIR; ++q) {
+        const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = mfma_bf16(fa[pa], wb[g][c][pb], acc[g]);
+      }
+    }
+
+    float hn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ar = acc[0][r], az = acc[1][r], an = acc[2][r];
+      const float rr = bf_sigmoid(gr[r] + (ar + bhr));
+      const float zz = bf_sigmoid(gz[r] + (az + bhz));
+      const float nn = bf_tanh(gn[r] + rr * (an + bhn));
+      hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+    }
+    unsigned char* __restrict__ hnext = &hbuf[cur ^ 1][0][0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned short sp[NS];
+      split_bf16<NS>(hn[r], sp);
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<unsigned short*>(hnext + pl * (16 * ROWB) + h_off[r]) = sp[pl];
+      if (o_off[r] >= 0) outd[(size_t)t * out_ts + o_off[r]] = hn[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { hprev[r] = hn[r]; gr[r] = ngr[r]; gz[r] = ngz[r]; gn[r] = ngn[r]; }
+    __syncthreads();
+  }
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
+                                    const float* b_hh_fwd, const float* b_hh_rev, float* out, int64_t T, int64_t B,
+                                    int64_t H, int64_t D, int nsplit, void* stream) {
+  SLU_REQUIRE(gx && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd_bf16: null pointer");
+  SLU_REQUIRE(D == 1 || (D == 2 && w_hh_rev && b_hh_rev), "slu_gru_seq_fwd_bf16: D must be 1 or 2 (with reverse weights)");
+  SLU_REQUIRE(T > 0 && B > 0, "slu_gru_seq_fwd_bf16: non-positive T or B");
+  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_gru_seq_fwd_bf16: nsplit must be 1 or 3");
+  if (H != 64 && H != 128)
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_bf16: hidden size %lld not instantiated (64, 128)", (long long)H);
+  SLU_REQUIRE(cdiv(B, 16) <= 65535 && B * D * 3 * H < (1LL << 31), "slu_gru_seq_fwd_bf16: B too large");
+  GruBfParams p;
+  p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
+  p.out = out; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
+  hipStream_t st = (hipStream_t)stream;
+  if (H == 128) {
+    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 3>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 1>), grid, dim3(512), 0, st, p);
+  } else {
+    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 3>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 1>), grid, dim3(256), 0, st, p);
+  }
+  SLU_CHECK_LAUNCH("gru_bf_fwd_kernel");
+  return SLU_OK;
+}

@@ -228,6 +228,15 @@ def gemm_bf16(planes, packed, bias, N, K, out=None):
     return out
 
 
+def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit):
+    """Frozen-layer recurrence on the split-precision MFMA kernels (no reserve) -> out (T, B, D*H) fp32."""
+    L = _lib.load()
+    out = torch.empty(T, B, D * H, dtype=torch.float32, device=gx.device)
+    _lib.check(L.slu_gru_seq_fwd_bf16(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r),
+                                      out.data_ptr(), T, B, H, D, nsplit, _stream()), "slu_gru_seq_fwd_bf16")
+    return out
+
+
 def colsum(x2d, out=None, accumulate=False):
     L = _lib.load()
     M, N = x2d.shape

@@ -129,6 +129,12 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
                   const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int nsplit,
                   void* stream);
 
+/* Persistent GRU recurrence of a frozen layer on the split-precision MFMA path (forward only: no saved gates);
+ * arguments as slu_gru_seq_fwd, 16-sequence tiles, W_hh (3 x nsplit bf16 planes) resident in VGPRs. H = 64 / 128. */
+int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
+                         const float* b_hh_rev, float* out, int64_t T, int64_t B, int64_t H, int64_t D,
+                         int nsplit, void* stream);
+
 /* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
  *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)
  *   w_hh[d] (3H, H), b_hh[d] (3H): weight_hh_l0 / bias_hh_l0 (d = 0) and *_reverse (d = 1)

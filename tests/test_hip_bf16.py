@@ -47,3 +47,22 @@ def test_gemm_bf16_vs_float64(ops, M, N, K, nsplit):
     err_f32 = (exact - ref).abs().max().item() / scale
     print("gemm_bf16 nsplit=%d M=%d N=%d K=%d: rel err %.2e (torch fp32 GEMM: %.2e)" % (nsplit, M, N, K, err, err_f32))
     assert err <= (4e-7 if nsplit == 3 else 2e-2)
+
+
+@pytest.mark.parametrize("T,B,H", [(40, 64, 128), (23, 37, 128), (9, 5, 64), (300, 768, 128)])
+@pytest.mark.parametrize("nsplit", [3, 1])
+def test_gru_bf16_vs_exact_fp32_kernel(ops, T, B, H, nsplit):
+    """slu_gru_seq_fwd_bf16 against the exact-fp32 persistent kernel (itself held to the oracle in
+    test_hip_ops / test_hip_bench_path): nsplit = 3 must agree to fp32 round-off accumulated over T steps."""
+    torch.manual_seed(T + B)
+    D = 2
+    gx = torch.randn(T, B, D * 3 * H).cuda()
+    k = 1.0 / H ** 0.5
+    wf, wr = ((torch.rand(3 * H, H) * 2 - 1) * k).cuda(), ((torch.rand(3 * H, H) * 2 - 1) * k).cuda()
+    bf, br = ((torch.rand(3 * H) * 2 - 1) * k).cuda(), ((torch.rand(3 * H) * 2 - 1) * k).cuda()
+    ref, _ = ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, False)
+    out = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit)
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item()
+    print("gru bf16 nsplit=%d T=%d B=%d H=%d: max-abs deviation from the fp32 kernel %.2e" % (nsplit, T, B, H, err))
+    assert err <= (5e-6 if nsplit == 3 else 5e-2)

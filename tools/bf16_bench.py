@@ -26,3 +26,17 @@ if "gemm" in what:
             byt = pl.numel() * 2 + out.numel() * 4
             line += " | nsplit=%d %.1f us (%.1f TF-equivalent, %.2f TB/s)" % (ns, 1e3 * ms, 2.0 * M * N * K / ms / 1e9, byt / ms / 1e9)
         print(line, flush=True)
+
+if "gru" in what:
+    H, D = 128, 2
+    for T in (300, 150, 75, 38):
+        gx = torch.randn(T, B, D * 3 * H, device="cuda")
+        wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+        bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+        fl = 2.0 * B * H * 3 * H * D * T
+        ms32 = _timed_graph(lambda: ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, False), st)
+        line = "gru T=%d B=%d: fp32 %.1f us (%.2f us/step, %.1f TF)" % (T, B, 1e3 * ms32, 1e3 * ms32 / T, fl / ms32 / 1e9)
+        for ns in (3, 1):
+            ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, ns), st)
+            line += " | nsplit=%d %.1f us (%.2f us/step, %.1f TF-equivalent)" % (ns, 1e3 * ms, 1e3 * ms / T, fl / ms / 1e9)
+        print(line, flush=True)
