@@ -278,10 +278,17 @@ def _timed_graph(fn, stream, reps=20):
     return ms
 
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable per the same guide)
+
+
 def kernel_table(model, trainer, batch, samples, width, asr=False):
     """Top kernels of the step by GPU time with the algorithmic flops and the measured average duration of
     every distinct launch shape (frozen stages at `width` x batch sequences on the look-ahead stream,
-    trainable stages at `batch` sequences on the training stream)."""
+    trainable stages at `batch` sequences on the training stream).  Each stage is launched through the same
+    wrappers, with the same arithmetic (exact fp32 MFMA, or the split-precision bf16 MFMA kernels for frozen
+    GRU layers), as in the timed steps."""
+    import models
     from slu_hip import ops
     dev = next(model.parameters()).device
     pm = model.pretrained_model if hasattr(model, "pretrained_model") else model
@@ -290,7 +297,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
     side = slots[0].stream if slots else torch.cuda.Stream(dev)
     main = getattr(trainer, "_train_stream", None) if width > 1 else getattr(trainer, "_full_stream", None)
     main = main or torch.cuda.Stream(dev)
-    rows = {"wconv_fwd_kernel": [], "gemm_f32_kernel<true,true,2>": [], "gru_seq_fwd4_kernel<128>": []}
+    rows = {}
     stages = pm._stages() + list(getattr(model, "_intent_stages", []))
     L, C = samples, 1
     for si, st in enumerate(stages):
@@ -310,49 +317,90 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             pool = st.pool if st.pool in (1, 2) else 1
             tm = si == len(pm._cnn_stages) - 1
             ms = _timed_graph(lambda: ops.wconv_fwd(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, False), stream)
-            rows["wconv_fwd_kernel"].append({"shape": "B=%d L=%d Cin=%d Cout=%d k=%d stride=%d (%s)" % (B, L, C, c_out, k, stride, where),
-                                             "flops": 2.0 * B * l_conv * c_out * k * C, "ms": ms})
+            rows.setdefault("wconv_fwd_kernel", []).append(
+                {"shape": "B=%d L=%d Cin=%d Cout=%d k=%d stride=%d (%s)" % (B, L, C, c_out, k, stride, where),
+                 "flops": 2.0 * B * l_conv * c_out * k * C, "ms": ms, "mfma_mult": 1.0, "peak": PEAK_FP32_MFMA_TFLOPS,
+                 "bytes": 4.0 * (B * L * C + B * (-(-l_conv // pool)) * c_out)})
             L, C = -(-l_conv // pool), c_out
             del x
         else:                                                           # GRU layer
             gru = st.gru
             H, D, I = gru.hidden_size, 2 if gru.bidirectional else 1, gru.input_size
             T = L
+            is_frozen = not any(q.requires_grad for q in gru.parameters())
+            ns = models.contraction_nsplit(is_frozen)
+            if not ops.split_path_supported(H, D):
+                ns = 0
             w_ih, b_ih = gru._stacked_ih()
+            w_ih, b_ih = w_ih.detach(), b_ih.detach()
             x = torch.randn(T * B, I, device=dev)
-            ms = _timed_graph(lambda: ops.gemm(x, w_ih.detach().t(), b_ih.detach()), stream)
-            rows["gemm_f32_kernel<true,true,2>"].append({"shape": "M=%d N=%d K=%d input projection (%s)" % (T * B, D * 3 * H, I, where),
-                                                         "flops": 2.0 * T * B * D * 3 * H * I, "ms": ms,
-                                                         "bytes": 4.0 * (T * B * I + D * 3 * H * I + T * B * D * 3 * H)})
-            gx = torch.randn(T, B, D * 3 * H, device=dev)
+            N = D * 3 * H
             wr = gru.weight_hh_l0_reverse.detach() if D == 2 else None
             br = gru.bias_hh_l0_reverse.detach() if D == 2 else None
-            ms = _timed_graph(lambda: ops.gru_seq_fwd(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
-                                                      T, B, H, D, not frozen), stream)
-            rows["gru_seq_fwd4_kernel<128>"].append({"shape": "T=%d B=%d H=%d D=%d (%s)" % (T, B, H, D, where),
-                                                     "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
-                                                     "bytes": 4.0 * (T * B * D * 3 * H + T * B * D * H + D * 3 * H * H)})
+            gx = torch.randn(T, B, N, device=dev)
+            if ns:
+                planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
+                mult = 6.0 if ns == 3 else 1.0
+                ms = _timed_graph(lambda: ops.gemm_bf16(planes, packed, b_ih, N, I), stream)
+                rows.setdefault("gemm_bf_kernel<%d>" % ns, []).append(
+                    {"shape": "M=%d N=%d K=%d input projection, %d bf16 plane(s) (%s)" % (T * B, N, I, ns, where),
+                     "flops": 2.0 * T * B * N * I, "ms": ms, "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
+                     "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + 2.0 * ns * N * ops.round_up(I, 32) + 4.0 * T * B * N})
+                ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                               T, B, H, D, ns, not is_frozen), stream)
+                rows.setdefault("gru_bf_fwd_kernel<%d,%d>" % (H, ns), []).append(
+                    {"shape": "T=%d B=%d H=%d D=%d (%s)" % (T, B, H, D, where), "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
+                     "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS, "bytes": 4.0 * (T * B * N + T * B * D * H + D * 3 * H * H)})
+            else:
+                ms = _timed_graph(lambda: ops.gemm(x, w_ih.t(), b_ih), stream)
+                rows.setdefault("gemm_f32_kernel<true,true,2>", []).append(
+                    {"shape": "M=%d N=%d K=%d input projection (%s)" % (T * B, N, I, where), "flops": 2.0 * T * B * N * I, "ms": ms,
+                     "mfma_mult": 1.0, "peak": PEAK_FP32_MFMA_TFLOPS, "bytes": 4.0 * (T * B * I + N * I + T * B * N)})
+                ms = _timed_graph(lambda: ops.gru_seq_fwd(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                          T, B, H, D, not is_frozen), stream)
+                rows.setdefault("gru_seq_fwd4_kernel<%d>" % H, []).append(
+                    {"shape": "T=%d B=%d H=%d D=%d (%s)" % (T, B, H, D, where), "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
+                     "mfma_mult": 1.0, "peak": PEAK_FP32_MFMA_TFLOPS, "bytes": 4.0 * (T * B * N + T * B * D * H + D * 3 * H * H)})
             L, C = -(-T // st.factor), D * H
             del x, gx
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     out = []
     for name, shapes in rows.items():
-        if not shapes:
-            continue
         # per optimisation step: a frozen-stage launch serves `width` steps
         t_step = sum(s["ms"] / (width if "look-ahead" in s["shape"] else 1) for s in shapes)
         flops = sum(s["flops"] for s in shapes)
+        mfma = sum(s["flops"] * s["mfma_mult"] for s in shapes)
+        byts = sum(s["bytes"] for s in shapes)
         ms = sum(s["ms"] for s in shapes)
-        tf = flops / (ms * 1e-3) / 1e12
-        out.append({"kernel": name, "launches_per_cycle": len(shapes), "flops": flops, "avg_us": round(1e3 * ms / len(shapes), 2),
-                    "tflops": round(tf, 2), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+        peak = shapes[0]["peak"]
+        tf_mfma = mfma / (ms * 1e-3) / 1e12
+        tbs = byts / (ms * 1e-3) / 1e12
+        f_mfma, f_hbm = tf_mfma / peak, tbs / PEAK_HBM_TBS
+        out.append({"kernel": name, "launches_per_cycle": len(shapes), "algorithmic_gflop": round(flops / 1e9, 2),
+                    "avg_us": round(1e3 * ms / len(shapes), 2),
+                    "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),       # fp32-equivalent work rate
+                    "mfma_tflops": round(tf_mfma, 2), "mfma_peak": peak, "mfma_frac": round(f_mfma, 4),
+                    "hbm_tbs": round(tbs, 3), "hbm_frac": round(f_hbm, 4),
+                    "bound": "mfma" if f_mfma >= f_hbm else "hbm", "frac": round(max(f_mfma, f_hbm), 4),
                     "gpu_ms_per_step": round(t_step, 4),
                     "shapes": [{"shape": s["shape"], "gflop": round(s["flops"] / 1e9, 3), "us": round(1e3 * s["ms"], 2),
-                                "tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
-                                "algorithmic_MB": round(s["bytes"] / 1e6, 2) if "bytes" in s else None} for s in shapes]})
+                                "algorithmic_tflops": round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2),
+                                "algorithmic_MB": round(s["bytes"] / 1e6, 2),
+                                "hbm_tbs": round(s["bytes"] / (s["ms"] * 1e-3) / 1e12, 3)} for s in shapes]})
     out.sort(key=lambda r: -r["gpu_ms_per_step"])
     return out
+
+
+def dtype_label():
+    """The arithmetic the path computes in (not a precision claim)."""
+    import models
+    if models.contraction_nsplit(False) == 1:
+        return "bf16 (forward contractions on bf16 MFMA, fp32 accumulation / gate math / gradients / master weights)"
+    if models.contraction_nsplit(True) == 3:
+        return ("f32 (trainable stages and every convolution: exact fp32 MFMA; GRU contractions of FROZEN layers: fp32 "
+                "operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation - fp32-class, parity <= 1e-4)")
+    return "f32"
 
 
 def pmc_traffic(kernel):
@@ -464,6 +512,8 @@ def main():
     ap.add_argument("--workload", default="no_unfreezing", choices=sorted(CFG))
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=SECONDS)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="bf16: BASELINE configs[4] arithmetic (SLU_DTYPE=bf16) - reported as a separate line, never the headline")
     ap.add_argument("--hidden", type=int, default=0,
                     help="GRU hidden size of every layer (default: the cfg's 128); any other value is a labelled "
                          "synthetic variant (SURVEY 8.0-A: H = 512 extra point), never the headline")
@@ -475,6 +525,8 @@ def main():
                     help="with --gpus N > visible GPUs: run the N ranks on the visible GPUs over gloo (functional check)")
     args = ap.parse_args()
 
+    if args.dtype == "bf16":
+        os.environ["SLU_DTYPE"] = "bf16"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
         return
@@ -559,7 +611,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype_label(), "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.workload] + (
                            " -- SYNTHETIC VARIANT: GRU hidden size %d in every layer (reference cfgs use 128)" % args.hidden
                            if args.hidden else ""),
@@ -581,18 +633,23 @@ def main():
             note("kernel table")
             table = kernel_table(model, trainer, args.batch, samples, width, asr)
             top = table[0]
-            algo_bytes = sum(s["algorithmic_MB"] or 0 for s in top["shapes"]) * 1e6 / max(1, len(top["shapes"]))
+            is_mfma = top["bound"] == "mfma"
             out["roofline"] = {
-                "bound": "mfma", "achieved": top["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": top["frac"], "traffic": pmc_traffic(top["kernel"]),
-                "algorithmic_bytes_per_launch": round(algo_bytes) if algo_bytes else None,
+                "bound": top["bound"],
+                "achieved": top["mfma_tflops"] if is_mfma else top["hbm_tbs"] * 1e3,
+                "peak": top["mfma_peak"] if is_mfma else PEAK_HBM_TBS * 1e3,
+                "unit": "TFLOP/s" if is_mfma else "GB/s", "frac": top["frac"],
+                "traffic": pmc_traffic(top["kernel"]),
+                "algorithmic_bytes_per_launch": round(sum(s["algorithmic_MB"] for s in top["shapes"]) * 1e6 / len(top["shapes"])),
                 "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
-                "kernels": table[:3],
-                "note": "per kernel: sum of the algorithmic fp32 flops of its distinct launch shapes in one "
-                        "look-ahead cycle (%d steps) / sum of their average durations; each shape is launched "
-                        "20x back to back (one hipGraph) on the CU-masked stream it runs on during the timed "
-                        "steps (frozen stages: %d sequences on CUs [64,256); trainable stages: %d sequences on "
-                        "CUs [0,64)) between two HIP events on that stream.  Peak = whole-chip fp32 MFMA."
+                "kernels": table[:4],
+                "note": "per kernel: sums over its distinct launch shapes in one look-ahead cycle (%d steps) of the "
+                        "algorithmic fp32 flops (mfma_tflops counts the bf16 MFMA products actually issued: 6 per fp32 "
+                        "product on the split-precision kernels) and of the algorithmic HBM bytes / sum of the average "
+                        "durations; each shape is launched 20x back to back (one hipGraph) on the CU-masked stream it "
+                        "runs on during the timed steps (frozen stages: %d sequences on CUs [64,256); trainable stages: "
+                        "%d sequences on CUs [0,64)) between two HIP events on that stream.  Peaks are whole-chip: fp32 "
+                        "MFMA 157.3, dense bf16 MFMA 2500 TFLOP/s, HBM 8 TB/s; `frac` is against the kernel's binding one."
                         % (width, args.batch * width, args.batch)}
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.

@@ -30,6 +30,7 @@ struct GruBfParams {
   const float* w_hh[2];   // (3H, H) fp32
   const float* b_hh[2];   // (3H)
   float* out;             // (T, B, D*H)
+  float* reserve;         // null, or the saved gates in gru_seq_bwd_kernel's layout [D][T][NBT][NW][5][64][4]
   int T, B, D;
 };
 
@@ -140,14 +141,23 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       }
     }
 
-    float hn[4];
+    float hn[4], rr[4], zz[4], nn[4], qq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float ar = acc[0][r], az = acc[1][r], an = acc[2][r];
-      const float rr = bf_sigmoid(gr[r] + (ar + bhr));
-      const float zz = bf_sigmoid(gz[r] + (az + bhz));
-      const float nn = bf_tanh(gn[r] + rr * (an + bhn));
-      hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+      rr[r] = bf_sigmoid(gr[r] + (acc[0][r] + bhr));
+      zz[r] = bf_sigmoid(gz[r] + (acc[1][r] + bhz));
+      qq[r] = acc[2][r] + bhn;
+      nn[r] = bf_tanh(gn[r] + rr[r] * qq[r]);
+      hn[r] = (1.0f - zz[r]) * nn[r] + zz[r] * hprev[r];
+    }
+    if (p.reserve) {      // trainable layer (bf16 forward, fp32 BPTT): the gates the exact BPTT kernels read
+      float4* __restrict__ rs = reinterpret_cast<float4*>(
+          p.reserve + ((((size_t)dir * T + t) * gridDim.x + blockIdx.x) * NW + w) * (5 * 256)) + lane;
+      rs[0 * 64] = make_float4(rr[0], rr[1], rr[2], rr[3]);
+      rs[1 * 64] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+      rs[2 * 64] = make_float4(nn[0], nn[1], nn[2], nn[3]);
+      rs[3 * 64] = make_float4(qq[0], qq[1], qq[2], qq[3]);
+      rs[4 * 64] = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
     }
     unsigned char* __restrict__ hnext = &hbuf[cur ^ 1][0][0];
 #pragma unroll
@@ -169,8 +179,8 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 using namespace slu;
 
 extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
-                                    const float* b_hh_fwd, const float* b_hh_rev, float* out, int64_t T, int64_t B,
-                                    int64_t H, int64_t D, int nsplit, void* stream) {
+                                    const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
+                                    int64_t T, int64_t B, int64_t H, int64_t D, int nsplit, void* stream) {
   SLU_REQUIRE(gx && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd_bf16: null pointer");
   SLU_REQUIRE(D == 1 || (D == 2 && w_hh_rev && b_hh_rev), "slu_gru_seq_fwd_bf16: D must be 1 or 2 (with reverse weights)");
   SLU_REQUIRE(T > 0 && B > 0, "slu_gru_seq_fwd_bf16: non-positive T or B");
@@ -180,7 +190,7 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
   SLU_REQUIRE(cdiv(B, 16) <= 65535 && B * D * 3 * H < (1LL << 31), "slu_gru_seq_fwd_bf16: B too large");
   GruBfParams p;
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
-  p.out = out; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
   dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   hipStream_t st = (hipStream_t)stream;
   if (H == 128) {

@@ -93,6 +93,20 @@ def _site(module, idx):
     return _SITE_BASE[module] + idx
 
 
+def contraction_nsplit(frozen):
+    """Arithmetic of the forward contractions of a GRU layer (input projection and recurrence):
+      0  exact fp32 MFMA — trainable layers (default);
+      3  fp32 values as three bf16 terms, six bf16 MFMA products (fp32-class, csrc/slu_bf16.h) — FROZEN layers
+         (default; SLU_FROZEN_MATH=fp32 switches it off);
+      1  plain bf16 operands, fp32 accumulation and gate math — every layer when SLU_DTYPE=bf16
+         (BASELINE configs[4]: bf16 weights / activations; gradients stay fp32)."""
+    if os.environ.get("SLU_DTYPE", "f32") == "bf16":
+        return 1
+    if frozen and os.environ.get("SLU_FROZEN_MATH", "bf16x3") != "fp32":
+        return 3
+    return 0
+
+
 def _require_device(t):
     if not t.is_cuda:
         raise _lib.SluHipError("the HIP kernels are the only compute path of this package: move the "
@@ -256,6 +270,7 @@ class GRU(torch.nn.Module):
 
     def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1):
         w_ih, b_ih = self._stacked_ih()
+        nsplit = contraction_nsplit(not any(q.requires_grad for q in self.parameters()))
         if self.bidirectional:
             ih = (self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse)
             rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse)
@@ -263,7 +278,7 @@ class GRU(torch.nn.Module):
             ih = (self.weight_ih_l0, None, self.bias_ih_l0, None)
             rev = (None, None)
         return _ops.GRULayerFn.apply(xt, w_ih.detach(), b_ih.detach(), *ih, self.weight_hh_l0, self.bias_hh_l0,
-                                     rev[0], rev[1], p, mask, seed, offset, method, factor)
+                                     rev[0], rev[1], p, mask, seed, offset, method, factor, nsplit)
 
     def forward(self, x):
         _require_device(x)

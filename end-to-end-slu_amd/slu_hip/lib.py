@@ -42,7 +42,7 @@ SIGNATURES = {
     "slu_gemm_bf16_pack_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "slu_gemm_bf16_pack": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gemm_bf16": (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
-    "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
+    "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64, c_i64]),

@@ -228,13 +228,40 @@ def gemm_bf16(planes, packed, bias, N, K, out=None):
     return out
 
 
-def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit):
-    """Frozen-layer recurrence on the split-precision MFMA kernels (no reserve) -> out (T, B, D*H) fp32."""
+def split_path_supported(H, D):
+    """Shapes the split-precision kernels are instantiated for (else the exact fp32 kernels run)."""
+    return H in (64, 128) and (D * 3 * H) % 64 == 0
+
+
+_PACKED = {}
+
+
+def packed_weight(w, nsplit, cache):
+    """B-fragment-ordered bf16 planes of an (N, K) weight; cached per (storage, version) for frozen weights
+    (a trainable weight is updated in place by the HIP optimiser, which torch's version counter does not see)."""
+    if not cache:
+        return gemm_bf16_pack(w, nsplit)
+    key = (w.data_ptr(), tuple(w.shape), nsplit)
+    hit = _PACKED.get(key)
+    if hit is None or hit[0] != w._version:
+        if len(_PACKED) > 64:
+            _PACKED.clear()
+        hit = (w._version, gemm_bf16_pack(w, nsplit))
+        _PACKED[key] = hit
+    return hit[1]
+
+
+def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False):
+    """Recurrence on the split-precision MFMA kernels -> (out (T, B, D*H) fp32, reserve or None)."""
     L = _lib.load()
     out = torch.empty(T, B, D * H, dtype=torch.float32, device=gx.device)
+    reserve = None
+    if want_reserve:
+        reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=gx.device)
     _lib.check(L.slu_gru_seq_fwd_bf16(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r),
-                                      out.data_ptr(), T, B, H, D, nsplit, _stream()), "slu_gru_seq_fwd_bf16")
-    return out
+                                      out.data_ptr(), _ptr(reserve), T, B, H, D, nsplit, _stream()),
+               "slu_gru_seq_fwd_bf16")
+    return out, reserve
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -496,14 +523,23 @@ class GRULayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, b_ih, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r,
-                p, mask, seed, offset, method, factor):
+                p, mask, seed, offset, method, factor, nsplit=0):
+        """nsplit: 0 = exact fp32 MFMA; 3 / 1 = the two contractions of the FORWARD pass (x W_ih^T and the
+        recurrence's h W_hh^T) on the split-precision bf16 MFMA kernels (csrc/slu_bf16.h) — 3: fp32-class (used
+        for frozen layers), 1: plain bf16 (BASELINE configs[4]); the backward pass is exact fp32 either way."""
         x = x.contiguous()
         T, B, I = x.shape
         H = w_hh_f.shape[1]
         D = 1 if w_hh_r is None else 2
-        gx = gemm(x.view(T * B, I), w_ih.t(), b_ih)                       # (T*B, D*3H)
         need = any(ctx.needs_input_grad[:11])
-        raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
+        if nsplit and split_path_supported(H, D):
+            planes = split_bf16(x.view(T * B, I), nsplit)
+            packed = packed_weight(w_ih, nsplit, cache=not need)
+            gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
+            raw, reserve = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, need)
+        else:
+            gx = gemm(x.view(T * B, I), w_ih.t(), b_ih)                   # (T*B, D*3H)
+            raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
         offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
         if p == 0.0 and (factor == 1):
             y = raw
@@ -534,7 +570,7 @@ class GRULayerFn(torch.autograd.Function):
         g2 = d_gx.view(T * B, D * 3 * H)
         h2 = d_gh.view(T * B, D * 3 * H)
         r2 = raw.view(T * B, D * H)
-        grads = [None] * 17
+        grads = [None] * 18
         dev = x.device
         # The weight-gradient GEMMs are independent of each other and of the data-gradient GEMM: they
         # run on auxiliary streams (graph branches under capture) while dx proceeds on this one.

@@ -41,17 +41,25 @@ def _max_step_graphs():
     return int(os.environ.get("SLU_MAX_STEP_GRAPHS", "8"))
 
 
+def _param_signature(model):
+    return tuple(True if p.requires_grad else p._version for p in model.parameters())
+
+
 def _lookahead_width(depth, batch_size):
-    """Batches per look-ahead super-batch: explicit, or as many as give every CU the side streams may use
-    two 4-sequence recurrence workgroups (its register-limited occupancy) per direction, i.e. 4 sequences
-    per CU: 768 on the 192 CUs of the default partition (best of a 4..14 sweep on MI355X)."""
+    """Batches per look-ahead super-batch: explicit, or as many as give every CU the side streams may use one
+    recurrence workgroup per direction at the kernels' sequence-tile size.  Split-precision recurrence of the
+    frozen layers (default): one 16-sequence workgroup per CU and direction = 8 sequences per CU, 1536 on the
+    192 CUs of the default partition; exact-fp32 kernels (SLU_FROZEN_MATH=fp32): two 4-sequence workgroups per
+    CU and direction = 4 sequences per CU, 768 (best of a 4..14 sweep on MI355X)."""
     if depth > 0:
         return depth
     from slu_hip import pipeline
+    from models import contraction_nsplit
     cus = 256
     if torch.cuda.is_available():
         cus = pipeline.n_compute_units(torch.cuda.current_device()) - pipeline.cu_split()
-    return max(2, min(32, (4 * cus) // max(1, batch_size)))
+    per_cu = 8 if contraction_nsplit(True) else 4
+    return max(2, min(32, (per_cu * cus) // max(1, batch_size)))
 
 
 class Trainer:
@@ -248,8 +256,9 @@ class Trainer:
             pm, forward = self.model.pretrained_model, self._slu_forward(0)
         else:
             pm, forward = self.model, self._asr_forward
-        # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it)
-        trainable = tuple(p.requires_grad for p in self.model.parameters())
+        # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it) and to
+        # the frozen weights' contents (their packed bf16 planes are baked into the graph)
+        trainable = _param_signature(self.model)
         try:
             with torch.cuda.stream(main):
                 pm.warm_weight_caches()
@@ -330,7 +339,7 @@ class Trainer:
         use_graph = pipeline.graphs_enabled()
         step_graphs = use_graph and self._graphable()
         forward = self._slu_forward(n_prefix)
-        trainable = tuple(p.requires_grad for p in self.model.parameters())
+        trainable = _param_signature(self.model)
         pending = collections.deque()
         it = iter(loader)
         carry = []                                    # a batch read ahead that did not fit its group

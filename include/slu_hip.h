@@ -129,11 +129,13 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
                   const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int nsplit,
                   void* stream);
 
-/* Persistent GRU recurrence of a frozen layer on the split-precision MFMA path (forward only: no saved gates);
- * arguments as slu_gru_seq_fwd, 16-sequence tiles, W_hh (3 x nsplit bf16 planes) resident in VGPRs. H = 64 / 128. */
+/* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
+ * W_hh (3 gates x nsplit bf16 planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
+ * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)
+ * back-propagates through a bf16 forward (BASELINE configs[4]: bf16 forward contractions, fp32 gradients).     */
 int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
-                         const float* b_hh_rev, float* out, int64_t T, int64_t B, int64_t H, int64_t D,
-                         int nsplit, void* stream);
+                         const float* b_hh_rev, float* out, float* reserve, int64_t T, int64_t B, int64_t H,
+                         int64_t D, int nsplit, void* stream);
 
 /* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
  *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)

@@ -1,6 +1,6 @@
 """GPU parity of the EXACT path bench.py times (BASELINE.json configs[3] at full size: no_unfreezing
-architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 12 batches (768 sequences, 4-sequence
-recurrence kernels, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
+architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 24 batches (1536 sequences, split-precision
+bf16x3 MFMA input projections and 16-sequence recurrence kernels for the frozen layers, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
 step, against (1) the plain sequential eager loop, bit for bit, and (2) the CPU oracle (<= 1e-4).
 
 Chain proven here:  oracle == HIP kernels at super-batch size (mask-in)  and  sequential eager ==
@@ -57,15 +57,15 @@ def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps):
 
 
 def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, monkeypatch):
-    """72 steps of B = 64 x 3 s: six 12-batch super-batches, three per look-ahead slot: each slot captures its shape on the
-    second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
+    """144 steps of B = 64 x 3 s: six 24-batch super-batches, three per look-ahead slot: each slot captures its shape
+    on the second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
     Per-step losses and final parameters must be bit-equal to the eager sequential loop."""
     import data
     cfg = _full_cfg(tmp_path)
     torch.manual_seed(1)
     torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
     ds = data.SyntheticSLUDataset(4, 64, 48000, cfg.values_per_slot, seed=1234)
-    n_steps = 72
+    n_steps = 144
     loader = [ds.batches[i % 4] for i in range(n_steps)]
     ref_tr, ref_losses, ref_sd = _run_training(cfg, loader, monkeypatch, "0", "0", n_steps)
     assert ref_tr.graph_stats() == {"step_graphs": 0, "prefix_graphs": 0, "capture_failures": 0}
@@ -78,15 +78,15 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k
 
-    # the bench.py default: automatic look-ahead width (12 batches = 768 sequences) + graphs
+    # the bench.py default: automatic look-ahead width (24 batches = 1536 sequences) + graphs
     tr, losses, sd = _run_training(cfg, loader, monkeypatch, "auto", "1", n_steps)
     import training
-    assert training._lookahead_width(-1, 64) == 12
+    assert training._lookahead_width(-1, 64) == 24
     stats = tr.graph_stats()
     assert stats["step_graphs"] == 1 and stats["capture_failures"] == 0
     assert all(len([g for g in slot.graphs.values() if g is not None]) >= 1 for slot in tr._slots)
     assert stats["prefix_graphs"] == 2
-    # every slot replayed its captured graph at least once (seen >= 3 for the 12-batch key)
+    # every slot replayed its captured graph at least once (seen >= 3 for the 24-batch key)
     assert all(max(slot.seen.values()) >= 3 for slot in tr._slots)
     assert losses == ref_losses
     for k, v in ref_sd.items():
@@ -124,13 +124,15 @@ def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path):
     assert err <= 1e-4
 
 
-@pytest.mark.parametrize("tile", ["4", "16"])
+@pytest.mark.parametrize("tile", ["bf16x3", "4", "16"])
 def test_recurrence_at_super_batch_size_vs_oracle(tile, monkeypatch):
-    """slu_gru_seq_fwd at B = 768, T = 300, I = 60, H = 128, both directions (phone_rnn0 of a super-batch),
-    forced onto the 4-sequence (the bench's) and the 16-sequence kernels, against the oracle's GRU
-    (torch.nn.GRU semantics, models.py:232)."""
+    """The GRU layer at B = 768, T = 300, I = 60, H = 128, both directions (phone_rnn0 of a super-batch) against
+    the oracle's GRU (torch.nn.GRU semantics, models.py:232): the split-precision path the bench runs for
+    frozen layers (slu_gemm_bf16 + slu_gru_seq_fwd_bf16, three bf16 terms) and the exact-fp32 kernels forced
+    onto 4- and 16-sequence workgroups."""
     from slu_hip import ops
-    monkeypatch.setenv("SLU_GRU_TILE", tile)
+    if tile != "bf16x3":
+        monkeypatch.setenv("SLU_GRU_TILE", tile)
     T, B, I, H = 300, 768, 60, 128
     torch.manual_seed(3)
     p = {}
@@ -147,9 +149,14 @@ def test_recurrence_at_super_batch_size_vs_oracle(tile, monkeypatch):
     xt = x.transpose(0, 1).contiguous().cuda()
     w_ih = torch.cat([d["weight_ih_l0"], d["weight_ih_l0_reverse"]])
     b_ih = torch.cat([d["bias_ih_l0"], d["bias_ih_l0_reverse"]])
-    gx = ops.gemm(xt.view(T * B, I), w_ih.t(), b_ih)
-    out, _ = ops.gru_seq_fwd(gx, d["weight_hh_l0"], d["weight_hh_l0_reverse"], d["bias_hh_l0"],
-                             d["bias_hh_l0_reverse"], T, B, H, 2, False)
+    if tile == "bf16x3":
+        gx = ops.gemm_bf16(ops.split_bf16(xt.view(T * B, I), 3), ops.gemm_bf16_pack(w_ih, 3), b_ih, 6 * H, I)
+        out, _ = ops.gru_seq_fwd_bf16(gx, d["weight_hh_l0"], d["weight_hh_l0_reverse"], d["bias_hh_l0"],
+                                      d["bias_hh_l0_reverse"], T, B, H, 2, 3)
+    else:
+        gx = ops.gemm(xt.view(T * B, I), w_ih.t(), b_ih)
+        out, _ = ops.gru_seq_fwd(gx, d["weight_hh_l0"], d["weight_hh_l0_reverse"], d["bias_hh_l0"],
+                                 d["bias_hh_l0_reverse"], T, B, H, 2, False)
     torch.cuda.synchronize()
     err = (out.transpose(0, 1).cpu() - ref).abs().max().item()
     print("GRU B=768 T=300 tile %s: max-abs deviation vs oracle %.3e" % (tile, err))

@@ -61,7 +61,7 @@ def test_gru_bf16_vs_exact_fp32_kernel(ops, T, B, H, nsplit):
     wf, wr = ((torch.rand(3 * H, H) * 2 - 1) * k).cuda(), ((torch.rand(3 * H, H) * 2 - 1) * k).cuda()
     bf, br = ((torch.rand(3 * H) * 2 - 1) * k).cuda(), ((torch.rand(3 * H) * 2 - 1) * k).cuda()
     ref, _ = ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, False)
-    out = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit)
+    out, _ = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit)
     torch.cuda.synchronize()
     err = (out - ref).abs().max().item()
     print("gru bf16 nsplit=%d T=%d B=%d H=%d: max-abs deviation from the fp32 kernel %.2e" % (nsplit, T, B, H, err))

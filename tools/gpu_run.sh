@@ -20,8 +20,8 @@ try:
     d=json.loads(open("$OUT/$f.json").read().strip().splitlines()[-1])
     r=d.get("roofline") or {}
     print({k:d.get(k) for k in ("value","ms_per_step","pipeline_fill_ms","graphs_captured","parity","steady_state")})
-    print("roofline", {k:r.get(k) for k in ("kernel","achieved","frac","avg_launch_ms")})
-    for k in r.get("kernels",[]): print("  ", k["kernel"], k["tflops"], k["frac"], k["gpu_ms_per_step"], [(s["us"], s["tflops"]) for s in k["shapes"]])
+    print("roofline", {k:r.get(k) for k in ("kernel","bound","achieved","peak","frac","avg_launch_ms")})
+    for k in r.get("kernels",[]): print("  ", k["kernel"], k["bound"], k["frac"], k["algorithmic_tflops"], k["gpu_ms_per_step"], [(s["us"], s["algorithmic_tflops"]) for s in k["shapes"]])
     print("cpu", d.get("cpu_baseline"))
 except Exception as e: print("no json:", e)
 PY
