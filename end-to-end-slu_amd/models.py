@@ -270,7 +270,16 @@ class GRU(torch.nn.Module):
 
     def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1):
         w_ih, b_ih = self._stacked_ih()
-        nsplit = contraction_nsplit(not any(q.requires_grad for q in self.parameters()))
+        frozen = not any(q.requires_grad for q in self.parameters())
+        nsplit = contraction_nsplit(frozen)
+        packed = None
+        if nsplit and frozen and _ops.split_path_supported(self.hidden_size, 2 if self.bidirectional else 1):
+            # bf16 planes of the frozen W_ih in MFMA fragment order, rebuilt when the weight changes (the cache
+            # lives with the weight's owner: a global table keyed by address would outlive the tensor)
+            key = (nsplit, w_ih.data_ptr(), w_ih._version)
+            if getattr(self, "_packed_ih", (None, None))[0] != key:
+                self._packed_ih = (key, _ops.gemm_bf16_pack(w_ih.detach(), nsplit))
+            packed = self._packed_ih[1]
         if self.bidirectional:
             ih = (self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse)
             rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse)
@@ -278,7 +287,7 @@ class GRU(torch.nn.Module):
             ih = (self.weight_ih_l0, None, self.bias_ih_l0, None)
             rev = (None, None)
         return _ops.GRULayerFn.apply(xt, w_ih.detach(), b_ih.detach(), *ih, self.weight_hh_l0, self.bias_hh_l0,
-                                     rev[0], rev[1], p, mask, seed, offset, method, factor, nsplit)
+                                     rev[0], rev[1], p, mask, seed, offset, method, factor, nsplit, packed)
 
     def forward(self, x):
         _require_device(x)

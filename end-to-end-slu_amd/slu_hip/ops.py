@@ -233,24 +233,6 @@ def split_path_supported(H, D):
     return H in (64, 128) and (D * 3 * H) % 64 == 0
 
 
-_PACKED = {}
-
-
-def packed_weight(w, nsplit, cache):
-    """B-fragment-ordered bf16 planes of an (N, K) weight; cached per (storage, version) for frozen weights
-    (a trainable weight is updated in place by the HIP optimiser, which torch's version counter does not see)."""
-    if not cache:
-        return gemm_bf16_pack(w, nsplit)
-    key = (w.data_ptr(), tuple(w.shape), nsplit)
-    hit = _PACKED.get(key)
-    if hit is None or hit[0] != w._version:
-        if len(_PACKED) > 64:
-            _PACKED.clear()
-        hit = (w._version, gemm_bf16_pack(w, nsplit))
-        _PACKED[key] = hit
-    return hit[1]
-
-
 def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False):
     """Recurrence on the split-precision MFMA kernels -> (out (T, B, D*H) fp32, reserve or None)."""
     L = _lib.load()
@@ -523,7 +505,7 @@ class GRULayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, b_ih, w_ih_f, w_ih_r, b_ih_f, b_ih_r, w_hh_f, b_hh_f, w_hh_r, b_hh_r,
-                p, mask, seed, offset, method, factor, nsplit=0):
+                p, mask, seed, offset, method, factor, nsplit=0, packed_ih=None):
         """nsplit: 0 = exact fp32 MFMA; 3 / 1 = the two contractions of the FORWARD pass (x W_ih^T and the
         recurrence's h W_hh^T) on the split-precision bf16 MFMA kernels (csrc/slu_bf16.h) — 3: fp32-class (used
         for frozen layers), 1: plain bf16 (BASELINE configs[4]); the backward pass is exact fp32 either way."""
@@ -534,7 +516,8 @@ class GRULayerFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:11])
         if nsplit and split_path_supported(H, D):
             planes = split_bf16(x.view(T * B, I), nsplit)
-            packed = packed_weight(w_ih, nsplit, cache=not need)
+            # packed_ih: the owner's cached bf16 planes of a FROZEN W_ih (models.GRU keeps them per weight version)
+            packed = packed_ih if packed_ih is not None else gemm_bf16_pack(w_ih, nsplit)
             gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
             raw, reserve = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, need)
         else:
@@ -570,7 +553,7 @@ class GRULayerFn(torch.autograd.Function):
         g2 = d_gx.view(T * B, D * 3 * H)
         h2 = d_gh.view(T * B, D * 3 * H)
         r2 = raw.view(T * B, D * H)
-        grads = [None] * 18
+        grads = [None] * 19
         dev = x.device
         # The weight-gradient GEMMs are independent of each other and of the data-gradient GEMM: they
         # run on auxiliary streams (graph branches under capture) while dx proceeds on this one.
