@@ -58,3 +58,55 @@ extern "C" int slu_stream_create_cu_range(int64_t first_cu, int64_t n_cus, void*
   *stream_out = (void*)st;
   return SLU_OK;
 }
+
+// ---- fused staging of a captured step's inputs -----------------------------------------------------------
+// A hipGraph-captured step reads its inputs from static buffers; refreshing them took one copy kernel per
+// input plus a fill for the dropout-stream offset (3 launches of ~5 us on a 64-CU partition).  One launch:
+// up to 4 strided 2-D byte copies (rows x row_bytes, 16-byte granules when aligned) and one int64 store.
+namespace slu {
+struct StageSeg { const unsigned char* src; unsigned char* dst; long long rows, row_bytes, src_stride; };
+struct StageArgs { StageSeg seg[4]; int nseg; long long* set_ptr; long long set_value; };
+
+__global__ void __launch_bounds__(256)
+stage_inputs_kernel(const StageArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.set_ptr) *a.set_ptr = a.set_value;
+  for (int k = 0; k < a.nseg; ++k) {
+    const StageSeg sg = a.seg[k];
+    const bool vec = ((sg.row_bytes | sg.src_stride | (long long)(uintptr_t)sg.src | (long long)(uintptr_t)sg.dst) & 15) == 0;
+    if (vec) {
+      const long long per_row = sg.row_bytes >> 4, total = sg.rows * per_row;
+      for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / per_row, c = i - r * per_row;
+        reinterpret_cast<uint4*>(sg.dst + r * sg.row_bytes)[c] = reinterpret_cast<const uint4*>(sg.src + r * sg.src_stride)[c];
+      }
+    } else {
+      const long long total = sg.rows * sg.row_bytes;
+      for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / sg.row_bytes, c = i - r * sg.row_bytes;
+        sg.dst[r * sg.row_bytes + c] = sg.src[r * sg.src_stride + c];
+      }
+    }
+  }
+}
+}  // namespace slu
+
+extern "C" int slu_stage_inputs(const void* const* src, void* const* dst, const int64_t* rows, const int64_t* row_bytes,
+                                const int64_t* src_stride_bytes, int64_t count, int64_t* set_ptr, int64_t set_value,
+                                void* stream) {
+  SLU_REQUIRE(count >= 0 && count <= 4, "slu_stage_inputs: at most 4 segments");
+  slu::StageArgs a;
+  long long bytes = 0;
+  for (int k = 0; k < (int)count; ++k) {
+    SLU_REQUIRE(src[k] && dst[k] && rows[k] > 0 && row_bytes[k] > 0, "slu_stage_inputs: bad segment %d", k);
+    a.seg[k].src = (const unsigned char*)src[k]; a.seg[k].dst = (unsigned char*)dst[k];
+    a.seg[k].rows = rows[k]; a.seg[k].row_bytes = row_bytes[k]; a.seg[k].src_stride = src_stride_bytes[k];
+    bytes += rows[k] * row_bytes[k];
+  }
+  a.nseg = (int)count; a.set_ptr = (long long*)set_ptr; a.set_value = set_value;
+  long long blocks = (bytes / 16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(slu::stage_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("stage_inputs_kernel");
+  return SLU_OK;
+}

@@ -345,7 +345,9 @@ static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper, int*
   int64_t ks = 1;
   if (tiles < 128 && K >= 512) {
     // two co-resident workgroups per CU (each is four waves with a barrier per k-tile: the second one fills
-    // the first one's staging phases) and never a partial second round: at most 512 workgroups
+    // the first one's staging phases) and never a partial second round: at most 512 workgroups.  The plan is a
+    // function of the shape only: the summation order (hence every bit of the result) must not depend on which
+    // stream / CU partition the GEMM is launched on (pipelined == sequential training, bit for bit).
     ks = 512 / tiles;
     const int64_t max_ks = K / 128;            // keep >= 128 k per split
     if (ks > max_ks) ks = max_ks;

@@ -40,14 +40,30 @@ head_fwd_kernel(const HeadParams p) {
   float* sm = sl + (size_t)p.T * p.V;                  // [V] pooled logits
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = p.T, C = p.C, V = p.V, LD = p.C + 1;
-  // stage rows with independent, unrolled loads (one coalesced row segment per iteration)
-#pragma unroll 4
-  for (int t = 0; t < T; ++t)
-    for (int c = tid; c < C; c += HEAD_THREADS) sh[t * LD + c] = p.h[((size_t)t * p.B + b) * C + c];
-  if (p.w_in_lds) {
-#pragma unroll 4
-    for (int v = 0; v < V; ++v)
-      for (int c = tid; c < C; c += HEAD_THREADS) sw[v * LD + c] = p.W[(size_t)v * C + c];
+  // stage the T feature rows and the V classifier rows: eight independent loads in flight per thread, then
+  // their LDS stores (a load -> store chain per element exposes the memory latency once per element: 20 us here)
+  {
+    const int nh = T * C, nw = p.w_in_lds ? V * C : 0;
+    constexpr int U = 8;
+    for (int base = 0; base < nh + nw; base += HEAD_THREADS * U) {
+      float v[U];
+      int off[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        // every lane loads unconditionally from a clamped, valid address (a branch around a load makes the
+        // compiler wait for each load where it is issued)
+        const int idx = base + j * HEAD_THREADS + tid;
+        const bool ok = idx < nh + nw, isw = idx >= nh;
+        const int e = ok ? (isw ? idx - nh : idx) : 0;
+        const int row = e / C, c = e - row * C;
+        const float* src = (ok && isw) ? p.W + e : p.h + ((size_t)row * p.B + b) * C + c;
+        v[j] = *src;
+        off[j] = ok ? ((isw ? T + row : row) * LD + c) : -1;     // sw = sh + T * LD
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+        if (off[j] >= 0) sh[off[j]] = v[j];
+    }
   }
   __syncthreads();
   // each thread owns whole (t, v) dot products: a[t][:] is an LDS broadcast within the threads of
@@ -158,6 +174,8 @@ head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ a
                    float* __restrict__ d_W, float* __restrict__ d_bias, int T, int B, int C, int V) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* part = reinterpret_cast<float*>(smem);         // [4][C]
+  float* s_dl = part + 4 * C;                           // [HEAD_THREADS] this output's d_logits, 256 utterances at a time
+  int* s_at = reinterpret_cast<int*>(s_dl + HEAD_THREADS);
   __shared__ float s_b[4];
   const int v = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float g = gscale[0];
@@ -166,14 +184,27 @@ head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ a
   float acc[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) acc[k] = 0.0f;
-  for (int b = w; b < B; b += 4) {                       // independent loads across k: 4-16 in flight
-    const float dl = d_logits[(size_t)b * V + v];
-    const float* hr = h + ((size_t)argmax_t[(size_t)b * V + v] * B + b) * C;
-    bsum += dl;
+  // The per-utterance scalars (d_logits, arg-max step) are fetched for 256 utterances at once, so that the row
+  // loads below depend on LDS only and several utterances' rows are in flight (the dependent scalar -> row
+  // chain per utterance cost 1.5 us x B/4).  Same per-wave summation order as before (b = w, w+4, ...).
+  for (int bb = 0; bb < B; bb += HEAD_THREADS) {
+    __syncthreads();
+    if (bb + (int)threadIdx.x < B) {
+      s_dl[threadIdx.x] = d_logits[(size_t)(bb + threadIdx.x) * V + v];
+      s_at[threadIdx.x] = argmax_t[(size_t)(bb + threadIdx.x) * V + v];
+    }
+    __syncthreads();
+    const int nb = min(HEAD_THREADS, B - bb);
+#pragma unroll 4
+    for (int bl = w; bl < nb; bl += 4) {
+      const float dl = s_dl[bl];
+      const float* hr = h + ((size_t)s_at[bl] * B + (bb + bl)) * C;
+      bsum += dl;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      const int c = lane + 64 * k;
-      if (c < C) acc[k] = fmaf(dl, hr[c], acc[k]);
+      for (int k = 0; k < KMAX; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) acc[k] = fmaf(dl, hr[c], acc[k]);
+      }
     }
   }
 #pragma unroll
@@ -253,7 +284,8 @@ extern "C" int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argm
     SLU_CHECK_LAUNCH("head_bwd_dh_kernel");
   }
   if (d_weight) {
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)V), dim3(HEAD_THREADS), (size_t)4 * C * sizeof(float), st,
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)V), dim3(HEAD_THREADS),
+                       ((size_t)4 * C + 2 * HEAD_THREADS) * sizeof(float), st,
                        d_logits, argmax_t, h, grad_scale, d_weight, d_bias, (int)T, (int)B, (int)C, (int)V);
     SLU_CHECK_LAUNCH("head_bwd_dw_kernel");
   }

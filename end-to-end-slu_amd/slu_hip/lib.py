@@ -24,6 +24,7 @@ SIGNATURES = {
     "slu_device_check": (c_int, []),
     "slu_device_arch": (ctypes.c_char_p, []),
     "slu_stream_create_cu_range": (c_int, [c_i64, c_i64, vp]),
+    "slu_stage_inputs": (c_int, [vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp]),
     "slu_sinc_filters_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_f64, vp]),
     "slu_sinc_filters_bwd": (c_int, [vp, vp, vp, vp, vp, c_i64, c_i64, c_f64, vp]),
     "slu_wconv_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),

@@ -190,6 +190,32 @@ def gemm(a, b, bias=None, out=None, accumulate=False):
     return out
 
 
+def stage_inputs(pairs, set_tensor=None, set_value=0):
+    """One launch refreshing static input buffers: pairs = [(dst contiguous, src)] with src contiguous or strided
+    along dim 0 only; optionally set_tensor[0] = set_value (int64).  Returns the pairs it could not take."""
+    import ctypes
+    L = _lib.load()
+    segs, rest = [], []
+    for dst, src in pairs:
+        ok = src.is_cuda and src.dtype == dst.dtype and tuple(src.shape) == tuple(dst.shape) and dst.is_contiguous()
+        if ok and src.is_contiguous():
+            segs.append((src.data_ptr(), dst.data_ptr(), 1, src.numel() * src.element_size(), 0))
+        elif ok and src.dim() >= 2 and src[0].is_contiguous():
+            row = src[0].numel() * src.element_size()
+            segs.append((src.data_ptr(), dst.data_ptr(), src.shape[0], row, src.stride(0) * src.element_size()))
+        else:
+            rest.append((dst, src))
+    while len(segs) > 4:
+        rest.append(None)       # never happens for the step inputs (<= 3 tensors); guard for other callers
+        segs.pop()
+    n = len(segs)
+    arr = lambda k, ty: (ty * max(n, 1))(*([sg[k] for sg in segs] or [0]))
+    _lib.check(L.slu_stage_inputs(arr(0, ctypes.c_void_p), arr(1, ctypes.c_void_p), arr(2, ctypes.c_int64),
+                                  arr(3, ctypes.c_int64), arr(4, ctypes.c_int64), n, _ptr(set_tensor), int(set_value),
+                                  _stream()), "slu_stage_inputs")
+    return [r for r in rest if r is not None]
+
+
 # -- split-precision (bf16 MFMA) path of the frozen stages: see csrc/slu_bf16.h --------------------------
 def round_up(n, m):
     return -(-n // m) * m

@@ -194,9 +194,9 @@ class StepGraph:
         self.signature = bucket.signature
 
     def run(self, inputs, step):
-        for dst, src in zip(self.inputs, inputs):
+        # static inputs + dropout-stream offset in ONE launch (device-resident sources; others fall back to copy_)
+        for dst, src in ops.stage_inputs(list(zip(self.inputs, inputs)), self.rng, step * 16):
             dst.copy_(src, non_blocking=True)
-        self.rng.fill_(step * 16)
         self.g1.replay()
         if self.world > 1:                          # one collective per gradient dtype; the mean's 1/N is
             self.trainer.bucket.allreduce_flats()   # folded into the Adam kernel (HipAdam.grad_div)

@@ -51,6 +51,13 @@ const char* slu_device_arch(void);        /* gcnArchName of the current device (
  * contiguous range is spread over all XCDs); look-ahead pipeline of training.Trainer. Never freed. */
 int slu_stream_create_cu_range(int64_t first_cu, int64_t n_cus, void** stream_out);
 
+/* One launch for the per-step input refresh of a captured step: up to 4 strided 2-D copies (rows x row_bytes
+ * from src + r * src_stride_bytes to a dense dst) and *set_ptr = set_value (set_ptr may be NULL).  Pointer
+ * arrays are HOST arrays of device pointers.                                                                   */
+int slu_stage_inputs(const void* const* src, void* const* dst, const int64_t* rows, const int64_t* row_bytes,
+                     const int64_t* src_stride_bytes, int64_t count, int64_t* set_ptr, int64_t set_value,
+                     void* stream);
+
 /* -------- Sinc filterbank: models.py:79-106 (SincLayer.forward up to the conv), :7-24 ------- */
 /* filters[n_filt][filt_dim] (float32) from the two float64 parameters, filt_dim odd.            */
 int slu_sinc_filters_fwd(const double* filt_b1, const double* filt_band, float* filters,
