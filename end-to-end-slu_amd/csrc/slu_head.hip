@@ -40,14 +40,15 @@ head_fwd_kernel(const HeadParams p) {
   float* sm = sl + (size_t)p.T * p.V;                  // [V] pooled logits
   const int b = blockIdx.x, tid = threadIdx.x;
   const int T = p.T, C = p.C, V = p.V, LD = p.C + 1;
-  // stage the T feature rows and the V classifier rows: eight independent loads in flight per thread, then
-  // their LDS stores (a load -> store chain per element exposes the memory latency once per element: 20 us here)
+  // stage the T feature rows and the V classifier rows: ALL of a thread's loads are issued before its first LDS
+  // store (48 in flight: the whole staging costs one memory round trip; on the training stream's small CU
+  // partition, beside the look-ahead kernels' traffic, a round trip is 2-3 us and a load -> store chain per
+  // batch of 4 or 8 elements cost 20-30 us here)
   {
     const int nh = T * C, nw = p.w_in_lds ? V * C : 0;
-    constexpr int U = 8;
+    constexpr int U = 48;
     for (int base = 0; base < nh + nw; base += HEAD_THREADS * U) {
       float v[U];
-      int off[U];
 #pragma unroll
       for (int j = 0; j < U; ++j) {
         // every lane loads unconditionally from a clamped, valid address (a branch around a load makes the
@@ -58,11 +59,15 @@ head_fwd_kernel(const HeadParams p) {
         const int row = e / C, c = e - row * C;
         const float* src = (ok && isw) ? p.W + e : p.h + ((size_t)row * p.B + b) * C + c;
         v[j] = *src;
-        off[j] = ok ? ((isw ? T + row : row) * LD + c) : -1;     // sw = sh + T * LD
       }
 #pragma unroll
-      for (int j = 0; j < U; ++j)
-        if (off[j] >= 0) sh[off[j]] = v[j];
+      for (int j = 0; j < U; ++j) {
+        const int idx = base + j * HEAD_THREADS + tid;
+        const bool ok = idx < nh + nw, isw = idx >= nh;
+        const int e = ok ? (isw ? idx - nh : idx) : 0;
+        const int row = e / C, c = e - row * C;
+        if (ok) sh[(isw ? T + row : row) * LD + c] = v[j];      // sw = sh + T * LD
+      }
     }
   }
   __syncthreads();
@@ -195,15 +200,41 @@ head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ a
     }
     __syncthreads();
     const int nb = min(HEAD_THREADS, B - bb);
-#pragma unroll 4
-    for (int bl = w; bl < nb; bl += 4) {
-      const float dl = s_dl[bl];
-      const float* hr = h + ((size_t)s_at[bl] * B + (bb + bl)) * C;
-      bsum += dl;
+    // 8 utterances' rows in flight per wave (8 x C/64 loads), accumulated in the fixed order b = w, w+4, ...
+    for (int bl0 = w; bl0 < nb; bl0 += 32) {
+      float hv[8][KMAX > 4 ? 4 : KMAX];
+      if (C <= 256) {
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        const int c = lane + 64 * k;
-        if (c < C) acc[k] = fmaf(dl, hr[c], acc[k]);
+        for (int u = 0; u < 8; ++u) {
+          const int bl = min(bl0 + 4 * u, nb - 1);
+          const float* hr = h + ((size_t)s_at[bl] * B + (bb + bl)) * C;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hv[u][k] = hr[min(lane + 64 * k, C - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int bl = bl0 + 4 * u;
+          if (bl < nb) {
+            const float dl = s_dl[bl];
+            bsum += dl;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (lane + 64 * k < C) acc[k] = fmaf(dl, hv[u][k], acc[k]);
+          }
+        }
+      } else {
+        for (int u = 0; u < 8; ++u) {
+          const int bl = bl0 + 4 * u;
+          if (bl >= nb) break;
+          const float dl = s_dl[bl];
+          const float* hr = h + ((size_t)s_at[bl] * B + (bb + bl)) * C;
+          bsum += dl;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) acc[k] = fmaf(dl, hr[c], acc[k]);
+          }
+        }
       }
     }
   }
