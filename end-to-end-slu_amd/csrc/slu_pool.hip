@@ -6,7 +6,7 @@
 // (float4 accesses, a wave covers a contiguous 1 KB row segment), 2-D grid (time on y) so that all
 // index arithmetic is 32-bit, and ONE Philox4x32-10 evaluation per four elements (its four output
 // words are exactly the four channels).  A scalar kernel covers other channel counts.
-#include "slu_common.h"
+#include "slu_bf16.h"
 
 namespace slu {
 
@@ -146,9 +146,13 @@ __device__ __forceinline__ float4 keep_scale4(const PoolParams& q, uint64_t off_
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-// grid: x over B*C/4 quads, y over output frames
+// grid: x over B*C/4 quads, y over output frames.  NS = 0: fp32 output y; NS = 1 / 3: the output goes straight
+// into the split-precision activation format (NS bf16 planes of (T_out*B) x C, plane stride `plane` elements)
+// that the next frozen layer's input-projection GEMM reads (slu_gemm_bf16): no fp32 round trip, no split pass.
+template <int NS>
 __global__ void __launch_bounds__(256)
-dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, const PoolParams q) {
+dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned short* __restrict__ planes,
+                         long long plane, const PoolParams q) {
   const int C4 = q.C >> 2;
   const unsigned e = blockIdx.x * 256u + threadIdx.x;
   if (e >= (unsigned)q.B * C4) return;
@@ -174,7 +178,17 @@ dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, con
       acc.x = acc.x / n; acc.y = acc.y / n; acc.z = acc.z / n; acc.w = acc.w / n;
     }
   }
-  *reinterpret_cast<float4*>(y + to * row + col) = acc;
+  if (NS == 0) {
+    *reinterpret_cast<float4*>(y + to * row + col) = acc;
+  } else {
+    constexpr int NP = NS == 0 ? 1 : NS;
+    unsigned short h[4][NP];
+    split_bf16<NP>(acc.x, h[0]); split_bf16<NP>(acc.y, h[1]); split_bf16<NP>(acc.z, h[2]); split_bf16<NP>(acc.w, h[3]);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+      *reinterpret_cast<uint2*>(planes + (size_t)pl * plane + to * row + col) =
+          make_uint2(h[0][pl] | ((unsigned)h[1][pl] << 16), h[2][pl] | ((unsigned)h[3][pl] << 16));
+  }
 }
 
 // grid: x over B*C/4 quads, y over OUTPUT frames; a thread writes dx for every input frame of its window
@@ -257,8 +271,8 @@ extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m
   int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
   if (pool_vec_ok(q, x, y, mask)) {
-    hipLaunchKernelGGL(dropout_pool_fwd4_kernel, dim3((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out),
-                       dim3(256), 0, (hipStream_t)stream, x, y, q);
+    hipLaunchKernelGGL(dropout_pool_fwd4_kernel<0>, dim3((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out),
+                       dim3(256), 0, (hipStream_t)stream, x, y, (unsigned short*)nullptr, 0LL, q);
     SLU_CHECK_LAUNCH("dropout_pool_fwd4_kernel");
     return SLU_OK;
   }
@@ -266,6 +280,30 @@ extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m
   hipLaunchKernelGGL(dropout_pool_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, x, y, q);
   SLU_CHECK_LAUNCH("dropout_pool_fwd_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st, int64_t m_sb,
+                                           float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                           int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor,
+                                           void* planes, int64_t plane_stride, int nsplit, int64_t T, int64_t B,
+                                           int64_t C, void* stream) {
+  SLU_REQUIRE(x && planes, "slu_dropout_pool_fwd_planes: null pointer");
+  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_dropout_pool_fwd_planes: nsplit must be 1 or 3");
+  PoolParams q;
+  int rc = pool_fill(q, "slu_dropout_pool_fwd_planes", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
+  if (rc) return rc;
+  if (C % 32 != 0 || !pool_vec_ok(q, x, x, mask) || (reinterpret_cast<uintptr_t>(planes) & 15) || (plane_stride & 7))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_dropout_pool_fwd_planes: needs C %% 32 == 0 (got %lld), aligned buffers, T_out <= 65535", (long long)C);
+  SLU_REQUIRE(plane_stride >= (int64_t)q.T_out * B * C, "slu_dropout_pool_fwd_planes: plane stride too small");
+  dim3 grid((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out);
+  if (nsplit == 3)
+    hipLaunchKernelGGL(dropout_pool_fwd4_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
+                       (unsigned short*)planes, (long long)plane_stride, q);
+  else
+    hipLaunchKernelGGL(dropout_pool_fwd4_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
+                       (unsigned short*)planes, (long long)plane_stride, q);
+  SLU_CHECK_LAUNCH("dropout_pool_fwd4_kernel(planes)");
   return SLU_OK;
 }
 

@@ -268,7 +268,14 @@ class GRU(torch.nn.Module):
             self._ih_storage = (W, b)
         return self._ih_storage
 
-    def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1):
+    def split_frozen(self):
+        """nsplit (1 / 3) when this layer runs FROZEN on the split-precision kernels, else 0."""
+        if any(q.requires_grad for q in self.parameters()):
+            return 0
+        nsplit = contraction_nsplit(True)
+        return nsplit if _ops.split_path_supported(self.hidden_size, 2 if self.bidirectional else 1) else 0
+
+    def run_time_major(self, xt, p=0.0, mask=None, seed=0, offset=0, method="none", factor=1, out_planes=False):
         w_ih, b_ih = self._stacked_ih()
         frozen = not any(q.requires_grad for q in self.parameters())
         nsplit = contraction_nsplit(frozen)
@@ -280,6 +287,12 @@ class GRU(torch.nn.Module):
             if getattr(self, "_packed_ih", (None, None))[0] != key:
                 self._packed_ih = (key, _ops.gemm_bf16_pack(w_ih.detach(), nsplit))
             packed = self._packed_ih[1]
+            if isinstance(xt, _ops.SplitAct) or not xt.requires_grad:
+                # nothing to differentiate: the whole layer outside autograd, activations may stay in bf16 planes
+                rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse) if self.bidirectional else (None, None)
+                with torch.no_grad():
+                    return _ops.gru_layer_frozen(xt, w_ih, b_ih, packed, self.weight_hh_l0, self.bias_hh_l0, rev[0],
+                                                 rev[1], p, mask, seed, offset, method, factor, nsplit, out_planes)
         if self.bidirectional:
             ih = (self.weight_ih_l0, self.weight_ih_l0_reverse, self.bias_ih_l0, self.bias_ih_l0_reverse)
             rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse)
@@ -388,9 +401,10 @@ class _RnnStage:
     def parameters(self):
         return list(self.gru.parameters())
 
-    def run(self, xt, training):
+    def run(self, xt, training, out_planes=False):
+        """out_planes: the consumer is another frozen split-precision GRU layer: hand over bf16 planes."""
         p, mask, seed, offset = _dropout_args(self.drop_name, self.site, self.p, training)
-        return self.gru.run_time_major(xt, p, mask, seed, offset, self.method, self.factor)
+        return self.gru.run_time_major(xt, p, mask, seed, offset, self.method, self.factor, out_planes)
 
 
 def _build_rnn_stack(layers, stages, prefix, in_dim, hidden, bidirectional, drops, ds_types, ds_lens):
@@ -475,8 +489,18 @@ class PretrainedModel(torch.nn.Module):
         self._cnn_stages[-1].time_major = True
         if first == 0:
             h = h.float()
-        for st in self._stages()[first:last]:
-            h = st.run(h, self.training)
+        stages = self._stages()
+        for k in range(first, last):
+            st = stages[k]
+            if isinstance(st, _RnnStage):
+                # two consecutive frozen GRU layers inside this call: the activation between them stays in the
+                # split-precision format (bf16 planes written by the dropout+pool kernel, read by the GEMM)
+                nxt = stages[k + 1] if k + 1 < last else None
+                planes = (isinstance(nxt, _RnnStage) and st.gru.split_frozen() > 0
+                          and nxt.gru.split_frozen() == st.gru.split_frozen())
+                h = st.run(h, self.training, planes)
+            else:
+                h = st.run(h, self.training)
         return h
 
     def frozen_prefix_len(self):

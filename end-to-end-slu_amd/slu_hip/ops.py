@@ -254,6 +254,52 @@ def gemm_bf16(planes, packed, bias, N, K, out=None):
     return out
 
 
+class SplitAct:
+    """A time-major activation (T, B, C) in the split-precision format: `planes` = (nsplit, T*B, round_up(C, 32))
+    bf16 (csrc/slu_bf16.h).  Travels only between FROZEN stages (no autograd)."""
+
+    def __init__(self, planes, T, B, C):
+        self.planes, self.T, self.B, self.C = planes, T, B, C
+
+
+def dropout_pool_fwd_planes(x, mask, p, seed, offset, method, factor, nsplit, offset_dev=None, sub_batch=0):
+    """dropout_pool_fwd whose result is written as split-precision planes (C % 32 == 0) -> SplitAct."""
+    L = _lib.load()
+    T, B, C = x.shape
+    T_out = -(-T // factor)
+    planes = torch.empty(nsplit, T_out * B, C, dtype=torch.bfloat16, device=x.device)
+    mp, mst, msb = _mask_args(mask, T, B, C)
+    _lib.check(L.slu_dropout_pool_fwd_planes(x.data_ptr(), mp, mst, msb, float(p), int(seed), int(offset),
+                                             _ptr(offset_dev), int(sub_batch), 16, METHODS[method], factor,
+                                             planes.data_ptr(), planes.stride(0), nsplit, T, B, C, _stream()),
+               "slu_dropout_pool_fwd_planes")
+    return SplitAct(planes, T_out, B, C)
+
+
+def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p, mask, seed, offset, method, factor,
+                     nsplit, out_planes):
+    """A FROZEN GRU layer + Dropout + Downsample on the split-precision kernels, outside autograd.
+    x: fp32 (T, B, I) or a SplitAct; out_planes: return a SplitAct for the next frozen layer (when the pooled
+    channel count allows it) instead of fp32 (T_out, B, D*H)."""
+    H = w_hh_f.shape[1]
+    D = 1 if w_hh_r is None else 2
+    if isinstance(x, SplitAct):
+        T, B, I, planes = x.T, x.B, x.C, x.planes
+    else:
+        x = x.contiguous()
+        T, B, I = x.shape
+        planes = split_bf16(x.view(T * B, I), nsplit)
+    packed = packed_ih if packed_ih is not None else gemm_bf16_pack(w_ih, nsplit)
+    gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
+    raw, _ = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, False)
+    offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
+    if out_planes and (D * H) % 32 == 0 and -(-T // factor) <= 65535:
+        return dropout_pool_fwd_planes(raw, mask, p, seed, offset, method, factor, nsplit, offset_dev, sub_batch)
+    if p == 0.0 and factor == 1:
+        return raw
+    return dropout_pool_fwd(raw, mask, p, seed, offset, method, factor, offset_dev, sub_batch)
+
+
 def split_path_supported(H, D):
     """Shapes the split-precision kernels are instantiated for (else the exact fp32 kernels run)."""
     return H in (64, 128) and (D * 3 * H) % 64 == 0

@@ -340,6 +340,12 @@ class Trainer:
         step_graphs = use_graph and self._graphable()
         forward = self._slu_forward(n_prefix)
         trainable = _param_signature(self.model)
+        # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so no
+        # super-batch is wider than half the run — the second half's encoders then overlap the first half's steps
+        try:
+            width_cap = max(2, -(-len(loader) // 2))
+        except TypeError:
+            width_cap = 1 << 30
         pending = collections.deque()
         it = iter(loader)
         carry = []                                    # a batch read ahead that did not fit its group
@@ -350,7 +356,7 @@ class Trainer:
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
             nonlocal launched
             group = [carry.pop()] if carry else []
-            while not group or len(group) < _lookahead_width(depth, len(group[0][0])):
+            while not group or len(group) < min(width_cap, _lookahead_width(depth, len(group[0][0]))):
                 try:
                     batch = next(it)
                 except StopIteration:

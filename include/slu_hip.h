@@ -193,6 +193,12 @@ int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_
                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                          int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, float* y,
                          int64_t T, int64_t B, int64_t C, void* stream);
+/* The same, writing the result straight into the split-precision activation format (nsplit bf16 planes of
+ * (T_out*B) x C, see slu_split_bf16) read by the next frozen layer's slu_gemm_bf16.  C % 32 == 0.             */
+int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st, int64_t m_sb, float p,
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t sub_batch,
+                                uint64_t sub_stride, int method, int64_t factor, void* planes,
+                                int64_t plane_stride, int nsplit, int64_t T, int64_t B, int64_t C, void* stream);
 /* dx (T,B,C) from dy (T_out,B,C); x and y (forward input/output) are needed for method 2 only. */
 int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const float* mask,
                          int64_t m_st, int64_t m_sb, float p, uint64_t seed, uint64_t offset,
