@@ -219,7 +219,13 @@ class Trainer:
                 self._step_graphs.pop(key, None)
                 self.capture_failures += 1
         if sg is not None:
+            self._last_key = key
             return sg.run(inputs, step)
+        # only runs of equally-shaped steps are worth a capture (~50 ms, a private activation pool): with ragged
+        # batches (real-data loaders without length bucketing) the count restarts at every shape change
+        if getattr(self, "_last_key", None) != key and self._eager_steps.get(key, 0) >= 0:
+            self._eager_steps[key] = 0
+        self._last_key = key
         self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
         metrics, loss = forward(inputs, step)
         self._step(loss)

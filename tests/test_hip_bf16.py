@@ -66,3 +66,55 @@ def test_gru_bf16_vs_exact_fp32_kernel(ops, T, B, H, nsplit):
     err = (out - ref).abs().max().item()
     print("gru bf16 nsplit=%d T=%d B=%d H=%d: max-abs deviation from the fp32 kernel %.2e" % (nsplit, T, B, H, err))
     assert err <= (5e-6 if nsplit == 3 else 5e-2)
+
+
+def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):
+    """BASELINE configs[4] arithmetic (SLU_DTYPE=bf16: the GRU layers' forward contractions on bf16 MFMA with
+    fp32 accumulation and gate math, exact-fp32 backward on the saved gates).  The reference has no reduced
+    precision path (plain fp32 nn.GRU, models.py:232/:262/:686), so the yardstick is the fp32 oracle:
+    predicted intents must agree, the logit deviation is reported and bounded empirically, gradients must point
+    the same way."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import slu_oracle as O
+    import data
+    import models
+    cfg = O.OracleConfig(pretraining_type=0)                  # full-size no_unfreezing architecture, all trainable
+    cfg.folder = str(tmp_path)
+    cfg.starting_unfreezing_index = 1
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    torch.manual_seed(5)
+    monkeypatch.setenv("SLU_DTYPE", "bf16")
+    model = models.Model(cfg)
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x = 0.1 * torch.randn(8, 16000, generator=g)
+    y = torch.stack([torch.randint(0, n, (8,), generator=g) for n in cfg.values_per_slot], dim=1)
+    masks = O.draw_dropout_masks(cfg, x, seed=21)
+    models.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
+    try:
+        model.train()
+        loss, acc = model(x, y)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        models.set_dropout_masks(None)
+    rloss, racc, rlogits, rpred = O.slu_forward(sd, x, y, cfg, masks, explicit_gru=False)
+    rloss.backward()
+    model.eval()
+    with torch.no_grad():
+        logits, pred = model.predict_intents(x)
+        _, _, elogits, epred = O.slu_forward({k: v.detach() for k, v in sd.items()}, x, y, cfg, None, explicit_gru=False)
+    dev = (logits.cpu() - elogits).abs().max().item()
+    print("bf16 mode: eval logits max-abs deviation vs fp32 oracle %.3e (logit range %.2f), train loss %.5f vs %.5f"
+          % (dev, elogits.abs().max().item(), loss.item(), rloss.item()))
+    assert torch.equal(pred.cpu(), epred)                      # intent decisions unchanged
+    assert dev <= 2e-2 and abs(loss.item() - rloss.item()) <= 2e-2
+    worst = 1.0
+    for k, p in model.named_parameters():
+        if sd[k].grad is None or p.grad is None:
+            continue
+        a, b = p.grad.cpu().double().flatten(), sd[k].grad.double().flatten()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        worst = min(worst, cos)
+    print("bf16 mode: worst gradient cosine vs fp32 oracle %.5f" % worst)
+    assert worst >= 0.99
