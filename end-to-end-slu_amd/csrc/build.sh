@@ -7,7 +7,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${SLU_EXTRA_FLAGS:-}"
 OBJS=()
-for f in slu_api slu_sinc slu_wconv slu_gemm slu_gemm_bf16 slu_gru slu_gru_step slu_gru_bf16 slu_pool slu_head slu_optim slu_framece; do
+for f in slu_api slu_sinc slu_wconv slu_gemm slu_gemm_bf16 slu_gru slu_gru_step slu_gru_bf16 slu_pool slu_head slu_optim slu_framece slu_comm; do
   if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/slu_common.h" -nt "$OUT/$f.o" ] || [ "$HERE/slu_bf16.h" -nt "$OUT/$f.o" ] \
      || [ "$HERE/../../include/slu_hip.h" -nt "$OUT/$f.o" ]; then
     echo "[build] $f.hip"
@@ -15,5 +15,5 @@ for f in slu_api slu_sinc slu_wconv slu_gemm slu_gemm_bf16 slu_gru slu_gru_step 
   fi
   OBJS+=("$OUT/$f.o")
 done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "$OUT/libslu_hip.so"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -o "$OUT/libslu_hip.so"
 echo "[build] $OUT/libslu_hip.so"

@@ -42,6 +42,39 @@ def init_from_env(backend=None):
     return rank, ws, local
 
 
+class DirectComm:
+    """RCCL communicator driven through the C ABI (slu_comm_* of include/slu_hip.h): the all-reduce is enqueued on
+    the CURRENT stream (the training stream, between the captured backward and Adam graphs) instead of going
+    through torch.distributed's collective stream.  Opt-in (SLU_COMM=rccl); the unique id travels over the
+    already initialised torch.distributed group."""
+
+    def __init__(self, rank, world_size, device):
+        import ctypes
+        from . import lib as _lib
+        self._lib, self._L = _lib, _lib.load()
+        buf = (ctypes.c_char * 128)()
+        if rank == 0:
+            _lib.check(self._L.slu_comm_unique_id(buf), "slu_comm_unique_id")
+        if world_size > 1:
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=0)
+            buf = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self._L.slu_comm_init(ctypes.byref(self._handle), buf, world_size, rank), "slu_comm_init")
+        self.world_size = world_size
+
+    def allreduce(self, flat):
+        fn = {torch.float32: self._L.slu_comm_allreduce_f32, torch.float64: self._L.slu_comm_allreduce_f64}[flat.dtype]
+        self._lib.check(fn(self._handle, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream),
+                        "slu_comm_allreduce")
+
+    def close(self):
+        if self._handle:
+            self._lib.check(self._L.slu_comm_destroy(self._handle), "slu_comm_destroy")
+            self._handle = None
+
+
 class GradBucket:
     """Flat gradient buckets (one per dtype: the Sinc parameters are float64) for the per-step
     all-reduce.  After backward the fresh gradients are packed with ONE concatenation kernel per
@@ -57,6 +90,7 @@ class GradBucket:
         self.groups = {}
         self.signature = None
         self.divide = True        # False: the optimiser divides by the world size itself (HipAdam.grad_div)
+        self.comm = None          # DirectComm: all-reduce through slu_comm_* on the current stream (SLU_COMM=rccl)
 
     def reset(self):
         """Forget the bucket (call after the trainable set changed, e.g. unfreeze_one_layer)."""
@@ -104,7 +138,10 @@ class GradBucket:
         division by the world size unless the optimiser folds it into its update (`divide` False)."""
         ws = world()[1]
         for flat in self.flats.values():
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if self.comm is not None:
+                self.comm.allreduce(flat)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             if self.divide:
                 flat.div_(ws)
 

@@ -44,6 +44,12 @@ SIGNATURES = {
     "slu_gemm_bf16_pack": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gemm_bf16": (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
+    "slu_comm_version": (c_int, []),
+    "slu_comm_unique_id": (c_int, [vp]),
+    "slu_comm_init": (c_int, [vp, vp, c_i64, c_i64]),
+    "slu_comm_allreduce_f32": (c_int, [vp, vp, c_i64, vp]),
+    "slu_comm_allreduce_f64": (c_int, [vp, vp, c_i64, vp]),
+    "slu_comm_destroy": (c_int, [vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64, c_i64]),

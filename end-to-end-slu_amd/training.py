@@ -93,6 +93,9 @@ class Trainer:
             # data-parallel mean: the all-reduce delivers the SUM, Adam divides by the world size in-kernel
             self.optimizer.grad_div = float(self.world_size)
             self.bucket.divide = False
+            if os.environ.get("SLU_COMM", "torch") == "rccl" and torch.distributed.get_backend() == "nccl":
+                dev = next(model.parameters()).device
+                self.bucket.comm = dp.DirectComm(self.rank, self.world_size, dev)
 
     # -- checkpoints / log (reference training.py:23-45) -------------------------------------------
     def load_checkpoint(self):

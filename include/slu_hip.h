@@ -251,6 +251,21 @@ int slu_adam_multi(void* const* params, const void* const* grads, void* const* e
                    double grad_div, void* stream);
 int slu_adam_advance_step(int64_t* step_dev, uint64_t cohort_mask, void* stream);
 
+/* -------- data parallelism: the gradient all-reduce over the GPUs of a node (RCCL over xGMI) -----------------
+ * The reference has no distributed code; these are thin wrappers over the RCCL instance the process already
+ * holds (resolved at run time, not linked), so that the one collective of a training step can be enqueued on
+ * the training stream between the captured backward and Adam graphs.  Protocol: rank 0 calls
+ * slu_comm_unique_id and broadcasts the 128 bytes (any side channel: torch.distributed, a file, MPI); every
+ * rank calls slu_comm_init with its rank (collective, like ncclCommInitRank); all-reduces are in place, SUM,
+ * asynchronous on `stream`; the mean's 1/N lives in slu_adam_multi's grad_div.  slu_comm_version() = the RCCL
+ * version code (0 when no RCCL library is mapped).                                                             */
+int slu_comm_version(void);
+int slu_comm_unique_id(void* id128);
+int slu_comm_init(void** comm_out, const void* id128, int64_t nranks, int64_t rank);
+int slu_comm_allreduce_f32(void* comm, float* buf, int64_t count, void* stream);
+int slu_comm_allreduce_f64(void* comm, double* buf, int64_t count, void* stream);
+int slu_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -470,3 +470,24 @@ def test_frame_head_all_frames_unlabelled_is_nan_like_torch(ops):
     y = torch.full((2, 2), -1, dtype=torch.int64).cuda()
     loss, acc = ops.FrameHeadFn.apply(h, W, torch.zeros(5).cuda(), y)
     assert torch.isnan(loss).item()                                  # F.cross_entropy gives nan as well
+
+
+@pytest.mark.gpu
+def test_slu_comm_single_rank_allreduce():
+    """slu_comm_* (RCCL through the C ABI): a one-rank communicator on the box's GPU — init, in-place all-reduce
+    of the fp32 and fp64 gradient buckets on a side stream (identity for one rank), destroy."""
+    from slu_hip import dp, lib
+    L = lib.load()
+    assert L.slu_comm_version() >= 20000
+    comm = dp.DirectComm(0, 1, torch.device("cuda", 0))
+    st = torch.cuda.Stream()
+    a = torch.randn(302616, device="cuda")
+    b = torch.randn(160, device="cuda", dtype=torch.float64)
+    a0, b0 = a.clone(), b.clone()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        comm.allreduce(a)
+        comm.allreduce(b)
+    st.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    comm.close()
