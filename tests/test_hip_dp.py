@@ -1,7 +1,7 @@
 """GPU: the data-parallel training step of the HIP model, two processes (gloo; both ranks on the box's one GPU —
 RCCL refuses duplicate devices): flat gradient buckets (fp32 + the Sinc layer's float64), one collective per
 dtype, the mean's 1/N folded into the Adam kernel.  Two half-batch ranks must end with IDENTICAL parameters,
-equal (to summation-order round-off) to the single-process run on the full batches."""
+equal (to summation-order round-off, amplified by Adam's normalisation) to the single-process run on the full batches."""
 import os
 import socket
 import subprocess
@@ -43,7 +43,9 @@ def test_two_rank_hip_training_equals_single_process(tmp_path):
         scale = max(v.abs().max().item(), 1e-6)
         worst = max(worst, (v.double() - a["sd"][k].double()).abs().max().item() / scale)
     print("two half-batch ranks vs one full batch: worst relative parameter deviation %.2e" % worst)
-    assert worst <= 2e-5
+    # Adam divides the step by sqrt(v) ~ |g|: where a gradient entry is ~0 the two summation orders can differ in
+    # sign, which moves that parameter by up to lr = 3e-3 per step (absolute) — hence a bound of this size, not 1e-6
+    assert worst <= 2e-3
     # the per-rank losses are means over the rank's half: their mean is the full-batch loss
     for l1, la, lb in zip(one["losses"], a["losses"], b["losses"]):
         assert abs(0.5 * (la + lb) - l1) <= 1e-5
