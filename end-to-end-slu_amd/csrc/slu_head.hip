@@ -71,22 +71,37 @@ head_fwd_kernel(const HeadParams p) {
     }
   }
   __syncthreads();
-  // each thread owns whole (t, v) dot products: a[t][:] is an LDS broadcast within the threads of
-  // one t, w[v][:] rows sit on distinct banks (row stride C+1); no cross-lane reduction
-  for (int o = tid; o < T * V; o += HEAD_THREADS) {
-    const int t = o / V, v = o - t * V;
-    const float* a = sh + t * LD;
-    const float* w = p.w_in_lds ? sw + v * LD : p.W + (size_t)v * C;
-    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-    int c = 0;
-    for (; c + 3 < C; c += 4) {
-      acc0 = fmaf(a[c], w[c], acc0);
-      acc1 = fmaf(a[c + 1], w[c + 1], acc1);
-      acc2 = fmaf(a[c + 2], w[c + 2], acc2);
-      acc3 = fmaf(a[c + 3], w[c + 3], acc3);
+  // logits_t (T x V) = h (T x C) W^T on the fp32 MFMA (16 x 16 tiles, exact fp32): wave w takes tiles w, w+4, ...
+  // Rows / columns past T / V are clamped duplicates whose results are dropped.  (The previous formulation —
+  // one thread per (t, v) dot product, 2 C LDS reads each — was LDS-latency bound: 30 us for 15 MFLOP.)
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kg = lane >> 4;
+    const int MT = (T + 15) >> 4, NT = (V + 15) >> 4;
+    for (int tile = wave; tile < MT * NT; tile += HEAD_THREADS / 64) {
+      const int mt = tile / NT, nt = tile - mt * NT;
+      const float* a = sh + min(mt * 16 + i, T - 1) * LD + kg;
+      const int vb = min(nt * 16 + i, V - 1);
+      const float* w = (p.w_in_lds ? sw + vb * LD : p.W + (size_t)vb * C) + kg;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      int k0 = 0;
+      for (; k0 + 31 < C; k0 += 32) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = a[k0 + 4 * u]; bv[u] = w[k0 + 4 * u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma16(av[u], bv[u], acc);
+      }
+      for (; k0 < C; k0 += 4) {
+        const bool ok = k0 + kg < C;
+        acc = mfma16(ok ? a[k0] : 0.0f, ok ? w[k0] : 0.0f, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = mt * 16 + 4 * kg + r, v = nt * 16 + i;
+        if (t < T && v < V) sl[t * V + v] = acc[r] + p.bias[v];
+      }
     }
-    for (; c < C; ++c) acc0 = fmaf(a[c], w[c], acc0);
-    sl[o] = ((acc0 + acc1) + (acc2 + acc3)) + p.bias[v];
   }
   __syncthreads();
   if (tid < V) {
