@@ -217,19 +217,13 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
   const float* __restrict__ gxd = p.gx + (size_t)dir * 3 * H + j;
   float* __restrict__ outd = p.out + (size_t)dir * H + j;
 
-  // x-side pre-activations are fetched TWO steps ahead (cur <- nxt <- the load issued this step): one step of
-  // lead (~1 us) does not cover a global-memory round trip when the chip is busy (2-3 us beside the look-ahead
-  // super-batches), and the intent layer's T = 19 steps then ran at 1.7 instead of 1.1 us each
-  float gr[2], gz[2], gn[2], xgr[2], xgz[2], xgn[2];
+  float gr[2], gz[2], gn[2];
   {
     const int t0 = dir ? T - 1 : 0;
-    const int t1 = T > 1 ? (dir ? T - 2 : 1) : t0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float* g = gxd + (size_t)t0 * gx_ts + grow[e] * D * 3 * H;
       gr[e] = g[0]; gz[e] = g[H]; gn[e] = g[2 * H];
-      const float* g1 = gxd + (size_t)t1 * gx_ts + grow[e] * D * 3 * H;
-      xgr[e] = g1[0]; xgz[e] = g1[H]; xgn[e] = g1[2 * H];
     }
   }
   // reserve element (sequence b, unit j, component c) lives where the 16-sequence kernel puts it
@@ -241,13 +235,16 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     float ngr[2], ngz[2], ngn[2];
-    {
-      const int tn = (s + 2 < T) ? (dir ? t - 2 : t + 2) : t;     // the last two steps re-read a valid row (unused)
+    if (s + 1 < T) {
+      const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const float* g = gxd + (size_t)tn * gx_ts + grow[e] * D * 3 * H;
         ngr[e] = g[0]; ngz[e] = g[H]; ngn[e] = g[2 * H];
       }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { ngr[e] = 0.f; ngz[e] = 0.f; ngn[e] = 0.f; }
     }
 
     float af[NQ];
@@ -307,11 +304,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
       *reinterpret_cast<float2*>(rs + 4 * 256) = make_float2(hprev[0], hprev[1]);
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      hprev[e] = hn[e];
-      gr[e] = xgr[e]; gz[e] = xgz[e]; gn[e] = xgn[e];
-      xgr[e] = ngr[e]; xgz[e] = ngz[e]; xgn[e] = ngn[e];
-    }
+    for (int e = 0; e < 2; ++e) { hprev[e] = hn[e]; gr[e] = ngr[e]; gz[e] = ngz[e]; gn[e] = ngn[e]; }
     __syncthreads();
   }
 }
@@ -553,37 +546,28 @@ gru_seq_bwd4_kernel(const GruBwdParams p, const int NBT16) {
     return p.reserve + ((((size_t)dir * T + t) * NBT16) * NW16 + rsv_wave) * (5 * 256) + rsv_lane;
   };
 
-  // saved gates / upstream gradient of the current step, prefetched TWO steps ahead (c <- x <- this step's loads:
-  // see gru_seq_fwd4_kernel)
-  float2 c_r, c_z, c_n, c_q, c_h, x_r, x_z, x_n, x_q, x_h;
-  float c_do[2], x_do[2];
+  // saved gates / upstream gradient of the current step (prefetched one step ahead)
+  float2 c_r, c_z, c_n, c_q, c_h;
+  float c_do[2];
   {
-    const int t = tindex(0), t1 = tindex(T > 1 ? 1 : 0);
+    const int t = tindex(0);
     const float* rs = rsv(t);
     c_r = *reinterpret_cast<const float2*>(rs);
     c_z = *reinterpret_cast<const float2*>(rs + 256);
     c_n = *reinterpret_cast<const float2*>(rs + 512);
     c_q = *reinterpret_cast<const float2*>(rs + 768);
     c_h = *reinterpret_cast<const float2*>(rs + 1024);
-    const float* rs1 = rsv(t1);
-    x_r = *reinterpret_cast<const float2*>(rs1);
-    x_z = *reinterpret_cast<const float2*>(rs1 + 256);
-    x_n = *reinterpret_cast<const float2*>(rs1 + 512);
-    x_q = *reinterpret_cast<const float2*>(rs1 + 768);
-    x_h = *reinterpret_cast<const float2*>(rs1 + 1024);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float v = dod[(size_t)t * out_ts + grow[e] * D * H];
       c_do[e] = rowok[e] ? v : 0.f;
-      const float v1 = dod[(size_t)t1 * out_ts + grow[e] * D * H];
-      x_do[e] = rowok[e] ? v1 : 0.f;
     }
   }
 
   for (int s = 0; s < T; ++s) {
     const int t = tindex(s);
     const int cur = s & 1;
-    const int tn = tindex(s + 2 < T ? s + 2 : s);
+    const int tn = tindex(s + 1 < T ? s + 1 : s);
     const float* rsn = rsv(tn);
     const float2 n_r = *reinterpret_cast<const float2*>(rsn);
     const float2 n_z = *reinterpret_cast<const float2*>(rsn + 256);
@@ -655,11 +639,9 @@ gru_seq_bwd4_kernel(const GruBwdParams p, const int NBT16) {
       const float hi = (ar[e + 2] + az[e + 2]) + an[e + 2];
       auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
       dcarry[e] = ddirect[e] + (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
-      c_do[e] = x_do[e];
-      x_do[e] = n_do[e];
+      c_do[e] = n_do[e];
     }
-    c_r = x_r; c_z = x_z; c_n = x_n; c_q = x_q; c_h = x_h;
-    x_r = n_r; x_z = n_z; x_n = n_n; x_q = n_q; x_h = n_h;
+    c_r = n_r; c_z = n_z; c_n = n_n; c_q = n_q; c_h = n_h;
     // gbuf[cur] is rewritten two steps from now; the barrier of the next step orders that.
   }
 
