@@ -34,17 +34,11 @@ def _f32c(t, what):
 _AUX = {}
 
 
-def _aux_streams(device, n, cu_range=None):
-    """Auxiliary streams of `device`; cu_range = (first, count): streams confined to that CU range (branches of a
-    step that itself runs on a CU-masked stream must not spill onto the other partition's CUs)."""
-    key = (device.type, device.index, cu_range)
+def _aux_streams(device, n):
+    key = (device.type, device.index)
     pool = _AUX.setdefault(key, [])
     while len(pool) < n:
-        if cu_range is None:
-            pool.append(torch.cuda.Stream(device))
-        else:
-            from . import pipeline as _pl
-            pool.append(_pl.cu_range_stream(device, cu_range[0], cu_range[1]))
+        pool.append(torch.cuda.Stream(device))
     return pool[:n]
 
 
@@ -53,8 +47,7 @@ class _Fork:
     _Fork.join(device) makes the current stream wait for every auxiliary stream used since."""
     _used = {}
 
-    capture_forks = False     # set by pipeline.StepGraph while it captures a step whose branches may run in parallel
-    cu_range = None           # (first, count): the CU partition the forking step is confined to, or None
+    capture_forks = False     # set by pipeline.StepGraph while it captures a step with nothing running beside it
 
     def __init__(self, device, i):
         # Inside a captured step of the look-ahead pipeline the branches land on extra hardware queues that
@@ -64,9 +57,9 @@ class _Fork:
         self.active = _Fork.capture_forks or not torch.cuda.is_current_stream_capturing()
         if self.active:
             self.cur = torch.cuda.current_stream(device)
-            self.side = _aux_streams(device, i + 1, _Fork.cu_range)[i]
+            self.side = _aux_streams(device, i + 1)[i]
             self.ctx = torch.cuda.stream(self.side)
-            _Fork._used.setdefault((device.type, device.index), set()).add((i, _Fork.cu_range))
+            _Fork._used.setdefault((device.type, device.index), set()).add(i)
 
     def __enter__(self):
         if self.active:
@@ -81,8 +74,8 @@ class _Fork:
     def join(device):
         cur = torch.cuda.current_stream(device)
         key = (device.type, device.index)
-        for i, rng in sorted(_Fork._used.pop(key, ()), key=lambda t: t[0]):
-            cur.wait_stream(_AUX[key + (rng,)][i])
+        for i in sorted(_Fork._used.pop(key, ())):
+            cur.wait_stream(_AUX[key][i])
 
 
 def _workspace(nbytes, device):

@@ -160,10 +160,9 @@ class StepGraph:
     forward(static_inputs, rng_dev) -> (metrics, loss): `metrics` a 1-D device tensor (what the epoch
     statistics accumulate), `loss` the 0-d tensor to back-propagate."""
 
-    def __init__(self, trainer, inputs, forward, stream, forks=False, cu_range=None):
-        """forks: keep the backward pass' independent branches (ops._Fork) as parallel graph branches;
-        cu_range = (first, count): the branches' streams are confined to that CU range (the step runs on a
-        CU-masked stream beside the look-ahead partition)."""
+    def __init__(self, trainer, inputs, forward, stream, forks=False):
+        """forks: keep the backward pass' independent branches (ops._Fork) as parallel graph branches —
+        for steps that have the device to themselves (no look-ahead streams beside them)."""
         dev = next(trainer.model.parameters()).device
         self.trainer = trainer
         self.inputs = [torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for t in inputs]
@@ -178,9 +177,8 @@ class StepGraph:
         bucket.release_grads()
         self.one = torch.ones((), dtype=torch.float32, device=dev)      # root gradient (no per-step fill)
         self.g1 = torch.cuda.CUDAGraph()
-        ops._aux_streams(dev, 3, cu_range)          # created before the capture starts
+        ops._aux_streams(dev, 3)                    # created before the capture starts
         ops._Fork.capture_forks = bool(forks)
-        ops._Fork.cu_range = cu_range
         try:
             with torch.cuda.graph(self.g1, stream=stream, capture_error_mode="thread_local"):
                 self.metrics, self.loss = forward(self.inputs, self.rng)
@@ -189,7 +187,6 @@ class StepGraph:
                     bucket.pack()                   # one concatenation kernel per dtype; .grad -> slices
         finally:
             ops._Fork.capture_forks = False
-            ops._Fork.cu_range = None
         self.g2 = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
             trainer.optimizer.step()

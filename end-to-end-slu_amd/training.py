@@ -203,7 +203,7 @@ class Trainer:
                 "prefix_graphs": sum(1 for sl in slots for g in sl.graphs.values() if g is not None),
                 "capture_failures": self.capture_failures + sum(sl.capture_failures for sl in slots)}
 
-    def _graph_step(self, key, inputs, step, forward, stream, forks=False, cu_range=None):
+    def _graph_step(self, key, inputs, step, forward, stream, forks=False):
         """One optimisation step on `inputs` (device tensors): replay of the hipGraph captured for `key`
         (captured after three eager steps of that key), else eagerly.  -> metrics (tensor or list)."""
         from slu_hip import pipeline
@@ -214,7 +214,7 @@ class Trainer:
             if key not in self._step_graphs and len(self._step_graphs) >= _max_step_graphs():
                 self._step_graphs.pop(next(iter(self._step_graphs)))     # evict the oldest capture
             try:
-                sg = pipeline.StepGraph(self, inputs, forward, stream, forks, cu_range)
+                sg = pipeline.StepGraph(self, inputs, forward, stream, forks)
                 self._step_graphs[key] = sg
             except RuntimeError as e:                   # keep training eagerly if capture fails
                 print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
@@ -349,10 +349,6 @@ class Trainer:
         step_graphs = use_graph and self._graphable()
         forward = self._slu_forward(n_prefix)
         trainable = _param_signature(self.model)
-        # parallel branches inside the captured suffix (independent weight-gradient GEMMs), confined to the training
-        # partition's CUs: opt-in (SLU_SUFFIX_FORKS=1)
-        suffix_forks = os.environ.get("SLU_SUFFIX_FORKS", "0") == "1"
-        suffix_range = (0, pipeline.cu_split()) if pipeline.cu_split() > 0 else None
         # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so no
         # super-batch is wider than half the run — the second half's encoders then overlap the first half's steps
         try:
@@ -407,8 +403,7 @@ class Trainer:
                         y = batch[1].to(dev, non_blocking=True)
                         if step_graphs:
                             key = (tuple(feats.shape), tuple(y.shape), n_prefix, trainable)
-                            vals = self._graph_step(key, [feats, y], steps[k], forward, main, forks=suffix_forks,
-                                                    cu_range=suffix_range)
+                            vals = self._graph_step(key, [feats, y], steps[k], forward, main)
                         else:
                             loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
                             self._step(loss)
