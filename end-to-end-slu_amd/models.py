@@ -365,6 +365,30 @@ class _ConvStage:
         tm = time_major and fused_pool and self.drop == 0.0
         pool = self.pool if fused_pool else 1
         slope = self.slope if fused_pool else 1.0
+        # FROZEN block with nothing to differentiate: the convolution on the split-precision kernels, outside
+        # autograd (same decision in the pipelined and the sequential loop: it depends on requires_grad only)
+        nsplit = contraction_nsplit(True) if not any(q.requires_grad for q in self.parameters()) else 0
+        if os.environ.get("SLU_DTYPE", "f32") == "bf16" and not nsplit:
+            nsplit = 0                                 # trainable convolutions stay exact fp32 in bf16 mode
+        c_in = 1 if (self.is_sinc or h.dim() == 2) else h.shape[2]
+        if (nsplit and fused_pool and not h.requires_grad
+                and _ops.wconv_bf16_supported(c_in, self.conv.stride, pool)):
+            with torch.no_grad():
+                if self.is_sinc:
+                    w = self.conv.filters().view(self.conv.N_filt, 1, self.conv.Filt_dim)
+                    bias, do_abs = None, self.do_abs
+                else:
+                    w, bias, do_abs = self.conv.weight.detach(), self.conv.bias.detach(), self.do_abs
+                x3 = h if h.dim() == 3 else h.unsqueeze(2)
+                B, l_in = x3.shape[0], x3.shape[1]
+                h = _ops.wconv_fwd_bf16(x3.contiguous(), w, bias, B, l_in, c_in, self.conv.stride, do_abs, pool, slope,
+                                        tm, nsplit)
+            if self.drop > 0.0 and training:
+                p, mask, seed, offset = _dropout_args(self.drop_name, self.site, self.drop, training, cnn=True)
+                h = _DropOnlyFn.apply(h.contiguous(), p, mask, seed, offset)
+            if time_major and not tm:
+                h = h.transpose(0, 1).contiguous()
+            return h
         if self.is_sinc:
             h = _ops.SincBlockFn.apply(h, self.conv.filt_b1, self.conv.filt_band, self.conv.Filt_dim,
                                        self.conv.fs, self.conv.stride, pool, slope, tm,

@@ -254,6 +254,33 @@ def gemm_bf16(planes, packed, bias, N, K, out=None):
     return out
 
 
+def wconv_bf16_supported(c_in, stride, pool):
+    """Shapes slu_wconv_fwd_bf16 takes (else the exact fp32 kernel runs)."""
+    return pool in (1, 2) and ((c_in == 1 and stride % 8 == 0) or (c_in > 1 and stride == 1))
+
+
+def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit):
+    """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in)."""
+    L = _lib.load()
+    x = _f32c(x, "x")
+    weight = _f32c(weight, "weight")
+    c_out, _, k_t = weight.shape
+    l_conv = conv_out_len(l_in, k_t, stride)
+    l_out = -(-l_conv // pool)
+    if time_major:
+        out = torch.empty(l_out, B, c_out, dtype=torch.float32, device=x.device)
+        sb, sl = c_out, B * c_out
+    else:
+        out = torch.empty(B, l_out, c_out, dtype=torch.float32, device=x.device)
+        sb, sl = l_out * c_out, c_out
+    wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
+    ws = _workspace(wsb, x.device)
+    _lib.check(L.slu_wconv_fwd_bf16(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), B, l_in, c_in, c_out,
+                                    k_t, stride, int(do_abs), pool, float(slope), sb, sl, ws.data_ptr(), wsb, nsplit,
+                                    _stream()), "slu_wconv_fwd_bf16")
+    return out
+
+
 class SplitAct:
     """A time-major activation (T, B, C) in the split-precision format: `planes` = (nsplit, T*B, round_up(C, 32))
     bf16 (csrc/slu_bf16.h).  Travels only between FROZEN stages (no autograd)."""

@@ -121,3 +121,31 @@ def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):
     total = dots / (na ** 0.5 * nb ** 0.5)
     print("bf16 mode: gradient cosine vs fp32 oracle: whole model %.5f, worst tensor %.5f (%s)" % (total, worst, worst_name))
     assert total >= 0.995 and worst >= 0.9                     # bounds set empirically (measured 0.9996 / 0.963)
+
+
+@pytest.mark.parametrize("case", ["sinc", "sinc_odd", "conv1", "conv2", "conv2_tm"])
+@pytest.mark.parametrize("nsplit", [3, 1])
+def test_wconv_bf16_vs_exact_fp32_kernel(ops, case, nsplit):
+    """slu_wconv_fwd_bf16 (frozen CNN blocks) against the exact-fp32 windowed-conv kernel, epilogue included: the
+    Sinc layer (1 -> 80 channels, 401 taps, stride 80, abs + max-pool 2 + LeakyReLU; odd length = partial pool window),
+    conv1 (80 -> 60, k = 5) and conv2 (60 -> 60: input channels padded to 64 inside the kernel; time-major output)."""
+    torch.manual_seed(11)
+    if case.startswith("sinc"):
+        B, l_in, c_in, c_out, k, stride, do_abs, pool, tm = 5, (16000 if case == "sinc" else 15930), 1, 80, 401, 80, True, 2, False
+        x = (0.1 * torch.randn(B, l_in)).cuda()
+        w = (torch.randn(c_out, 1, k) * 0.05).cuda()
+        bias = None
+    else:
+        c_in, c_out = (80, 60) if case == "conv1" else (60, 60)
+        B, l_in, k, stride, do_abs, pool, tm = 7, 301, 5, 1, False, 1, case.endswith("_tm")
+        x = torch.randn(B, l_in, c_in).abs().cuda()
+        w = (torch.randn(c_out, c_in, k) * 0.05).cuda()
+        bias = (torch.randn(c_out) * 0.1).cuda()
+    assert ops.wconv_bf16_supported(c_in, stride, pool)
+    ref, _, _ = ops.wconv_fwd(x, w, bias, B, l_in, c_in, stride, do_abs, pool, 0.2, tm, False)
+    out = ops.wconv_fwd_bf16(x, w, bias, B, l_in, c_in, stride, do_abs, pool, 0.2, tm, nsplit)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    print("wconv bf16 %s nsplit=%d: max deviation from the fp32 kernel %.2e of the output range" % (case, nsplit, err))
+    assert err <= (1e-6 if nsplit == 3 else 2e-2)
