@@ -316,6 +316,85 @@ colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int
   if (w == 0 && n < N) out[n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// ---- batched small "A^T B" GEMMs: the weight gradients of ONE small GRU layer in one launch -------------------
+//   C_q (M_q x N_q) = A_q^T B_q,  A_q (K_q x M_q, row stride lda), B_q (K_q x N_q, row stride ldb), q < count <= 4
+// (dW_ih = d_gx^T x and dW_hh = d_gh^T h_prev of each direction).  With K = T*B of a few thousand rows (the intent
+// layer of the look-ahead pipeline: 1216) the generic kernel needs split-K plus a reduce launch per matrix to fill
+// the device: three GEMMs + three reduces, 75 us on the training stream's 64 CUs for 0.7 GFLOP.  Here a workgroup
+// owns a 32 x 32 output tile of one of the matrices, its four waves split the k range, operands go straight from
+// global memory into the exact-fp32 MFMA (both are k-slow: for a fixed k sixteen lanes read 64 contiguous bytes)
+// and the four partial tiles are summed through LDS in a fixed order (deterministic, no workspace, no second launch).
+struct TnProblem {
+  const float* A; const float* B; float* C;
+  long long lda, ldb, ldc;
+  int M, N, K;
+  int tile_end;       // exclusive prefix of tile counts
+  int tiles_n;
+};
+struct TnArgs { TnProblem p[4]; int count; };
+
+__global__ void __launch_bounds__(256)
+gemm_tn_small_kernel(const TnArgs a) {
+  __shared__ float red[4][4][256];                     // [wave][tile][lane*4 + r]
+  int q = 0;
+  while (q + 1 < a.count && (int)blockIdx.x >= a.p[q].tile_end) ++q;
+  const TnProblem& P = a.p[q];
+  const int tile = blockIdx.x - (q ? a.p[q - 1].tile_end : 0);
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+  const int m0 = tm * 32, n0 = tn * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  // this wave's k range: quarters of the 4-row MFMA steps
+  const int steps = (P.K + 3) >> 2;
+  const int per = (steps + 3) >> 2;
+  const int s0 = w * per, s1 = min(steps, s0 + per);
+  const bool mok0 = m0 + i < P.M, mok1 = m0 + 16 + i < P.M, nok0 = n0 + i < P.N, nok1 = n0 + 16 + i < P.N;
+  const float* __restrict__ pa = P.A + m0 + i;
+  const float* __restrict__ pb = P.B + n0 + i;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  constexpr int U = 4;
+  for (int sb = s0; sb < s1; sb += U) {
+    float av[U][2], bv[U][2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                      // 16 independent loads in flight
+      const int k = 4 * (sb + u) + kg;
+      const bool kok = (sb + u) < s1 && k < P.K;
+      const long long ka = (long long)(kok ? k : 0) * P.lda, kb = (long long)(kok ? k : 0) * P.ldb;
+      const float a0 = pa[ka + (mok0 ? 0 : -(m0 + i))], a1 = pa[ka + (mok1 ? 16 : -(m0 + i))];
+      const float b0 = pb[kb + (nok0 ? 0 : -(n0 + i))], b1 = pb[kb + (nok1 ? 16 : -(n0 + i))];
+      av[u][0] = (kok && mok0) ? a0 : 0.0f; av[u][1] = (kok && mok1) ? a1 : 0.0f;
+      bv[u][0] = (kok && nok0) ? b0 : 0.0f; bv[u][1] = (kok && nok1) ? b1 : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc[0][0] = mfma16(av[u][0], bv[u][0], acc[0][0]);
+      acc[0][1] = mfma16(av[u][0], bv[u][1], acc[0][1]);
+      acc[1][0] = mfma16(av[u][1], bv[u][0], acc[1][0]);
+      acc[1][1] = mfma16(av[u][1], bv[u][1], acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][2 * x + y][lane * 4 + r] = acc[x][y][r];
+  __syncthreads();
+  // wave w finishes tile w = (x, y): element (lane, r) is row 4*kg + r, column i of that 16 x 16 tile
+  {
+    const int x = w >> 1, y = w & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane * 4 + r;
+      const float v = ((red[0][w][e] + red[1][w][e]) + red[2][w][e]) + red[3][w][e];
+      const int m = m0 + 16 * x + 4 * kg + r, n = n0 + 16 * y + i;
+      if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v;
+    }
+  }
+}
+
 int colsum_splits(int64_t M) {
   int64_t rs = cdiv(M, 64);
   return (int)(rs > 256 ? 256 : (rs < 1 ? 1 : rs));
@@ -418,6 +497,29 @@ extern "C" int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const fl
                        KS, accumulate);
     SLU_CHECK_LAUNCH("gemm_splitk_reduce_kernel");
   }
+  return SLU_OK;
+}
+
+extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                   float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
+                                   const int64_t* K, int64_t count, void* stream) {
+  SLU_REQUIRE(A && B && C && lda && ldb && ldc && M && N && K, "slu_gemm_tn_batched: null pointer");
+  SLU_REQUIRE(count >= 1 && count <= 4, "slu_gemm_tn_batched: 1..4 problems per call");
+  TnArgs a;
+  int tiles = 0;
+  for (int q = 0; q < (int)count; ++q) {
+    SLU_REQUIRE(A[q] && B[q] && C[q] && M[q] > 0 && N[q] > 0 && K[q] > 0, "slu_gemm_tn_batched: bad problem %d", q);
+    SLU_REQUIRE(M[q] < (1LL << 30) && N[q] < (1LL << 30) && K[q] < (1LL << 30), "slu_gemm_tn_batched: size overflow");
+    a.p[q].A = A[q]; a.p[q].B = B[q]; a.p[q].C = C[q];
+    a.p[q].lda = lda[q]; a.p[q].ldb = ldb[q]; a.p[q].ldc = ldc[q];
+    a.p[q].M = (int)M[q]; a.p[q].N = (int)N[q]; a.p[q].K = (int)K[q];
+    a.p[q].tiles_n = (int)cdiv(N[q], 32);
+    tiles += (int)(cdiv(M[q], 32) * cdiv(N[q], 32));
+    a.p[q].tile_end = tiles;
+  }
+  a.count = (int)count;
+  hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("gemm_tn_small_kernel");
   return SLU_OK;
 }
 

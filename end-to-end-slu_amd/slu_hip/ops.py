@@ -345,6 +345,27 @@ def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, wan
     return out, reserve
 
 
+TN_SMALL_ROWS = 4096      # weight gradients of a GRU layer with T*B up to this many rows go through ONE batched launch
+
+
+def gemm_tn_batched(problems):
+    """problems: [(A (K, M), B (K, N), C (M, N))] 2-D fp32 views with unit column stride (row strides free);
+    C_q = A_q^T B_q for up to four problems in one launch (slu_gemm_tn_batched)."""
+    import ctypes
+    L = _lib.load()
+    n = len(problems)
+    for A, B, C in problems:
+        assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1 and A.shape[0] == B.shape[0]
+        assert C.shape == (A.shape[1], B.shape[1])
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    arr = lambda ty, vals: (ty * n)(*vals)
+    _lib.check(L.slu_gemm_tn_batched(arr(vp, [p[0].data_ptr() for p in problems]), arr(i64, [p[0].stride(0) for p in problems]),
+                                     arr(vp, [p[1].data_ptr() for p in problems]), arr(i64, [p[1].stride(0) for p in problems]),
+                                     arr(vp, [p[2].data_ptr() for p in problems]), arr(i64, [p[2].stride(0) for p in problems]),
+                                     arr(i64, [p[2].shape[0] for p in problems]), arr(i64, [p[2].shape[1] for p in problems]),
+                                     arr(i64, [p[0].shape[0] for p in problems]), n, _stream()), "slu_gemm_tn_batched")
+
+
 def colsum(x2d, out=None, accumulate=False):
     L = _lib.load()
     M, N = x2d.shape
@@ -654,6 +675,35 @@ class GRULayerFn(torch.autograd.Function):
         r2 = raw.view(T * B, D * H)
         grads = [None] * 19
         dev = x.device
+        small = T * B <= TN_SMALL_ROWS and T > 1 and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
+        if small:
+            # a few thousand rows (the intent layer of the look-ahead pipeline): every weight gradient of the layer
+            # in ONE launch (no split-K workspaces, no reduce launches).  The choice depends on the shape only.
+            n = (T - 1) * B
+            dW = torch.empty(D * 3 * H, I, dtype=torch.float32, device=dev)
+            probs = [(g2, x2, dW)]
+            outs = []
+            for d in range(D):
+                hd = h2[:, d * 3 * H:(d + 1) * 3 * H]
+                ga, hp = (hd[B:], r2[:n, :H]) if d == 0 else (hd[:n], r2[B:, H:])
+                dWh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
+                probs.append((ga, hp, dWh))
+                outs.append(dWh)
+            gemm_tn_batched(probs)
+            grads[3] = dW[:3 * H]
+            if D == 2:
+                grads[4] = dW[3 * H:]
+            for d in range(D):
+                grads[7 + 2 * d] = outs[d]
+                if ng[8 + 2 * d]:
+                    grads[8 + 2 * d] = dbp[d, 3 * H:]
+            if ng[0]:
+                grads[0] = gemm(g2, w_ih).view(T, B, I)
+            if ng[5]:
+                grads[5] = dbp[0, :3 * H]
+            if D == 2 and ng[6]:
+                grads[6] = dbp[1, :3 * H]
+            return tuple(grads)
         # The weight-gradient GEMMs are independent of each other and of the data-gradient GEMM: they
         # run on auxiliary streams (graph branches under capture) while dx proceeds on this one.
         if ng[3] or ng[4]:                                 # dW_ih = d_gx^T x, one GEMM for both directions

@@ -114,6 +114,13 @@ int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
                  int64_t b_cs, float* C, int64_t c_rs, int64_t c_cs, const float* bias_n,
                  int64_t M, int64_t N, int64_t K, int accumulate, void* workspace,
                  size_t workspace_bytes, void* stream);
+/* Up to four small weight-gradient GEMMs in ONE launch, no workspace, deterministic:
+ * C_q (M_q x N_q, row stride ldc) = A_q^T B_q with A_q (K_q x M_q, row stride lda), B_q (K_q x N_q, row stride ldb)
+ * — dW_ih = d_gx^T x and dW_hh = d_gh^T h_prev (per direction) of one GRU layer when T*B is a few thousand rows
+ * (the generic kernel would need split-K and a reduce launch per matrix).  Pointer / size arrays are HOST arrays. */
+int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                        float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K,
+                        int64_t count, void* stream);
 /* out[n] = [out[n] if accumulate] + sum_m X[m*x_rs + n]   (bias gradients)                       */
 int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,
                    int accumulate, void* stream);
