@@ -354,11 +354,11 @@ gemm_tn_small_kernel(const TnArgs a) {
   f32x4 acc[2][2];
 #pragma unroll
   for (int x = 0; x < 2; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  constexpr int U = 4;
-  for (int sb = s0; sb < s1; sb += U) {
+  constexpr int U = 16;                                // 64 independent loads in flight per lane: a wave has only
+  for (int sb = s0; sb < s1; sb += U) {                // ceil(K / 64 / U) memory round trips (2-3 us each under load)
     float av[U][2], bv[U][2];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {                      // 16 independent loads in flight
+    for (int u = 0; u < U; ++u) {
       const int k = 4 * (sb + u) + kg;
       const bool kok = (sb + u) < s1 && k < P.K;
       const long long ka = (long long)(kok ? k : 0) * P.lda, kb = (long long)(kok ? k : 0) * P.ldb;
