@@ -349,8 +349,8 @@ gemm_tn_small_kernel(const TnArgs a) {
   // stored, so no select sits between a load and its MFMA (a select there makes the compiler wait for each load
   // where it is issued: measured 80 us instead of 20 for the intent layer's three matrices).
   const int steps = P.K >> 2;
-  const int per = (steps + 3) >> 2;
-  const int s0 = w * per, s1 = min(steps, s0 + per);
+  const int per = ((((steps + 3) >> 2) + 7) >> 3) << 3;   // a multiple of the batch size U = 8: no per-step tail loop
+  const int s0 = min(steps, w * per), s1 = min(steps, s0 + per);
   const float* __restrict__ pa0 = P.A + (m0 + i < P.M ? m0 + i : 0);
   const float* __restrict__ pa1 = P.A + (m0 + 16 + i < P.M ? m0 + 16 + i : 0);
   const float* __restrict__ pb0 = P.B + (n0 + i < P.N ? n0 + i : 0);
