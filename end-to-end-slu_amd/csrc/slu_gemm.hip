@@ -351,10 +351,11 @@ gemm_tn_small_kernel(const TnArgs a) {
   const int steps = P.K >> 2;
   const int per = ((((steps + 3) >> 2) + 7) >> 3) << 3;   // a multiple of the batch size U = 8: no per-step tail loop
   const int s0 = min(steps, w * per), s1 = min(steps, s0 + per);
-  const float* __restrict__ pa0 = P.A + (m0 + i < P.M ? m0 + i : 0);
-  const float* __restrict__ pa1 = P.A + (m0 + 16 + i < P.M ? m0 + 16 + i : 0);
-  const float* __restrict__ pb0 = P.B + (n0 + i < P.N ? n0 + i : 0);
-  const float* __restrict__ pb1 = P.B + (n0 + 16 + i < P.N ? n0 + 16 + i : 0);
+  // ONE 8-byte load per operand and k row feeds both 16-wide MFMA tiles of its dimension: lane i holds columns
+  // 2i and 2i+1, i.e. MFMA tile x covers the columns m0 + 2*(0..15) + x (a permutation, undone at the store).
+  // Sixteen lanes read 128 contiguous bytes.  (M, N even: checked by the launcher.)
+  const float* __restrict__ pa = P.A + (m0 + 2 * i + 1 < P.M ? m0 + 2 * i : 0);
+  const float* __restrict__ pb = P.B + (n0 + 2 * i + 1 < P.N ? n0 + 2 * i : 0);
   f32x4 acc[2][2];
 #pragma unroll
   for (int x = 0; x < 2; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -363,20 +364,20 @@ gemm_tn_small_kernel(const TnArgs a) {
   // loads, which would send the register arrays through scratch memory)
   constexpr int U = 8;
   const int nb = (s1 > s0) ? (s1 - s0) / U : 0;
-  float avA[U][2], bvA[U][2], avB[U][2], bvB[U][2];
+  float2 avA[U], bvA[U], avB[U], bvB[U];
 #define TN_LOAD(av, bv, batch)                                                        \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
     const long long k = 4 * (s0 + (batch) * U + u) + kg;                               \
-    av[u][0] = pa0[k * P.lda]; av[u][1] = pa1[k * P.lda];                              \
-    bv[u][0] = pb0[k * P.ldb]; bv[u][1] = pb1[k * P.ldb];                              \
+    av[u] = *reinterpret_cast<const float2*>(pa + k * P.lda);                          \
+    bv[u] = *reinterpret_cast<const float2*>(pb + k * P.ldb);                          \
   }                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define TN_MFMA(av, bv)                                                                \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
-    acc[0][0] = mfma16(av[u][0], bv[u][0], acc[0][0]);                                 \
-    acc[0][1] = mfma16(av[u][0], bv[u][1], acc[0][1]);                                 \
-    acc[1][0] = mfma16(av[u][1], bv[u][0], acc[1][0]);                                 \
-    acc[1][1] = mfma16(av[u][1], bv[u][1], acc[1][1]);                                 \
+    acc[0][0] = mfma16(av[u].x, bv[u].x, acc[0][0]);                                   \
+    acc[0][1] = mfma16(av[u].x, bv[u].y, acc[0][1]);                                   \
+    acc[1][0] = mfma16(av[u].y, bv[u].x, acc[1][0]);                                   \
+    acc[1][1] = mfma16(av[u].y, bv[u].y, acc[1][1]);                                   \
   }                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
   if (nb > 0) {
@@ -393,18 +394,19 @@ gemm_tn_small_kernel(const TnArgs a) {
   int sb = s0 + nb * U;
   for (; sb < s1; ++sb) {                              // fewer than U full steps left
     const long long k = 4 * sb + kg;
-    const float a0 = pa0[k * P.lda], a1 = pa1[k * P.lda], b0 = pb0[k * P.ldb], b1 = pb1[k * P.ldb];
-    acc[0][0] = mfma16(a0, b0, acc[0][0]); acc[0][1] = mfma16(a0, b1, acc[0][1]);
-    acc[1][0] = mfma16(a1, b0, acc[1][0]); acc[1][1] = mfma16(a1, b1, acc[1][1]);
+    const float2 a = *reinterpret_cast<const float2*>(pa + k * P.lda), b = *reinterpret_cast<const float2*>(pb + k * P.ldb);
+    acc[0][0] = mfma16(a.x, b.x, acc[0][0]); acc[0][1] = mfma16(a.x, b.y, acc[0][1]);
+    acc[1][0] = mfma16(a.y, b.x, acc[1][0]); acc[1][1] = mfma16(a.y, b.y, acc[1][1]);
   }
   if (w == 3 && (P.K & 3)) {                           // partial last step: zero the rows past K
     const long long k = 4 * steps + kg;
     const bool kok = k < P.K;
     const long long kc = kok ? k : 0;
-    float a0 = pa0[kc * P.lda], a1 = pa1[kc * P.lda], b0 = pb0[kc * P.ldb], b1 = pb1[kc * P.ldb];
-    a0 = kok ? a0 : 0.0f; a1 = kok ? a1 : 0.0f;
-    acc[0][0] = mfma16(a0, b0, acc[0][0]); acc[0][1] = mfma16(a0, b1, acc[0][1]);
-    acc[1][0] = mfma16(a1, b0, acc[1][0]); acc[1][1] = mfma16(a1, b1, acc[1][1]);
+    float2 a = *reinterpret_cast<const float2*>(pa + kc * P.lda);
+    const float2 b = *reinterpret_cast<const float2*>(pb + kc * P.ldb);
+    a.x = kok ? a.x : 0.0f; a.y = kok ? a.y : 0.0f;
+    acc[0][0] = mfma16(a.x, b.x, acc[0][0]); acc[0][1] = mfma16(a.x, b.y, acc[0][1]);
+    acc[1][0] = mfma16(a.y, b.x, acc[1][0]); acc[1][1] = mfma16(a.y, b.y, acc[1][1]);
   }
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -420,7 +422,7 @@ gemm_tn_small_kernel(const TnArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int e = lane * 4 + r;
       const float v = ((red[0][w][e] + red[1][w][e]) + red[2][w][e]) + red[3][w][e];
-      const int m = m0 + 16 * x + 4 * kg + r, n = n0 + 16 * y + i;
+      const int m = m0 + 2 * (4 * kg + r) + x, n = n0 + 2 * i + y;      // MFMA tile (x, y), row 4*kg + r, column i
       if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v;
     }
   }
@@ -541,6 +543,8 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
   for (int q = 0; q < (int)count; ++q) {
     SLU_REQUIRE(A[q] && B[q] && C[q] && M[q] > 0 && N[q] > 0 && K[q] > 0, "slu_gemm_tn_batched: bad problem %d", q);
     SLU_REQUIRE(M[q] < (1LL << 30) && N[q] < (1LL << 30) && K[q] < (1LL << 30), "slu_gemm_tn_batched: size overflow");
+    if ((M[q] | N[q] | lda[q] | ldb[q]) & 1 || ((uintptr_t)A[q] | (uintptr_t)B[q]) & 7)
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: M, N and the row strides must be even, operands 8-byte aligned");
     a.p[q].A = A[q]; a.p[q].B = B[q]; a.p[q].C = C[q];
     a.p[q].lda = lda[q]; a.p[q].ldb = ldb[q]; a.p[q].ldc = ldc[q];
     a.p[q].M = (int)M[q]; a.p[q].N = (int)N[q]; a.p[q].K = (int)K[q];
