@@ -116,32 +116,44 @@ head_fwd_kernel(const HeadParams p) {
     p.argmax_t[(size_t)b * V + tid] = arg;
   }
   __syncthreads();
-  if (tid == 0) {
-    float loss = 0.0f;
-    bool all_ok = true;
-    for (int s = 0; s < p.S; ++s) {
-      const int v0 = p.slot_begin[s], v1 = p.slot_begin[s + 1];
-      float mx = sm[v0];
-      int am = v0;
-      for (int v = v0 + 1; v < v1; ++v) if (sm[v] > mx) { mx = sm[v]; am = v; }
-      p.pred[(size_t)b * p.S + s] = am - v0;
-      if (p.y) {
-        float den = 0.0f;
-        for (int v = v0; v < v1; ++v) den += expf(sm[v] - mx);
-        const int yv = (int)p.y[(size_t)b * p.S + s];
-        loss += logf(den) - (sm[v0 + yv] - mx);       // -log softmax[y]
-        all_ok = all_ok && (am - v0 == yv);
-        if (p.d_logits) {
-          const float inv = 1.0f / (den * (float)p.B);
-          for (int v = v0; v < v1; ++v)
-            p.d_logits[(size_t)b * V + v] = expf(sm[v] - mx) * inv - ((v - v0 == yv) ? 1.0f / (float)p.B : 0.0f);
-        }
+  // per-slot softmax / cross-entropy / arg-max: lane v of wave 0 handles classifier output v (each lane scans its own
+  // slot, <= a few dozen values; one lane for everything was a ~100-expf serial chain), lane 0 then folds the slots
+  __shared__ float s_part[HEAD_THREADS];               // per output: its slot's -log softmax[y] (on the slot's first lane)
+  __shared__ int s_ok[HEAD_THREADS];
+  if (tid < V) {
+    int sl_ = 0;
+    while (sl_ + 1 < p.S && tid >= p.slot_begin[sl_ + 1]) ++sl_;
+    const int v0 = p.slot_begin[sl_], v1 = p.slot_begin[sl_ + 1];
+    float mx = sm[v0];
+    int am = v0;
+    for (int v = v0 + 1; v < v1; ++v) if (sm[v] > mx) { mx = sm[v]; am = v; }       // first maximum wins
+    if (tid == v0) p.pred[(size_t)b * p.S + sl_] = am - v0;
+    s_part[tid] = 0.0f;
+    s_ok[tid] = 1;
+    if (p.y) {
+      float den = 0.0f;
+      for (int v = v0; v < v1; ++v) den += expf(sm[v] - mx);                          // same order for every lane
+      const int yv = (int)p.y[(size_t)b * p.S + sl_];
+      if (tid == v0) {
+        s_part[tid] = logf(den) - (sm[v0 + yv] - mx);                                 // -log softmax[y]
+        s_ok[tid] = (am - v0 == yv) ? 1 : 0;
+      }
+      if (p.d_logits) {
+        const float inv = 1.0f / (den * (float)p.B);
+        p.d_logits[(size_t)b * V + tid] = expf(sm[tid] - mx) * inv - ((tid - v0 == yv) ? 1.0f / (float)p.B : 0.0f);
       }
     }
-    if (p.y) {
-      p.row_stats[2 * b] = loss;
-      p.row_stats[2 * b + 1] = all_ok ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  if (tid == 0 && p.y) {
+    float loss = 0.0f;
+    bool all_ok = true;
+    for (int s2 = 0; s2 < p.S; ++s2) {                  // slot order: the summation order of the reference's loop
+      loss += s_part[p.slot_begin[s2]];
+      all_ok = all_ok && (s_ok[p.slot_begin[s2]] != 0);
     }
+    p.row_stats[2 * b] = loss;
+    p.row_stats[2 * b + 1] = all_ok ? 1.0f : 0.0f;
   }
 }
 
