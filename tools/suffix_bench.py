@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Times the kernels of the trainable suffix of the pipelined step (intent layer, B = 64, T = 19) ALONE on a
+64-CU masked stream (20 launches back to back in one hipGraph): what each costs without the look-ahead
+partition's traffic beside it.   python tools/suffix_bench.py"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "end-to-end-slu_amd"))
+import torch
+from bench import _timed_graph
+from slu_hip import ops, pipeline
+
+dev = torch.device("cuda", 0)
+st = pipeline.cu_range_stream(dev, 0, 64)
+T, B, I, H, D, V = 19, 64, 256, 128, 2, 24
+x = torch.randn(T * B, I, device=dev)
+w_ih = torch.randn(D * 3 * H, I, device=dev) * 0.05
+b_ih = torch.randn(D * 3 * H, device=dev)
+gx = torch.randn(T, B, D * 3 * H, device=dev)
+wf, wr = torch.randn(3 * H, H, device=dev) * 0.08, torch.randn(3 * H, H, device=dev) * 0.08
+bf, br = torch.randn(3 * H, device=dev), torch.randn(3 * H, device=dev)
+print("input projection gemm (1216 x 768 x 256): %.1f us" % (1e3 * _timed_graph(lambda: ops.gemm(x, w_ih.t(), b_ih), st)))
+print("gru_seq_fwd (4-seq, reserve): %.1f us" % (1e3 * _timed_graph(lambda: ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, True), st)))
+out, rsv = ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, True)
+d_out = torch.randn(T, B, D * H, device=dev)
+print("gru_seq_bwd (4-seq): %.1f us" % (1e3 * _timed_graph(lambda: ops.gru_seq_bwd(d_out, rsv, wf, wr, T, B, H, D), st)))
+d_gx, d_gh, dbp = ops.gru_seq_bwd(d_out, rsv, wf, wr, T, B, H, D)
+g2, h2, r2 = d_gx.view(T * B, -1), d_gh.view(T * B, -1), out.view(T * B, -1)
+n = (T - 1) * B
+dW = torch.empty(D * 3 * H, I, device=dev)
+dWf, dWr = torch.empty(3 * H, H, device=dev), torch.empty(3 * H, H, device=dev)
+probs = [(g2, x, dW), (h2[B:, :3 * H], r2[:n, :H], dWf), (h2[:n, 3 * H:], r2[B:, H:], dWr)]
+print("gemm_tn_batched (3 weight gradients): %.1f us" % (1e3 * _timed_graph(lambda: ops.gemm_tn_batched(probs), st)))
+def old():
+    ops.gemm(g2.t(), x, out=dW); ops.gemm(probs[1][0].t(), probs[1][1], out=dWf); ops.gemm(probs[2][0].t(), probs[2][1], out=dWr)
+print("three split-K gemms + reduces (round-1 path): %.1f us" % (1e3 * _timed_graph(old, st)))
+h = torch.randn(T, B, D * H, device=dev)
+cw, cb = torch.randn(V, D * H, device=dev) * 0.05, torch.randn(V, device=dev)
+y = torch.stack([torch.randint(0, k, (B,)) for k in (6, 14, 4)], 1).to(dev)
+print("head fwd (+reduce): %.1f us" % (1e3 * _timed_graph(lambda: ops.cls_maxpool_ce_fwd(h, cw, cb, y, (6, 14, 4), True), st)))
+print("dropout_pool fwd: %.1f us" % (1e3 * _timed_graph(lambda: ops.dropout_pool_fwd(out, None, 0.5, 1, 16, "none", 1), st)))
