@@ -320,9 +320,9 @@ colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int
 //   C_q (M_q x N_q) = A_q^T B_q,  A_q (K_q x M_q, row stride lda), B_q (K_q x N_q, row stride ldb), q < count <= 4
 // (dW_ih = d_gx^T x and dW_hh = d_gh^T h_prev of each direction).  With K = T*B of a few thousand rows (the intent
 // layer of the look-ahead pipeline: 1216) the generic kernel needs split-K plus a reduce launch per matrix to fill
-// the device: three GEMMs + three reduces, 75 us on the training stream's 64 CUs for 0.7 GFLOP.  Here a workgroup
-// owns a 32 x 32 output tile of one of the matrices, its four waves split the k range, operands go straight from
-// global memory into the exact-fp32 MFMA (both are k-slow: for a fixed k sixteen lanes read 64 contiguous bytes)
+// the device: three GEMMs + three reduces, 66-75 us on the training stream's 64 CUs for 0.7 GFLOP.  Here a workgroup
+// owns a 64 x 32 output tile of one of the matrices, its four waves split the k range, operands go straight from
+// global memory into the exact-fp32 MFMA (both are k-slow: for a fixed k sixteen lanes read 256 / 128 contiguous bytes)
 // and the four partial tiles are summed through LDS in a fixed order (deterministic, no workspace, no second launch).
 struct TnProblem {
   const float* A; const float* B; float* C;
@@ -335,50 +335,53 @@ struct TnArgs { TnProblem p[4]; int count; };
 
 __global__ void __launch_bounds__(256)
 gemm_tn_small_kernel(const TnArgs a) {
-  __shared__ float red[4][4][256];                     // [wave][tile][lane*4 + r]
+  __shared__ float red[4][8][256];                     // [wave][tile][lane*4 + r]
   int q = 0;
   while (q + 1 < a.count && (int)blockIdx.x >= a.p[q].tile_end) ++q;
   const TnProblem& P = a.p[q];
   const int tile = blockIdx.x - (q ? a.p[q - 1].tile_end : 0);
   const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
-  const int m0 = tm * 32, n0 = tn * 32;
+  const int m0 = tm * 64, n0 = tn * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kg = lane >> 4;
   // this wave's k range: quarters of the FULL 4-row MFMA steps; a partial last step (K % 4 != 0) goes to wave 3.
   // Rows / columns of the tile past M / N read column 0 instead: the accumulator rows / columns they feed are never
   // stored, so no select sits between a load and its MFMA (a select there makes the compiler wait for each load
-  // where it is issued: measured 80 us instead of 20 for the intent layer's three matrices).
+  // where it is issued: measured 80 us instead of 50 for the intent layer's three matrices).
   const int steps = P.K >> 2;
   const int per = ((((steps + 3) >> 2) + 7) >> 3) << 3;   // a multiple of the batch size U = 8: no per-step tail loop
   const int s0 = min(steps, w * per), s1 = min(steps, s0 + per);
-  // ONE 8-byte load per operand and k row feeds both 16-wide MFMA tiles of its dimension: lane i holds columns
-  // 2i and 2i+1, i.e. MFMA tile x covers the columns m0 + 2*(0..15) + x (a permutation, undone at the store).
-  // Sixteen lanes read 128 contiguous bytes.  (M, N even: checked by the launcher.)
-  const float* __restrict__ pa = P.A + (m0 + 2 * i + 1 < P.M ? m0 + 2 * i : 0);
+  // ONE 16-byte (A) and ONE 8-byte (B) load per k row feed all MFMA tiles of a 64 x 32 output tile: lane i holds
+  // columns 4i..4i+3 of A and 2i, 2i+1 of B, i.e. MFMA row-tile x covers the rows m0 + 4*(0..15) + x and column-tile
+  // y the columns n0 + 2*(0..15) + y (a permutation, undone at the store).  A workgroup moves (64 + 32) K floats
+  // for 64 x 32 x K MACs: the kernel is bound by what one CU can pull through its L1 (~60 GB/s), 32 x 32 tiles
+  // moved 1.5x as much per MAC.  (M % 4 == 0, N % 2 == 0: checked by the launcher.)
+  const float* __restrict__ pa = P.A + (m0 + 4 * i + 3 < P.M ? m0 + 4 * i : 0);
   const float* __restrict__ pb = P.B + (n0 + 2 * i + 1 < P.N ? n0 + 2 * i : 0);
-  f32x4 acc[2][2];
+  f32x4 acc[4][2];
 #pragma unroll
-  for (int x = 0; x < 2; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // batches of U = 8 MFMA steps (32 loads per lane), software-pipelined over two register sets: the next batch's
+  for (int x = 0; x < 4; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // batches of U = 8 MFMA steps (16 loads per lane), software-pipelined over two register sets: the next batch's
   // loads are issued before the current batch's MFMAs (the batch index is clamped instead of branching around the
   // loads, which would send the register arrays through scratch memory)
   constexpr int U = 8;
   const int nb = (s1 > s0) ? (s1 - s0) / U : 0;
-  float2 avA[U], bvA[U], avB[U], bvB[U];
+  float4 avA[U], avB[U];
+  float2 bvA[U], bvB[U];
 #define TN_LOAD(av, bv, batch)                                                        \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
     const long long k = 4 * (s0 + (batch) * U + u) + kg;                               \
-    av[u] = *reinterpret_cast<const float2*>(pa + k * P.lda);                          \
+    av[u] = *reinterpret_cast<const float4*>(pa + k * P.lda);                          \
     bv[u] = *reinterpret_cast<const float2*>(pb + k * P.ldb);                          \
   }                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
+#define TN_STEP(a_, b_)                                                                \
+  acc[0][0] = mfma16(a_.x, b_.x, acc[0][0]); acc[0][1] = mfma16(a_.x, b_.y, acc[0][1]); \
+  acc[1][0] = mfma16(a_.y, b_.x, acc[1][0]); acc[1][1] = mfma16(a_.y, b_.y, acc[1][1]); \
+  acc[2][0] = mfma16(a_.z, b_.x, acc[2][0]); acc[2][1] = mfma16(a_.z, b_.y, acc[2][1]); \
+  acc[3][0] = mfma16(a_.w, b_.x, acc[3][0]); acc[3][1] = mfma16(a_.w, b_.y, acc[3][1]);
 #define TN_MFMA(av, bv)                                                                \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
-    acc[0][0] = mfma16(av[u].x, bv[u].x, acc[0][0]);                                   \
-    acc[0][1] = mfma16(av[u].x, bv[u].y, acc[0][1]);                                   \
-    acc[1][0] = mfma16(av[u].y, bv[u].x, acc[1][0]);                                   \
-    acc[1][1] = mfma16(av[u].y, bv[u].y, acc[1][1]);                                   \
-  }                                                                                    \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) { TN_STEP(av[u], bv[u]) }              \
   __builtin_amdgcn_sched_barrier(0);
   if (nb > 0) {
     TN_LOAD(avA, bvA, 0)
@@ -389,43 +392,42 @@ gemm_tn_small_kernel(const TnArgs a) {
       if (bt + 1 < nb) { TN_MFMA(avB, bvB) }
     }
   }
-#undef TN_MFMA
-#undef TN_LOAD
   int sb = s0 + nb * U;
   for (; sb < s1; ++sb) {                              // fewer than U full steps left
     const long long k = 4 * sb + kg;
-    const float2 a = *reinterpret_cast<const float2*>(pa + k * P.lda), b = *reinterpret_cast<const float2*>(pb + k * P.ldb);
-    acc[0][0] = mfma16(a.x, b.x, acc[0][0]); acc[0][1] = mfma16(a.x, b.y, acc[0][1]);
-    acc[1][0] = mfma16(a.y, b.x, acc[1][0]); acc[1][1] = mfma16(a.y, b.y, acc[1][1]);
+    const float4 av = *reinterpret_cast<const float4*>(pa + k * P.lda);
+    const float2 bv = *reinterpret_cast<const float2*>(pb + k * P.ldb);
+    TN_STEP(av, bv)
   }
   if (w == 3 && (P.K & 3)) {                           // partial last step: zero the rows past K
     const long long k = 4 * steps + kg;
     const bool kok = k < P.K;
     const long long kc = kok ? k : 0;
-    float2 a = *reinterpret_cast<const float2*>(pa + kc * P.lda);
-    const float2 b = *reinterpret_cast<const float2*>(pb + kc * P.ldb);
-    a.x = kok ? a.x : 0.0f; a.y = kok ? a.y : 0.0f;
-    acc[0][0] = mfma16(a.x, b.x, acc[0][0]); acc[0][1] = mfma16(a.x, b.y, acc[0][1]);
-    acc[1][0] = mfma16(a.y, b.x, acc[1][0]); acc[1][1] = mfma16(a.y, b.y, acc[1][1]);
+    float4 av = *reinterpret_cast<const float4*>(pa + kc * P.lda);
+    const float2 bv = *reinterpret_cast<const float2*>(pb + kc * P.ldb);
+    av.x = kok ? av.x : 0.0f; av.y = kok ? av.y : 0.0f; av.z = kok ? av.z : 0.0f; av.w = kok ? av.w : 0.0f;
+    TN_STEP(av, bv)
   }
+#undef TN_MFMA
+#undef TN_STEP
+#undef TN_LOAD
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[w][2 * x + y][lane * 4 + r] = acc[x][y][r];
   __syncthreads();
-  // wave w finishes tile w = (x, y): element (lane, r) is row 4*kg + r, column i of that 16 x 16 tile
-  {
-    const int x = w >> 1, y = w & 1;
+  // wave w finishes the two tiles of row-tile x = w: element (lane, r) is row 4*kg + r, column i of a 16 x 16 tile
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e = lane * 4 + r;
-      const float v = ((red[0][w][e] + red[1][w][e]) + red[2][w][e]) + red[3][w][e];
-      const int m = m0 + 2 * (4 * kg + r) + x, n = n0 + 2 * i + y;      // MFMA tile (x, y), row 4*kg + r, column i
+      const int e = lane * 4 + r, t = 2 * w + y;
+      const float v = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+      const int m = m0 + 4 * (4 * kg + r) + w, n = n0 + 2 * i + y;
       if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v;
     }
-  }
 }
 
 int colsum_splits(int64_t M) {
@@ -543,13 +545,13 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
   for (int q = 0; q < (int)count; ++q) {
     SLU_REQUIRE(A[q] && B[q] && C[q] && M[q] > 0 && N[q] > 0 && K[q] > 0, "slu_gemm_tn_batched: bad problem %d", q);
     SLU_REQUIRE(M[q] < (1LL << 30) && N[q] < (1LL << 30) && K[q] < (1LL << 30), "slu_gemm_tn_batched: size overflow");
-    if ((M[q] | N[q] | lda[q] | ldb[q]) & 1 || ((uintptr_t)A[q] | (uintptr_t)B[q]) & 7)
-      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: M, N and the row strides must be even, operands 8-byte aligned");
+    if ((M[q] | lda[q]) & 3 || (N[q] | ldb[q]) & 1 || ((uintptr_t)A[q] & 15) || ((uintptr_t)B[q] & 7))
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: M and lda must be multiples of 4 (A 16-byte aligned), N and ldb even (B 8-byte aligned)");
     a.p[q].A = A[q]; a.p[q].B = B[q]; a.p[q].C = C[q];
     a.p[q].lda = lda[q]; a.p[q].ldb = ldb[q]; a.p[q].ldc = ldc[q];
     a.p[q].M = (int)M[q]; a.p[q].N = (int)N[q]; a.p[q].K = (int)K[q];
     a.p[q].tiles_n = (int)cdiv(N[q], 32);
-    tiles += (int)(cdiv(M[q], 32) * cdiv(N[q], 32));
+    tiles += (int)(cdiv(M[q], 64) * cdiv(N[q], 32));
     a.p[q].tile_end = tiles;
   }
   a.count = (int)count;

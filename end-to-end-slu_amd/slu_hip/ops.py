@@ -676,7 +676,7 @@ class GRULayerFn(torch.autograd.Function):
         grads = [None] * 19
         dev = x.device
         small = (T * B <= TN_SMALL_ROWS and T > 1 and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
-                 and I % 2 == 0 and H % 2 == 0)
+                 and I % 4 == 0 and H % 4 == 0)
         if small:
             # a few thousand rows (the intent layer of the look-ahead pipeline): every weight gradient of the layer
             # in ONE launch (no split-K workspaces, no reduce launches).  The choice depends on the shape only.

@@ -117,7 +117,7 @@ int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
 /* Up to four small weight-gradient GEMMs in ONE launch, no workspace, deterministic:
  * C_q (M_q x N_q, row stride ldc) = A_q^T B_q with A_q (K_q x M_q, row stride lda), B_q (K_q x N_q, row stride ldb)
  * — dW_ih = d_gx^T x and dW_hh = d_gh^T h_prev (per direction) of one GRU layer when T*B is a few thousand rows
- * (the generic kernel would need split-K and a reduce launch per matrix).  M, N, lda, ldb even.  Pointer / size
+ * (the generic kernel would need split-K and a reduce launch per matrix).  M, lda multiples of 4; N, ldb even.  Pointer / size
  * arrays are HOST arrays.                                                                                        */
 int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
                         float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K,
