@@ -38,6 +38,15 @@ elif what == "gru_bf":
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
         ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, 3)
+elif what == "tn":
+    # the intent layer's three weight gradients in one batched launch (T = 19, B = 64)
+    T, B, I, H, D = 19, 64, 256, 128, 2
+    x = torch.randn(T * B, I, device="cuda"); g2 = torch.randn(T * B, D * 3 * H, device="cuda"); h2 = torch.randn(T * B, D * 3 * H, device="cuda")
+    r2 = torch.randn(T * B, D * H, device="cuda"); n = (T - 1) * B
+    dW = torch.empty(D * 3 * H, I, device="cuda"); dWf = torch.empty(3 * H, H, device="cuda"); dWr = torch.empty(3 * H, H, device="cuda")
+    probs = [(g2, x, dW), (h2[B:, :3 * H], r2[:n, :H], dWf), (h2[:n, 3 * H:], r2[B:, H:], dWr)]
+    for _ in range(10):
+        ops.gemm_tn_batched(probs)
 elif what == "gru":
     T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 128
     gx = torch.randn(T, B, 6 * H, device="cuda")
