@@ -46,20 +46,18 @@ def _param_signature(model):
 
 
 def _lookahead_width(depth, batch_size):
-    """Batches per look-ahead super-batch: explicit, or as many as give every CU the side streams may use one
-    recurrence workgroup per direction at the kernels' sequence-tile size.  Split-precision recurrence of the
-    frozen layers (default): one 16-sequence workgroup per CU and direction = 8 sequences per CU, 1536 on the
-    192 CUs of the default partition; exact-fp32 kernels (SLU_FROZEN_MATH=fp32): two 4-sequence workgroups per
-    CU and direction = 4 sequences per CU, 768 (best of a 4..14 sweep on MI355X)."""
+    """Batches per look-ahead super-batch: explicit, or four sequences per CU the side streams may use: 768
+    sequences = 12 batches of 64 on the 192 CUs of the default partition.  Measured on MI355X (bench.py, 512 steps,
+    round 2): 8 / 10 / 12 / 14 / 18 / 24 / 32 batches -> 214 / 232 / 249 / 250 / 244 / 233-240 / 241 k utt/s: wider
+    super-batches make the frozen stages more efficient in isolation (190 vs 231 us per step at 24 vs 12) but every
+    group boundary of the pipeline costs about a millisecond per 24 batches, which outweighs it."""
     if depth > 0:
         return depth
     from slu_hip import pipeline
-    from models import contraction_nsplit
     cus = 256
     if torch.cuda.is_available():
         cus = pipeline.n_compute_units(torch.cuda.current_device()) - pipeline.cu_split()
-    per_cu = 8 if contraction_nsplit(True) else 4
-    return max(2, min(32, (per_cu * cus) // max(1, batch_size)))
+    return max(2, min(32, (4 * cus) // max(1, batch_size)))
 
 
 class Trainer:

@@ -78,3 +78,22 @@ def g2_only(n):
         for i in range(n):
             sg.g2.replay()
 print("CPU enqueue cost: G1 replay %.1f us, G2 replay %.1f us" % (cpu_cost(g1_only, 12), cpu_cost(g2_only, 12)))
+
+# (f) is the real loop host-bound?  wall time until the step loop RETURNS (everything enqueued) vs until the GPU is done
+def loop_host_vs_gpu(n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bench.run_steps(model, trainer, batches, n)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6
+h, g = loop_host_vs_gpu(8 * P)
+print("real loop, %d steps: host returns after %.1f us / step, GPU done after %.1f us / step" % (8 * P, h, g))
+import cProfile, pstats
+pr = cProfile.Profile()
+pr.enable()
+bench.run_steps(model, trainer, batches, 4 * P)
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
