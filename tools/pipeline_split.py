@@ -97,3 +97,41 @@ bench.run_steps(model, trainer, batches, 4 * P)
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+# (g) which ingredient of the real loop makes its steps slower than (d)?  add them one at a time
+y_in = sg.inputs[1]
+B = a.batch
+def variant(consumer, slices, lockstep):
+    sums = torch.zeros(2, dtype=torch.float64, device=dev)
+    slots = trainer._slots
+    gs = [next(v for v in s.graphs.values() if v is not None) for s in slots]
+    def fn(n):
+        done = [None, None]
+        consumed = [None, None]
+        for g in range(n):
+            s = slots[g % 2]
+            with torch.cuda.stream(s.stream):
+                if lockstep and consumed[g % 2] is not None:
+                    s.stream.wait_event(consumed[g % 2])
+                if lockstep and done[(g + 1) % 2] is not None:
+                    s.stream.wait_event(done[(g + 1) % 2])
+                gs[g % 2][0].replay()
+                e = torch.cuda.Event(); e.record(s.stream); done[g % 2] = e
+            if lockstep and g == 0:
+                continue                                  # the suffix runs one group behind the prefix
+            gg = g - 1 if lockstep else g
+            with torch.cuda.stream(main):
+                if lockstep:
+                    main.wait_event(done[gg % 2])
+                feats_cat = gs[gg % 2][2]
+                for k in range(P):
+                    ins = [feats_cat[:, k * B:(k + 1) * B], y_in] if slices else sg.inputs
+                    m = sg.run(ins, 3000 + k)
+                    if consumer:
+                        sums.add_(m.double())
+                if lockstep:
+                    e = torch.cuda.Event(); e.record(main); consumed[gg % 2] = e
+    return wall(fn, 8) / P
+for name, args_ in (("(d) again", (0, 0, 0)), ("+ metric accumulation", (1, 0, 0)),
+                    ("+ inputs = slices of the prefix output", (1, 1, 0)), ("+ lockstep events", (1, 1, 1))):
+    print("%-42s %7.1f us / step" % (name, variant(*args_)))
