@@ -331,11 +331,26 @@ struct TnProblem {
   int tile_end;       // exclusive prefix of tile counts
   int tiles_n;
 };
-struct TnArgs { TnProblem p[4]; int count; };
+struct TnArgs {
+  TnProblem p[4];
+  int count;
+  // optional extra job of the same launch: rs_dst[c] = sum_r rs_src[r * rs_cols + c] (rows added in order), done by
+  // the workgroups past the last tile — the layer's bias gradients (per-tile partial sums of the BPTT kernel)
+  const float* rs_src; float* rs_dst; int rs_rows, rs_cols, tiles;
+};
 
 __global__ void __launch_bounds__(256)
 gemm_tn_small_kernel(const TnArgs a) {
   __shared__ float red[4][8][256];                     // [wave][tile][lane*4 + r]
+  if ((int)blockIdx.x >= a.tiles) {                    // the row-sum job
+    const int c = ((int)blockIdx.x - a.tiles) * 256 + threadIdx.x;
+    if (c < a.rs_cols) {
+      float s = a.rs_src[c];
+      for (int r = 1; r < a.rs_rows; ++r) s += a.rs_src[(long long)r * a.rs_cols + c];
+      a.rs_dst[c] = s;
+    }
+    return;
+  }
   int q = 0;
   while (q + 1 < a.count && (int)blockIdx.x >= a.p[q].tile_end) ++q;
   const TnProblem& P = a.p[q];
@@ -537,8 +552,12 @@ extern "C" int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const fl
 
 extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
                                    float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
-                                   const int64_t* K, int64_t count, void* stream) {
+                                   const int64_t* K, int64_t count, const float* rowsum_src, int64_t rowsum_rows,
+                                   int64_t rowsum_cols, float* rowsum_dst, void* stream) {
   SLU_REQUIRE(A && B && C && lda && ldb && ldc && M && N && K, "slu_gemm_tn_batched: null pointer");
+  SLU_REQUIRE((rowsum_src == nullptr) == (rowsum_dst == nullptr), "slu_gemm_tn_batched: rowsum_src and rowsum_dst go together");
+  SLU_REQUIRE(!rowsum_src || (rowsum_rows >= 1 && rowsum_cols >= 1 && rowsum_rows < (1LL << 30) && rowsum_cols < (1LL << 30)),
+              "slu_gemm_tn_batched: bad row-sum size");
   SLU_REQUIRE(count >= 1 && count <= 4, "slu_gemm_tn_batched: 1..4 problems per call");
   TnArgs a;
   int tiles = 0;
@@ -555,7 +574,10 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
     a.p[q].tile_end = tiles;
   }
   a.count = (int)count;
-  hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+  a.tiles = tiles;
+  a.rs_src = rowsum_src; a.rs_dst = rowsum_dst; a.rs_rows = (int)rowsum_rows; a.rs_cols = (int)rowsum_cols;
+  const int extra = rowsum_src ? (int)cdiv(rowsum_cols, 256) : 0;
+  hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
   SLU_CHECK_LAUNCH("gemm_tn_small_kernel");
   return SLU_OK;
 }

@@ -11,6 +11,8 @@
 // glue, fused to replace ~35 small ATen launches per training step by 4.
 #include "slu_common.h"
 
+#include <algorithm>
+
 namespace slu {
 
 constexpr int HEAD_THREADS = 256;
@@ -26,10 +28,46 @@ struct HeadParams {
   long long* pred;         // (B, S)
   float* d_logits;         // (B, V) or null: d loss / d logits
   float* row_stats;        // (B, 2): per-utterance loss and all-slots-correct flag
+  float* loss_acc;         // (2): batch loss and accuracy — written by the LAST workgroup when `ticket` is given
+  double* epoch_sums;      // (2) or null: += B * (loss, acc), the epoch statistics of training.py:100-104
+  unsigned int* ticket;    // zero-initialised device word (zero again afterwards) or null: separate reduce launch
   int T, B, C, V, S;
   int w_in_lds;            // 0: the classifier rows are read from L2 (T x C + V x C does not fit the LDS)
   int slot_begin[HEAD_MAX_SLOTS + 1];
 };
+
+// loss = sum_b row_loss / B (each slot's CE is a mean over the batch), acc = mean_b correct.  256 threads.
+// COHERENT: the rows were written by other workgroups of the SAME launch (possibly on another XCD, i.e. behind
+// another L2): read them with agent-scope loads.
+template <bool COHERENT>
+__device__ __forceinline__ void head_reduce_body(const float* row_stats, float* loss_acc, double* epoch_sums, int B) {
+  __shared__ float r0[256], r1[256];
+  float a = 0.0f, c = 0.0f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    if (COHERENT) {
+      a += __hip_atomic_load(row_stats + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c += __hip_atomic_load(row_stats + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      a += row_stats[2 * b]; c += row_stats[2 * b + 1];
+    }
+  }
+  r0[threadIdx.x] = a; r1[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float loss = r0[0] / (float)B, acc = r1[0] / (float)B;
+    loss_acc[0] = loss; loss_acc[1] = acc;
+    if (epoch_sums) { epoch_sums[0] += (double)loss * (double)B; epoch_sums[1] += (double)acc * (double)B; }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+head_reduce_kernel(const float* __restrict__ row_stats, float* __restrict__ loss_acc, double* epoch_sums, int B) {
+  head_reduce_body<false>(row_stats, loss_acc, epoch_sums, B);
+}
 
 __global__ void __launch_bounds__(HEAD_THREADS)
 head_fwd_kernel(const HeadParams p) {
@@ -155,35 +193,34 @@ head_fwd_kernel(const HeadParams p) {
     p.row_stats[2 * b] = loss;
     p.row_stats[2 * b + 1] = all_ok ? 1.0f : 0.0f;
   }
-}
-
-// loss = sum_b row_loss / B (each slot's CE is a mean over the batch), acc = mean_b correct
-__global__ void __launch_bounds__(256)
-head_reduce_kernel(const float* __restrict__ row_stats, float* __restrict__ loss_acc, int B) {
-  __shared__ float r0[256], r1[256];
-  float a = 0.0f, c = 0.0f;
-  for (int b = threadIdx.x; b < B; b += 256) { a += row_stats[2 * b]; c += row_stats[2 * b + 1]; }
-  r0[threadIdx.x] = a; r1[threadIdx.x] = c;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { r0[threadIdx.x] += r0[threadIdx.x + o]; r1[threadIdx.x] += r1[threadIdx.x + o]; }
+  // batch loss / accuracy by the last workgroup to get here (same summation as head_reduce_kernel, whichever
+  // workgroup runs it): saves the 1-workgroup reduce launch of every training step
+  if (p.ticket && p.y) {
+    __shared__ int s_last;
+    if (tid == 0) {
+      __threadfence();                                   // this utterance's row_stats visible device-wide first
+      s_last = (atomicAdd(p.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
     __syncthreads();
+    if (s_last) {
+      __threadfence();
+      head_reduce_body<true>(p.row_stats, p.loss_acc, p.epoch_sums, p.B);
+      if (tid == 0) *p.ticket = 0u;
+    }
   }
-  if (threadIdx.x == 0) { loss_acc[0] = r0[0] / (float)B; loss_acc[1] = r1[0] / (float)B; }
 }
 
 // d_h[t][b][c] = g * sum_v [t == argmax_t[b][v]] d_logits[b][v] W[v][c]
 // One workgroup per utterance; thread c owns column c of a (T x C) LDS accumulator and adds, for
 // each classifier output v, d_logits[v] * W[v][c] into the row of v's arg-max time step.
-__global__ void __launch_bounds__(HEAD_THREADS)
-head_bwd_dh_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
-                   const float* __restrict__ W, const float* __restrict__ gscale,
-                   float* __restrict__ d_h, int T, int B, int C, int V) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void
+head_bwd_dh_body(char* smem, const int b, const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
+                 const float* __restrict__ W, const float* __restrict__ gscale,
+                 float* __restrict__ d_h, int T, int B, int C, int V) {
   float* acc = reinterpret_cast<float*>(smem);          // [T][C]
   __shared__ float s_dl[HEAD_THREADS];
   __shared__ int s_at[HEAD_THREADS];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const float g = gscale[0];
   if (tid < V) { s_dl[tid] = d_logits[(size_t)b * V + tid] * g; s_at[tid] = argmax_t[(size_t)b * V + tid]; }
   for (int idx = tid; idx < T * C; idx += HEAD_THREADS) acc[idx] = 0.0f;
@@ -200,16 +237,15 @@ head_bwd_dh_kernel(const float* __restrict__ d_logits, const int* __restrict__ a
 // d_W[v][c] = g * sum_b d_logits[b][v] h[argmax_t[b][v]][b][c];   d_bias[v] = g * sum_b d_logits[b][v]
 // One workgroup per classifier output v: wave w accumulates utterances b = w, w+4, ... for its 64-lane
 // slices of C (fixed order -> deterministic), then the four partial rows are summed through LDS.
-__global__ void __launch_bounds__(HEAD_THREADS)
-head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
-                   const float* __restrict__ h, const float* __restrict__ gscale,
-                   float* __restrict__ d_W, float* __restrict__ d_bias, int T, int B, int C, int V) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void
+head_bwd_dw_body(char* smem, const int v, const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
+                 const float* __restrict__ h, const float* __restrict__ gscale,
+                 float* __restrict__ d_W, float* __restrict__ d_bias, int T, int B, int C, int V) {
   float* part = reinterpret_cast<float*>(smem);         // [4][C]
   float* s_dl = part + 4 * C;                           // [HEAD_THREADS] this output's d_logits, 256 utterances at a time
   int* s_at = reinterpret_cast<int*>(s_dl + HEAD_THREADS);
   __shared__ float s_b[4];
-  const int v = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float g = gscale[0];
   float bsum = 0.0f;
   constexpr int KMAX = 16;                               // C <= 1024
@@ -278,6 +314,19 @@ head_bwd_dw_kernel(const float* __restrict__ d_logits, const int* __restrict__ a
   (void)T;
 }
 
+// Both gradients of the head in ONE launch: workgroups [0, n_dh) = one utterance of d_h each, the rest = one
+// classifier output of (d_W, d_bias) each (n_dh = 0 or B; d_W null: no such workgroups are launched).
+__global__ void __launch_bounds__(HEAD_THREADS)
+head_bwd_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t, const float* __restrict__ h,
+                const float* __restrict__ W, const float* __restrict__ gscale, float* __restrict__ d_h,
+                float* __restrict__ d_W, float* __restrict__ d_bias, int n_dh, int T, int B, int C, int V) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < n_dh)
+    head_bwd_dh_body(smem, blockIdx.x, d_logits, argmax_t, W, gscale, d_h, T, B, C, V);
+  else
+    head_bwd_dw_body(smem, (int)blockIdx.x - n_dh, d_logits, argmax_t, h, gscale, d_W, d_bias, T, B, C, V);
+}
+
 }  // namespace slu
 
 using namespace slu;
@@ -286,7 +335,7 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
                                       const int64_t* y, const int64_t* values_per_slot,
                                       int64_t num_slots, float* logits, int32_t* argmax_t,
                                       int64_t* pred, float* d_logits, float* row_stats,
-                                      float* loss_acc, int64_t T, int64_t B, int64_t C,
+                                      float* loss_acc, double* epoch_sums, uint32_t* ticket, int64_t T, int64_t B, int64_t C,
                                       void* stream) {
   SLU_REQUIRE(h && weight && bias && logits && argmax_t && pred && values_per_slot, "slu_cls_maxpool_ce_fwd: null pointer");
   SLU_REQUIRE(num_slots >= 1 && num_slots <= HEAD_MAX_SLOTS, "slu_cls_maxpool_ce_fwd: 1..%d slots supported", HEAD_MAX_SLOTS);
@@ -295,6 +344,7 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
   HeadParams p;
   p.h = h; p.W = weight; p.bias = bias; p.y = (const long long*)y; p.logits = logits; p.argmax_t = argmax_t;
   p.pred = (long long*)pred; p.d_logits = d_logits; p.row_stats = row_stats;
+  p.loss_acc = loss_acc; p.epoch_sums = y ? epoch_sums : nullptr; p.ticket = (unsigned int*)ticket;
   p.T = (int)T; p.B = (int)B; p.C = (int)C; p.S = (int)num_slots;
   int V = 0;
   for (int s = 0; s < num_slots; ++s) { p.slot_begin[s] = V; V += (int)values_per_slot[s]; }
@@ -315,8 +365,8 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)B), dim3(HEAD_THREADS), lds, st, p);
   SLU_CHECK_LAUNCH("head_fwd_kernel");
-  if (y) {
-    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)row_stats, loss_acc, (int)B);
+  if (y && !ticket) {
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)row_stats, loss_acc, epoch_sums, (int)B);
     SLU_CHECK_LAUNCH("head_reduce_kernel");
   }
   return SLU_OK;
@@ -330,22 +380,20 @@ extern "C" int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argm
   SLU_REQUIRE((d_weight == nullptr) == (d_bias == nullptr), "slu_cls_maxpool_ce_bwd: d_weight and d_bias go together");
   SLU_REQUIRE(C <= 1024, "slu_cls_maxpool_ce_bwd: C <= 1024");
   hipStream_t st = (hipStream_t)stream;
+  size_t lds = 0;
   if (d_h) {
     SLU_REQUIRE(V <= HEAD_THREADS && T * C * 4 <= 160 * 1024 - 4096, "slu_cls_maxpool_ce_bwd: T*C too large for the LDS");
-    const size_t lds = (size_t)T * C * sizeof(float);
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)head_bwd_dh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_cls_maxpool_ce_bwd: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(head_bwd_dh_kernel, dim3((unsigned)B), dim3(HEAD_THREADS), lds, st, d_logits, argmax_t,
-                       weight, grad_scale, d_h, (int)T, (int)B, (int)C, (int)V);
-    SLU_CHECK_LAUNCH("head_bwd_dh_kernel");
+    lds = (size_t)T * C * sizeof(float);
   }
-  if (d_weight) {
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((unsigned)V), dim3(HEAD_THREADS),
-                       ((size_t)4 * C + 2 * HEAD_THREADS) * sizeof(float), st,
-                       d_logits, argmax_t, h, grad_scale, d_weight, d_bias, (int)T, (int)B, (int)C, (int)V);
-    SLU_CHECK_LAUNCH("head_bwd_dw_kernel");
+  if (d_weight) lds = std::max(lds, ((size_t)4 * C + 2 * HEAD_THREADS) * sizeof(float));
+  if (!d_h && !d_weight) return SLU_OK;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_cls_maxpool_ce_bwd: %s", hipGetErrorString(e));
   }
+  const int n_dh = d_h ? (int)B : 0;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(n_dh + (d_weight ? V : 0))), dim3(HEAD_THREADS), lds, st,
+                     d_logits, argmax_t, h, weight, grad_scale, d_h, d_weight, d_bias, n_dh, (int)T, (int)B, (int)C, (int)V);
+  SLU_CHECK_LAUNCH("head_bwd_kernel");
   return SLU_OK;
 }

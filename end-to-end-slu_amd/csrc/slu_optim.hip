@@ -28,11 +28,13 @@ struct AdamList {
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, const double lr,
-                  const double b1, const double b2, const double eps, const double grad_div) {
+adam_multi_kernel(const AdamList L, long long* step_dev, const double lr,
+                  const double b1, const double b2, const double eps, const double grad_div,
+                  unsigned int* ticket) {
   __shared__ float s_coef[2];
+  const long long step_now = *step_dev;                    // read by every thread before the block takes its ticket
   if (threadIdx.x == 0) {
-    const double t = (double)(*step_dev + 1);
+    const double t = (double)(step_now + 1);
     s_coef[0] = (float)(lr / (1.0 - pow(b1, t)));          // step size
     s_coef[1] = (float)sqrt(1.0 - pow(b2, t));             // sqrt of bias correction 2
   }
@@ -67,10 +69,22 @@ adam_multi_kernel(const AdamList L, const long long* __restrict__ step_dev, cons
       double mm = (double)m[e], vv = (double)v[e];
       mm = mm + (gg - mm) * (1.0 - b1);
       vv = b2 * vv + (1.0 - b2) * gg * gg;
-      const double t = (double)(*step_dev + 1);
+      const double t = (double)(step_now + 1);
       const double denom = sqrt(vv) / sqrt(1.0 - pow(b2, t)) + eps;
       p[e] = (T)((double)p[e] - (lr / (1.0 - pow(b1, t))) * (mm / denom));
       m[e] = (T)mm; v[e] = (T)vv;
+    }
+  }
+  // Advance the step counter from inside the launch (saves the 1-thread increment kernel of every step): every
+  // workgroup has read the counter before it takes a ticket, so the LAST one to finish may write it.
+  if (ticket) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int done = atomicAdd(ticket, 1u);
+      if (done == gridDim.x - 1) {
+        *step_dev = step_now + 1;
+        *ticket = 0u;                                      // ready for the next launch (stream order)
+      }
     }
   }
 }
@@ -85,15 +99,16 @@ using namespace slu;
 
 extern "C" int slu_adam_max_tensors(void) { return ADAM_MAX_TENSORS; }
 
-// One Adam update of `count` tensors of one dtype (elem_bytes 4 = float32, 8 = float64); the step
-// counter (*step_dev, int64, number of updates done so far) is NOT advanced: call
-// slu_adam_advance_step (which adds 1 to the counters selected by a bit mask) once per optimisation
-// step after all the tensor lists.  Gradients are divided by grad_div first (the world size under data
+// One Adam update of `count` tensors of one dtype (elem_bytes 4 = float32, 8 = float64).  The step
+// counter (*step_dev, int64, number of updates done so far) is advanced by this launch when `ticket`
+// (a zero-initialised device uint32 owned by the caller, left at zero again) is given — pass it with the
+// LAST tensor list of an optimisation step that uses this counter — and left alone when ticket is null:
+// then slu_adam_advance_step (adds 1 to the counters selected by a bit mask) does it.  Gradients are divided by grad_div first (the world size under data
 // parallelism: the all-reduce delivers the sum), 1.0 = as they are.
 extern "C" int slu_adam_multi(void* const* params, const void* const* grads, void* const* exp_avg,
                               void* const* exp_avg_sq, const int64_t* numel, int64_t count,
-                              int elem_bytes, const int64_t* step_dev, double lr, double beta1,
-                              double beta2, double eps, double grad_div, void* stream) {
+                              int elem_bytes, int64_t* step_dev, double lr, double beta1,
+                              double beta2, double eps, double grad_div, uint32_t* ticket, void* stream) {
   SLU_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && step_dev, "slu_adam_multi: null pointer");
   SLU_REQUIRE(count > 0 && count <= ADAM_MAX_TENSORS, "slu_adam_multi: 1..%d tensors per call", ADAM_MAX_TENSORS);
   SLU_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "slu_adam_multi: elem_bytes must be 4 or 8");
@@ -110,10 +125,10 @@ extern "C" int slu_adam_multi(void* const* params, const void* const* grads, voi
   hipStream_t st = (hipStream_t)stream;
   if (elem_bytes == 4)
     hipLaunchKernelGGL(adam_multi_kernel<float>, dim3((unsigned)chunks), dim3(256), 0, st, L,
-                       (const long long*)step_dev, lr, beta1, beta2, eps, grad_div);
+                       (long long*)step_dev, lr, beta1, beta2, eps, grad_div, (unsigned int*)ticket);
   else
     hipLaunchKernelGGL(adam_multi_kernel<double>, dim3((unsigned)chunks), dim3(256), 0, st, L,
-                       (const long long*)step_dev, lr, beta1, beta2, eps, grad_div);
+                       (long long*)step_dev, lr, beta1, beta2, eps, grad_div, (unsigned int*)ticket);
   SLU_CHECK_LAUNCH("adam_multi_kernel");
   return SLU_OK;
 }

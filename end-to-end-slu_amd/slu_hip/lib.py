@@ -53,13 +53,13 @@ SIGNATURES = {
     "slu_comm_allreduce_f32": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_allreduce_f64": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_destroy": (c_int, [vp]),
-    "slu_gemm_tn_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp]),
+    "slu_gemm_tn_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "slu_frame_ce_fwd": (c_int, [vp, vp, c_i64, c_i64, c_i64, c_int, vp, vp, vp]),
     "slu_adam_max_tensors": (c_int, []),
-    "slu_adam_multi": (c_int, [vp, vp, vp, vp, vp, c_i64, c_int, vp, c_f64, c_f64, c_f64, c_f64, c_f64, vp]),
+    "slu_adam_multi": (c_int, [vp, vp, vp, vp, vp, c_i64, c_int, vp, c_f64, c_f64, c_f64, c_f64, c_f64, vp, vp]),
     "slu_adam_advance_step": (c_int, [vp, c_u64, vp]),
     "slu_gru_seq_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
     "slu_gru_seq_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
@@ -69,7 +69,7 @@ SIGNATURES = {
                                             c_i64, vp, c_i64, c_int, c_i64, c_i64, c_i64, vp]),
     "slu_dropout_pool_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64,
                                      c_int, c_i64, vp, c_i64, c_i64, c_i64, vp]),
-    "slu_cls_maxpool_ce_fwd": (c_int, [vp, vp, vp, vp, ctypes.POINTER(c_i64), c_i64, vp, vp, vp, vp, vp, vp,
+    "slu_cls_maxpool_ce_fwd": (c_int, [vp, vp, vp, vp, ctypes.POINTER(c_i64), c_i64, vp, vp, vp, vp, vp, vp, vp, vp,
                                        c_i64, c_i64, c_i64, vp]),
     "slu_cls_maxpool_ce_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
 }

@@ -348,22 +348,30 @@ def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, wan
 TN_SMALL_ROWS = 4096      # weight gradients of a GRU layer with T*B up to this many rows go through ONE batched launch
 
 
-def gemm_tn_batched(problems):
+def gemm_tn_batched(problems, rowsum=None):
     """problems: [(A (K, M), B (K, N), C (M, N))] 2-D fp32 views with unit column stride (row strides free);
-    C_q = A_q^T B_q for up to four problems in one launch (slu_gemm_tn_batched)."""
+    C_q = A_q^T B_q for up to four problems in one launch (slu_gemm_tn_batched).
+    rowsum: optional (src (R, ...) contiguous fp32, dst (numel of a row)) — dst = src.sum(0) in the same launch."""
     import ctypes
     L = _lib.load()
     n = len(problems)
     for A, B, C in problems:
         assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1 and A.shape[0] == B.shape[0]
         assert C.shape == (A.shape[1], B.shape[1])
+    if rowsum:
+        src, dst = rowsum
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32
+        assert src.numel() == src.shape[0] * dst.numel()
     vp, i64 = ctypes.c_void_p, ctypes.c_int64
     arr = lambda ty, vals: (ty * n)(*vals)
     _lib.check(L.slu_gemm_tn_batched(arr(vp, [p[0].data_ptr() for p in problems]), arr(i64, [p[0].stride(0) for p in problems]),
                                      arr(vp, [p[1].data_ptr() for p in problems]), arr(i64, [p[1].stride(0) for p in problems]),
                                      arr(vp, [p[2].data_ptr() for p in problems]), arr(i64, [p[2].stride(0) for p in problems]),
                                      arr(i64, [p[2].shape[0] for p in problems]), arr(i64, [p[2].shape[1] for p in problems]),
-                                     arr(i64, [p[0].shape[0] for p in problems]), n, _stream()), "slu_gemm_tn_batched")
+                                     arr(i64, [p[0].shape[0] for p in problems]), n,
+                                     rowsum[0].data_ptr() if rowsum else None, rowsum[0].shape[0] if rowsum else 0,
+                                     rowsum[1].numel() if rowsum else 0, rowsum[1].data_ptr() if rowsum else None,
+                                     _stream()), "slu_gemm_tn_batched")
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -438,8 +446,25 @@ def dropout_pool_bwd(dy, x, mask, p, seed, offset, method, factor, offset_dev=No
     return dx
 
 
-def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad):
-    """-> (loss_acc (2) or None, logits (B,V), pred (B,S), argmax_t (B,V) int32, d_logits or None)"""
+_TICKETS = {}
+
+
+def _ticket(dev):
+    """A persistent zeroed device word per (device, stream) for kernels whose last workgroup finishes a reduction
+    (it leaves the word at zero).  None while a hipGraph capture is running and the word does not exist yet (memory
+    allocated during a capture belongs to the graph): the caller then takes the separate-launch path."""
+    key = (dev.index, _stream())
+    t = _TICKETS.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad, epoch_sums=None):
+    """-> (loss_acc (2) or None, logits (B,V), pred (B,S), argmax_t (B,V) int32, d_logits or None)
+    epoch_sums: optional float64 (2) device tensor; B * (loss, acc) is added to it by the same launch."""
     import ctypes
     L = _lib.load()
     T, B, C = h.shape
@@ -455,7 +480,9 @@ def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad):
     vps = (ctypes.c_int64 * S)(*[int(v) for v in values_per_slot])
     _lib.check(L.slu_cls_maxpool_ce_fwd(h.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(y), vps, S,
                                         logits.data_ptr(), argmax_t.data_ptr(), pred.data_ptr(), _ptr(d_logits),
-                                        _ptr(row_stats), _ptr(loss_acc), T, B, C, _stream()),
+                                        _ptr(row_stats), _ptr(loss_acc), _ptr(epoch_sums),
+                                        _ptr(_ticket(dev)) if y is not None else 0,
+                                        T, B, C, _stream()),
                "slu_cls_maxpool_ce_fwd")
     return loss_acc, logits, pred, argmax_t, d_logits
 
@@ -468,13 +495,17 @@ class IntentHeadFn(torch.autograd.Function):
     (reference models.py:709, :112-123, :811-821).  h time-major (T,B,C), y (B,S) int64.
     Returns (loss, acc, logits (B,V), pred (B,S)); only `loss` carries a gradient."""
     last_loss_acc = None
+    epoch_sums = None       # float64 (2) device tensor while a training loop wants B * (loss, acc) accumulated in-kernel
 
     @staticmethod
     def forward(ctx, h, weight, bias, y, values_per_slot):
         h = h.contiguous()
         y = y.contiguous()
         need = any(ctx.needs_input_grad[:3])
-        loss_acc, logits, pred, argmax_t, d_logits = cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, need)
+        sums = IntentHeadFn.epoch_sums
+        if sums is not None:
+            assert sums.dtype == torch.float64 and sums.numel() >= 2 and sums.is_contiguous() and sums.device == h.device
+        loss_acc, logits, pred, argmax_t, d_logits = cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, need, sums)
         if need:
             ctx.save_for_backward(h, weight, argmax_t, d_logits)
         ctx.set_materialize_grads(False)       # no zero-filled gradients for acc / logits / pred
@@ -667,8 +698,7 @@ class GRULayerFn(torch.autograd.Function):
         ng = ctx.needs_input_grad
         # positions: 0 x | 1 w_ih 2 b_ih (storage, no grad) | 3 w_ih_f 4 w_ih_r 5 b_ih_f 6 b_ih_r |
         #            7 w_hh_f 8 b_hh_f 9 w_hh_r 10 b_hh_r
-        if ng[5] or ng[6] or ng[8] or ng[10]:
-            dbp = dbp.sum(0)                               # (D, 6H): [d(b_ih) (3H) | d(b_hh) (3H)]
+        need_bias = ng[5] or ng[6] or ng[8] or ng[10]
         x2 = x.view(T * B, I)
         g2 = d_gx.view(T * B, D * 3 * H)
         h2 = d_gh.view(T * B, D * 3 * H)
@@ -677,6 +707,8 @@ class GRULayerFn(torch.autograd.Function):
         dev = x.device
         small = (T * B <= TN_SMALL_ROWS and T > 1 and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
                  and I % 4 == 0 and H % 4 == 0)
+        if need_bias and not small:
+            dbp = dbp.sum(0)                               # (D, 6H): [d(b_ih) (3H) | d(b_hh) (3H)]
         if small:
             # a few thousand rows (the intent layer of the look-ahead pipeline): every weight gradient of the layer
             # in ONE launch (no split-K workspaces, no reduce launches).  The choice depends on the shape only.
@@ -690,7 +722,12 @@ class GRULayerFn(torch.autograd.Function):
                 dWh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
                 probs.append((ga, hp, dWh))
                 outs.append(dWh)
-            gemm_tn_batched(probs)
+            rowsum = None
+            if need_bias:                                  # the per-tile bias partial sums, summed by the same launch
+                db = torch.empty(dbp.shape[1:], dtype=torch.float32, device=dev)
+                rowsum = (dbp.contiguous(), db)
+                dbp = db
+            gemm_tn_batched(probs, rowsum)
             grads[3] = dW[:3 * H]
             if D == 2:
                 grads[4] = dW[3 * H:]

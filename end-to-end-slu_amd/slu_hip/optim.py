@@ -16,6 +16,7 @@ class HipAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._steps = None            # int64 device vector: updates done so far, per cohort
+        self._tickets = None          # uint32 device vector: workgroup tickets of the launch that advances a counter
         self._n_cohorts = 0
         self._plan = None             # cached launch arguments, keyed by the identity of every (param, grad)
         self._plan_key = None
@@ -60,10 +61,19 @@ class HipAdam(torch.optim.Optimizer):
                 n = len(part)
                 arr = lambda j: (ctypes.c_void_p * n)(*[t[j].data_ptr() for t in part])
                 numel = (ctypes.c_int64 * n)(*[t[0].numel() for t in part])
-                plan.append((gi, arr(0), arr(1), arr(2), arr(3), numel, n, 4 if dtype == torch.float32 else 8, cohort))
+                plan.append([gi, arr(0), arr(1), arr(2), arr(3), numel, n, 4 if dtype == torch.float32 else 8, cohort, 0])
+        # the LAST launch that reads a cohort's step counter also advances it (ticket: its last workgroup writes
+        # the counter after every workgroup has read it) — no separate increment launch per step
+        seen = set()
+        for entry in reversed(plan):
+            if entry[8] not in seen:
+                seen.add(entry[8])
+                entry[9] = 1
         self._plan_mask = 0
         for (_, _, cohort) in lists:
             self._plan_mask |= 1 << cohort
+        if self._tickets is None and lists:
+            self._tickets = torch.zeros(self.MAX_COHORTS, dtype=torch.int32, device=self._steps.device)
         return plan, tuple(key)
 
     @torch.no_grad()
@@ -78,16 +88,16 @@ class HipAdam(torch.optim.Optimizer):
         if not self._plan:
             return loss
         stream = torch.cuda.current_stream().cuda_stream
-        base = self._steps.data_ptr()
-        for gi, p, g, m, v, numel, n, eb, cohort in self._plan:
+        base, tickets = self._steps.data_ptr(), self._tickets.data_ptr()
+        # only the cohorts updated in this step advance (torch.optim.Adam counts steps per parameter and
+        # skips parameters without a gradient)
+        for gi, p, g, m, v, numel, n, eb, cohort, advance in self._plan:
             grp = self.param_groups[gi]
             b1, b2 = grp["betas"]
             _lib.check(L.slu_adam_multi(p, g, m, v, numel, n, eb, base + 8 * cohort, float(grp["lr"]), float(b1),
-                                        float(b2), float(grp["eps"]), float(self.grad_div), stream),
+                                        float(b2), float(grp["eps"]), float(self.grad_div),
+                                        tickets + 4 * cohort if advance else None, stream),
                        "slu_adam_multi")
-        # only the cohorts updated in this step advance (torch.optim.Adam counts steps per parameter and
-        # skips parameters without a gradient)
-        _lib.check(L.slu_adam_advance_step(base, self._plan_mask, stream), "slu_adam_advance_step")
         return loss
 
     # -- checkpointing: the per-parameter `step` of torch.optim.Adam's state_dict ----------------------

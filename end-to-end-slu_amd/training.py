@@ -46,18 +46,20 @@ def _param_signature(model):
 
 
 def _lookahead_width(depth, batch_size):
-    """Batches per look-ahead super-batch: explicit, or four sequences per CU the side streams may use: 768
-    sequences = 12 batches of 64 on the 192 CUs of the default partition.  Measured on MI355X (bench.py, 512 steps,
-    round 2): 8 / 10 / 12 / 14 / 18 / 24 / 32 batches -> 214 / 232 / 249 / 250 / 244 / 233-240 / 241 k utt/s: wider
-    super-batches make the frozen stages more efficient in isolation (190 vs 231 us per step at 24 vs 12) but every
-    group boundary of the pipeline costs about a millisecond per 24 batches, which outweighs it."""
+    """Batches per look-ahead super-batch: explicit, or 16/3 sequences per CU the side streams may use: 1024
+    sequences = 16 batches of 64 on the 192 CUs of the default partition.  Measured on MI355X (bench.py, 512 steps,
+    round 2, after the small-kernel fusions of the trainable step): 12 / 14 / 16 / 18 / 24 batches -> 246 / 254 /
+    262 / 261 / 249 k utt/s.  Wider super-batches make the frozen stages more efficient (190 vs 231 us per step at 24
+    vs 12 batches, alone on their partition), but the two partitions share the power budget: with all 256 CUs busy
+    the clock drops to ~1.7 GHz and the latency-bound trainable step (194 us alone) takes ~250 us, so past the
+    point where the frozen stages keep up with it a wider super-batch only lengthens the pipeline fill."""
     if depth > 0:
         return depth
     from slu_hip import pipeline
     cus = 256
     if torch.cuda.is_available():
         cus = pipeline.n_compute_units(torch.cuda.current_device()) - pipeline.cu_split()
-    return max(2, min(32, (4 * cus) // max(1, batch_size)))
+    return max(2, min(32, (16 * cus) // max(1, 3 * batch_size)))
 
 
 class Trainer:
@@ -232,13 +234,35 @@ class Trainer:
         self._step(loss)
         return metrics
 
-    def _slu_forward(self, n_prefix):
+    def _slu_forward(self, n_prefix, sums=None):
+        """sums: float64 device tensor the intent head's own launch adds B * (loss, acc) to (the epoch statistics
+        of reference training.py:100-104), so that the loop needs no accumulation kernel per step."""
         from slu_hip import ops
 
         def forward(ins, rng):
-            loss, _ = self.model.forward_from(ins[0], n_prefix, ins[1], rng)
+            ops.IntentHeadFn.epoch_sums = sums
+            try:
+                loss, _ = self.model.forward_from(ins[0], n_prefix, ins[1], rng)
+            finally:
+                ops.IntentHeadFn.epoch_sums = None
             return ops.IntentHeadFn.last_loss_acc, loss          # (2,) float32 [loss, acc]
         return forward
+
+    def _sums_buffer(self):
+        """Persistent float64 (4) device tensor: the running B-weighted sums of the step metrics of one epoch
+        (a fixed address, so that captured steps can accumulate into it)."""
+        dev = next(self.model.parameters()).device
+        if getattr(self, "epoch_sums", None) is None or self.epoch_sums.device != dev:
+            self.epoch_sums = torch.zeros(4, dtype=torch.float64, device=dev)
+        return self.epoch_sums
+
+    @staticmethod
+    def _accumulate(sums, vals, batch_size):
+        if torch.is_tensor(vals):
+            sums[:vals.numel()].add_(vals, alpha=batch_size)
+        else:
+            step_vals = torch.stack([v.detach().to(sums.device).double().reshape(()) for v in vals])
+            sums[:len(vals)].add_(step_vals, alpha=batch_size)
 
     def _asr_forward(self, ins, rng):
         vals, loss = self._forward_losses(ins, True, rng)
@@ -248,7 +272,7 @@ class Trainer:
                             for v in vals])
         return vals, loss
 
-    def _iterate_full_steps(self, loader, asr):
+    def _iterate_full_steps(self, loader, asr, sums=None):
         """Training with nothing to look ahead to (ASR pre-training, SLU with an unfrozen first layer or
         SLU_LOOKAHEAD=0): each step is ~100 short launches, so fixed-shape steps are captured as hipGraphs
         (StepGraph) on a dedicated stream; the losses and parameters are those of the eager loop."""
@@ -259,8 +283,9 @@ class Trainer:
             self._full_stream = torch.cuda.Stream(dev)
         main = self._full_stream
         main.wait_stream(outer)
+        fused = sums is not None and hasattr(self.model, "pretrained_model")
         if hasattr(self.model, "pretrained_model"):
-            pm, forward = self.model.pretrained_model, self._slu_forward(0)
+            pm, forward = self.model.pretrained_model, self._slu_forward(0, sums)
         else:
             pm, forward = self.model, self._asr_forward
         # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it) and to
@@ -272,15 +297,24 @@ class Trainer:
                 for batch in loader:
                     ins = [t.to(dev, non_blocking=True) for t in batch]
                     ins[0] = ins[0].float()
-                    key = ("full", asr, trainable) + tuple(tuple(t.shape) for t in ins)
+                    key = ("full", asr, trainable, fused) + tuple(tuple(t.shape) for t in ins)
                     vals = self._graph_step(key, ins, next_rng_step(), forward, main,
                                             forks=os.environ.get("SLU_GRAPH_FORKS", "1") != "0")
+                    if sums is not None and not fused:
+                        self._accumulate(sums, vals, len(batch[0]))
                     yield vals, len(batch[0])
         finally:
             outer.wait_stream(main)
 
-    def _iterate(self, loader, train, asr):
-        """Yields ([metric tensors], batch_size) per batch, doing the optimisation step when `train`."""
+    def _iterate(self, loader, train, asr, accumulate=False):
+        """Yields ([metric tensors], batch_size) per batch, doing the optimisation step when `train`.
+        accumulate: also keep the epoch statistics on the device — self.epoch_sums[:n] (float64, zeroed here)
+        receives batch_size * metrics of every batch, inside the step's own kernels where they are captured
+        (no per-step accumulation launch); the consumer reads it when the generator is exhausted."""
+        sums = None
+        if accumulate:
+            sums = self._sums_buffer()
+            sums.zero_()
         depth, n_prefix = self.lookahead_depth(train, asr)
         group_eval = (not train and not asr and hasattr(self.model, "eval_group") and not models_masks_injected()
                       and all(p.is_cuda for p in self.model.parameters())
@@ -292,6 +326,9 @@ class Trainer:
             def flush():
                 res = self.model.eval_group([b[0] for b in group], [b[1] for b in group])
                 out = [([l, a], len(b[0])) for (l, a), b in zip(res, group)]
+                if sums is not None:
+                    for vals, bs in out:
+                        self._accumulate(sums, vals, bs)
                 group.clear()
                 return out
 
@@ -305,13 +342,15 @@ class Trainer:
             return
         if depth == 0:
             if train and self._graphable():
-                yield from self._iterate_full_steps(loader, asr)
+                yield from self._iterate_full_steps(loader, asr, sums)
                 return
             for batch in loader:
                 with torch.set_grad_enabled(train):
                     vals, loss = self._forward_losses(batch, asr)
                     if train:
                         self._step(loss)
+                if sums is not None:
+                    self._accumulate(sums, vals, len(batch[0]))
                 yield vals, len(batch[0])
             return
         # ---- encoder look-ahead pipeline (slu_hip/pipeline.py) --------------------------------------
@@ -345,7 +384,7 @@ class Trainer:
             slot.stream.wait_stream(main)
         use_graph = pipeline.graphs_enabled()
         step_graphs = use_graph and self._graphable()
-        forward = self._slu_forward(n_prefix)
+        forward = self._slu_forward(n_prefix, sums if step_graphs else None)
         trainable = _param_signature(self.model)
         # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so no
         # super-batch is wider than half the run — the second half's encoders then overlap the first half's steps
@@ -400,12 +439,14 @@ class Trainer:
                         feats = feats_cat[:, k * B:(k + 1) * B] if len(group) > 1 else feats_cat
                         y = batch[1].to(dev, non_blocking=True)
                         if step_graphs:
-                            key = (tuple(feats.shape), tuple(y.shape), n_prefix, trainable)
+                            key = (tuple(feats.shape), tuple(y.shape), n_prefix, trainable, sums is not None)
                             vals = self._graph_step(key, [feats, y], steps[k], forward, main)
                         else:
                             loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
                             self._step(loss)
                             vals = [loss, acc]
+                            if sums is not None:
+                                self._accumulate(sums, vals, len(batch[0]))
                         if k == len(group) - 1:
                             slot.consumed = torch.cuda.Event()
                             slot.consumed.record(main)
@@ -419,7 +460,6 @@ class Trainer:
         names = (["phoneme loss", "word loss", "phoneme acc", "word acc"] if asr
                  else ["intent loss", "intent acc"])
         dev = next(self.model.parameters()).device
-        sums = torch.zeros(len(names), dtype=torch.float64, device=dev)
         num_examples = 0
         self.model.train(train)
         if train and not asr:
@@ -435,19 +475,16 @@ class Trainer:
             it = tqdm(it)
         # closing(): if the loop is left early (exception, KeyboardInterrupt) the generator's finally clause
         # runs NOW — the current stream returns to the caller's and it waits for the training stream
-        with contextlib.closing(self._iterate(it, train, asr)) as steps:
+        # the batch_size-weighted sums of the metrics (reference training.py:100-104) stay on the device:
+        # self.epoch_sums, filled by the step loop itself (inside the captured step's kernels where it can)
+        with contextlib.closing(self._iterate(it, train, asr, accumulate=True)) as steps:
             for idx, (vals, batch_size) in enumerate(steps):
                 num_examples += batch_size
-                if torch.is_tensor(vals):                              # captured step: one fused accumulate
-                    step_vals = vals
-                    sums.add_(vals, alpha=batch_size)
-                else:
-                    step_vals = torch.stack([v.detach().to(dev).double().reshape(()) for v in vals])
-                    sums += step_vals * batch_size
                 if train and idx % print_interval == 0 and self.rank == 0:
-                    for n, v in zip(names, step_vals.tolist()):       # one host sync per print interval
+                    step_vals = vals if torch.is_tensor(vals) else [v.detach().reshape(()) for v in vals]
+                    for n, v in zip(names, [float(v) for v in step_vals]):   # one host sync per print interval
                         print(n + ": " + str(v))
-        return self._epoch_means(sums.tolist(), num_examples, dev)
+        return self._epoch_means(self.epoch_sums[:len(names)].tolist(), num_examples, dev)
 
     # -- reference API -----------------------------------------------------------------------------
     def train(self, dataset, print_interval=100):

@@ -118,10 +118,13 @@ int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
  * C_q (M_q x N_q, row stride ldc) = A_q^T B_q with A_q (K_q x M_q, row stride lda), B_q (K_q x N_q, row stride ldb)
  * — dW_ih = d_gx^T x and dW_hh = d_gh^T h_prev (per direction) of one GRU layer when T*B is a few thousand rows
  * (the generic kernel would need split-K and a reduce launch per matrix).  M, lda multiples of 4; N, ldb even.  Pointer / size
- * arrays are HOST arrays.                                                                                        */
+ * arrays are HOST arrays.  Optional extra job of the same launch (rowsum_src != NULL):
+ * rowsum_dst[c] = sum_r rowsum_src[r*rowsum_cols + c], rows added in order — the layer's bias gradients from the
+ * per-tile partial sums slu_gru_seq_bwd leaves (d_bias_part), instead of a reduce launch.                          */
 int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
                         float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K,
-                        int64_t count, void* stream);
+                        int64_t count, const float* rowsum_src, int64_t rowsum_rows, int64_t rowsum_cols,
+                        float* rowsum_dst, void* stream);
 /* out[n] = [out[n] if accumulate] + sum_m X[m*x_rs + n]   (bias gradients)                       */
 int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,
                    int accumulate, void* stream);
@@ -228,13 +231,19 @@ int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const 
  *   values_per_slot: HOST array of S entries (S <= 8) — the only host pointer of this ABI;
  *   logits (B,V) = max over t of h_t W^T + b;  argmax_t (B,V) int32;  pred (B,S) int64;
  *   d_logits (B,V) or NULL: d loss / d logits (softmax - onehot)/B per slot;
- *   row_stats (B,2) scratch;  loss_acc (2): loss = sum_slots mean_b CE, acc = mean_b [all slots right].
+ *   row_stats (B,2) scratch;  loss_acc (2): loss = sum_slots mean_b CE, acc = mean_b [all slots right];
+ *   epoch_sums (2 doubles) or NULL: += B * (loss, acc) — the running epoch statistics the reference accumulates on
+ *   the host after every step (training.py:100-104: loss.item() * batch_size), kept on the device instead;
+ *   ticket: NULL, or a zero-initialised device uint32 of the caller's (zero again afterwards; one per stream
+ *   that may run this call concurrently): the launch's last workgroup then reduces row_stats to loss_acc itself
+ *   instead of a second one-workgroup launch (same summation, same bits).
  * Backward: d_h (T,B,C), d_weight (V,C), d_bias (V), all scaled by the device scalar *grad_scale;
  * d_h or the (d_weight, d_bias) pair may be NULL.                                                  */
 int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const float* bias, const int64_t* y,
                            const int64_t* values_per_slot, int64_t num_slots, float* logits,
                            int32_t* argmax_t, int64_t* pred, float* d_logits, float* row_stats,
-                           float* loss_acc, int64_t T, int64_t B, int64_t C, void* stream);
+                           float* loss_acc, double* epoch_sums, uint32_t* ticket, int64_t T, int64_t B, int64_t C,
+                           void* stream);
 int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const float* h,
                            const float* weight, const float* grad_scale, float* d_h,
                            float* d_weight, float* d_bias, int64_t T, int64_t B, int64_t C,
@@ -252,9 +261,12 @@ int slu_frame_ce_fwd(float* logits, const int64_t* y, int64_t N, int64_t V, int6
 /* -------- Adam: torch.optim.Adam(model.parameters(), lr) (training.py:19, default betas / eps) ------
  * One launch updates up to slu_adam_max_tensors() tensors of one dtype (elem_bytes 4 / 8); the pointer
  * arrays are HOST arrays of device pointers (they travel in the kernel arguments: hipGraph-safe).
- * *step_dev (int64, device) = number of updates these tensors have received so far; it is read, not
- * advanced: slu_adam_advance_step adds 1 to the counters step_dev[i] whose bit i is set in cohort_mask,
- * once per optimisation step (only tensors that received a gradient advance, as in torch.optim.Adam).
+ * *step_dev (int64, device) = number of updates these tensors have received so far.  With `ticket` (a
+ * zero-initialised device uint32 of the caller's; zero again when the launch is done) the launch advances
+ * *step_dev itself — its last workgroup writes it, after every workgroup has read it: pass the ticket with
+ * the LAST tensor list that uses this counter in an optimisation step.  With ticket = NULL the counter is only
+ * read, and slu_adam_advance_step adds 1 to the counters step_dev[i] whose bit i is set in cohort_mask, once per
+ * optimisation step (only tensors that received a gradient advance, as in torch.optim.Adam).
  * grad_div: the gradients are divided by it before use (the world size under data parallelism, where
  * the RCCL all-reduce delivers the SUM over ranks; 1.0 otherwise).
  *   g /= grad_div;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;
@@ -262,8 +274,8 @@ int slu_frame_ce_fwd(float* logits, const int64_t* y, int64_t N, int64_t V, int6
 int slu_adam_max_tensors(void);
 int slu_adam_multi(void* const* params, const void* const* grads, void* const* exp_avg,
                    void* const* exp_avg_sq, const int64_t* numel, int64_t count, int elem_bytes,
-                   const int64_t* step_dev, double lr, double beta1, double beta2, double eps,
-                   double grad_div, void* stream);
+                   int64_t* step_dev, double lr, double beta1, double beta2, double eps,
+                   double grad_div, uint32_t* ticket, void* stream);
 int slu_adam_advance_step(int64_t* step_dev, uint64_t cohort_mask, void* stream);
 
 /* -------- data parallelism: the gradient all-reduce over the GPUs of a node (RCCL over xGMI) -----------------
