@@ -339,9 +339,21 @@ struct TnArgs {
   const float* rs_src; float* rs_dst; int rs_rows, rs_cols, tiles;
 };
 
+// MT = floats of A per lane and k row: 4 -> 64 x 32 output tiles (16-byte loads), 3 -> 48 x 32 tiles (12-byte loads).
+// The launcher picks the height whose tile count spreads evenly over the CUs (a tile's k range is summed the same
+// way for both, so the choice does not change a bit of the result).
+template <int MT> struct TnVec;
+template <> struct TnVec<4> { typedef float4 type; };
+template <> struct TnVec<3> { typedef float3 type; };
+template <int MT> __device__ __forceinline__ float tn_elem(const typename TnVec<MT>::type& v, int x);
+template <> __device__ __forceinline__ float tn_elem<4>(const float4& v, int x) { return x == 0 ? v.x : x == 1 ? v.y : x == 2 ? v.z : v.w; }
+template <> __device__ __forceinline__ float tn_elem<3>(const float3& v, int x) { return x == 0 ? v.x : x == 1 ? v.y : v.z; }
+
+template <int MT>
 __global__ void __launch_bounds__(256)
 gemm_tn_small_kernel(const TnArgs a) {
-  __shared__ float red[4][8][256];                     // [wave][tile][lane*4 + r]
+  typedef typename TnVec<MT>::type avec;
+  __shared__ float red[4][2 * MT][256];                // [wave][tile][lane*4 + r]
   if ((int)blockIdx.x >= a.tiles) {                    // the row-sum job
     const int c = ((int)blockIdx.x - a.tiles) * 256 + threadIdx.x;
     if (c < a.rs_cols) {
@@ -356,7 +368,7 @@ gemm_tn_small_kernel(const TnArgs a) {
   const TnProblem& P = a.p[q];
   const int tile = blockIdx.x - (q ? a.p[q - 1].tile_end : 0);
   const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
-  const int m0 = tm * 64, n0 = tn * 32;
+  const int m0 = tm * (16 * MT), n0 = tn * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int i = lane & 15, kg = lane >> 4;
   // this wave's k range: quarters of the FULL 4-row MFMA steps; a partial last step (K % 4 != 0) goes to wave 3.
@@ -366,35 +378,34 @@ gemm_tn_small_kernel(const TnArgs a) {
   const int steps = P.K >> 2;
   const int per = ((((steps + 3) >> 2) + 7) >> 3) << 3;   // a multiple of the batch size U = 8: no per-step tail loop
   const int s0 = min(steps, w * per), s1 = min(steps, s0 + per);
-  // ONE 16-byte (A) and ONE 8-byte (B) load per k row feed all MFMA tiles of a 64 x 32 output tile: lane i holds
-  // columns 4i..4i+3 of A and 2i, 2i+1 of B, i.e. MFMA row-tile x covers the rows m0 + 4*(0..15) + x and column-tile
-  // y the columns n0 + 2*(0..15) + y (a permutation, undone at the store).  A workgroup moves (64 + 32) K floats
-  // for 64 x 32 x K MACs: the kernel is bound by what one CU can pull through its L1 (~60 GB/s), 32 x 32 tiles
-  // moved 1.5x as much per MAC.  (M % 4 == 0, N % 2 == 0: checked by the launcher.)
-  const float* __restrict__ pa = P.A + (m0 + 4 * i + 3 < P.M ? m0 + 4 * i : 0);
+  // ONE 4*MT-byte (A) and ONE 8-byte (B) load per k row feed all MFMA tiles of the (16 MT) x 32 output tile: lane i
+  // holds columns MT*i .. MT*i + MT-1 of A and 2i, 2i+1 of B, i.e. MFMA row-tile x covers the rows m0 + MT*(0..15) + x
+  // and column-tile y the columns n0 + 2*(0..15) + y (a permutation, undone at the store).  (M % MT == 0, N % 2 == 0:
+  // checked by the launcher.)
+  const float* __restrict__ pa = P.A + (m0 + MT * i + MT - 1 < P.M ? m0 + MT * i : 0);
   const float* __restrict__ pb = P.B + (n0 + 2 * i + 1 < P.N ? n0 + 2 * i : 0);
-  f32x4 acc[4][2];
+  f32x4 acc[MT][2];
 #pragma unroll
-  for (int x = 0; x < 4; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int x = 0; x < MT; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   // batches of U = 8 MFMA steps (16 loads per lane), software-pipelined over two register sets: the next batch's
   // loads are issued before the current batch's MFMAs (the batch index is clamped instead of branching around the
   // loads, which would send the register arrays through scratch memory)
   constexpr int U = 8;
   const int nb = (s1 > s0) ? (s1 - s0) / U : 0;
-  float4 avA[U], avB[U];
+  avec avA[U], avB[U];
   float2 bvA[U], bvB[U];
 #define TN_LOAD(av, bv, batch)                                                        \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
     const long long k = 4 * (s0 + (batch) * U + u) + kg;                               \
-    av[u] = *reinterpret_cast<const float4*>(pa + k * P.lda);                          \
+    av[u] = *reinterpret_cast<const avec*>(pa + k * P.lda);                            \
     bv[u] = *reinterpret_cast<const float2*>(pb + k * P.ldb);                          \
   }                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 #define TN_STEP(a_, b_)                                                                \
-  acc[0][0] = mfma16(a_.x, b_.x, acc[0][0]); acc[0][1] = mfma16(a_.x, b_.y, acc[0][1]); \
-  acc[1][0] = mfma16(a_.y, b_.x, acc[1][0]); acc[1][1] = mfma16(a_.y, b_.y, acc[1][1]); \
-  acc[2][0] = mfma16(a_.z, b_.x, acc[2][0]); acc[2][1] = mfma16(a_.z, b_.y, acc[2][1]); \
-  acc[3][0] = mfma16(a_.w, b_.x, acc[3][0]); acc[3][1] = mfma16(a_.w, b_.y, acc[3][1]);
+  _Pragma("unroll") for (int x = 0; x < MT; ++x) {                                     \
+    acc[x][0] = mfma16(tn_elem<MT>(a_, x), b_.x, acc[x][0]);                           \
+    acc[x][1] = mfma16(tn_elem<MT>(a_, x), b_.y, acc[x][1]);                           \
+  }
 #define TN_MFMA(av, bv)                                                                \
   _Pragma("unroll") for (int u = 0; u < U; ++u) { TN_STEP(av[u], bv[u]) }              \
   __builtin_amdgcn_sched_barrier(0);
@@ -410,7 +421,7 @@ gemm_tn_small_kernel(const TnArgs a) {
   int sb = s0 + nb * U;
   for (; sb < s1; ++sb) {                              // fewer than U full steps left
     const long long k = 4 * sb + kg;
-    const float4 av = *reinterpret_cast<const float4*>(pa + k * P.lda);
+    const avec av = *reinterpret_cast<const avec*>(pa + k * P.lda);
     const float2 bv = *reinterpret_cast<const float2*>(pb + k * P.ldb);
     TN_STEP(av, bv)
   }
@@ -418,29 +429,31 @@ gemm_tn_small_kernel(const TnArgs a) {
     const long long k = 4 * steps + kg;
     const bool kok = k < P.K;
     const long long kc = kok ? k : 0;
-    float4 av = *reinterpret_cast<const float4*>(pa + kc * P.lda);
+    avec av = *reinterpret_cast<const avec*>(pa + kc * P.lda);
     const float2 bv = *reinterpret_cast<const float2*>(pb + kc * P.ldb);
-    av.x = kok ? av.x : 0.0f; av.y = kok ? av.y : 0.0f; av.z = kok ? av.z : 0.0f; av.w = kok ? av.w : 0.0f;
+    av.x = kok ? av.x : 0.0f; av.y = kok ? av.y : 0.0f; av.z = kok ? av.z : 0.0f;
+    if constexpr (MT == 4) av.w = kok ? av.w : 0.0f;
     TN_STEP(av, bv)
   }
 #undef TN_MFMA
 #undef TN_STEP
 #undef TN_LOAD
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int x = 0; x < MT; ++x)
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[w][2 * x + y][lane * 4 + r] = acc[x][y][r];
   __syncthreads();
   // wave w finishes the two tiles of row-tile x = w: element (lane, r) is row 4*kg + r, column i of a 16 x 16 tile
+  if (w >= MT) return;
 #pragma unroll
   for (int y = 0; y < 2; ++y)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int e = lane * 4 + r, t = 2 * w + y;
       const float v = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
-      const int m = m0 + 4 * (4 * kg + r) + w, n = n0 + 2 * i + y;
+      const int m = m0 + MT * (4 * kg + r) + w, n = n0 + 2 * i + y;
       if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v;
     }
 }
@@ -559,25 +572,42 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
   SLU_REQUIRE(!rowsum_src || (rowsum_rows >= 1 && rowsum_cols >= 1 && rowsum_rows < (1LL << 30) && rowsum_cols < (1LL << 30)),
               "slu_gemm_tn_batched: bad row-sum size");
   SLU_REQUIRE(count >= 1 && count <= 4, "slu_gemm_tn_batched: 1..4 problems per call");
+  // tile height: 64 rows (16-byte A loads) where the shapes allow it, else 48 rows (12-byte loads).  Measured for the
+  // intent layer (144 tiles of 64 rows vs 192 of 48 on 64 CUs): 52 vs 57 us — the even spread of the 48-row tiles does
+  // not pay for their extra B traffic per MAC.
+  int mt = 4;
+  {
+    bool ok4 = true, ok3 = true;
+    for (int q = 0; q < (int)count; ++q) {
+      ok4 = ok4 && ((M[q] | lda[q]) & 3) == 0 && ((uintptr_t)A[q] & 15) == 0;
+      ok3 = ok3 && (M[q] % 3) == 0;
+    }
+    if (!ok4 && !ok3)
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: M must be a multiple of 3, or M and lda multiples of 4 with A 16-byte aligned");
+    if (!ok4) mt = 3;
+  }
   TnArgs a;
   int tiles = 0;
   for (int q = 0; q < (int)count; ++q) {
     SLU_REQUIRE(A[q] && B[q] && C[q] && M[q] > 0 && N[q] > 0 && K[q] > 0, "slu_gemm_tn_batched: bad problem %d", q);
     SLU_REQUIRE(M[q] < (1LL << 30) && N[q] < (1LL << 30) && K[q] < (1LL << 30), "slu_gemm_tn_batched: size overflow");
-    if ((M[q] | lda[q]) & 3 || (N[q] | ldb[q]) & 1 || ((uintptr_t)A[q] & 15) || ((uintptr_t)B[q] & 7))
-      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: M and lda must be multiples of 4 (A 16-byte aligned), N and ldb even (B 8-byte aligned)");
+    if ((N[q] | ldb[q]) & 1 || ((uintptr_t)B[q] & 7))
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: N and ldb must be even (B 8-byte aligned)");
     a.p[q].A = A[q]; a.p[q].B = B[q]; a.p[q].C = C[q];
     a.p[q].lda = lda[q]; a.p[q].ldb = ldb[q]; a.p[q].ldc = ldc[q];
     a.p[q].M = (int)M[q]; a.p[q].N = (int)N[q]; a.p[q].K = (int)K[q];
     a.p[q].tiles_n = (int)cdiv(N[q], 32);
-    tiles += (int)(cdiv(M[q], 64) * cdiv(N[q], 32));
+    tiles += (int)(cdiv(M[q], 16 * mt) * cdiv(N[q], 32));
     a.p[q].tile_end = tiles;
   }
   a.count = (int)count;
   a.tiles = tiles;
   a.rs_src = rowsum_src; a.rs_dst = rowsum_dst; a.rs_rows = (int)rowsum_rows; a.rs_cols = (int)rowsum_cols;
   const int extra = rowsum_src ? (int)cdiv(rowsum_cols, 256) : 0;
-  hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
+  if (mt == 4)
+    hipLaunchKernelGGL(gemm_tn_small_kernel<4>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(gemm_tn_small_kernel<3>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
   SLU_CHECK_LAUNCH("gemm_tn_small_kernel");
   return SLU_OK;
 }

@@ -117,7 +117,8 @@ int slu_gemm_f32(const float* A, int64_t a_rs, int64_t a_cs, const float* B, int
 /* Up to four small weight-gradient GEMMs in ONE launch, no workspace, deterministic:
  * C_q (M_q x N_q, row stride ldc) = A_q^T B_q with A_q (K_q x M_q, row stride lda), B_q (K_q x N_q, row stride ldb)
  * — dW_ih = d_gx^T x and dW_hh = d_gh^T h_prev (per direction) of one GRU layer when T*B is a few thousand rows
- * (the generic kernel would need split-K and a reduce launch per matrix).  M, lda multiples of 4; N, ldb even.  Pointer / size
+ * (the generic kernel would need split-K and a reduce launch per matrix).  Every M a multiple of 3, or every M and lda a
+ * multiple of 4 with A 16-byte aligned (48- or 64-row output tiles); N, ldb even, B 8-byte aligned.  Pointer / size
  * arrays are HOST arrays.  Optional extra job of the same launch (rowsum_src != NULL):
  * rowsum_dst[c] = sum_r rowsum_src[r*rowsum_cols + c], rows added in order — the layer's bias gradients from the
  * per-tile partial sums slu_gru_seq_bwd leaves (d_bias_part), instead of a reduce launch.                          */

@@ -152,6 +152,42 @@ def test_gemm(ops, M, N, K, ta, tb):
     assert big[:, :3].abs().max().item() == 0 and big[:, 3 + N:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("shapes", [
+    # (K, M, N) per problem: the intent layer's three weight gradients (64-row tiles, 16-byte loads)
+    [(1216, 768, 256), (1152, 384, 128), (1152, 384, 128)],
+    # M not a multiple of 4: 48-row tiles with 12-byte loads; K % 4 != 0 (partial last MFMA step); ragged tiles
+    [(203, 30, 18), (57, 9, 34)],
+    [(64, 4, 2)],
+    [(301, 132, 70), (300, 64, 32), (299, 68, 6), (7, 8, 8)],
+])
+def test_gemm_tn_batched_vs_float64(ops, shapes):
+    """slu_gemm_tn_batched: C_q = A_q^T B_q for up to four problems in one launch (+ the row-sum job that rides the
+    same launch), against float64 matmuls; operands are strided views as GRULayerFn.backward passes them."""
+    torch.manual_seed(5)
+    probs, want = [], []
+    for K, M, N in shapes:
+        big_a = torch.randn(K + 3, M + 8, device="cuda")
+        big_b = torch.randn(K + 3, N + 6, device="cuda")
+        A, B = big_a[1:K + 1, :M], big_b[2:K + 2, :N]
+        if M % 4 == 0 and (A.data_ptr() % 16 or A.stride(0) % 4):     # keep the 64-row path reachable: aligned view
+            big_a = torch.randn(K + 3, M, device="cuda")
+            A = big_a[1:K + 1]
+        C = torch.full((M, N), float("nan"), device="cuda")
+        probs.append((A, B, C))
+        want.append(A.double().t() @ B.double())
+    part = torch.randn(13, 2, 96, device="cuda")
+    dst = torch.empty(2, 96, device="cuda")
+    ops.gemm_tn_batched(probs, (part, dst))
+    for (A, B, C), w in zip(probs, want):
+        assert torch.isfinite(C).all()
+        err = (C.double() - w).abs().max().item()
+        assert err <= 2e-5 * max(1.0, w.abs().max().item()), err
+    seq = part[0].clone()
+    for r in range(1, 13):
+        seq += part[r]
+    assert torch.equal(dst, seq)                      # rows added in order
+
+
 def test_colsum(ops):
     x = torch.randn(1000, 130)
     out = ops.colsum(cu(x))
