@@ -337,11 +337,130 @@ struct TnArgs {
   // optional extra job of the same launch: rs_dst[c] = sum_r rs_src[r * rs_cols + c] (rows added in order), done by
   // the workgroups past the last tile — the layer's bias gradients (per-tile partial sums of the BPTT kernel)
   const float* rs_src; float* rs_dst; int rs_rows, rs_cols, tiles;
+  int rs_blocks;      // the row-sum job takes the FIRST rs_blocks workgroups (it runs beside the tiles, not after them)
 };
 
-// MT = floats of A per lane and k row: 4 -> 64 x 32 output tiles (16-byte loads), 3 -> 48 x 32 tiles (12-byte loads).
-// The launcher picks the height whose tile count spreads evenly over the CUs (a tile's k range is summed the same
-// way for both, so the choice does not change a bit of the result).
+// the row-sum job of a batched launch: 16 rows in flight at a time (clamped row index instead of a branch around the
+// loads: one memory round trip per 16 rows, not one per row), added in row order
+__device__ __forceinline__ void tn_rowsum(const TnArgs& a, int c) {
+  if (c >= a.rs_cols) return;
+  float s = 0.0f;
+  for (int r0 = 0; r0 < a.rs_rows; r0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = a.rs_src[(long long)min(r0 + u, a.rs_rows - 1) * a.rs_cols + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s = (r0 + u < a.rs_rows) ? (r0 + u == 0 ? v[u] : s + v[u]) : s;
+  }
+  a.rs_dst[c] = s;
+}
+
+__global__ void __launch_bounds__(256)
+gemm_tn_small_kernel(const TnArgs a) {
+  __shared__ float red[4][8][256];                     // [wave][tile][lane*4 + r]
+  if ((int)blockIdx.x < a.rs_blocks) {                 // the row-sum job
+    tn_rowsum(a, (int)blockIdx.x * 256 + threadIdx.x);
+    return;
+  }
+  const int bid = (int)blockIdx.x - a.rs_blocks;
+  int q = 0;
+  while (q + 1 < a.count && bid >= a.p[q].tile_end) ++q;
+  const TnProblem& P = a.p[q];
+  const int tile = bid - (q ? a.p[q - 1].tile_end : 0);
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  // this wave's k range: quarters of the FULL 4-row MFMA steps; a partial last step (K % 4 != 0) goes to wave 3.
+  // Rows / columns of the tile past M / N read column 0 instead: the accumulator rows / columns they feed are never
+  // stored, so no select sits between a load and its MFMA (a select there makes the compiler wait for each load
+  // where it is issued: measured 80 us instead of 50 for the intent layer's three matrices).
+  const int steps = P.K >> 2;
+  const int per = ((((steps + 3) >> 2) + 7) >> 3) << 3;   // a multiple of the batch size U = 8: no per-step tail loop
+  const int s0 = min(steps, w * per), s1 = min(steps, s0 + per);
+  // ONE 16-byte (A) and ONE 8-byte (B) load per k row feed all MFMA tiles of a 64 x 32 output tile: lane i holds
+  // columns 4i..4i+3 of A and 2i, 2i+1 of B, i.e. MFMA row-tile x covers the rows m0 + 4*(0..15) + x and column-tile
+  // y the columns n0 + 2*(0..15) + y (a permutation, undone at the store).  A workgroup moves (64 + 32) K floats
+  // for 64 x 32 x K MACs: the kernel is bound by what one CU can pull through its L1 (~60 GB/s), 32 x 32 tiles
+  // moved 1.5x as much per MAC.  (M % 4 == 0, N % 2 == 0: checked by the launcher.)
+  const float* __restrict__ pa = P.A + (m0 + 4 * i + 3 < P.M ? m0 + 4 * i : 0);
+  const float* __restrict__ pb = P.B + (n0 + 2 * i + 1 < P.N ? n0 + 2 * i : 0);
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) { acc[x][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[x][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // batches of U = 8 MFMA steps (16 loads per lane), software-pipelined over two register sets: the next batch's
+  // loads are issued before the current batch's MFMAs (the batch index is clamped instead of branching around the
+  // loads, which would send the register arrays through scratch memory)
+  constexpr int U = 8;
+  const int nb = (s1 > s0) ? (s1 - s0) / U : 0;
+  float4 avA[U], avB[U];
+  float2 bvA[U], bvB[U];
+#define TN_LOAD(av, bv, batch)                                                        \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
+    const long long k = 4 * (s0 + (batch) * U + u) + kg;                               \
+    av[u] = *reinterpret_cast<const float4*>(pa + k * P.lda);                          \
+    bv[u] = *reinterpret_cast<const float2*>(pb + k * P.ldb);                          \
+  }                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+#define TN_STEP(a_, b_)                                                                \
+  acc[0][0] = mfma16(a_.x, b_.x, acc[0][0]); acc[0][1] = mfma16(a_.x, b_.y, acc[0][1]); \
+  acc[1][0] = mfma16(a_.y, b_.x, acc[1][0]); acc[1][1] = mfma16(a_.y, b_.y, acc[1][1]); \
+  acc[2][0] = mfma16(a_.z, b_.x, acc[2][0]); acc[2][1] = mfma16(a_.z, b_.y, acc[2][1]); \
+  acc[3][0] = mfma16(a_.w, b_.x, acc[3][0]); acc[3][1] = mfma16(a_.w, b_.y, acc[3][1]);
+#define TN_MFMA(av, bv)                                                                \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) { TN_STEP(av[u], bv[u]) }              \
+  __builtin_amdgcn_sched_barrier(0);
+  if (nb > 0) {
+    TN_LOAD(avA, bvA, 0)
+    for (int bt = 0; bt < nb; bt += 2) {
+      TN_LOAD(avB, bvB, min(bt + 1, nb - 1))
+      TN_MFMA(avA, bvA)
+      TN_LOAD(avA, bvA, min(bt + 2, nb - 1))
+      if (bt + 1 < nb) { TN_MFMA(avB, bvB) }
+    }
+  }
+  int sb = s0 + nb * U;
+  for (; sb < s1; ++sb) {                              // fewer than U full steps left
+    const long long k = 4 * sb + kg;
+    const float4 av = *reinterpret_cast<const float4*>(pa + k * P.lda);
+    const float2 bv = *reinterpret_cast<const float2*>(pb + k * P.ldb);
+    TN_STEP(av, bv)
+  }
+  if (w == 3 && (P.K & 3)) {                           // partial last step: zero the rows past K
+    const long long k = 4 * steps + kg;
+    const bool kok = k < P.K;
+    const long long kc = kok ? k : 0;
+    float4 av = *reinterpret_cast<const float4*>(pa + kc * P.lda);
+    const float2 bv = *reinterpret_cast<const float2*>(pb + kc * P.ldb);
+    av.x = kok ? av.x : 0.0f; av.y = kok ? av.y : 0.0f; av.z = kok ? av.z : 0.0f; av.w = kok ? av.w : 0.0f;
+    TN_STEP(av, bv)
+  }
+#undef TN_MFMA
+#undef TN_STEP
+#undef TN_LOAD
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][2 * x + y][lane * 4 + r] = acc[x][y][r];
+  __syncthreads();
+  // wave w finishes the two tiles of row-tile x = w: element (lane, r) is row 4*kg + r, column i of a 16 x 16 tile
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane * 4 + r, t = 2 * w + y;
+      const float v = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+      const int m = m0 + 4 * (4 * kg + r) + w, n = n0 + 2 * i + y;
+      if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v;
+    }
+}
+
+// The same kernel with MT floats of A per lane and k row: 3 -> 48 x 32 output tiles, 12-byte loads, for matrices whose
+// M is not a multiple of 4 (or whose A is not 16-byte aligned).  A tile's k range is summed exactly as above.  Kept
+// apart from the 64-row kernel: writing that one as the MT = 4 instance of this template cost it 14 us (53 -> 67 us
+// for the intent layer; same loads and MFMAs, a different schedule).
 template <int MT> struct TnVec;
 template <> struct TnVec<4> { typedef float4 type; };
 template <> struct TnVec<3> { typedef float3 type; };
@@ -351,22 +470,18 @@ template <> __device__ __forceinline__ float tn_elem<3>(const float3& v, int x) 
 
 template <int MT>
 __global__ void __launch_bounds__(256)
-gemm_tn_small_kernel(const TnArgs a) {
+gemm_tn_small_mt_kernel(const TnArgs a) {
   typedef typename TnVec<MT>::type avec;
   __shared__ float red[4][2 * MT][256];                // [wave][tile][lane*4 + r]
-  if ((int)blockIdx.x >= a.tiles) {                    // the row-sum job
-    const int c = ((int)blockIdx.x - a.tiles) * 256 + threadIdx.x;
-    if (c < a.rs_cols) {
-      float s = a.rs_src[c];
-      for (int r = 1; r < a.rs_rows; ++r) s += a.rs_src[(long long)r * a.rs_cols + c];
-      a.rs_dst[c] = s;
-    }
+  if ((int)blockIdx.x < a.rs_blocks) {                 // the row-sum job
+    tn_rowsum(a, (int)blockIdx.x * 256 + threadIdx.x);
     return;
   }
+  const int bid = (int)blockIdx.x - a.rs_blocks;
   int q = 0;
-  while (q + 1 < a.count && (int)blockIdx.x >= a.p[q].tile_end) ++q;
+  while (q + 1 < a.count && bid >= a.p[q].tile_end) ++q;
   const TnProblem& P = a.p[q];
-  const int tile = blockIdx.x - (q ? a.p[q - 1].tile_end : 0);
+  const int tile = bid - (q ? a.p[q - 1].tile_end : 0);
   const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
   const int m0 = tm * (16 * MT), n0 = tn * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -604,10 +719,11 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
   a.tiles = tiles;
   a.rs_src = rowsum_src; a.rs_dst = rowsum_dst; a.rs_rows = (int)rowsum_rows; a.rs_cols = (int)rowsum_cols;
   const int extra = rowsum_src ? (int)cdiv(rowsum_cols, 256) : 0;
+  a.rs_blocks = extra;
   if (mt == 4)
-    hipLaunchKernelGGL(gemm_tn_small_kernel<4>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL(gemm_tn_small_kernel<3>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(gemm_tn_small_mt_kernel<3>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
   SLU_CHECK_LAUNCH("gemm_tn_small_kernel");
   return SLU_OK;
 }

@@ -32,6 +32,9 @@ dW = torch.empty(D * 3 * H, I, device=dev)
 dWf, dWr = torch.empty(3 * H, H, device=dev), torch.empty(3 * H, H, device=dev)
 probs = [(g2, x, dW), (h2[B:, :3 * H], r2[:n, :H], dWf), (h2[:n, 3 * H:], r2[B:, H:], dWr)]
 print("gemm_tn_batched (3 weight gradients): %.1f us" % (1e3 * _timed_graph(lambda: ops.gemm_tn_batched(probs), st)))
+db = torch.empty(dbp.shape[1:], device=dev)
+print("gemm_tn_batched (3 weight gradients + bias-gradient row sums): %.1f us"
+      % (1e3 * _timed_graph(lambda: ops.gemm_tn_batched(probs, (dbp, db)), st)))
 def old():
     ops.gemm(g2.t(), x, out=dW); ops.gemm(probs[1][0].t(), probs[1][1], out=dWf); ops.gemm(probs[2][0].t(), probs[2][1], out=dWr)
 print("three split-K gemms + reduces (round-1 path): %.1f us" % (1e3 * _timed_graph(old, st)))
@@ -39,4 +42,15 @@ h = torch.randn(T, B, D * H, device=dev)
 cw, cb = torch.randn(V, D * H, device=dev) * 0.05, torch.randn(V, device=dev)
 y = torch.stack([torch.randint(0, k, (B,)) for k in (6, 14, 4)], 1).to(dev)
 print("head fwd (+reduce): %.1f us" % (1e3 * _timed_graph(lambda: ops.cls_maxpool_ce_fwd(h, cw, cb, y, (6, 14, 4), True), st)))
+hw = torch.randn(V, D * H, device=dev, requires_grad=True)
+_, logits, pred, argmax_t, d_logits = ops.cls_maxpool_ce_fwd(h, cw, cb, y, (6, 14, 4), True)
+one = torch.ones((), device=dev)
+import ctypes
+from slu_hip import lib as _lib
+L = _lib.load()
+dh, dWc, dbc = torch.empty_like(h), torch.empty_like(cw), torch.empty_like(cb)
+def head_bwd():
+    _lib.check(L.slu_cls_maxpool_ce_bwd(d_logits.data_ptr(), argmax_t.data_ptr(), h.data_ptr(), cw.data_ptr(), one.data_ptr(),
+                                        dh.data_ptr(), dWc.data_ptr(), dbc.data_ptr(), T, B, D * H, V, st.cuda_stream), "bwd")
+print("head bwd (d_h + d_W in one launch): %.1f us" % (1e3 * _timed_graph(head_bwd, st)))
 print("dropout_pool fwd: %.1f us" % (1e3 * _timed_graph(lambda: ops.dropout_pool_fwd(out, None, 0.5, 1, 16, "none", 1), st)))
