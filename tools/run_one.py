@@ -33,7 +33,7 @@ elif what in ("gemm_bf_ip0", "gemm_bf_ip1"):
     for _ in range(5):
         ops.gemm_bf16(planes, packed, bias, N, K, out=out)
 elif what == "gru_bf":
-    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 768), 128
+    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128
     gx = torch.randn(T, B, 6 * H, device="cuda")
     wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
