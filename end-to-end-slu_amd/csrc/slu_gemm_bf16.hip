@@ -211,6 +211,108 @@ gemm_bf_kernel(const GemmBfParams p) {
   }
 }
 
+
+// ---- K <= 64 (one or two k-chunks: the first frozen GRU layer's projection, K = 60 -> 768 outputs) ---------------------
+// That shape is HBM-WRITE bound (a 128-row panel reads 48 KB of A planes and writes 384 KB of fp32), and in the tiled
+// kernel above each 128 x 64 tile is a latency chain of its own (A DMA -> two chunks -> stores: 2.3 TB/s).  Here a
+// workgroup owns a 128-row PANEL: its A planes (all of K) are fetched once by LDS-DMA and stay in LDS, then it walks
+// the N/64 column tiles: W fragments and the bias of tile j+1 are in flight (registers, two alternating sets) during
+// the MFMAs and the stores of tile j, so the only thing a panel ever waits for after its first tile is the store
+// queue.  No LDS-DMA inside the loop, hence no conservative vmcnt(0) before LDS reads; no workgroup barrier either
+// (the epilogue buffer is per wave).  Two workgroups per CU (66 KB of LDS each).
+template <int NS, int KC>
+__global__ void __launch_bounds__(GB_THREADS, 2)
+gemm_bf_panel_kernel(const GemmBfParams p) {
+  constexpr int STAGE_U4 = NS * GB_BM * 4;
+  constexpr int EPI_FLOATS = 4 * 32 * 36;
+  __shared__ __attribute__((aligned(16))) char smem[KC * STAGE_U4 * 16 + EPI_FLOATS * 4];
+  uint4* const sA = reinterpret_cast<uint4*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 15, kg = lane >> 4;
+  const int NT = p.N / 16, NJ = p.N / GB_BN;
+  const int m0 = blockIdx.x * GB_BM;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  {
+    const int srow = tid >> 2, sslot = tid & 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = srow + 64 * h, m = m0 + r;
+      const unsigned short* src = p.A + (size_t)(m < p.M ? m : 0) * p.lda + swz_slot(r, sslot) * 8;
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)pl * p.a_plane + kc * 32),
+                                           (lptr_t)(sA + kc * STAGE_U4 + (pl * GB_BM + 64 * h + 16 * wave) * 4), 16, 0, 0);
+    }
+  }
+  const uint4* b_src = p.wp + (size_t)(wn * 2) * 64 + lane;
+  const size_t b_plane = (size_t)p.KC * NT * 64, b_chunk = (size_t)NT * 64;
+  int a_frag[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = wm * 64 + a * 16 + i;
+    a_frag[a] = r * 4 + swz_slot(r, kg);
+  }
+  const int col4 = (lane & 7) * 4;
+  float* const sC = reinterpret_cast<float*>(smem + KC * STAGE_U4 * 16) + wave * (32 * 36);
+  constexpr int NPAIR = NS == 1 ? 1 : 6;
+  uint4 rb0[KC][NS][2], rb1[KC][NS][2];
+  float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
+  // W fragments + bias of column tile j_ (clamped: the last tile prefetches itself; no branch around the arrays)
+#define GP_FETCH(j_, dst, bdst)                                                                         \
+  {                                                                                                     \
+    const int jj = min((j_), NJ - 1);                                                                   \
+    _Pragma("unroll") for (int kc = 0; kc < KC; ++kc) _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                     \
+        dst[kc][pl][b] = b_src[(size_t)pl * b_plane + (size_t)kc * b_chunk + (size_t)(jj * 4 + b) * 64]; \
+    if (p.bias) bdst = *reinterpret_cast<const float4*>(p.bias + jj * GB_BN + wn * 32 + col4);          \
+  }
+#define GP_TILE(j_, cur, bcur, nxt, bnxt)                                                               \
+  {                                                                                                     \
+    GP_FETCH((j_) + 1, nxt, bnxt)                                                                       \
+    __builtin_amdgcn_sched_barrier(0);   /* next tile's loads are issued HERE, ahead of this tile's MFMAs */ \
+    f32x4 acc[4][2];                                                                                    \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)         \
+      acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};                                                            \
+    _Pragma("unroll") for (int kc = 0; kc < KC; ++kc) {                                                 \
+      uint4 fa[NS][4];                                                                                  \
+      _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int a = 0; a < 4; ++a)   \
+        fa[pl][a] = sA[kc * STAGE_U4 + pl * GB_BM * 4 + a_frag[a]];                                     \
+      _Pragma("unroll") for (int q = 0; q < NPAIR; ++q) {                                               \
+        const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15; \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)     \
+          acc[a][b] = mfma_bf16(fa[pa][a], cur[kc][pb][b], acc[a][b]);                                  \
+      }                                                                                                 \
+    }                                                                                                   \
+    const int ncol = (j_) * GB_BN + wn * 32 + col4;                                                     \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                     \
+      _Pragma("unroll") for (int a2 = 0; a2 < 2; ++a2) _Pragma("unroll") for (int b = 0; b < 2; ++b)    \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+          sC[(a2 * 16 + 4 * kg + r) * 36 + b * 16 + i] = acc[2 * h + a2][b][r];                         \
+      _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                \
+        const int rl = (lane >> 3) + 8 * it;                                                            \
+        const int m = m0 + wm * 64 + h * 32 + rl;                                                       \
+        const float4 v = *reinterpret_cast<const float4*>(&sC[rl * 36 + col4]);                         \
+        if (m < p.M)                                                                                    \
+          *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + ncol) =                                  \
+              make_float4(v.x + bcur.x, v.y + bcur.y, v.z + bcur.z, v.w + bcur.w);                      \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+  GP_FETCH(0, rb0, bias0)
+  __syncthreads();                       // the A panel (all waves' DMA) and the first W fragments have landed
+  for (int j = 0; j < NJ; j += 2) {
+    GP_TILE(j, rb0, bias0, rb1, bias1)
+    if (j + 1 < NJ) GP_TILE(j + 1, rb1, bias1, rb0, bias0)
+  }
+#undef GP_TILE
+#undef GP_FETCH
+}
+
 }  // namespace slu
 
 using namespace slu;
@@ -266,6 +368,17 @@ extern "C" int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64
   p.A = (const unsigned short*)A_planes; p.a_plane = a_plane_stride; p.lda = lda;
   p.wp = (const uint4*)w_packed; p.bias = bias; p.C = C; p.ldc = ldc;
   p.M = (int)M; p.N = (int)N; p.KC = (int)(Kp / 32);
+  if (p.KC <= 2 && N >= 2 * GB_BN && (bias == nullptr || ((uintptr_t)bias & 15) == 0)) {
+    // row-panel kernel: A resident in LDS, column tiles walked by the workgroup (HBM-write-bound shapes)
+    const dim3 pg((unsigned)cdiv(M, GB_BM));
+    hipStream_t st = (hipStream_t)stream;
+    if (nsplit == 3 && p.KC == 2) hipLaunchKernelGGL((gemm_bf_panel_kernel<3, 2>), pg, dim3(GB_THREADS), 0, st, p);
+    else if (nsplit == 3) hipLaunchKernelGGL((gemm_bf_panel_kernel<3, 1>), pg, dim3(GB_THREADS), 0, st, p);
+    else if (p.KC == 2) hipLaunchKernelGGL((gemm_bf_panel_kernel<1, 2>), pg, dim3(GB_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((gemm_bf_panel_kernel<1, 1>), pg, dim3(GB_THREADS), 0, st, p);
+    SLU_CHECK_LAUNCH("gemm_bf_panel_kernel");
+    return SLU_OK;
+  }
   dim3 grid((unsigned)(N / GB_BN), (unsigned)cdiv(M, GB_BM));
   SLU_REQUIRE(grid.y <= 65535, "slu_gemm_bf16: M too large for one launch");
   if (nsplit == 3) hipLaunchKernelGGL(gemm_bf_kernel<3>, grid, dim3(GB_THREADS), 0, (hipStream_t)stream, p);
