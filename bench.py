@@ -344,7 +344,10 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                 planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
                 mult = 6.0 if ns == 3 else 1.0
                 ms = _timed_graph(lambda: ops.gemm_bf16(planes, packed, b_ih, N, I), stream)
-                rows.setdefault("gemm_bf_kernel<%d>" % ns, []).append(
+                kc = ops.round_up(I, 32) // 32
+                # K <= 64: the row-panel kernel (A resident in LDS, HBM-write bound); else the tiled kernel
+                gemm_name = "gemm_bf_panel_kernel<%d,%d>" % (ns, kc) if kc <= 2 else "gemm_bf_kernel<%d>" % ns
+                rows.setdefault(gemm_name, []).append(
                     {"shape": "M=%d N=%d K=%d input projection, %d bf16 plane(s) (%s)" % (T * B, N, I, ns, where),
                      "flops": 2.0 * T * B * N * I, "ms": ms, "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
                      "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + 2.0 * ns * N * ops.round_up(I, 32) + 4.0 * T * B * N})

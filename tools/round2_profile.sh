@@ -27,12 +27,12 @@ import csv, collections
 rows = list(csv.DictReader(open("$f")))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    if "gemm_bf_kernel" in r["Kernel_Name"] or "gru_bf_fwd" in r["Kernel_Name"]:
+    if "gemm_bf_kernel" in r["Kernel_Name"] or "gemm_bf_panel" in r["Kernel_Name"] or "gru_bf_fwd" in r["Kernel_Name"]:
         agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kname, cs in agg.items():
     for c, v in cs.items():
         print(kname, c, "launches", len(v), "mean", sum(v) / len(v))
-dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open("$k")) if "gemm_bf_kernel" in r["Kernel_Name"] or "gru_bf_fwd" in r["Kernel_Name"]]
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open("$k")) if "gemm_bf_kernel" in r["Kernel_Name"] or "gemm_bf_panel" in r["Kernel_Name"] or "gru_bf_fwd" in r["Kernel_Name"]]
 if dur: print("kernel duration under this pass: mean %.1f us over %d launches" % (sum(dur) / len(dur), len(dur)))
 PY
 done; done > $O/pmc_summary.txt 2>&1
