@@ -408,6 +408,16 @@ def dtype_label():
     return "f32"
 
 
+def _cu_split():
+    from slu_hip import pipeline
+    return pipeline.cu_split()
+
+
+def _n_cus():
+    from slu_hip import pipeline
+    return pipeline.n_compute_units(torch.cuda.current_device())
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (separate run,
     FETCH_SIZE x 2 correction of MI355X_MICROARCH.md): profiles/pmc_traffic.json, or None."""
@@ -657,10 +667,10 @@ def main():
                         "algorithmic fp32 flops (mfma_tflops counts the bf16 MFMA products actually issued: 6 per fp32 "
                         "product on the split-precision kernels) and of the algorithmic HBM bytes / sum of the average "
                         "durations; each shape is launched 20x back to back (one hipGraph) on the CU-masked stream it "
-                        "runs on during the timed steps (frozen stages: %d sequences on CUs [64,256); trainable stages: "
-                        "%d sequences on CUs [0,64)) between two HIP events on that stream.  Peaks are whole-chip: fp32 "
+                        "runs on during the timed steps (frozen stages: %d sequences on CUs [%d,%d); trainable stages: "
+                        "%d sequences on CUs [0,%d)) between two HIP events on that stream.  Peaks are whole-chip: fp32 "
                         "MFMA 157.3, dense bf16 MFMA 2500 TFLOP/s, HBM 8 TB/s; `frac` is against the kernel's binding one."
-                        % (width, args.batch * width, args.batch)}
+                        % (width, args.batch * width, _cu_split(), _n_cus(), args.batch, _cu_split())}
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
         if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing" and not args.hidden:

@@ -25,14 +25,18 @@ def cu_split(device=None):
     """CUs [0, n) of the device are reserved for the trainable part of the step, the look-ahead
     super-batches get the rest.  Without the partition the big frozen-prefix kernels keep every CU
     busy and each of the ~25 small, latency-bound kernels of the trainable part waits for workgroup
-    slots (measured: the two streams then take almost the SUM of their times).  Default: a quarter of
-    the device (64 of 256 CUs, best of a 0..128 sweep on MI355X); SLU_CU_SPLIT=n overrides, 0 = off."""
+    slots (measured: the two streams then take almost the SUM of their times).  Default: three eighths of
+    the device (96 of 256 CUs = 12 per XCD; the mask bits interleave over the 8 XCDs, odd counts per XCD split CU
+    pairs between the partitions and are markedly slower).  Round 2, after the trainable step shrank to ten
+    launches (bench.py, same box): 64 CUs + 16-batch super-batches 265-267 k utt/s, 96 CUs + 20-batch super-batches
+    (one recurrence workgroup per look-ahead CU) 278-281 k; 80 / 88 / 104 / 112 / 128 CUs: 268 / 236-277 / 208-228 /
+    208-240 / 223 k.  SLU_CU_SPLIT=n overrides, 0 = off."""
     v = os.environ.get("SLU_CU_SPLIT", "auto")
     if v != "auto":
         return int(v)
     if not torch.cuda.is_available():
         return 0
-    return n_compute_units(torch.cuda.current_device() if device is None else device) // 4
+    return 3 * n_compute_units(torch.cuda.current_device() if device is None else device) // 8
 
 
 _CU_MASK_BROKEN = [False]

@@ -46,20 +46,20 @@ def _param_signature(model):
 
 
 def _lookahead_width(depth, batch_size):
-    """Batches per look-ahead super-batch: explicit, or 16/3 sequences per CU the side streams may use: 1024
-    sequences = 16 batches of 64 on the 192 CUs of the default partition.  Measured on MI355X (bench.py, 512 steps,
-    round 2, after the small-kernel fusions of the trainable step): 12 / 14 / 16 / 18 / 24 batches -> 246 / 254 /
-    262 / 261 / 249 k utt/s.  Wider super-batches make the frozen stages more efficient (190 vs 231 us per step at 24
-    vs 12 batches, alone on their partition), but the two partitions share the power budget: with all 256 CUs busy
-    the clock drops to ~1.7 GHz and the latency-bound trainable step (194 us alone) takes ~250 us, so past the
-    point where the frozen stages keep up with it a wider super-batch only lengthens the pipeline fill."""
+    """Batches per look-ahead super-batch: explicit, or eight sequences per CU the side streams may use — one
+    16-sequence workgroup of the split-precision recurrence per direction and CU: 1280 sequences = 20 batches of 64 on
+    the 160 CUs of the default partition.  Measured on MI355X (bench.py, 512 steps, round 2, 96 + 160 CUs): 18 / 19 /
+    20 / 21 / 22 batches -> 272 / 265 / 272-282 / 232 / 238 k utt/s — one batch more and the recurrences need a second
+    round of workgroups.  Wider super-batches make the frozen stages more efficient, but the two partitions share the
+    power budget (with all 256 CUs busy the clock drops to ~1.8 GHz and the latency-bound trainable step slows by
+    20-30 %), and a wider first super-batch is a longer pipeline fill."""
     if depth > 0:
         return depth
     from slu_hip import pipeline
     cus = 256
     if torch.cuda.is_available():
         cus = pipeline.n_compute_units(torch.cuda.current_device()) - pipeline.cu_split()
-    return max(2, min(32, (16 * cus) // max(1, 3 * batch_size)))
+    return max(2, min(32, (8 * cus) // max(1, batch_size)))
 
 
 class Trainer:

@@ -1,5 +1,5 @@
 """GPU parity of the EXACT path bench.py times (BASELINE.json configs[3] at full size: no_unfreezing
-architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 16 batches (1024 sequences, split-precision
+architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 20 batches (1280 sequences, split-precision
 bf16x3 MFMA input projections and 16-sequence recurrence kernels for the frozen layers, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
 step, against (1) the plain sequential eager loop, bit for bit, and (2) the CPU oracle (<= 1e-4).
 
@@ -64,7 +64,7 @@ def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps):
 
 
 def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, monkeypatch):
-    """96 steps of B = 64 x 3 s: six 16-batch super-batches, three per look-ahead slot: each slot captures its shape
+    """120 steps of B = 64 x 3 s: six 20-batch super-batches, three per look-ahead slot: each slot captures its shape
     on the second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
     Per-step losses and final parameters must be bit-equal to the eager sequential loop."""
     import data
@@ -72,7 +72,7 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     torch.manual_seed(1)
     torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
     ds = data.SyntheticSLUDataset(4, 64, 48000, cfg.values_per_slot, seed=1234)
-    n_steps = 96
+    n_steps = 120
     loader = [ds.batches[i % 4] for i in range(n_steps)]
     ref_tr, ref_losses, ref_sd = _run_training(cfg, loader, monkeypatch, "0", "0", n_steps)
     assert ref_tr.graph_stats() == {"step_graphs": 0, "prefix_graphs": 0, "capture_failures": 0}
@@ -85,15 +85,15 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k
 
-    # the bench.py default: automatic look-ahead width (16 batches = 1024 sequences) + graphs
+    # the bench.py default: automatic look-ahead width (20 batches = 1280 sequences) + graphs
     tr, losses, sd = _run_training(cfg, loader, monkeypatch, "auto", "1", n_steps)
     import training
-    assert training._lookahead_width(-1, 64) == 16
+    assert training._lookahead_width(-1, 64) == 20
     stats = tr.graph_stats()
     assert stats["step_graphs"] == 1 and stats["capture_failures"] == 0
     assert all(len([g for g in slot.graphs.values() if g is not None]) >= 1 for slot in tr._slots)
     assert stats["prefix_graphs"] == 2
-    # every slot replayed its captured graph at least once (seen >= 3 for the 16-batch key)
+    # every slot replayed its captured graph at least once (seen >= 3 for the 20-batch key)
     assert all(max(slot.seen.values()) >= 3 for slot in tr._slots)
     assert losses == ref_losses
     for k, v in ref_sd.items():

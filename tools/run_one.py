@@ -17,23 +17,23 @@ elif what == "gemmbig":
     for _ in range(10):
         ops.gemm(a, w.t(), None, out=out)
 elif what in ("gemm_ip0", "gemm_ip1"):
-    # input projections of a 16-batch look-ahead super-batch (1024 sequences): phone_rnn0 (T=300, K=60), phone_rnn1 (T=150, K=256)
+    # input projections of a 20-batch look-ahead super-batch (1280 sequences): phone_rnn0 (T=300, K=60), phone_rnn1 (T=150, K=256)
     M, N, K = (300 * 768, 768, 60) if what == "gemm_ip0" else (150 * 768, 768, 256)
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); bias = torch.randn(N, device="cuda")
     out = torch.empty(M, N, device="cuda")
     for _ in range(5):
         ops.gemm(a, w.t(), bias, out=out)
 elif what in ("gemm_bf_ip0", "gemm_bf_ip1"):
-    # split-precision input projections of a 16-batch look-ahead super-batch (1024 sequences): phone_rnn0 (T=300, K=60),
+    # split-precision input projections of a 20-batch look-ahead super-batch (1280 sequences): phone_rnn0 (T=300, K=60),
     # phone_rnn1 (T=150, K=256); three bf16 planes in, fp32 out
-    S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
     M, N, K = (300 * S, 768, 60) if what == "gemm_bf_ip0" else (150 * S, 768, 256)
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.1; bias = torch.randn(N, device="cuda")
     planes = ops.split_bf16(a, 3); packed = ops.gemm_bf16_pack(w, 3); out = torch.empty(M, N, device="cuda")
     for _ in range(5):
         ops.gemm_bf16(planes, packed, bias, N, K, out=out)
 elif what == "gru_bf":
-    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128
+    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1280), 128
     gx = torch.randn(T, B, 6 * H, device="cuda")
     wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")

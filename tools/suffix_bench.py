@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the kernels of the trainable suffix of the pipelined step (intent layer, B = 64, T = 19) ALONE on a
-64-CU masked stream (20 launches back to back in one hipGraph): what each costs without the look-ahead
+training-stream CU partition (20 launches back to back in one hipGraph): what each costs without the look-ahead
 partition's traffic beside it.   python tools/suffix_bench.py"""
 import os
 import sys
@@ -12,7 +12,7 @@ from bench import _timed_graph
 from slu_hip import ops, pipeline
 
 dev = torch.device("cuda", 0)
-st = pipeline.cu_range_stream(dev, 0, 64)
+st = pipeline.cu_range_stream(dev, 0, pipeline.cu_split())      # the training stream's CU partition
 T, B, I, H, D, V = 19, 64, 256, 128, 2, 24
 x = torch.randn(T * B, I, device=dev)
 w_ih = torch.randn(D * 3 * H, I, device=dev) * 0.05
