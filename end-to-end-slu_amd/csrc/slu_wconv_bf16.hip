@@ -62,9 +62,15 @@ bf_wconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int c_
   }
 }
 
-template <int MT, int NT, int NS>
+// SPLITN: the four waves form a 2 x 2 grid (frames x channels) instead of 4 x 1: a wave then needs only half of the
+// filter fragments of a k-chunk.  With 4 x 1 every wave fetches ALL NT x NS fragments from L2 — 48 KB per workgroup
+// and chunk for 768 MFMA cycles = the whole 64 B/clk L2 port of the CU; 2 x 2 halves that (the A fragments, read
+// from LDS by two waves each, take the difference: 62 B/clk of the LDS' 128).  NT even only.
+template <int MT, int NT, int NS, bool SPLITN>
 __global__ void __launch_bounds__(WB_THREADS, 2)
 wconv_bf_fwd_kernel(const WconvBfParams p) {
+  constexpr int RT = SPLITN ? 2 * MT : MT;        // row (frame) tiles per wave
+  constexpr int CT = SPLITN ? NT / 2 : NT;        // column (channel) tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* lds = reinterpret_cast<unsigned short*>(smem);     // [NS][nrows][Sp]
   constexpr int F = 64 * MT;                      // frames per workgroup
@@ -75,6 +81,8 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   const int l0 = blockIdx.x * F;
   const float* __restrict__ inb = p.in + (size_t)b * p.in_row;
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
+  const int row0 = SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT;   // this wave's first frame in the tile
+  const int nb = SPLITN ? (wave & 1) * CT : 0;                        // ... and its first channel tile
 
   // ---- stage the window: LDS (row, col) <- global element u0 + row * S_real + col (col < S_real), zero elsewhere;
   //      two adjacent columns per thread and step (one 4-byte LDS store per plane), eight steps' loads in flight ----
@@ -115,62 +123,62 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   }
   __syncthreads();
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[RT][CT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < RT; ++m)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < CT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int i = lane & 15, kg = lane >> 4;
   // tap chunk (kc, kg) starts at padded tap q = kc*32 + kg*8: LDS row offset q / S, column q % S (multiple of 8)
   int qd = (kg * 8) / p.S, qm = kg * 8 - qd * p.S;
-  int abase[MT];
+  int abase[RT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) abase[m] = (wave * 16 * MT + m * 16 + i) * p.Sp;
-  const uint4* __restrict__ wp = p.wp + lane;
+  for (int m = 0; m < RT; ++m) abase[m] = (row0 + m * 16 + i) * p.Sp;
+  const uint4* __restrict__ wp = p.wp + (size_t)nb * 64 + lane;
   const size_t w_plane = (size_t)p.KC * NT * 64;
 
-  uint4 fb[NS][NT], fbn[NS][NT];
+  uint4 fb[NS][CT], fbn[NS][CT];
 #pragma unroll
   for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) fb[pl][n] = wp[pl * w_plane + (size_t)n * 64];
+    for (int n = 0; n < CT; ++n) fb[pl][n] = wp[pl * w_plane + (size_t)n * 64];
   for (int kc = 0; kc < p.KC; ++kc) {
     const int kn = min(kc + 1, p.KC - 1);          // unconditional prefetch (the last chunk re-reads itself)
 #pragma unroll
     for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) fbn[pl][n] = wp[pl * w_plane + ((size_t)kn * NT + n) * 64];
-    uint4 fa[NS][MT];
+      for (int n = 0; n < CT; ++n) fbn[pl][n] = wp[pl * w_plane + ((size_t)kn * NT + n) * 64];
+    uint4 fa[NS][RT];
     const int aoff = qd * p.Sp + qm;
 #pragma unroll
     for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) fa[pl][m] = *reinterpret_cast<const uint4*>(lds + pl * plane + abase[m] + aoff);
+      for (int m = 0; m < RT; ++m) fa[pl][m] = *reinterpret_cast<const uint4*>(lds + pl * plane + abase[m] + aoff);
     __builtin_amdgcn_sched_barrier(0);             // next chunk's filter loads and this chunk's fragments issued HERE
 #pragma unroll
     for (int q = 0; q < NPAIR; ++q) {
       const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < RT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = mfma_bf16(fa[pa][m], fb[pb][n], acc[m][n]);
+        for (int n = 0; n < CT; ++n) acc[m][n] = mfma_bf16(fa[pa][m], fb[pb][n], acc[m][n]);
     }
     qm += 32;
     while (qm >= p.S) { qm -= p.S; ++qd; }
 #pragma unroll
     for (int pl = 0; pl < NS; ++pl)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) fb[pl][n] = fbn[pl][n];
+      for (int n = 0; n < CT; ++n) fb[pl][n] = fbn[pl][n];
   }
 
   // ---- epilogue: bias, abs, max-pool over frame pairs, LeakyReLU, strided store (as wconv_fwd_kernel) ----
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int fbase = l0 + wave * 16 * MT + m * 16 + 4 * kg;   // multiple of 4
+  for (int m = 0; m < RT; ++m) {
+    const int fbase = l0 + row0 + m * 16 + 4 * kg;   // multiple of 4
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int c = n * 16 + i;
+    for (int n = 0; n < CT; ++n) {
+      const int c = (nb + n) * 16 + i;
       if (c >= p.c_out) continue;
       const float bias = p.bias ? p.bias[c] : 0.0f;
       float v[4];
@@ -212,12 +220,13 @@ static inline int bf_nt_for(int64_t c) {
 
 template <int MT, int NT, int NS>
 static int bf_launch(dim3 grid, size_t lds, hipStream_t st, const WconvBfParams& p) {
+  constexpr bool SPLITN = (NT % 2 == 0) && MT == 2;      // 2 x 2 waves where the channel tiles divide
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)wconv_bf_fwd_kernel<MT, NT, NS>,
+    hipError_t e = hipFuncSetAttribute((const void*)wconv_bf_fwd_kernel<MT, NT, NS, SPLITN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "wconv_bf16: cannot raise the dynamic LDS cap to %zu: %s", lds, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL((wconv_bf_fwd_kernel<MT, NT, NS>), grid, dim3(WB_THREADS), lds, st, p);
+  hipLaunchKernelGGL((wconv_bf_fwd_kernel<MT, NT, NS, SPLITN>), grid, dim3(WB_THREADS), lds, st, p);
   SLU_CHECK_LAUNCH("wconv_bf_fwd_kernel");
   return SLU_OK;
 }

@@ -40,3 +40,18 @@ if "gru" in what:
             ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, ns), st)
             line += " | nsplit=%d %.1f us (%.2f us/step, %.1f TF-equivalent)" % (ns, 1e3 * ms, 1e3 * ms / T, fl / ms / 1e9)
         print(line, flush=True)
+
+if "wconv" in what:
+    # the three convolution blocks of the frozen encoder (split-precision kernel vs the exact-fp32 one)
+    for name, L, C, Co, k, stride, do_abs, pool in (("sinc", 48000, 1, 80, 401, 80, True, 2), ("conv1", 300, 80, 60, 5, 1, False, 1),
+                                                    ("conv2", 300, 60, 60, 5, 1, False, 1)):
+        x = torch.randn(B, L, C, device="cuda") * 0.1
+        w = torch.randn(Co, C, k, device="cuda") * 0.05
+        bias = torch.randn(Co, device="cuda")
+        l_conv = ops.conv_out_len(L, k, stride)
+        fl = 2.0 * B * l_conv * Co * C * k
+        line = "%s B=%d L=%d %d->%d k=%d:" % (name, B, L, C, Co, k)
+        for ns in (3, 1):
+            ms = _timed_graph(lambda: ops.wconv_fwd_bf16(x, w, bias, B, L, C, stride, do_abs, pool, 0.2, False, ns), st)
+            line += " nsplit=%d %.1f us (%.1f TF-equivalent) |" % (ns, 1e3 * ms, fl / ms / 1e9)
+        print(line, flush=True)
