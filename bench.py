@@ -382,7 +382,12 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
         tf_mfma = mfma / (ms * 1e-3) / 1e12
         tbs = byts / (ms * 1e-3) / 1e12
         f_mfma, f_hbm = tf_mfma / peak, tbs / PEAK_HBM_TBS
+        # the kernel runs on its stream's CU partition only: its MFMA fraction of THAT partition's share of the peak
+        # (HBM is shared by the whole chip: no such rescaling)
+        n_cu, split = _n_cus(), _cu_split()
+        cus = (n_cu - split if "look-ahead" in shapes[0]["shape"] else split) if 0 < split < n_cu else n_cu
         out.append({"kernel": name, "launches_per_cycle": len(shapes), "algorithmic_gflop": round(flops / 1e9, 2),
+                    "cus": cus, "mfma_frac_of_partition_peak": round(f_mfma * n_cu / cus, 4),
                     "avg_us": round(1e3 * ms / len(shapes), 2),
                     "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),       # fp32-equivalent work rate
                     "mfma_tflops": round(tf_mfma, 2), "mfma_peak": peak, "mfma_frac": round(f_mfma, 4),
