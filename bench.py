@@ -667,7 +667,7 @@ def main():
                 "traffic": round(alg_per_launch * ratio) if ratio else None,
                 "algorithmic_bytes_per_launch": alg_per_launch, "traffic_pmc": pmc,
                 "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
-                "kernels": table[:4],
+                "kernels": table[:6],
                 "note": "per kernel: sums over its distinct launch shapes in one look-ahead cycle (%d steps) of the "
                         "algorithmic fp32 flops (mfma_tflops counts the bf16 MFMA products actually issued: 6 per fp32 "
                         "product on the split-precision kernels) and of the algorithmic HBM bytes / sum of the average "

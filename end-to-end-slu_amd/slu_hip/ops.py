@@ -7,6 +7,8 @@ Layouts used between kernels (the host mirror in models.py converts at the modul
 torch is plumbing here: it owns the device buffers, the stream and the autograd tape.  All
 arithmetic of the hot path happens in libslu_hip.so; there is no fallback path.
 """
+import os
+
 import torch
 
 from . import lib as _lib
@@ -453,6 +455,8 @@ def _ticket(dev):
     """A persistent zeroed device word per (device, stream) for kernels whose last workgroup finishes a reduction
     (it leaves the word at zero).  None while a hipGraph capture is running and the word does not exist yet (memory
     allocated during a capture belongs to the graph): the caller then takes the separate-launch path."""
+    if os.environ.get("SLU_HEAD_TICKET", "1") == "0":
+        return None
     key = (dev.index, _stream())
     t = _TICKETS.get(key)
     if t is None:

@@ -11,7 +11,7 @@ import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--lookahead", type=int, default=24)
+ap.add_argument("--lookahead", type=int, default=20)
 ap.add_argument("--steps", type=int, default=128)
 a = ap.parse_args()
 os.environ["SLU_LOOKAHEAD"] = str(a.lookahead)

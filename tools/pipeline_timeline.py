@@ -10,7 +10,7 @@ import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--lookahead", type=int, default=24)
+ap.add_argument("--lookahead", type=int, default=20)
 ap.add_argument("--groups", type=int, default=6)
 a = ap.parse_args()
 os.environ["SLU_LOOKAHEAD"] = str(a.lookahead)
