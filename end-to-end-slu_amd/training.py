@@ -386,12 +386,14 @@ class Trainer:
         step_graphs = use_graph and self._graphable()
         forward = self._slu_forward(n_prefix, sums if step_graphs else None)
         trainable = _param_signature(self.model)
-        # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so no
-        # super-batch is wider than half the run — the second half's encoders then overlap the first half's steps
+        # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so a run that
+        # fits in two super-batches is split 60 : 40 — the second, smaller one (its encoder runs beside the first
+        # one's steps, ~5 % slower than alone) is then ready when the first one's steps end (20 batches: 12 + 8;
+        # measured prefix times 0.94 + 0.153 ms per batch, 0.2 ms per step: 7.3 ms against 7.6 for 10 + 10)
         try:
-            width_cap = max(2, -(-len(loader) // 2))
+            n_run = len(loader)
         except TypeError:
-            width_cap = 1 << 30
+            n_run = 1 << 30
         pending = collections.deque()
         it = iter(loader)
         carry = []                                    # a batch read ahead that did not fit its group
@@ -402,7 +404,14 @@ class Trainer:
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
             nonlocal launched
             group = [carry.pop()] if carry else []
-            while not group or len(group) < min(width_cap, _lookahead_width(depth, len(group[0][0]))):
+            cap = [1 << 30]
+
+            def width():
+                w = _lookahead_width(depth, len(group[0][0]))
+                if launched == 0 and n_run < 2 * w:
+                    cap[0] = max(2, -(-3 * n_run // 5))
+                return min(cap[0], w)
+            while not group or len(group) < width():
                 try:
                     batch = next(it)
                 except StopIteration:

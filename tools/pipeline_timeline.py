@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--lookahead", type=int, default=20)
 ap.add_argument("--groups", type=int, default=6)
+ap.add_argument("--steps", type=int, default=0, help="run exactly this many steps (default: groups x lookahead)")
 a = ap.parse_args()
 os.environ["SLU_LOOKAHEAD"] = str(a.lookahead)
 import bench
@@ -22,11 +23,11 @@ dev = next(model.parameters()).device
 batches = [(x.to(dev), y.to(dev)) for x, y in train_ds.loader]
 P = a.lookahead
 for _ in range(3):
-    bench.run_steps(model, trainer, batches, 4 * P)
+    bench.run_steps(model, trainer, batches, a.steps or 4 * P)
 torch.cuda.synchronize()
 
 ev = lambda: torch.cuda.Event(enable_timing=True)
-prefix_marks, step_marks = [], []
+prefix_marks, step_marks, group_sizes = [], [], []
 orig_slot_run = pipeline.PrefixSlot.run
 def slot_run(self, model_, xs, n_prefix, step0, use_graph, after=None):
     e0, e1, e2 = ev(), ev(), ev()
@@ -47,6 +48,7 @@ def slot_run(self, model_, xs, n_prefix, step0, use_graph, after=None):
         pipeline.PrefixSlot._fill = staticmethod(orig_fill)
     e2.record(self.stream)
     prefix_marks.append((e0, e1, e2))
+    group_sizes.append(list(xs))
     return out
 pipeline.PrefixSlot.run = slot_run
 orig_sg_run = pipeline.StepGraph.run
@@ -62,18 +64,24 @@ pipeline.StepGraph.run = sg_run
 base = ev()
 with torch.cuda.stream(trainer._train_stream):
     base.record(trainer._train_stream)
-bench.run_steps(model, trainer, batches, a.groups * P)
+n_steps = a.steps or a.groups * P
+bench.run_steps(model, trainer, batches, n_steps)
 torch.cuda.synchronize()
 t = lambda e: base.elapsed_time(e) * 1e3
 print("all times in us since the loop start; super-batch = %d batches" % P)
 for g, (e0, e1, e2) in enumerate(prefix_marks):
     print("prefix %2d: deps ok %9.0f  copies done %9.0f (+%5.0f)  graph done %9.0f (+%6.0f)" %
           (g, t(e0), t(e1), t(e1) - t(e0), t(e2), t(e2) - t(e1)))
-for g in range(a.groups):
-    s = step_marks[g * P:(g + 1) * P]
+widths = [len(xs) for xs in group_sizes]
+pos = 0
+for g, w in enumerate(widths):
+    s = step_marks[pos:pos + w]
+    pos += w
+    if not s:
+        break
     durs = [t(b) - t(a_) for a_, b in s]
     gaps = [t(s[i + 1][0]) - t(s[i][1]) for i in range(len(s) - 1)]
-    print("steps  %2d: first starts %9.0f  last ends %9.0f  (%.0f us / step; step dur min %.0f med %.0f max %.0f; "
-          "first %.0f; gap max %.0f)" % (g, t(s[0][0]), t(s[-1][1]), (t(s[-1][1]) - t(s[0][0])) / P,
+    print("steps  %2d (%2d): first starts %9.0f  last ends %9.0f  (%.0f us / step; step dur min %.0f med %.0f max %.0f; "
+          "first %.0f; gap max %.0f)" % (g, w, t(s[0][0]), t(s[-1][1]), (t(s[-1][1]) - t(s[0][0])) / w,
                                           min(durs), sorted(durs)[len(durs) // 2], max(durs), durs[0],
                                           max(gaps) if gaps else 0))
