@@ -23,6 +23,9 @@ struct WconvBfParams {
   const uint4* wp;      // packed filters [plane][KC][NT][64]
   const float* bias;    // (c_out) or null
   float* out;
+  unsigned short* planes;   // null, or NS bf16 planes of (l_out * Bn) x Kp_out (time-major rows f * Bn + b, zero padded
+  long long plane;          // columns): the split-precision activation format the next frozen GRU layer's GEMM reads
+  int Kp_out, Bn;
   long long in_row;     // floats per batch row (l_in * c_in)
   long long out_sb, out_sl;
   int S, S_real, Sp;    // LDS row length (bf16 elements), global elements per row, LDS row stride
@@ -179,6 +182,26 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
 #pragma unroll
     for (int n = 0; n < CT; ++n) {
       const int c = (nb + n) * 16 + i;
+      if (p.planes) {
+        // straight into the split format (pool == 1 only): columns [c_out, Kp_out) are the zero padding
+        if (c >= p.Kp_out) continue;
+        const bool real = c < p.c_out;
+        const float bias = (real && p.bias) ? p.bias[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = fbase + r;
+          if (f >= p.l_conv) continue;
+          float t = acc[m][n][r] + bias;
+          t = p.do_abs ? fabsf(t) : t;
+          t = real ? (t > 0.0f ? t : t * p.slope) : 0.0f;
+          unsigned short sp[NS];
+          split_bf16<NS>(t, sp);
+#pragma unroll
+          for (int pl = 0; pl < NS; ++pl)
+            p.planes[(size_t)pl * p.plane + ((size_t)f * p.Bn + b) * p.Kp_out + c] = sp[pl];
+        }
+        continue;
+      }
       if (c >= p.c_out) continue;
       const float bias = p.bias ? p.bias[c] : 0.0f;
       float v[4];
@@ -255,8 +278,9 @@ extern "C" size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, in
 extern "C" int slu_wconv_fwd_bf16(const float* in, const float* weight, const float* bias, float* out, int64_t B,
                                   int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t,
                                   int do_abs, int pool, float slope, int64_t out_sb, int64_t out_sl,
+                                  void* out_planes, int64_t out_plane_stride,
                                   void* workspace, size_t workspace_bytes, int nsplit, void* stream) {
-  SLU_REQUIRE(in && weight && out, "slu_wconv_fwd_bf16: null pointer");
+  SLU_REQUIRE(in && weight && (out || out_planes), "slu_wconv_fwd_bf16: null pointer");
   SLU_REQUIRE(B > 0 && l_in > 0 && c_in > 0 && c_out > 0 && k_t > 0 && stride_t > 0, "slu_wconv_fwd_bf16: non-positive size");
   SLU_REQUIRE(pool == 1 || pool == 2, "slu_wconv_fwd_bf16: pool must be 1 or 2 (got %d)", pool);
   SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_wconv_fwd_bf16: nsplit must be 1 or 3");
@@ -289,6 +313,14 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* weight, const fl
   }
   WconvBfParams p;
   p.in = in; p.wp = wp; p.bias = bias; p.out = out;
+  p.planes = (unsigned short*)out_planes; p.plane = out_plane_stride; p.Kp_out = (int)(cdiv(c_out, 32) * 32); p.Bn = (int)B;
+  if (out_planes) {
+    if (pool != 1 || NT * 16 < p.Kp_out)
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_fwd_bf16: out_planes needs pool == 1 and a channel tiling that covers "
+               "round_up(c_out, 32) columns (c_out %lld)", (long long)c_out);
+    SLU_REQUIRE(out_plane_stride >= (int64_t)((l_in + 2 * (k_t / 2) - k_t) / stride_t + 1) * B * p.Kp_out,
+                "slu_wconv_fwd_bf16: plane stride too small");
+  }
   p.in_row = l_in * c_in; p.out_sb = out_sb; p.out_sl = out_sl;
   p.S = (int)S; p.S_real = (int)S_real; p.Sp = (int)S + 8;
   p.KC = (int)KC; p.pad = (int)(pad_t * c_in);

@@ -358,8 +358,10 @@ class _ConvStage:
     def parameters(self):
         return list(self.conv.parameters())
 
-    def run(self, h, training):
-        """h: (B,T) for the first block, else channels-last (B,L,C)."""
+    def run(self, h, training, out_planes=False):
+        """h: (B,T) for the first block, else channels-last (B,L,C).
+        out_planes: the consumer is a frozen split-precision GRU layer — hand over bf16 planes (SplitAct) when this
+        block runs on the split-precision kernel itself, time-major and without dropout (else plain fp32)."""
         time_major = self.time_major
         fused_pool = self.pool in (1, 2)
         tm = time_major and fused_pool and self.drop == 0.0
@@ -381,8 +383,12 @@ class _ConvStage:
                     w, bias, do_abs = self.conv.weight.detach(), self.conv.bias.detach(), self.do_abs
                 x3 = h if h.dim() == 3 else h.unsqueeze(2)
                 B, l_in = x3.shape[0], x3.shape[1]
+                planes = (out_planes and tm and not (self.drop > 0.0 and training)
+                          and _ops.wconv_bf16_planes_ok(w.shape[0], pool))
                 h = _ops.wconv_fwd_bf16(x3.contiguous(), w, bias, B, l_in, c_in, self.conv.stride, do_abs, pool, slope,
-                                        tm, nsplit)
+                                        tm, nsplit, planes)
+                if planes:
+                    return h
             if self.drop > 0.0 and training:
                 p, mask, seed, offset = _dropout_args(self.drop_name, self.site, self.drop, training, cnn=True)
                 h = _DropOnlyFn.apply(h.contiguous(), p, mask, seed, offset)
@@ -524,7 +530,13 @@ class PretrainedModel(torch.nn.Module):
                           and nxt.gru.split_frozen() == st.gru.split_frozen())
                 h = st.run(h, self.training, planes)
             else:
-                h = st.run(h, self.training)
+                # the last CNN block feeding a frozen split-precision GRU layer: bf16 planes straight from the
+                # convolution's epilogue (no fp32 round trip, no split pass)
+                nxt = stages[k + 1] if k + 1 < last else None
+                nsplit_c = contraction_nsplit(True) if not any(q.requires_grad for q in st.parameters()) else 0
+                planes = (st is self._cnn_stages[-1] and isinstance(nxt, _RnnStage) and nsplit_c > 0
+                          and nxt.gru.split_frozen() == nsplit_c)
+                h = st.run(h, self.training, planes)
         return h
 
     def frozen_prefix_len(self):

@@ -261,14 +261,32 @@ def wconv_bf16_supported(c_in, stride, pool):
     return pool in (1, 2) and ((c_in == 1 and stride % 8 == 0) or (c_in > 1 and stride == 1))
 
 
-def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit):
-    """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in)."""
+def wconv_bf16_planes_ok(c_out, pool):
+    """Can slu_wconv_fwd_bf16 write its result as split-precision planes?  (pool 1; the kernel's channel tiling
+    — 1, 2, 4, 5 or 8 tiles of 16 — has to cover round_up(c_out, 32) columns)"""
+    need = -(-c_out // 16)
+    nt = next((n for n in (1, 2, 4, 5, 8) if n >= need), None)
+    return pool == 1 and nt is not None and nt * 16 >= round_up(c_out, 32)
+
+
+def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit, out_planes=False):
+    """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in).
+    out_planes: return a SplitAct (time-major rows, bf16 planes) for the next frozen GRU layer instead of fp32."""
     L = _lib.load()
     x = _f32c(x, "x")
     weight = _f32c(weight, "weight")
     c_out, _, k_t = weight.shape
     l_conv = conv_out_len(l_in, k_t, stride)
     l_out = -(-l_conv // pool)
+    if out_planes:
+        assert time_major and wconv_bf16_planes_ok(c_out, pool)
+        planes = torch.empty(nsplit, l_out * B, round_up(c_out, 32), dtype=torch.bfloat16, device=x.device)
+        wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
+        ws = _workspace(wsb, x.device)
+        _lib.check(L.slu_wconv_fwd_bf16(x.data_ptr(), weight.data_ptr(), _ptr(bias), None, B, l_in, c_in, c_out,
+                                        k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
+                                        planes.stride(0), ws.data_ptr(), wsb, nsplit, _stream()), "slu_wconv_fwd_bf16")
+        return SplitAct(planes, l_out, B, c_out)
     if time_major:
         out = torch.empty(l_out, B, c_out, dtype=torch.float32, device=x.device)
         sb, sl = c_out, B * c_out
@@ -278,8 +296,8 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
     ws = _workspace(wsb, x.device)
     _lib.check(L.slu_wconv_fwd_bf16(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), B, l_in, c_in, c_out,
-                                    k_t, stride, int(do_abs), pool, float(slope), sb, sl, ws.data_ptr(), wsb, nsplit,
-                                    _stream()), "slu_wconv_fwd_bf16")
+                                    k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
+                                    nsplit, _stream()), "slu_wconv_fwd_bf16")
     return out
 
 

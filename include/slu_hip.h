@@ -149,12 +149,15 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
                   void* stream);
 
 /* slu_wconv_fwd for a FROZEN CNN block on the split-precision MFMA path (no `route`: forward only).  Needs
- * stride_t * c_in % 8 == 0 for c_in == 1, stride_t == 1 otherwise (channels are padded to a multiple of 8).    */
+ * stride_t * c_in % 8 == 0 for c_in == 1, stride_t == 1 otherwise (channels are padded to a multiple of 8).
+ * out_planes != NULL (pool == 1): the result goes straight into the split-precision activation format instead of
+ * `out` — nsplit bf16 planes (plane stride out_plane_stride elements) of (l_out * B) x round_up(c_out, 32), rows in
+ * time-major order l * B + b, zero padded columns — which slu_gemm_bf16 reads (no fp32 round trip, no slu_split_bf16). */
 size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t, int nsplit);
 int slu_wconv_fwd_bf16(const float* in, const float* weight, const float* bias, float* out, int64_t B,
                        int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t, int do_abs,
-                       int pool, float slope, int64_t out_sb, int64_t out_sl, void* workspace,
-                       size_t workspace_bytes, int nsplit, void* stream);
+                       int pool, float slope, int64_t out_sb, int64_t out_sl, void* out_planes,
+                       int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int nsplit, void* stream);
 /* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
  * W_hh (3 gates x nsplit bf16 planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
  * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)

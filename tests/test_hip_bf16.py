@@ -149,3 +149,23 @@ def test_wconv_bf16_vs_exact_fp32_kernel(ops, case, nsplit):
     err = (out - ref).abs().max().item() / ref.abs().max().item()
     print("wconv bf16 %s nsplit=%d: max deviation from the fp32 kernel %.2e of the output range" % (case, nsplit, err))
     assert err <= (3e-6 if nsplit == 3 else 2e-2)         # 401 mixed-sign taps: the two fp32-class sums differ by a few ulp of the range
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+def test_wconv_bf16_planes_output_equals_split_of_fp32_output(ops, nsplit):
+    """The last frozen CNN block hands its result to the next frozen GRU layer as bf16 planes written by the
+    convolution's own epilogue: bit-equal to slu_split_bf16 of the fp32 (time-major) output, zero padding included."""
+    torch.manual_seed(3)
+    B, l_in, c_in, c_out, k = 9, 301, 60, 60, 5
+    x = torch.randn(B, l_in, c_in).abs().cuda()
+    w = (torch.randn(c_out, c_in, k) * 0.05).cuda()
+    bias = (torch.randn(c_out) * 0.1).cuda()
+    assert ops.wconv_bf16_planes_ok(c_out, 1) and not ops.wconv_bf16_planes_ok(16, 1) and not ops.wconv_bf16_planes_ok(c_out, 2)
+    out = ops.wconv_fwd_bf16(x, w, bias, B, l_in, c_in, 1, False, 1, 0.2, True, nsplit)          # (l_out, B, c_out) fp32
+    act = ops.wconv_fwd_bf16(x, w, bias, B, l_in, c_in, 1, False, 1, 0.2, True, nsplit, out_planes=True)
+    torch.cuda.synchronize()
+    T = out.shape[0]
+    assert (act.T, act.B, act.C) == (T, B, c_out) and tuple(act.planes.shape) == (nsplit, T * B, 64)
+    want = ops.split_bf16(out.view(T * B, c_out), nsplit)
+    assert torch.equal(act.planes.view(torch.int16), want.view(torch.int16))
+    assert act.planes[:, :, c_out:].float().abs().max().item() == 0.0
