@@ -90,6 +90,26 @@ stage_inputs_kernel(const StageArgs a) {
 }
 }  // namespace slu
 
+// ---- a few 64-bit words from the host into device memory, by value in the kernel arguments (hipGraph-friendly:
+// no staging buffer whose lifetime the caller would have to track) — the row-pointer table and the dropout-stream
+// offset of a captured look-ahead super-batch ----
+namespace slu {
+struct StoreArgs { unsigned long long v[32]; unsigned long long* dst; int n; };
+__global__ void store_u64_kernel(const StoreArgs a) {
+  if ((int)threadIdx.x < a.n) a.dst[threadIdx.x] = a.v[threadIdx.x];
+}
+}  // namespace slu
+
+extern "C" int slu_store_u64(uint64_t* dst, const uint64_t* values, int64_t count, void* stream) {
+  SLU_REQUIRE(dst && values && count >= 1 && count <= 32, "slu_store_u64: 1..32 values");
+  slu::StoreArgs a;
+  for (int k = 0; k < (int)count; ++k) a.v[k] = values[k];
+  a.dst = (unsigned long long*)dst; a.n = (int)count;
+  hipLaunchKernelGGL(slu::store_u64_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("store_u64_kernel");
+  return SLU_OK;
+}
+
 extern "C" int slu_stage_inputs(const void* const* src, void* const* dst, const int64_t* rows, const int64_t* row_bytes,
                                 const int64_t* src_stride_bytes, int64_t count, int64_t* set_ptr, int64_t set_value,
                                 void* stream) {

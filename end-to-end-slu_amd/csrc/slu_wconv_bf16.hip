@@ -20,6 +20,8 @@ constexpr int WB_THREADS = 256;
 
 struct WconvBfParams {
   const float* in;      // (B, in_row) flat fp32 rows
+  const float* const* in_tab;   // null, or a device table of base pointers: row b = in_tab[b / tab_rows] + (b % tab_rows) * in_row
+  int tab_rows;                 // (a look-ahead super-batch reads its batches where they lie: no concatenation copy)
   const uint4* wp;      // packed filters [plane][KC][NT][64]
   const float* bias;    // (c_out) or null
   float* out;
@@ -82,7 +84,13 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
   const int l0 = blockIdx.x * F;
-  const float* __restrict__ inb = p.in + (size_t)b * p.in_row;
+  const float* __restrict__ inb;
+  if (p.in_tab) {
+    const int e = b / p.tab_rows;
+    inb = p.in_tab[e] + (size_t)(b - e * p.tab_rows) * p.in_row;
+  } else {
+    inb = p.in + (size_t)b * p.in_row;
+  }
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
   const int row0 = SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT;   // this wave's first frame in the tile
   const int nb = SPLITN ? (wave & 1) * CT : 0;                        // ... and its first channel tile
@@ -275,12 +283,14 @@ extern "C" size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, in
   return (size_t)nsplit * cdiv(Kw, 32) * nt * 64 * sizeof(uint4);
 }
 
-extern "C" int slu_wconv_fwd_bf16(const float* in, const float* weight, const float* bias, float* out, int64_t B,
+extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows,
+                                  const float* weight, const float* bias, float* out, int64_t B,
                                   int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t,
                                   int do_abs, int pool, float slope, int64_t out_sb, int64_t out_sl,
                                   void* out_planes, int64_t out_plane_stride,
                                   void* workspace, size_t workspace_bytes, int nsplit, void* stream) {
-  SLU_REQUIRE(in && weight && (out || out_planes), "slu_wconv_fwd_bf16: null pointer");
+  SLU_REQUIRE((in || in_table) && weight && (out || out_planes), "slu_wconv_fwd_bf16: null pointer");
+  SLU_REQUIRE(!in_table || (table_rows >= 1 && table_rows <= B), "slu_wconv_fwd_bf16: bad table_rows");
   SLU_REQUIRE(B > 0 && l_in > 0 && c_in > 0 && c_out > 0 && k_t > 0 && stride_t > 0, "slu_wconv_fwd_bf16: non-positive size");
   SLU_REQUIRE(pool == 1 || pool == 2, "slu_wconv_fwd_bf16: pool must be 1 or 2 (got %d)", pool);
   SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_wconv_fwd_bf16: nsplit must be 1 or 3");
@@ -313,6 +323,7 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* weight, const fl
   }
   WconvBfParams p;
   p.in = in; p.wp = wp; p.bias = bias; p.out = out;
+  p.in_tab = in_table; p.tab_rows = (int)(in_table ? table_rows : 1);
   p.planes = (unsigned short*)out_planes; p.plane = out_plane_stride; p.Kp_out = (int)(cdiv(c_out, 32) * 32); p.Bn = (int)B;
   if (out_planes) {
     if (pool != 1 || NT * 16 < p.Kp_out)

@@ -381,11 +381,14 @@ class _ConvStage:
                     bias, do_abs = None, self.do_abs
                 else:
                     w, bias, do_abs = self.conv.weight.detach(), self.conv.bias.detach(), self.do_abs
-                x3 = h if h.dim() == 3 else h.unsqueeze(2)
-                B, l_in = x3.shape[0], x3.shape[1]
+                if isinstance(h, _ops.RowTable):       # a look-ahead super-batch read where its batches lie
+                    x3, (B, l_in) = h, h.shape
+                else:
+                    x3 = (h if h.dim() == 3 else h.unsqueeze(2)).contiguous()
+                    B, l_in = x3.shape[0], x3.shape[1]
                 planes = (out_planes and tm and not (self.drop > 0.0 and training)
                           and _ops.wconv_bf16_planes_ok(w.shape[0], pool))
-                h = _ops.wconv_fwd_bf16(x3.contiguous(), w, bias, B, l_in, c_in, self.conv.stride, do_abs, pool, slope,
+                h = _ops.wconv_fwd_bf16(x3, w, bias, B, l_in, c_in, self.conv.stride, do_abs, pool, slope,
                                         tm, nsplit, planes)
                 if planes:
                     return h
@@ -547,6 +550,15 @@ class PretrainedModel(torch.nn.Module):
                 break
             n += 1
         return n
+
+    def accepts_row_table(self):
+        """Can stage 0 read a look-ahead super-batch through a row-pointer table (ops.RowTable) instead of a
+        concatenated copy?  Only the split-precision convolution kernel of a FROZEN first block does."""
+        st = self._cnn_stages[0]
+        if any(q.requires_grad for q in st.parameters()) or not contraction_nsplit(True):
+            return False
+        fused_pool = st.pool in (1, 2)
+        return fused_pool and _ops.wconv_bf16_supported(1, st.conv.stride, st.pool if fused_pool else 1)
 
     def warm_weight_caches(self):
         """Establish the direction-stacked input-projection storage of every GRU layer on the current

@@ -24,6 +24,7 @@ SIGNATURES = {
     "slu_device_check": (c_int, []),
     "slu_device_arch": (ctypes.c_char_p, []),
     "slu_stream_create_cu_range": (c_int, [c_i64, c_i64, vp]),
+    "slu_store_u64": (c_int, [vp, vp, c_i64, vp]),
     "slu_stage_inputs": (c_int, [vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp]),
     "slu_sinc_filters_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_f64, vp]),
     "slu_sinc_filters_bwd": (c_int, [vp, vp, vp, vp, vp, c_i64, c_i64, c_f64, vp]),
@@ -44,7 +45,7 @@ SIGNATURES = {
     "slu_gemm_bf16_pack": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gemm_bf16": (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
-    "slu_wconv_fwd_bf16": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
+    "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
                                    c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, vp]),
     "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_comm_version": (c_int, []),

@@ -261,6 +261,37 @@ def wconv_bf16_supported(c_in, stride, pool):
     return pool in (1, 2) and ((c_in == 1 and stride % 8 == 0) or (c_in > 1 and stride == 1))
 
 
+class RowTable:
+    """The input of a look-ahead super-batch WITHOUT a concatenation copy: `ptrs` = int64 device tensor of P base
+    addresses (one per batch of `rows` equally long fp32 rows); stands for a (P * rows, T) float32 tensor that only
+    slu_wconv_fwd_bf16 (in_table) can read.  The address table is refreshed with store_u64 before each replay."""
+    requires_grad = False
+
+    def __init__(self, ptrs, rows, T):
+        self.ptrs, self.rows = ptrs, rows
+        self.shape = (ptrs.numel() * rows, T)
+        self.device = ptrs.device
+
+    def dim(self):
+        return 2
+
+    def float(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+
+def store_u64(dst, values):
+    """dst (int64 device tensor)[:len(values)] = values, in one launch with the values in the kernel arguments."""
+    import ctypes
+    L = _lib.load()
+    n = len(values)
+    assert 1 <= n <= 32 and dst.dtype == torch.int64 and dst.numel() >= n and dst.is_contiguous()
+    arr = (ctypes.c_uint64 * n)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in values])
+    _lib.check(L.slu_store_u64(dst.data_ptr(), arr, n, _stream()), "slu_store_u64")
+
+
 def wconv_bf16_planes_ok(c_out, pool):
     """Can slu_wconv_fwd_bf16 write its result as split-precision planes?  (pool 1; the kernel's channel tiling
     — 1, 2, 4, 5 or 8 tiles of 16 — has to cover round_up(c_out, 32) columns)"""
@@ -273,7 +304,12 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in).
     out_planes: return a SplitAct (time-major rows, bf16 planes) for the next frozen GRU layer instead of fp32."""
     L = _lib.load()
-    x = _f32c(x, "x")
+    if isinstance(x, RowTable):
+        x_ptr, tab, tab_rows = None, x.ptrs.data_ptr(), x.rows
+        assert c_in == 1 and x.shape == (B, l_in)
+    else:
+        x = _f32c(x, "x")
+        x_ptr, tab, tab_rows = x.data_ptr(), None, 0
     weight = _f32c(weight, "weight")
     c_out, _, k_t = weight.shape
     l_conv = conv_out_len(l_in, k_t, stride)
@@ -283,7 +319,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
         planes = torch.empty(nsplit, l_out * B, round_up(c_out, 32), dtype=torch.bfloat16, device=x.device)
         wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
         ws = _workspace(wsb, x.device)
-        _lib.check(L.slu_wconv_fwd_bf16(x.data_ptr(), weight.data_ptr(), _ptr(bias), None, B, l_in, c_in, c_out,
+        _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, B, l_in, c_in, c_out,
                                         k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
                                         planes.stride(0), ws.data_ptr(), wsb, nsplit, _stream()), "slu_wconv_fwd_bf16")
         return SplitAct(planes, l_out, B, c_out)
@@ -295,7 +331,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
         sb, sl = l_out * c_out, c_out
     wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
     ws = _workspace(wsb, x.device)
-    _lib.check(L.slu_wconv_fwd_bf16(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), B, l_in, c_in, c_out,
+    _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), out.data_ptr(), B, l_in, c_in, c_out,
                                     k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
                                     nsplit, _stream()), "slu_wconv_fwd_bf16")
     return out

@@ -71,13 +71,16 @@ class PrefixSlot:
     kernels then launch #batches times as many workgroups (two per CU) and every other kernel sees a
     proportionally larger problem, at (nearly) the latency of a single batch."""
     MAX_GRAPHS = 4          # distinct (super-batch shape, prefix length, mode) keys kept per slot
+    MAX_TABLE = 31          # batches a super-batch may read through the row-pointer table (slu_store_u64: 32 words)
 
     def __init__(self, device):
         self.device = device
         n = cu_split()
         self.stream = (cu_range_stream(device, n, n_compute_units(device) - n) if n > 0
                        else torch.cuda.Stream(device))
-        self.rng = torch.zeros(1, dtype=torch.int64, device=device)      # step0*16, read by the kernels
+        # [row-pointer table of a super-batch (MAX_TABLE entries) | step0*16, read by the dropout kernels]
+        self.words = torch.zeros(self.MAX_TABLE + 1, dtype=torch.int64, device=device)
+        self.rng = self.words[self.MAX_TABLE:]
         self.graphs = {}
         self.seen = {}             # how often each super-batch shape was requested
         self.consumed = None       # event: the main stream is done with this slot's last output
@@ -103,7 +106,7 @@ class PrefixSlot:
                 self.stream.wait_event(after)
             feats = None
             if use_graph:
-                key = (len(xs), B, T, n_prefix, bool(model.training))
+                key = (len(xs), B, T, n_prefix, bool(model.training), self._table_ok(model, xs))
                 entry = self.graphs.get(key)
                 # capture a shape on its second appearance in this slot: a one-off shape (the ragged last
                 # group of an epoch, a short run) is cheaper launched eagerly than captured (~10 ms)
@@ -113,8 +116,13 @@ class PrefixSlot:
                     entry = self._capture(model, xs, n_prefix, step0, key)
                 if entry is not None:
                     graph, x_static, feats = entry
-                    self._fill(x_static, xs)
-                    self.rng.fill_(step0 * 16)
+                    if isinstance(x_static, ops.RowTable):
+                        # the batches are read where they lie: refresh the address table and the dropout-stream
+                        # offset (adjacent words of one buffer) in ONE launch instead of one copy per batch
+                        ops.store_u64(self.words, [x.data_ptr() for x in xs] + [0] * (self.MAX_TABLE - len(xs)) + [step0 * 16])
+                    else:
+                        self._fill(x_static, xs)
+                        self.rng.fill_(step0 * 16)
                     graph.replay()
             if feats is None:
                 x_cat = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
@@ -130,12 +138,26 @@ class PrefixSlot:
         for k, x in enumerate(xs):
             x_cat[k * B:(k + 1) * B].copy_(x, non_blocking=True)
 
+    def _table_ok(self, model, xs):
+        """Device-resident, contiguous fp32 batches and a first stage that can read through a row-pointer table: the
+        captured graph then reads the batches in place (they must stay alive and unchanged until it has run: the
+        training loop keeps them until their steps are done)."""
+        pm = getattr(model, "pretrained_model", model)
+        return (os.environ.get("SLU_ROW_TABLE", "1") != "0" and 1 < len(xs) <= self.MAX_TABLE
+                and hasattr(pm, "accepts_row_table") and pm.accepts_row_table()
+                and all(x.is_cuda and x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
+                        and x.data_ptr() % 16 == 0 for x in xs))
+
     def _capture(self, model, xs, n_prefix, step0, key):
         B, T = xs[0].shape
         sub = B if len(xs) > 1 else 0
-        x_static = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
-        self._fill(x_static, xs)
-        self.rng.fill_(step0 * 16)
+        if key[-1]:
+            x_static = ops.RowTable(self.words[:len(xs)], B, T)
+            ops.store_u64(self.words, [x.data_ptr() for x in xs] + [0] * (self.MAX_TABLE - len(xs)) + [step0 * 16])
+        else:
+            x_static = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
+            self._fill(x_static, xs)
+            self.rng.fill_(step0 * 16)
         model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)      # warm-up (lazy initialisation)
         self.stream.synchronize()
         graph = torch.cuda.CUDAGraph()

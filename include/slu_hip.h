@@ -51,6 +51,9 @@ const char* slu_device_arch(void);        /* gcnArchName of the current device (
  * contiguous range is spread over all XCDs); look-ahead pipeline of training.Trainer. Never freed. */
 int slu_stream_create_cu_range(int64_t first_cu, int64_t n_cus, void** stream_out);
 
+/* dst[0..count) = values[0..count) (count <= 32; `values` is a HOST array travelling in the kernel arguments): the
+ * row-pointer table (slu_wconv_fwd_bf16 in_table) and the dropout-stream offset of a captured super-batch.          */
+int slu_store_u64(uint64_t* dst, const uint64_t* values, int64_t count, void* stream);
 /* One launch for the per-step input refresh of a captured step: up to 4 strided 2-D copies (rows x row_bytes
  * from src + r * src_stride_bytes to a dense dst) and *set_ptr = set_value (set_ptr may be NULL).  Pointer
  * arrays are HOST arrays of device pointers.                                                                   */
@@ -152,9 +155,13 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
  * stride_t * c_in % 8 == 0 for c_in == 1, stride_t == 1 otherwise (channels are padded to a multiple of 8).
  * out_planes != NULL (pool == 1): the result goes straight into the split-precision activation format instead of
  * `out` — nsplit bf16 planes (plane stride out_plane_stride elements) of (l_out * B) x round_up(c_out, 32), rows in
- * time-major order l * B + b, zero padded columns — which slu_gemm_bf16 reads (no fp32 round trip, no slu_split_bf16). */
+ * time-major order l * B + b, zero padded columns — which slu_gemm_bf16 reads (no fp32 round trip, no slu_split_bf16).
+ * in_table != NULL: a DEVICE array of ceil(B / table_rows) base pointers; batch row b is read from
+ * in_table[b / table_rows] + (b % table_rows) * l_in * c_in instead of in + b * l_in * c_in — a look-ahead super-batch
+ * reads its batches where they lie instead of a concatenated copy (`in` is then ignored).                          */
 size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t, int nsplit);
-int slu_wconv_fwd_bf16(const float* in, const float* weight, const float* bias, float* out, int64_t B,
+int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows, const float* weight,
+                       const float* bias, float* out, int64_t B,
                        int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t, int do_abs,
                        int pool, float slope, int64_t out_sb, int64_t out_sl, void* out_planes,
                        int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int nsplit, void* stream);

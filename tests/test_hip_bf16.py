@@ -169,3 +169,19 @@ def test_wconv_bf16_planes_output_equals_split_of_fp32_output(ops, nsplit):
     want = ops.split_bf16(out.view(T * B, c_out), nsplit)
     assert torch.equal(act.planes.view(torch.int16), want.view(torch.int16))
     assert act.planes[:, :, c_out:].float().abs().max().item() == 0.0
+
+
+def test_wconv_bf16_row_table_input_equals_concatenated_input(ops):
+    """A look-ahead super-batch read through a row-pointer table (the batches where they lie, addresses refreshed by
+    slu_store_u64) == the same kernel on the concatenated copy, bit for bit."""
+    torch.manual_seed(4)
+    P, B, T = 5, 3, 16000
+    xs = [(0.1 * torch.randn(B, T)).cuda() for _ in range(P)]
+    w = (torch.randn(80, 1, 401) * 0.05).cuda()
+    ref = ops.wconv_fwd_bf16(torch.cat(xs).unsqueeze(2).contiguous(), w, None, P * B, T, 1, 80, True, 2, 0.2, False, 3)
+    words = torch.zeros(8, dtype=torch.int64, device="cuda")
+    ops.store_u64(words, [x.data_ptr() for x in xs] + [77])
+    assert words.tolist()[:P + 1] == [x.data_ptr() for x in xs] + [77]
+    out = ops.wconv_fwd_bf16(ops.RowTable(words[:P], B, T), w, None, P * B, T, 1, 80, True, 2, 0.2, False, 3)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
