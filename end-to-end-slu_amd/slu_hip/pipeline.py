@@ -68,7 +68,7 @@ def n_compute_units(device):
 class PrefixSlot:
     """One in-flight SUPER-BATCH: the frozen prefix of the encoder evaluated for several upcoming
     batches at once (concatenated along the batch axis) on this slot's side stream.  The recurrence
-    kernels then launch #batches times as many workgroups (two per CU) and every other kernel sees a
+    kernels then launch #batches times as many workgroups (one per CU and direction) and every other kernel sees a
     proportionally larger problem, at (nearly) the latency of a single batch."""
     MAX_GRAPHS = 4          # distinct (super-batch shape, prefix length, mode) keys kept per slot
     MAX_TABLE = 31          # batches a super-batch may read through the row-pointer table (slu_store_u64: 32 words)

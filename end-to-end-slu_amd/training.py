@@ -172,8 +172,8 @@ class Trainer:
         stage's output does not depend on earlier optimisation steps.  At 64 utterances per step a
         recurrence occupies a fraction of the 256 CUs, so several batches' encoders run as one
         super-batch; the per-batch dropout streams are step-indexed, so the result is the sequential
-        one.  depth -1 = automatic: as many batches as make a super-batch of ~512 utterances (one
-        4-sequence recurrence workgroup per CU and direction)."""
+        one.  depth -1 = automatic: see _lookahead_width (one 16-sequence recurrence workgroup per
+        look-ahead CU and direction)."""
         depth = _lookahead_env()
         if not train or asr or depth in (0, 1) or not hasattr(self.model, "prefix_features"):
             return 0, 0
