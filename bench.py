@@ -346,7 +346,12 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                 ms = _timed_graph(lambda: ops.gemm_bf16(planes, packed, b_ih, N, I), stream)
                 kc = ops.round_up(I, 32) // 32
                 # K <= 64: the row-panel kernel (A resident in LDS, HBM-write bound); else the tiled kernel
-                gemm_name = "gemm_bf_panel_kernel<%d,%d>" % (ns, kc) if kc <= 2 else "gemm_bf_kernel<%d>" % ns
+                if kc <= 2:
+                    gemm_name = "gemm_bf_panel_kernel<%d,%d>" % (ns, kc)
+                elif kc in (4, 8) and T * B >= 16 * 96 and os.environ.get("SLU_GEMM_PANEL96", "1") != "0":
+                    gemm_name = "gemm_bf_panel96_kernel<%d,%d>" % (ns, kc)        # 96-row panels, A resident in LDS
+                else:
+                    gemm_name = "gemm_bf_kernel<%d>" % ns
                 rows.setdefault(gemm_name, []).append(
                     {"shape": "M=%d N=%d K=%d input projection, %d bf16 plane(s) (%s)" % (T * B, N, I, ns, where),
                      "flops": 2.0 * T * B * N * I, "ms": ms, "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,

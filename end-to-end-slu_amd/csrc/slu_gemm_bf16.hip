@@ -17,6 +17,8 @@
 // K = 256 ones MFMA bound at 6/16 of the fp32-MFMA cycle count.
 #include "slu_bf16.h"
 
+#include <cstdlib>
+
 namespace slu {
 
 constexpr int GB_BM = 128, GB_BN = 64, GB_THREADS = 256;     // wave tile 64 x 32: 152 live VGPRs -> 3 waves / SIMD
@@ -313,6 +315,126 @@ gemm_bf_panel_kernel(const GemmBfParams p) {
 #undef GP_FETCH
 }
 
+
+// ---- 64 < K <= 256: row panels of 96 rows, A resident for the whole panel -----------------------------------------------
+// The tiled kernel moves 48 KB through the CU's L2 port per 768 MFMA cycles and exposes one L2/HBM round trip per k-chunk
+// (its LDS reads wait for ALL pending LDS-DMA).  Here a workgroup fetches its 96-row panel of A (KC x NS planes, 147 KB
+// for K = 256) ONCE by LDS-DMA, waits once, and then walks the N/64 column tiles with nothing but LDS fragment reads,
+// MFMAs and W fragments from L2 (24 KB per 576 MFMA cycles; three chunks ahead in a ring of four register sets — one
+// workgroup per CU, one wave per SIMD, i.e. the whole 512-register file per wave).  2 x 2 waves: 48 rows x 32 columns
+// each.  The panel load is exposed (~20 % of the panel's MFMA time); everything after it is not.
+constexpr int GP_ROWS = 96;
+
+template <int NS, int KC>
+__global__ void __launch_bounds__(GB_THREADS, 1)
+gemm_bf_panel96_kernel(const GemmBfParams p) {
+  constexpr int CH_U4 = NS * GP_ROWS * 4;                  // uint4 per k-chunk of the panel
+  constexpr int NPAIR = NS == 1 ? 1 : 6;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  uint4* const sA = reinterpret_cast<uint4*>(dsmem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i = lane & 15, kg = lane >> 4;
+  const int NT = p.N / 16, NJ = p.N / GB_BN;
+  const int m0 = blockIdx.x * GP_ROWS;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  {
+    // (k-chunk, plane, 16-row group) units of 1 KiB, dealt round-robin to the four waves
+    const int rrow = lane >> 2, rslot = lane & 3;
+    for (int u = wave; u < KC * NS * (GP_ROWS / 16); u += 4) {
+      const int rg = u % (GP_ROWS / 16), pl = (u / (GP_ROWS / 16)) % NS, kc = u / ((GP_ROWS / 16) * NS);
+      const int r = rg * 16 + rrow, m = m0 + r;
+      const unsigned short* src = p.A + (size_t)pl * p.a_plane + (size_t)(m < p.M ? m : 0) * p.lda + kc * 32 + swz_slot(r, rslot) * 8;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + kc * CH_U4 + (pl * GP_ROWS + rg * 16) * 4), 16, 0, 0);
+    }
+  }
+  const uint4* b_src = p.wp + (size_t)(wn * 2) * 64 + lane;
+  const size_t b_plane = (size_t)p.KC * NT * 64, b_chunk = (size_t)NT * 64;
+  int a_frag[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int r = wm * 48 + a * 16 + i;
+    a_frag[a] = r * 4 + swz_slot(r, kg);
+  }
+  const int col4 = (lane & 7) * 4;
+  float* const sC = reinterpret_cast<float*>(dsmem + (size_t)KC * CH_U4 * 16) + wave * (16 * 36);
+
+  uint4 wr[4][NS][2];                  // ring of W fragment sets: chunk c of a tile lives in set c % 4 (KC % 4 == 0 or
+                                       // the ring position is carried: see SETOF)
+  // flattened (tile, chunk) sequence: step s = j * KC + kc; its set is s % 4
+#define G9_FETCH(s_, set_)                                                                              \
+  {                                                                                                     \
+    const int ss = min((s_), NJ * KC - 1);                                                              \
+    const int jj = ss / KC, kk = ss - jj * KC;                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int b = 0; b < 2; ++b)     \
+      wr[set_][pl][b] = b_src[(size_t)pl * b_plane + (size_t)kk * b_chunk + (size_t)(jj * 4 + b) * 64]; \
+  }
+  G9_FETCH(0, 0) G9_FETCH(1, 1) G9_FETCH(2, 2)
+  __syncthreads();                     // the panel has landed (every wave's DMA)
+
+  f32x4 acc[3][2];
+  float4 bias_v = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one (tile, chunk) step with ring set SET (literal): W fragments of step s + 3 into set (SET + 3) % 4 and the A
+  // fragments of step s + 1 (LDS) are requested first, then the MFMAs of step s run on what was requested earlier —
+  // with one wave per SIMD nothing else would hide the LDS latency
+#define G9_READ_A(s_, dst)                                                                              \
+  {                                                                                                     \
+    const int kc_ = (s_) % KC;                                                                          \
+    _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int a = 0; a < 3; ++a)     \
+      dst[pl][a] = sA[kc_ * CH_U4 + pl * GP_ROWS * 4 + a_frag[a]];                                      \
+  }
+#define G9_STEP(s_, SET, fcur, fnxt)                                                                    \
+  {                                                                                                     \
+    G9_FETCH((s_) + 3, (SET + 3) % 4)                                                                   \
+    G9_READ_A((s_) + 1, fnxt)                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    _Pragma("unroll") for (int q = 0; q < NPAIR; ++q) {                                                 \
+      const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15; \
+      _Pragma("unroll") for (int a = 0; a < 3; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)       \
+        acc[a][b] = mfma_bf16(fcur[pa][a], wr[SET][pb][b], acc[a][b]);                                  \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+  uint4 fa0[NS][3], fa1[NS][3];
+  G9_READ_A(0, fa0)
+  static_assert(KC % 4 == 0, "the register ring assumes a multiple of four k-chunks per tile");
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { acc[a][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[a][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (p.bias) bias_v = *reinterpret_cast<const float4*>(p.bias + j * GB_BN + wn * 32 + col4);
+#pragma unroll
+    for (int k4 = 0; k4 < KC; k4 += 4) {
+      G9_STEP(j * KC + k4 + 0, 0, fa0, fa1)
+      G9_STEP(j * KC + k4 + 1, 1, fa1, fa0)
+      G9_STEP(j * KC + k4 + 2, 2, fa0, fa1)
+      G9_STEP(j * KC + k4 + 3, 3, fa1, fa0)
+    }
+    // epilogue of the tile: three passes of 16 rows per wave through its private LDS strip, row-contiguous stores
+    const int ncol = j * GB_BN + wn * 32 + col4;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sC[(4 * kg + r) * 36 + b * 16 + i] = acc[a][b][r];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int rl = (lane >> 3) + 8 * it;
+        const int m = m0 + wm * 48 + a * 16 + rl;
+        const float4 v = *reinterpret_cast<const float4*>(&sC[rl * 36 + col4]);
+        if (m < p.M)
+          *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + ncol) =
+              make_float4(v.x + bias_v.x, v.y + bias_v.y, v.z + bias_v.z, v.w + bias_v.w);
+      }
+    }
+  }
+#undef G9_STEP
+#undef G9_READ_A
+#undef G9_FETCH
+}
+
 }  // namespace slu
 
 using namespace slu;
@@ -377,6 +499,26 @@ extern "C" int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64
     else if (p.KC == 2) hipLaunchKernelGGL((gemm_bf_panel_kernel<1, 2>), pg, dim3(GB_THREADS), 0, st, p);
     else hipLaunchKernelGGL((gemm_bf_panel_kernel<1, 1>), pg, dim3(GB_THREADS), 0, st, p);
     SLU_CHECK_LAUNCH("gemm_bf_panel_kernel");
+    return SLU_OK;
+  }
+  if ((p.KC == 4 || p.KC == 8) && N >= 2 * GB_BN && M >= 16 * GP_ROWS && (bias == nullptr || ((uintptr_t)bias & 15) == 0)
+      && !(getenv("SLU_GEMM_PANEL96") && atoi(getenv("SLU_GEMM_PANEL96")) == 0)) {     // SLU_GEMM_PANEL96=0: tiled kernel
+    const size_t lds = (size_t)p.KC * nsplit * GP_ROWS * 64 + 4 * 16 * 36 * sizeof(float);
+    const dim3 pg((unsigned)cdiv(M, GP_ROWS));
+    hipStream_t st = (hipStream_t)stream;
+#define SLU_P96(NS_, KC_)                                                                                            \
+    {                                                                                                                \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_bf_panel96_kernel<NS_, KC_>,                              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+      if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_gemm_bf16: cannot raise the dynamic LDS cap to %zu: %s", lds, hipGetErrorString(e)); \
+      hipLaunchKernelGGL((gemm_bf_panel96_kernel<NS_, KC_>), pg, dim3(GB_THREADS), lds, st, p);                      \
+    }
+    if (nsplit == 3 && p.KC == 8) SLU_P96(3, 8)
+    else if (nsplit == 3) SLU_P96(3, 4)
+    else if (p.KC == 8) SLU_P96(1, 8)
+    else SLU_P96(1, 4)
+#undef SLU_P96
+    SLU_CHECK_LAUNCH("gemm_bf_panel96_kernel");
     return SLU_OK;
   }
   dim3 grid((unsigned)(N / GB_BN), (unsigned)cdiv(M, GB_BM));
