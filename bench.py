@@ -348,7 +348,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                 # K <= 64: the row-panel kernel (A resident in LDS, HBM-write bound); else the tiled kernel
                 if kc <= 2:
                     gemm_name = "gemm_bf_panel_kernel<%d,%d>" % (ns, kc)
-                elif kc in (4, 8) and T * B >= 16 * 96 and os.environ.get("SLU_GEMM_PANEL96", "1") != "0":
+                elif kc in (4, 8) and T * B >= 128 * 1024 and os.environ.get("SLU_GEMM_PANEL96", "1") != "0":
                     gemm_name = "gemm_bf_panel96_kernel<%d,%d>" % (ns, kc)        # 96-row panels, A resident in LDS
                 else:
                     gemm_name = "gemm_bf_kernel<%d>" % ns

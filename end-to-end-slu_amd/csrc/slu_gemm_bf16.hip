@@ -324,6 +324,7 @@ gemm_bf_panel_kernel(const GemmBfParams p) {
 // workgroup per CU, one wave per SIMD, i.e. the whole 512-register file per wave).  2 x 2 waves: 48 rows x 32 columns
 // each.  The panel load is exposed (~20 % of the panel's MFMA time); everything after it is not.
 constexpr int GP_ROWS = 96;
+constexpr int64_t GP_PANEL_MIN_M = 128 * 1024;          // below: the tiled kernel (see slu_gemm_bf16)
 
 template <int NS, int KC>
 __global__ void __launch_bounds__(GB_THREADS, 1)
@@ -501,7 +502,9 @@ extern "C" int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64
     SLU_CHECK_LAUNCH("gemm_bf_panel_kernel");
     return SLU_OK;
   }
-  if ((p.KC == 4 || p.KC == 8) && N >= 2 * GB_BN && M >= 16 * GP_ROWS && (bias == nullptr || ((uintptr_t)bias & 15) == 0)
+  // panels pay their A load once per panel and leave a tail of idle CUs in the last round: they win from ~1300 panels
+  // on (M = 192 000 on 160 CUs: 585 vs 624 us; 96 000: 319 vs 319; 48 640: 173 vs 134 — the tiled kernel keeps those)
+  if ((p.KC == 4 || p.KC == 8) && N >= 2 * GB_BN && M >= GP_PANEL_MIN_M && (bias == nullptr || ((uintptr_t)bias & 15) == 0)
       && !(getenv("SLU_GEMM_PANEL96") && atoi(getenv("SLU_GEMM_PANEL96")) == 0)) {     // SLU_GEMM_PANEL96=0: tiled kernel
     const size_t lds = (size_t)p.KC * nsplit * GP_ROWS * 64 + 4 * 16 * 36 * sizeof(float);
     const dim3 pg((unsigned)cdiv(M, GP_ROWS));

@@ -32,7 +32,7 @@ def test_split_planes_are_exact(ops):
     assert torch.equal(one[0, :, :60], x.to(torch.bfloat16))  # round to nearest even
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 768, 60), (4097, 768, 256), (130, 384, 256), (64, 128, 33), (333, 192, 20), (129, 64, 60), (2000, 128, 100), (1600, 192, 256)])
+@pytest.mark.parametrize("M,N,K", [(1000, 768, 60), (4097, 768, 256), (130, 384, 256), (64, 128, 33), (333, 192, 20), (129, 64, 60), (140000, 128, 100), (131073, 192, 256)])
 @pytest.mark.parametrize("nsplit", [3, 1])
 def test_gemm_bf16_vs_float64(ops, M, N, K, nsplit):
     torch.manual_seed(M + K)
