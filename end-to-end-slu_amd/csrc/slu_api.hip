@@ -130,3 +130,78 @@ extern "C" int slu_stage_inputs(const void* const* src, void* const* dst, const 
   SLU_CHECK_LAUNCH("stage_inputs_kernel");
   return SLU_OK;
 }
+
+// ---- several small device-to-device copies / in-place scalings in ONE launch (lists by value in the kernel
+// arguments): packing the fresh gradients into the flat all-reduce bucket (slu_hip/dp.py) and applying an upstream
+// scalar to the few gradients of a loss head ----
+namespace slu {
+constexpr int MULTI_MAX = 32;
+struct MultiArgs { const unsigned char* src[MULTI_MAX]; unsigned char* dst[MULTI_MAX]; long long bytes[MULTI_MAX]; int n; };
+
+__global__ void __launch_bounds__(256)
+copy_multi_kernel(const MultiArgs a) {
+  const int k = blockIdx.y;
+  if (k >= a.n) return;
+  const unsigned char* __restrict__ s = a.src[k];
+  unsigned char* __restrict__ d = a.dst[k];
+  const long long nb = a.bytes[k];
+  const bool vec = (((long long)(uintptr_t)s | (long long)(uintptr_t)d | nb) & 15) == 0;
+  if (vec) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (nb >> 4); i += (long long)gridDim.x * 256)
+      reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else {            // every tensor is a whole number of 4-byte words (fp32 / fp64 elements)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (nb >> 2); i += (long long)gridDim.x * 256)
+      reinterpret_cast<unsigned*>(d)[i] = reinterpret_cast<const unsigned*>(s)[i];
+  }
+}
+
+struct ScaleArgs { float* ptr[MULTI_MAX]; long long numel[MULTI_MAX]; int n; const float* g; };
+
+__global__ void __launch_bounds__(256)
+scale_multi_kernel(const ScaleArgs a) {
+  const int k = blockIdx.y;
+  if (k >= a.n) return;
+  const float g = a.g[0];
+  float* __restrict__ p = a.ptr[k];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.numel[k]; i += (long long)gridDim.x * 256) p[i] *= g;
+}
+}  // namespace slu
+
+extern "C" int slu_multi_max(void) { return slu::MULTI_MAX; }
+
+extern "C" int slu_copy_multi(const void* const* src, void* const* dst, const int64_t* nbytes, int64_t count, void* stream) {
+  SLU_REQUIRE(src && dst && nbytes && count >= 1 && count <= slu::MULTI_MAX, "slu_copy_multi: 1..%d segments", slu::MULTI_MAX);
+  slu::MultiArgs a;
+  long long most = 0;
+  for (int k = 0; k < (int)count; ++k) {
+    SLU_REQUIRE(src[k] && dst[k] && nbytes[k] > 0 && nbytes[k] % 4 == 0 && (((uintptr_t)src[k] | (uintptr_t)dst[k]) & 3) == 0,
+                "slu_copy_multi: segment %d must be a non-empty, 4-byte aligned run of whole words", k);
+    a.src[k] = (const unsigned char*)src[k]; a.dst[k] = (unsigned char*)dst[k]; a.bytes[k] = nbytes[k];
+    if (nbytes[k] > most) most = nbytes[k];
+  }
+  a.n = (int)count;
+  long long bx = (most / 16 + 255) / 256;
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(slu::copy_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("copy_multi_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_scale_multi(float* const* ptrs, const int64_t* numel, int64_t count, const float* scale_dev, void* stream) {
+  SLU_REQUIRE(ptrs && numel && scale_dev && count >= 1 && count <= slu::MULTI_MAX, "slu_scale_multi: 1..%d tensors", slu::MULTI_MAX);
+  slu::ScaleArgs a;
+  long long most = 0;
+  for (int k = 0; k < (int)count; ++k) {
+    SLU_REQUIRE(ptrs[k] && numel[k] > 0, "slu_scale_multi: bad tensor %d", k);
+    a.ptr[k] = ptrs[k]; a.numel[k] = numel[k];
+    if (numel[k] > most) most = numel[k];
+  }
+  a.n = (int)count; a.g = scale_dev;
+  long long bx = (most + 1023) / 1024;
+  if (bx < 1) bx = 1;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(slu::scale_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("scale_multi_kernel");
+  return SLU_OK;
+}

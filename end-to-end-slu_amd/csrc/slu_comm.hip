@@ -5,7 +5,7 @@
 //
 // RCCL is not linked: the process already holds a copy (torch's bundled librccl.so, the one backend "nccl" uses),
 // and two RCCL instances in one process would each build their own topology / IPC state.  The entry points are
-// resolved at run time from the library that is already mapped (dlopen RTLD_NOLOAD first).
+// resolved at run time from the library that is already mapped (dlopen RTLD_NOLOAD only: never a second copy).
 #include "slu_common.h"
 #include <dlfcn.h>
 #include <string.h>
@@ -36,12 +36,14 @@ static Rccl* rccl() {
   static bool tried = false;
   if (tried) return r.handle ? &r : nullptr;
   tried = true;
+  // ONLY a library that is already mapped (RTLD_NOLOAD): loading a second RCCL copy beside the one torch.distributed
+  // uses is exactly what must not happen; a host without torch maps RCCL itself (dlopen RTLD_GLOBAL) before the
+  // first slu_comm_* call, else every entry point reports SLU_ERR_UNSUPPORTED
   const char* names[] = {"librccl.so", "librccl.so.1"};
-  for (int pass = 0; pass < 2 && !r.handle; ++pass)          // pass 0: only a library that is already mapped
-    for (const char* n : names) {
-      r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-      if (r.handle) break;
-    }
+  for (const char* n : names) {
+    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (r.handle) break;
+  }
   if (!r.handle) return nullptr;
   r.get_version = (GetVersionFn)dlsym(r.handle, "ncclGetVersion");
   r.get_unique_id = (GetUniqueIdFn)dlsym(r.handle, "ncclGetUniqueId");

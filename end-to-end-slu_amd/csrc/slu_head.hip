@@ -353,11 +353,13 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
   SLU_REQUIRE(V >= 1 && V <= HEAD_THREADS, "slu_cls_maxpool_ce_fwd: 1..%d classifier outputs supported", HEAD_THREADS);
   size_t lds = ((size_t)(T + V) * (C + 1) + (size_t)T * V + V) * sizeof(float);
   p.w_in_lds = 1;
-  if (lds > 160 * 1024) {                      // wide features (H > 128): keep only the T x C rows in LDS
+  // the kernel also owns ~4 KB of STATIC LDS (slot partials, last-workgroup reduce): the dynamic part gets the rest
+  const size_t lds_cap = 160 * 1024 - 4096;
+  if (lds > lds_cap) {                         // wide features (H > 128): keep only the T x C rows in LDS
     p.w_in_lds = 0;
     lds = ((size_t)T * (C + 1) + (size_t)T * V + V) * sizeof(float);
   }
-  if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_cls_maxpool_ce_fwd: T=%lld x C=%lld does not fit the LDS", (long long)T, (long long)C);
+  if (lds > lds_cap) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_cls_maxpool_ce_fwd: T=%lld x C=%lld does not fit the LDS", (long long)T, (long long)C);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_cls_maxpool_ce_fwd: %s", hipGetErrorString(e));

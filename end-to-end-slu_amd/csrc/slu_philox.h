@@ -1,0 +1,39 @@
+// Philox4x32-10 counter-based generator shared by every kernel that draws dropout masks (slu_pool.hip,
+// slu_seq2seq.hip, the recurrence epilogue of slu_gru_bf16.hip): element `idx` of the stream (seed, offset) is word
+// idx % 4 of the block with counter (idx / 4, offset) — a mask does not depend on which kernel or lane draws it.
+#pragma once
+#include "slu_common.h"
+
+namespace slu {
+
+// Philox4x32-10 (Salmon et al.), counter = (element index / 4, offset), key = seed.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
+  uint32_t c[4] = {(uint32_t)(idx >> 2), (uint32_t)(idx >> 34), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+  const uint32_t x = c[idx & 3];
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// the four words of the block holding elements 4 * blk .. 4 * blk + 3
+__device__ __forceinline__ void philox_block(uint64_t seed, uint64_t offset, uint64_t blk, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float philox_to_uniform(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+}  // namespace slu

@@ -7,27 +7,9 @@
 // index arithmetic is 32-bit, and ONE Philox4x32-10 evaluation per four elements (its four output
 // words are exactly the four channels).  A scalar kernel covers other channel counts.
 #include "slu_bf16.h"
+#include "slu_philox.h"
 
 namespace slu {
-
-// Philox4x32-10 (Salmon et al.), counter = (element index / 4, offset), key = seed.
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-  const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
-  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-  k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-
-__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {
-  uint32_t c[4] = {(uint32_t)(idx >> 2), (uint32_t)(idx >> 34), (uint32_t)offset, (uint32_t)(offset >> 32)};
-  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-  for (int r = 0; r < 10; ++r) philox_round(c, k);
-  const uint32_t x = c[idx & 3];
-  return (float)(x >> 8) * (1.0f / 16777216.0f);
-}
 
 struct PoolParams {
   const float* mask; long long m_st, m_sb;
@@ -234,6 +216,47 @@ dropout_pool_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__
   }
 }
 
+// ---- MaxPool1d(k, ceil_mode) + [Abs before it] + LeakyReLU / ReLU after it, for pool widths the convolution's
+// epilogue does not fuse (k > 2; reference models.py:163-168, :205, :211-213 allow any cnn_max_pool_len).  x channels-last
+// (B, L, C); y[b, lo, c] at b * out_sb + lo * out_sl + c; route (B, L_out, C) = arg-max offset | sign bit (abs) << 7.
+__global__ void __launch_bounds__(256)
+pool_act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ route, int B, int L,
+                    int C, int L_out, int pool, int do_abs, float slope, long long out_sb, long long out_sl) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)B * L_out * C) return;
+  const int c = (int)(e % C);
+  const long long bl = e / C;
+  const int lo = (int)(bl % L_out), b = (int)(bl / L_out);
+  const int l0 = lo * pool, l1 = min(L, l0 + pool);
+  float best = -INFINITY;
+  int arg = 0, neg = 0;
+  for (int l = l0; l < l1; ++l) {
+    const float v = x[((size_t)b * L + l) * C + c];
+    const float u = do_abs ? fabsf(v) : v;
+    if (u > best) { best = u; arg = l - l0; neg = (do_abs && v < 0.0f) ? 1 : 0; }
+  }
+  y[(size_t)b * out_sb + (size_t)lo * out_sl + c] = best > 0.0f ? best : best * slope;
+  if (route) route[e] = (unsigned char)(arg | (neg << 7));
+}
+
+__global__ void __launch_bounds__(256)
+pool_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const unsigned char* __restrict__ route,
+                    float* __restrict__ dx, int B, int L, int C, int L_out, int pool, float slope, long long out_sb,
+                    long long out_sl) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)B * L_out * C) return;
+  const int c = (int)(e % C);
+  const long long bl = e / C;
+  const int lo = (int)(bl % L_out), b = (int)(bl / L_out);
+  const int l0 = lo * pool, l1 = min(L, l0 + pool);
+  const size_t o = (size_t)b * out_sb + (size_t)lo * out_sl + c;
+  const unsigned char r = route[e];
+  float g = dy[o] * (y[o] > 0.0f ? 1.0f : slope);
+  if (r & 0x80) g = -g;
+  const int arg = r & 0x7f;
+  for (int l = l0; l < l1; ++l) dx[((size_t)b * L + l) * C + c] = (l - l0 == arg) ? g : 0.0f;
+}
+
 static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t m_st, int64_t m_sb,
                      float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                      int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, int64_t T,
@@ -329,5 +352,27 @@ extern "C" int slu_dropout_pool_bwd(const float* dy, const float* x, const float
   hipLaunchKernelGGL(dropout_pool_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, dy, x, dx, q);
   SLU_CHECK_LAUNCH("dropout_pool_bwd_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_pool_act_fwd(const float* x, float* y, uint8_t* route, int64_t B, int64_t L, int64_t C, int64_t pool,
+                                int do_abs, float slope, int64_t out_sb, int64_t out_sl, void* stream) {
+  SLU_REQUIRE(x && y, "slu_pool_act_fwd: null pointer");
+  SLU_REQUIRE(B > 0 && L > 0 && C > 0 && pool >= 1 && pool <= 127, "slu_pool_act_fwd: bad size (pool width 1..127)");
+  const int64_t L_out = cdiv(L, pool);
+  hipLaunchKernelGGL(pool_act_fwd_kernel, dim3((unsigned)cdiv(B * L_out * C, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     route, (int)B, (int)L, (int)C, (int)L_out, (int)pool, do_abs, slope, (long long)out_sb, (long long)out_sl);
+  SLU_CHECK_LAUNCH("pool_act_fwd_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_pool_act_bwd(const float* dy, const float* y, const uint8_t* route, float* dx, int64_t B, int64_t L,
+                                int64_t C, int64_t pool, float slope, int64_t out_sb, int64_t out_sl, void* stream) {
+  SLU_REQUIRE(dy && y && route && dx, "slu_pool_act_bwd: null pointer");
+  SLU_REQUIRE(B > 0 && L > 0 && C > 0 && pool >= 1 && pool <= 127, "slu_pool_act_bwd: bad size (pool width 1..127)");
+  const int64_t L_out = cdiv(L, pool);
+  hipLaunchKernelGGL(pool_act_bwd_kernel, dim3((unsigned)cdiv(B * L_out * C, 256)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                     route, dx, (int)B, (int)L, (int)C, (int)L_out, (int)pool, slope, (long long)out_sb, (long long)out_sl);
+  SLU_CHECK_LAUNCH("pool_act_bwd_kernel");
   return SLU_OK;
 }

@@ -288,7 +288,7 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
                                   int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t,
                                   int do_abs, int pool, float slope, int64_t out_sb, int64_t out_sl,
                                   void* out_planes, int64_t out_plane_stride,
-                                  void* workspace, size_t workspace_bytes, int nsplit, void* stream) {
+                                  void* workspace, size_t workspace_bytes, int packed_valid, int nsplit, void* stream) {
   SLU_REQUIRE((in || in_table) && weight && (out || out_planes), "slu_wconv_fwd_bf16: null pointer");
   SLU_REQUIRE(!in_table || (table_rows >= 1 && table_rows <= B), "slu_wconv_fwd_bf16: bad table_rows");
   SLU_REQUIRE(B > 0 && l_in > 0 && c_in > 0 && c_out > 0 && k_t > 0 && stride_t > 0, "slu_wconv_fwd_bf16: non-positive size");
@@ -311,7 +311,7 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   SLU_REQUIRE(l_conv > 0, "slu_wconv_fwd_bf16: input shorter than the filter");
   hipStream_t st = (hipStream_t)stream;
   uint4* wp = reinterpret_cast<uint4*>(workspace);
-  {
+  if (!packed_valid) {     // else: the workspace still holds the pack of these very filters (frozen block, caller's cache)
     const int total = (int)(KC * NT * 64);
     if (nsplit == 3)
       hipLaunchKernelGGL(bf_wconv_pack_kernel<3>, dim3((total + 255) / 256), dim3(256), 0, st, weight, wp, (int)c_out,
@@ -337,10 +337,15 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   p.KC = (int)KC; p.pad = (int)(pad_t * c_in);
   p.l_conv = (int)l_conv; p.l_out = (int)cdiv(l_conv, pool); p.c_out = (int)c_out;
   p.do_abs = do_abs; p.pool = pool; p.slope = slope;
-  const int MT = (B * cdiv(l_conv, 128) >= 256) ? 2 : 1;
-  const int F = 64 * MT;
+  int MT = (B * cdiv(l_conv, 128) >= 256) ? 2 : 1;
+  int F = 64 * MT;
   p.nrows = F + (int)cdiv(KC * 32, S) + 1;
-  const size_t lds = (size_t)nsplit * p.nrows * p.Sp * sizeof(unsigned short);
+  size_t lds = (size_t)nsplit * p.nrows * p.Sp * sizeof(unsigned short);
+  if (lds > 160 * 1024 && MT == 2) {           // long hops (stride ~200 and up at three planes): 64-frame tiles still fit
+    MT = 1; F = 64;
+    p.nrows = F + (int)cdiv(KC * 32, S) + 1;
+    lds = (size_t)nsplit * p.nrows * p.Sp * sizeof(unsigned short);
+  }
   if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_fwd_bf16: window of %zu bytes exceeds the 160 KiB LDS", lds);
   dim3 grid((unsigned)cdiv(l_conv, F), (unsigned)B);
   return nsplit == 3 ? bf_launch_nt<3>(MT, NT, grid, lds, st, p) : bf_launch_nt<1>(MT, NT, grid, lds, st, p);

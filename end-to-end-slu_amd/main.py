@@ -45,6 +45,7 @@ def run(args):
             say("*words*| train accuracy: %.2f| train loss: %.2f| valid accuracy: %.2f| valid loss: %.2f\n"
                 % (tr[2], tr[3], va[2], va[3]))
             trainer.save_checkpoint()
+        trainer.close()
 
     if args.train:
         train_dataset, valid_dataset, test_dataset = get_SLU_datasets(config)
@@ -66,6 +67,7 @@ def run(args):
         say("========= Test results =========")
         say("*intents*| test accuracy: %.2f| test loss: %.2f| valid accuracy: %.2f| valid loss: %.2f\n"
             % (test_acc, test_loss, valid_acc, valid_loss))
+        trainer.close()
 
 
 if __name__ == "__main__":

@@ -358,6 +358,19 @@ class _ConvStage:
     def parameters(self):
         return list(self.conv.parameters())
 
+    def _frozen_cache(self, nsplit):
+        """What a FROZEN block recomputed per call in round 2: the Sinc filterbank and the filters packed in MFMA
+        fragment order.  Kept per (weight version, arithmetic, HIP stream): a look-ahead slot's graph reads its own
+        copy, built by that stream's first (eager) call, so no stream ever waits for another one's pack."""
+        key = (nsplit, torch.cuda.current_stream().cuda_stream) + tuple((q.data_ptr(), q._version) for q in self.parameters())
+        caches = self.__dict__.setdefault("_caches", {})
+        c = caches.get(key)
+        if c is None:
+            if len(caches) >= 8:                   # weights were reloaded / streams retired: drop the stale entries
+                caches.clear()
+            c = caches[key] = {"filters": None, "pack": {}}
+        return c
+
     def run(self, h, training, out_planes=False):
         """h: (B,T) for the first block, else channels-last (B,L,C).
         out_planes: the consumer is a frozen split-precision GRU layer — hand over bf16 planes (SplitAct) when this
@@ -373,11 +386,16 @@ class _ConvStage:
         if os.environ.get("SLU_DTYPE", "f32") == "bf16" and not nsplit:
             nsplit = 0                                 # trainable convolutions stay exact fp32 in bf16 mode
         c_in = 1 if (self.is_sinc or h.dim() == 2) else h.shape[2]
+        k_t = self.conv.Filt_dim if self.is_sinc else self.conv.kernel_size
         if (nsplit and fused_pool and not h.requires_grad
-                and _ops.wconv_bf16_supported(c_in, self.conv.stride, pool)):
+                and _ops.wconv_bf16_supported(c_in, self.conv.stride, pool, k_t, nsplit)):
             with torch.no_grad():
+                cache = self._frozen_cache(nsplit)
                 if self.is_sinc:
-                    w = self.conv.filters().view(self.conv.N_filt, 1, self.conv.Filt_dim)
+                    if cache.get("filters") is None and not torch.cuda.is_current_stream_capturing():
+                        cache["filters"] = self.conv.filters()
+                    filt = cache.get("filters")
+                    w = (filt if filt is not None else self.conv.filters()).view(self.conv.N_filt, 1, self.conv.Filt_dim)
                     bias, do_abs = None, self.do_abs
                 else:
                     w, bias, do_abs = self.conv.weight.detach(), self.conv.bias.detach(), self.do_abs
@@ -389,7 +407,7 @@ class _ConvStage:
                 planes = (out_planes and tm and not (self.drop > 0.0 and training)
                           and _ops.wconv_bf16_planes_ok(w.shape[0], pool))
                 h = _ops.wconv_fwd_bf16(x3, w, bias, B, l_in, c_in, self.conv.stride, do_abs, pool, slope,
-                                        tm, nsplit, planes)
+                                        tm, nsplit, planes, pack_cache=cache["pack"])
                 if planes:
                     return h
             if self.drop > 0.0 and training:
@@ -407,12 +425,8 @@ class _ConvStage:
                 h = h.unsqueeze(2)
             h = _ops.ConvBlockFn.apply(h, self.conv.weight, self.conv.bias, self.conv.stride,
                                        self.do_abs and fused_pool, pool, slope, tm)
-        if not fused_pool:          # unusual pool widths: generic (unfused) tail
-            h = h.transpose(1, 2)
-            if self.do_abs:
-                h = h.abs()
-            h = torch.nn.functional.max_pool1d(h, self.pool, ceil_mode=True)
-            h = torch.nn.functional.leaky_relu(h, self.slope).transpose(1, 2)
+        if not fused_pool:          # pool widths the convolution's epilogue does not fuse (> 2): slu_pool_act_*
+            h = _ops.PoolActFn.apply(h, self.pool, self.do_abs, self.slope, False)
         if self.drop > 0.0 and training:
             # nn.Dropout of the CNN block (models.py:217-220) on the same step-indexed Philox stream as
             # the RNN sites (or the injected mask, given in the reference's (B,C,L) shape)
@@ -558,7 +572,9 @@ class PretrainedModel(torch.nn.Module):
         if any(q.requires_grad for q in st.parameters()) or not contraction_nsplit(True):
             return False
         fused_pool = st.pool in (1, 2)
-        return fused_pool and _ops.wconv_bf16_supported(1, st.conv.stride, st.pool if fused_pool else 1)
+        k_t = st.conv.Filt_dim if st.is_sinc else st.conv.kernel_size
+        return fused_pool and _ops.wconv_bf16_supported(1, st.conv.stride, st.pool if fused_pool else 1, k_t,
+                                                        contraction_nsplit(True))
 
     def warm_weight_caches(self):
         """Establish the direction-stacked input-projection storage of every GRU layer on the current
@@ -606,9 +622,13 @@ class PretrainedModel(torch.nn.Module):
         (x,) = self._to_device(x)
         _DropoutState.current = next_rng_step()
         ph_tm = self._phoneme_features_tm(x)
-        phoneme_logits = self.phoneme_linear(ph_tm.transpose(0, 1))
-        word_logits = self.word_linear(self._word_features_tm(ph_tm).transpose(0, 1))
-        return phoneme_logits, word_logits
+        wd_tm = self._word_features_tm(ph_tm)
+
+        def head(lin, h_tm):                       # Linear on every frame: slu_gemm_f32 (no gradient path: inference)
+            T, B, C = h_tm.shape
+            out = _ops.gemm(h_tm.detach().contiguous().view(T * B, C), lin.weight.detach().t(), lin.bias.detach())
+            return out.view(T, B, -1).transpose(0, 1)
+        return head(self.phoneme_linear, ph_tm), head(self.word_linear, wd_tm)
 
     def compute_features(self, x):
         """(B,T) waveform -> (B,T',C) encoder features (reference models.py:349-361)."""

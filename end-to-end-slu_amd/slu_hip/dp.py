@@ -70,9 +70,16 @@ class DirectComm:
                         "slu_comm_allreduce")
 
     def close(self):
-        if self._handle:
+        if getattr(self, "_handle", None):
+            torch.cuda.synchronize()              # nothing of ours may still be in flight on the communicator
             self._lib.check(self._L.slu_comm_destroy(self._handle), "slu_comm_destroy")
             self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                         # interpreter shutdown: the runtime may be gone already
+            pass
 
 
 class GradBucket:
@@ -127,11 +134,18 @@ class GradBucket:
         self.observe()
         for dtype, ps in self.groups.items():
             flat = self.flats[dtype]
-            torch.cat([p.grad.reshape(-1) for p in ps], out=flat)
-            off = 0
+            views, off = [], 0
             for p in ps:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                views.append(flat[off:off + p.numel()])
                 off += p.numel()
+            if flat.is_cuda:
+                # ONE slu_copy_multi launch per 32 tensors (device pointers in the kernel arguments): no ATen kernel
+                from . import ops
+                ops.copy_multi([(v, p.grad.contiguous().reshape(-1)) for v, p in zip(views, ps)])
+            else:                                     # host tensors: the gloo tests of the bucket logic
+                torch.cat([p.grad.reshape(-1) for p in ps], out=flat)
+            for v, p in zip(views, ps):
+                p.grad = v.view_as(p)
 
     def allreduce_flats(self):
         """ONE collective per gradient dtype over the packed flat buffers: the sum over ranks, and the
@@ -155,11 +169,16 @@ class GradBucket:
         self.allreduce_flats()
 
 
-def allreduce_sums(values, device):
-    """Sum a short list of Python floats over ranks (epoch metrics); identity for one process."""
+def allreduce_sums(values, device, comm=None):
+    """Sum a short list of Python floats over ranks (epoch metrics); identity for one process.  comm: the step's
+    DirectComm (SLU_COMM=rccl) — the reduction then goes through the same communicator, on the current stream, so
+    that every collective of the process is ordered by one stream."""
     rank, ws = world()
     if ws == 1:
         return list(values)
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if comm is not None and t.is_cuda:
+        comm.allreduce(t)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.tolist()

@@ -26,6 +26,23 @@ SIGNATURES = {
     "slu_stream_create_cu_range": (c_int, [c_i64, c_i64, vp]),
     "slu_store_u64": (c_int, [vp, vp, c_i64, vp]),
     "slu_stage_inputs": (c_int, [vp, vp, vp, vp, vp, c_i64, vp, c_i64, vp]),
+    "slu_multi_max": (c_int, []),
+    "slu_copy_multi": (c_int, [vp, vp, vp, c_i64, vp]),
+    "slu_scale_multi": (c_int, [vp, vp, c_i64, vp, vp]),
+    "slu_pool_act_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_i64, c_i64, vp]),
+    "slu_pool_act_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_i64, c_i64, vp]),
+    "slu_gru_cell_fwd": (c_int, [vp, vp, vp, c_i64, vp, c_i64, vp, vp, vp, c_f32, c_u64, c_u64, vp, c_u64, c_i64, c_i64, vp]),
+    "slu_gru_cell_bwd": (c_int, [vp, c_i64, vp, vp, vp, c_i64, vp, vp, vp, c_i64, vp, c_f32, c_u64, c_u64, vp, c_u64,
+                                 c_i64, c_i64, vp]),
+    "slu_attention_fwd": (c_int, [vp, c_i64, c_i64, vp, c_i64, c_i64, vp, c_i64, vp, c_i64, vp, c_f32, c_i64, c_i64, c_i64,
+                                  c_i64, vp]),
+    "slu_attention_bwd": (c_int, [vp, c_i64, c_i64, vp, c_i64, c_i64, vp, c_i64, vp, c_i64, vp, vp, vp, vp, c_i64, c_f32,
+                                  c_i64, c_i64, c_i64, c_i64, vp]),
+    "slu_logsoftmax_dot_fwd": (c_int, [vp, vp, c_i64, vp, vp, c_i64, c_i64, vp]),
+    "slu_logsoftmax_dot_bwd": (c_int, [vp, vp, c_i64, vp, vp, c_i64, vp, c_i64, c_i64, vp]),
+    "slu_neg_mean_f32": (c_int, [vp, vp, c_i64, vp]),
+    "slu_fill_scaled_f32": (c_int, [vp, c_i64, vp, c_f32, vp]),
+    "slu_broadcast_rows_f32": (c_int, [vp, vp, c_i64, c_i64, c_i64, vp]),
     "slu_sinc_filters_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_f64, vp]),
     "slu_sinc_filters_bwd": (c_int, [vp, vp, vp, vp, vp, c_i64, c_i64, c_f64, vp]),
     "slu_wconv_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
@@ -46,7 +63,7 @@ SIGNATURES = {
     "slu_gemm_bf16": (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
-                                   c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, vp]),
+                                   c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp]),
     "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_comm_version": (c_int, []),
     "slu_comm_unique_id": (c_int, [vp]),
@@ -76,7 +93,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 3          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

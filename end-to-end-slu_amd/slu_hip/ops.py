@@ -218,6 +218,78 @@ def stage_inputs(pairs, set_tensor=None, set_value=0):
     return [r for r in rest if r is not None]
 
 
+def copy_multi(pairs):
+    """[(dst, src)] contiguous same-sized tensors (whole 4-byte words): all copies in ceil(n / 32) launches."""
+    import ctypes
+    L = _lib.load()
+    step = L.slu_multi_max()
+    for i in range(0, len(pairs), step):
+        part = pairs[i:i + step]
+        n = len(part)
+        for dst, src in part:
+            assert dst.is_contiguous() and src.is_contiguous() and dst.numel() * dst.element_size() == src.numel() * src.element_size()
+        src = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in part])
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in part])
+        nb = (ctypes.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part])
+        _lib.check(L.slu_copy_multi(src, dst, nb, n, _stream()), "slu_copy_multi")
+
+
+def scale_multi(tensors, scale_dev):
+    """x *= scale_dev[0] for every contiguous fp32 tensor of the list (one launch per 32 tensors)."""
+    import ctypes
+    if not tensors:
+        return
+    L = _lib.load()
+    scale_dev = scale_dev.reshape(-1)
+    assert scale_dev.dtype == torch.float32 and scale_dev.is_cuda
+    step = L.slu_multi_max()
+    for i in range(0, len(tensors), step):
+        part = tensors[i:i + step]
+        n = len(part)
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in part)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in part])
+        numel = (ctypes.c_int64 * n)(*[t.numel() for t in part])
+        _lib.check(L.slu_scale_multi(ptrs, numel, n, scale_dev.data_ptr(), _stream()), "slu_scale_multi")
+
+
+class PoolActFn(torch.autograd.Function):
+    """[Abs ->] MaxPool1d(pool, ceil) -> LeakyReLU / ReLU for pool widths the convolution epilogue does not fuse
+    (cnn_max_pool_len > 2; reference models.py:163-168, :205, :211-213).  x channels-last (B, L, C) ->
+    (B, L_out, C), or time-major (L_out, B, C)."""
+
+    @staticmethod
+    def forward(ctx, x, pool, do_abs, slope, time_major):
+        L = _lib.load()
+        x = _f32c(x, "x")
+        B, Lin, C = x.shape
+        l_out = -(-Lin // pool)
+        if time_major:
+            y = torch.empty(l_out, B, C, dtype=torch.float32, device=x.device)
+            sb, sl = C, B * C
+        else:
+            y = torch.empty(B, l_out, C, dtype=torch.float32, device=x.device)
+            sb, sl = l_out * C, C
+        need = ctx.needs_input_grad[0]
+        route = torch.empty(B, l_out, C, dtype=torch.uint8, device=x.device) if need else None
+        _lib.check(L.slu_pool_act_fwd(x.data_ptr(), y.data_ptr(), _ptr(route), B, Lin, C, pool, int(do_abs), float(slope),
+                                      sb, sl, _stream()), "slu_pool_act_fwd")
+        if need:
+            ctx.save_for_backward(y, route)
+            ctx.cfg = (B, Lin, C, pool, slope, sb, sl)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.load()
+        y, route = ctx.saved_tensors
+        B, Lin, C, pool, slope, sb, sl = ctx.cfg
+        dy = _f32c(dy, "dy")
+        dx = torch.empty(B, Lin, C, dtype=torch.float32, device=dy.device)
+        _lib.check(L.slu_pool_act_bwd(dy.data_ptr(), y.data_ptr(), route.data_ptr(), dx.data_ptr(), B, Lin, C, pool,
+                                      float(slope), sb, sl, _stream()), "slu_pool_act_bwd")
+        return dx, None, None, None, None
+
+
 # -- split-precision (bf16 MFMA) path of the frozen stages: see csrc/slu_bf16.h --------------------------
 def round_up(n, m):
     return -(-n // m) * m
@@ -256,9 +328,19 @@ def gemm_bf16(planes, packed, bias, N, K, out=None):
     return out
 
 
-def wconv_bf16_supported(c_in, stride, pool):
-    """Shapes slu_wconv_fwd_bf16 takes (else the exact fp32 kernel runs)."""
-    return pool in (1, 2) and ((c_in == 1 and stride % 8 == 0) or (c_in > 1 and stride == 1))
+def wconv_bf16_supported(c_in, stride, pool, k_t=None, nsplit=3):
+    """Shapes slu_wconv_fwd_bf16 takes (else the exact fp32 kernel runs).  With k_t given the launcher's LDS limit
+    is mirrored too: nsplit planes of (64 frames + window overhang) rows of stride * c_pad + 8 bf16 must fit 160 KiB
+    (the launcher falls back from 128- to 64-frame tiles before giving up)."""
+    if not (pool in (1, 2) and ((c_in == 1 and stride % 8 == 0) or (c_in > 1 and stride == 1))):
+        return False
+    if k_t is None:
+        return True
+    c_pad = 1 if c_in == 1 else round_up(c_in, 8)
+    S = stride * c_pad
+    kc = -(-(k_t * c_pad) // 32)
+    nrows = 64 + -(-(kc * 32) // S) + 1
+    return nsplit * nrows * (S + 8) * 2 <= 160 * 1024
 
 
 class RowTable:
@@ -300,9 +382,12 @@ def wconv_bf16_planes_ok(c_out, pool):
     return pool == 1 and nt is not None and nt * 16 >= round_up(c_out, 32)
 
 
-def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit, out_planes=False):
+def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit, out_planes=False,
+                   pack_cache=None):
     """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in).
-    out_planes: return a SplitAct (time-major rows, bf16 planes) for the next frozen GRU layer instead of fp32."""
+    out_planes: return a SplitAct (time-major rows, bf16 planes) for the next frozen GRU layer instead of fp32.
+    pack_cache: a dict of the caller's (one per frozen block and weight version): the packed filters are built by
+    the first call and reused by the following ones (no pack launch per super-batch)."""
     L = _lib.load()
     if isinstance(x, RowTable):
         x_ptr, tab, tab_rows = None, x.ptrs.data_ptr(), x.rows
@@ -317,11 +402,10 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     if out_planes:
         assert time_major and wconv_bf16_planes_ok(c_out, pool)
         planes = torch.empty(nsplit, l_out * B, round_up(c_out, 32), dtype=torch.bfloat16, device=x.device)
-        wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
-        ws = _workspace(wsb, x.device)
+        ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
         _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, B, l_in, c_in, c_out,
                                         k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
-                                        planes.stride(0), ws.data_ptr(), wsb, nsplit, _stream()), "slu_wconv_fwd_bf16")
+                                        planes.stride(0), ws.data_ptr(), wsb, valid, nsplit, _stream()), "slu_wconv_fwd_bf16")
         return SplitAct(planes, l_out, B, c_out)
     if time_major:
         out = torch.empty(l_out, B, c_out, dtype=torch.float32, device=x.device)
@@ -329,12 +413,27 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     else:
         out = torch.empty(B, l_out, c_out, dtype=torch.float32, device=x.device)
         sb, sl = l_out * c_out, c_out
-    wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
-    ws = _workspace(wsb, x.device)
+    ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
     _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), out.data_ptr(), B, l_in, c_in, c_out,
                                     k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
-                                    nsplit, _stream()), "slu_wconv_fwd_bf16")
+                                    valid, nsplit, _stream()), "slu_wconv_fwd_bf16")
     return out
+
+
+def _wconv_pack_ws(L, cache, c_out, c_in, k_t, nsplit, device):
+    """-> (workspace, bytes, packed_valid) of slu_wconv_fwd_bf16: a fresh workspace, or the caller's cached one whose
+    filter pack the first call built (valid from the second call on)."""
+    wsb = L.slu_wconv_bf16_workspace_bytes(c_out, c_in, k_t, nsplit)
+    if cache is None:
+        return _workspace(wsb, device), wsb, 0
+    key = (c_out, c_in, k_t, nsplit, str(device))
+    ws = cache.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return _workspace(wsb, device), wsb, 0      # memory allocated under capture belongs to the graph: no caching
+        cache[key] = ws = _workspace(wsb, device)
+        return ws, wsb, 0
+    return ws, wsb, 1
 
 
 class SplitAct:
@@ -631,11 +730,12 @@ class FrameHeadFn(torch.autograd.Function):
         g = d_loss.float()
         dh = dW = db = None
         if ctx.needs_input_grad[0]:
-            dh = gemm(d_logits, weight).mul_(g).view(T, B, C)
+            dh = gemm(d_logits, weight).view(T, B, C)
         if ctx.needs_input_grad[1]:
-            dW = gemm(d_logits.t(), hn).mul_(g)
+            dW = gemm(d_logits.t(), hn)
         if ctx.needs_input_grad[2]:
-            db = colsum(d_logits).mul_(g)
+            db = colsum(d_logits)
+        scale_multi([t for t in (dh, dW, db) if t is not None], g)      # d loss upstream (a device scalar), one launch
         return dh, dW, db, None
 
 
@@ -766,7 +866,8 @@ class GRULayerFn(torch.autograd.Function):
         small = (T * B <= TN_SMALL_ROWS and T > 1 and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
                  and I % 4 == 0 and H % 4 == 0)
         if need_bias and not small:
-            dbp = dbp.sum(0)                               # (D, 6H): [d(b_ih) (3H) | d(b_hh) (3H)]
+            # (tiles, D, 6H) per-tile partials -> (D, 6H): [d(b_ih) (3H) | d(b_hh) (3H)]  (slu_colsum_f32, deterministic)
+            dbp = colsum(dbp.view(dbp.shape[0], D * 6 * H)).view(D, 6 * H)
         if small:
             # a few thousand rows (the intent layer of the look-ahead pipeline): every weight gradient of the layer
             # in ONE launch (no split-K workspaces, no reduce launches).  The choice depends on the shape only.

@@ -36,7 +36,10 @@ def cu_split(device=None):
         return int(v)
     if not torch.cuda.is_available():
         return 0
-    return 3 * n_compute_units(torch.cuda.current_device() if device is None else device) // 8
+    n = n_compute_units(torch.cuda.current_device() if device is None else device)
+    # three eighths, rounded to whole CU PAIRS per XCD (a multiple of 16: the mask bits interleave over 8 XCDs and an
+    # odd count per XCD splits a pair between the partitions); 256 CUs -> 96, other parts their nearest even share
+    return max(16, (3 * n // 8) // 16 * 16) if n >= 32 else 0
 
 
 _CU_MASK_BROKEN = [False]

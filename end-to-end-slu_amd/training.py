@@ -141,8 +141,16 @@ class Trainer:
             print(text)
 
     def _epoch_means(self, sums, num_examples, device):
-        tot = dp.allreduce_sums([float(s) for s in sums] + [float(num_examples)], device)
+        comm = self.bucket.comm if self.bucket is not None else None
+        tot = dp.allreduce_sums([float(s) for s in sums] + [float(num_examples)], device, comm)
         return [v / tot[-1] for v in tot[:-1]]
+
+    def close(self):
+        """Release what the trainer holds outside torch's allocator: the direct RCCL communicator (SLU_COMM=rccl).
+        Called by main.py / bench.py at the end of a run; harmless to call twice."""
+        if self.bucket is not None and self.bucket.comm is not None:
+            self.bucket.comm.close()
+            self.bucket.comm = None
 
     def _forward_losses(self, batch, asr, rng_step=None):
         """-> ([metric tensors in log order], loss to back-propagate).  rng_step: None = the model draws the
@@ -208,11 +216,13 @@ class Trainer:
         (captured after three eager steps of that key), else eagerly.  -> metrics (tensor or list)."""
         from slu_hip import pipeline
         sg = self._step_graphs.get(key)
+        if sg is not None:
+            self._step_graphs[key] = self._step_graphs.pop(key)          # most recently used last
         if sg is not None and sg.signature != self.bucket.signature:
             sg = None                                   # trainable set changed since capture
         if sg is None and self._eager_steps.get(key, 0) >= 3 and self.bucket.active:
             if key not in self._step_graphs and len(self._step_graphs) >= _max_step_graphs():
-                self._step_graphs.pop(next(iter(self._step_graphs)))     # evict the oldest capture
+                self._step_graphs.pop(next(iter(self._step_graphs)))     # evict the LEAST RECENTLY USED capture
             try:
                 sg = pipeline.StepGraph(self, inputs, forward, stream, forks)
                 self._step_graphs[key] = sg
@@ -230,6 +240,9 @@ class Trainer:
             self._eager_steps[key] = 0
         self._last_key = key
         self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
+        if len(self._eager_steps) > 256:                # ragged real-data shapes: keep the table bounded
+            keep = {k: v for k, v in self._eager_steps.items() if v < 0 or k == key or k in self._step_graphs}
+            self._eager_steps = keep
         metrics, loss = forward(inputs, step)
         self._step(loss)
         return metrics

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 2
+#define SLU_ABI_VERSION 3
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -60,6 +60,14 @@ int slu_store_u64(uint64_t* dst, const uint64_t* values, int64_t count, void* st
 int slu_stage_inputs(const void* const* src, void* const* dst, const int64_t* rows, const int64_t* row_bytes,
                      const int64_t* src_stride_bytes, int64_t count, int64_t* set_ptr, int64_t set_value,
                      void* stream);
+
+/* Up to slu_multi_max() small device-to-device copies in ONE launch (HOST arrays of device pointers and byte counts,
+ * travelling in the kernel arguments; every segment a whole number of 4-byte words): packing the fresh gradients of a
+ * step into the flat all-reduce bucket.  slu_scale_multi: x_k[i] *= *scale_dev for up to slu_multi_max() fp32 tensors
+ * (an upstream scalar applied to the few gradients of a loss head).                                                    */
+int slu_multi_max(void);
+int slu_copy_multi(const void* const* src, void* const* dst, const int64_t* nbytes, int64_t count, void* stream);
+int slu_scale_multi(float* const* ptrs, const int64_t* numel, int64_t count, const float* scale_dev, void* stream);
 
 /* -------- Sinc filterbank: models.py:79-106 (SincLayer.forward up to the conv), :7-24 ------- */
 /* filters[n_filt][filt_dim] (float32) from the two float64 parameters, filt_dim odd.            */
@@ -158,13 +166,16 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
  * time-major order l * B + b, zero padded columns — which slu_gemm_bf16 reads (no fp32 round trip, no slu_split_bf16).
  * in_table != NULL: a DEVICE array of ceil(B / table_rows) base pointers; batch row b is read from
  * in_table[b / table_rows] + (b % table_rows) * l_in * c_in instead of in + b * l_in * c_in — a look-ahead super-batch
- * reads its batches where they lie instead of a concatenated copy (`in` is then ignored).                          */
+ * reads its batches where they lie instead of a concatenated copy (`in` is then ignored).
+ * packed_valid != 0: `workspace` still holds the filter pack a previous call built from these very weights (a frozen
+ * block: the caller keeps the workspace per weight version) — the pack launch is skipped.                           */
 size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t, int nsplit);
 int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows, const float* weight,
                        const float* bias, float* out, int64_t B,
                        int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t, int do_abs,
                        int pool, float slope, int64_t out_sb, int64_t out_sl, void* out_planes,
-                       int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int nsplit, void* stream);
+                       int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,
+                       void* stream);
 /* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
  * W_hh (3 gates x nsplit bf16 planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
  * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)
@@ -235,6 +246,16 @@ int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const 
                          int method, int64_t factor, float* dx, int64_t T, int64_t B, int64_t C,
                          void* stream);
 
+/* [Abs ->] MaxPool1d(pool, ceil_mode=True) -> LeakyReLU(slope) / ReLU (slope 0) for pool widths the convolution's
+ * epilogue does not fuse (any cnn_max_pool_len > 2: models.py:163-168, :205, :211-213).  x channels-last (B, L, C);
+ * y[b, lo, c] at b * out_sb + lo * out_sl + c (channels-last or time-major); route (B, ceil(L / pool), C) bytes =
+ * arg-max offset inside the window | (input was negative, abs) << 7, NULL when no backward follows; pool <= 127.
+ * Backward: dx (B, L, C) fully written (zeros off the arg-max).                                                    */
+int slu_pool_act_fwd(const float* x, float* y, uint8_t* route, int64_t B, int64_t L, int64_t C, int64_t pool,
+                     int do_abs, float slope, int64_t out_sb, int64_t out_sl, void* stream);
+int slu_pool_act_bwd(const float* dy, const float* y, const uint8_t* route, float* dx, int64_t B, int64_t L,
+                     int64_t C, int64_t pool, float slope, int64_t out_sb, int64_t out_sl, void* stream);
+
 /* -------- intent head: Linear "final_classifier" (models.py:709) -> FinalPool max over time
  * (:112-123) -> per-slot cross-entropy, accuracy and arg-max (:811-821, :839-844) ------------------
  *   h (T,B,C) time-major intent-GRU output; weight (V,C), bias (V), V = sum(values_per_slot);
@@ -268,6 +289,46 @@ int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const
  *   row_stats: workspace of 2 N floats.  Targets must lie in [0, V) or equal ignore_index.            */
 int slu_frame_ce_fwd(float* logits, const int64_t* y, int64_t N, int64_t V, int64_t ignore_index,
                      int write_grad, float* row_stats, float* out3, void* stream);
+
+/* -------- seq2seq intent decoder (models.py:418-557: Attention, DecoderRNN, Seq2SeqDecoder.forward) ------------------
+ * The decoder's Linear layers and the GRUCell projections are slu_gemm_f32 calls; these are the step's other pieces,
+ * forward and backward.  All (B, n) operands are row-major with the stated row strides (in elements).
+ *   slu_gru_cell_fwd   torch.nn.GRUCell gate math: gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh (B, 3H, gates [r; z; n])
+ *                      -> h_out = (1 - z) n + z h_prev; save (NULL or (4, B, H)) = r, z, n, gh_n for the backward;
+ *                      drop_out (NULL or (B, H)) = nn.Dropout(p) of h_out (models.py:455: the next layer's input):
+ *                      keep-mask from `mask` ((B, H) {0,1} floats) or Philox(seed, offset [+ *offset_dev]) at element
+ *                      index idx_base + b * H + j (one index space for all steps and layers of a forward)
+ *   slu_gru_cell_bwd   d_h (B, H; NULL = 0) + d_drop (NULL or (B, H), gradient of drop_out) -> d_gi, d_gh (B, 3H) and
+ *                      d_h_prev = dh * z (the recurrent part through W_hh is the caller's GEMM); d_h_prev may alias d_h
+ *   slu_attention_fwd  scores_t = <keys[b,t], query[b]> * inv_scale, weights = softmax_t, ctx[b] = sum_t weights_t
+ *                      values[b,t]; keys[b,t,:] at keys + t * k_st + b * k_sb (time- or batch-major), values likewise
+ *   slu_attention_bwd  d_keys / d_values are ACCUMULATED into (+=, same addressing: the encoder states are shared by
+ *                      all decoding steps), d_query (B, Kd) is overwritten
+ *   slu_logsoftmax_dot_fwd  logp_acc[b] += sum_v log_softmax(logits[b])_v * y[b, v]; lse[b] (NULL or B) = logsumexp
+ *   slu_logsoftmax_dot_bwd  d_logits[b, v] = g[b * g_stride] * (y[b, v] - softmax_v * sum_v' y[b, v'])
+ *   slu_neg_mean_f32   out[0] = -mean(x[0..n))  (loss = -log_probs.mean(), models.py:825)
+ *   slu_fill_scaled_f32 dst[0..n) = g[0] * scale;  slu_broadcast_rows_f32 dst[b, 0..n) = src[0..n) for b < rows        */
+int slu_gru_cell_fwd(const float* gi, const float* gh, const float* h_prev, int64_t ld_prev, float* h_out,
+                     int64_t ld_out, float* save, float* drop_out, const float* mask, float p, uint64_t seed,
+                     uint64_t offset, const uint64_t* offset_dev, uint64_t idx_base, int64_t B, int64_t H, void* stream);
+int slu_gru_cell_bwd(const float* d_h, int64_t ld_dh, const float* d_drop, const float* save, const float* h_prev,
+                     int64_t ld_prev, float* d_gi, float* d_gh, float* d_h_prev, int64_t ld_dprev, const float* mask,
+                     float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, uint64_t idx_base, int64_t B,
+                     int64_t H, void* stream);
+int slu_attention_fwd(const float* keys, int64_t k_st, int64_t k_sb, const float* values, int64_t v_st, int64_t v_sb,
+                      const float* query, int64_t ld_q, float* ctx, int64_t ld_ctx, float* weights, float inv_scale,
+                      int64_t B, int64_t T, int64_t Kd, int64_t Vd, void* stream);
+int slu_attention_bwd(const float* keys, int64_t k_st, int64_t k_sb, const float* values, int64_t v_st, int64_t v_sb,
+                      const float* query, int64_t ld_q, const float* d_ctx, int64_t ld_dctx, const float* weights,
+                      float* d_keys, float* d_values, float* d_query, int64_t ld_dq, float inv_scale, int64_t B,
+                      int64_t T, int64_t Kd, int64_t Vd, void* stream);
+int slu_logsoftmax_dot_fwd(const float* logits, const float* y, int64_t ld_y, float* logp_acc, float* lse, int64_t B,
+                           int64_t V, void* stream);
+int slu_logsoftmax_dot_bwd(const float* logits, const float* y, int64_t ld_y, const float* lse, const float* g,
+                           int64_t g_stride, float* d_logits, int64_t B, int64_t V, void* stream);
+int slu_neg_mean_f32(const float* x, float* out, int64_t n, void* stream);
+int slu_fill_scaled_f32(float* dst, int64_t n, const float* g, float scale, void* stream);
+int slu_broadcast_rows_f32(const float* src, float* dst, int64_t ld_dst, int64_t rows, int64_t n, void* stream);
 
 /* -------- Adam: torch.optim.Adam(model.parameters(), lr) (training.py:19, default betas / eps) ------
  * One launch updates up to slu_adam_max_tensors() tensors of one dtype (elem_bytes 4 / 8); the pointer

@@ -489,3 +489,190 @@ def draw_dropout_masks(cfg, x_bt, seed, include_intent=True):
             L = -(-L // cfg.intent_downsample_len[r]) if cfg.intent_downsample_type[r] != "none" \
                 else len(range(0, L, cfg.intent_downsample_len[r]))
     return masks
+
+
+# --------------------------------------------------------------------------------------------
+# seq2seq intent head (models.py:381-651, hooks :720-725, :825-828, :848-851)
+# State-dict keys as the reference's Model registers them: "encoder.layers.{3i}.*" (nn.GRU),
+# "decoder.embed.*", "decoder.attention.{key,query,value}_linear.*", "decoder.rnn.layers.{2l}.*"
+# (nn.GRUCell: weight_ih, weight_hh, bias_ih, bias_hh), "decoder.initial_state", "decoder.linear.*".
+# --------------------------------------------------------------------------------------------
+
+
+def seq2seq_encoder(sd, feats_btc, cfg, masks=None, explicit_gru=True):
+    """Seq2SeqEncoder.forward (models.py:381-416): per layer biGRU -> RNNSelect -> Dropout(0.5)."""
+    masks = masks or {}
+    out = feats_btc
+    for i in range(cfg.num_intent_encoder_layers):
+        out = gru_layer(out, _gru_params(sd, "encoder.layers.%d." % (3 * i)), True, explicit_gru)    # :388
+        out = dropout_with_mask(out, 0.5, masks.get("intent_encoder_dropout%d" % i))                 # :401
+    return out
+
+
+def attention(sd, enc_btc, dec_state_bd, key_dim):
+    """Attention.forward (models.py:427-438): dot-product attention of one query over the encoder states."""
+    p = "decoder.attention."
+    keys = enc_btc @ sd[p + "key_linear.weight"].t() + sd[p + "key_linear.bias"]
+    values = enc_btc @ sd[p + "value_linear.weight"].t() + sd[p + "value_linear.bias"]
+    query = dec_state_bd @ sd[p + "query_linear.weight"].t() + sd[p + "query_linear.bias"]
+    scale = torch.sqrt(torch.tensor(key_dim).float())                                                # :421
+    scores = torch.matmul(keys, query.unsqueeze(2)) / scale                                          # (B,T,1)
+    w = torch.softmax(scores, dim=1).transpose(1, 2)
+    return torch.matmul(w, values).squeeze(1)
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """torch.nn.GRUCell (models.py:450-452): one GRU step, gate order [r; z; n]."""
+    H = h.shape[1]
+    gi = x @ w_ih.t() + b_ih
+    gh = h @ w_hh.t() + b_hh
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    return (1 - z) * n + z * h
+
+
+def decoder_rnn(sd, inp, prev_state_bld, num_layers, step_masks=None):
+    """DecoderRNN.forward (models.py:462-485): stacked GRUCells, Dropout(0.5) between them (the dropout after the
+    LAST cell draws a mask too, its output is discarded).  step_masks: None or list of (B, D) keep-masks per layer."""
+    state = []
+    out = inp
+    for l in range(num_layers):
+        p = "decoder.rnn.layers.%d." % (2 * l)
+        out = gru_cell(out, prev_state_bld[:, l], sd[p + "weight_ih"], sd[p + "weight_hh"], sd[p + "bias_ih"], sd[p + "bias_hh"])
+        state.append(out)
+        out = dropout_with_mask(out, 0.5, None if step_masks is None else step_masks[l])
+    return torch.stack(state, dim=1)
+
+
+def seq2seq_decoder_forward(sd, enc_btc, y_buv, cfg, masks=None, SOS=0):
+    """Seq2SeqDecoder.forward (models.py:504-557): teacher-forced log p(y|x) per utterance."""
+    B, U, V = y_buv.shape
+    L = cfg.num_intent_decoder_layers
+    state = torch.stack([sd["decoder.initial_state"]] * B)                                           # :521
+    log_p = 0
+    y_prev = torch.zeros(B, V)
+    y_prev[:, SOS] = 1.0                                                                             # :525-526
+    for u in range(U):
+        ctx = attention(sd, enc_btc, state[:, -1], cfg.intent_decoder_key_dim)                       # :530
+        emb = y_prev @ sd["decoder.embed.weight"].t() + sd["decoder.embed.bias"]                     # :531
+        sm = None if not masks else [masks["decoder_dropout_u%d_l%d" % (u, l)] for l in range(L)]
+        state = decoder_rnn(sd, torch.cat([emb, ctx], dim=1), state, L, sm)                          # :532-533
+        out = torch.log_softmax(state[:, -1] @ sd["decoder.linear.weight"].t() + sd["decoder.linear.bias"], dim=1)
+        log_p = log_p + (out * y_buv[:, u, :]).sum(dim=1)                                            # :537-540
+        y_prev = y_buv[:, u, :]                                                                      # :543
+    return log_p
+
+
+def seq2seq_forward(sd, x_bt, y_buv, cfg, masks=None, explicit_gru=True, SOS=0):
+    """Model.forward, seq2seq branch (models.py:825-828): -> (loss = -mean log p(y|x), log_p (B))."""
+    st = encoder_stages(sd, x_bt, cfg, masks, prefix="pretrained_model.", explicit_gru=explicit_gru)
+    enc = seq2seq_encoder(sd, st["features"], cfg, masks, explicit_gru)
+    log_p = seq2seq_decoder_forward(sd, enc, y_buv, cfg, masks, SOS)
+    return -log_p.mean(), log_p
+
+
+def sort_beam(ext, scores, ptrs):
+    """sort_beam (models.py:487-502): per utterance, order the candidate extensions by score, descending.
+    ext (W, B, V), scores (W, B), ptrs (W, B) with W candidates."""
+    order = scores.sort(dim=0, descending=True)[1]
+    cols = torch.arange(scores.shape[1])
+    return ext[order, cols], scores[order, cols], ptrs[order, cols]
+
+
+def seq2seq_infer(sd, enc_btc, cfg, num_labels, beam=4, max_len=200):
+    """Seq2SeqDecoder.infer (models.py:559-651) in eval mode: beam search of width `beam`; the first input is the
+    all-zero vector (:596), only hypothesis 0 is expanded at the first step (:625).
+    Returns (beam_scores (beam, B), beam (beam, B, max_len, V) one-hot)."""
+    Bsz = enc_btc.shape[0]
+    L = cfg.num_intent_decoder_layers
+    init = torch.stack([sd["decoder.initial_state"]] * Bsz)
+    hyp = torch.zeros(beam, Bsz, max_len, num_labels)
+    hyp_scores = torch.zeros(beam, Bsz)
+    states = torch.zeros(beam, *init.shape)
+    for u in range(max_len):
+        exts, ext_scores, ptrs = [], [], []
+        for b in range(beam):
+            if u == 0:
+                state, score, y_prev = init, hyp_scores[b], torch.zeros(Bsz, num_labels)
+            else:
+                state, score, y_prev = states[b], hyp_scores[b], hyp[b][:, u - 1, :]
+            ctx = attention(sd, enc_btc, state[:, -1], cfg.intent_decoder_key_dim)
+            emb = y_prev @ sd["decoder.embed.weight"].t() + sd["decoder.embed.bias"]
+            state = decoder_rnn(sd, torch.cat([emb, ctx], dim=1), state, L, None)
+            states[b] = state
+            out = torch.log_softmax(state[:, -1] @ sd["decoder.linear.weight"].t() + sd["decoder.linear.bias"], dim=1)
+            top_s, top_i = out.topk(beam)                                                            # :612
+            for e in range(beam):
+                onehot = torch.zeros(Bsz, num_labels)
+                onehot[torch.arange(Bsz), top_i[:, e]] = 1.0
+                exts.append(onehot)
+                ext_scores.append(top_s[:, e] + score)
+                ptrs.append(torch.full((Bsz,), b, dtype=torch.long))
+            if u == 0:
+                break
+        exts, ext_scores, ptrs = sort_beam(torch.stack(exts), torch.stack(ext_scores), torch.stack(ptrs))
+        old_hyp, old_states = hyp.clone(), states.clone()
+        cols = torch.arange(Bsz)
+        for b in range(beam):                                                                        # :640-647
+            hyp[b] = old_hyp[ptrs[b], cols]
+            hyp[b, :, u, :] = exts[b]
+            hyp_scores[b] = ext_scores[b]
+            states[b] = old_states[ptrs[b], cols]
+    return hyp_scores, hyp
+
+
+def one_hot_to_string(onehot_uv, S):
+    """Model.one_hot_to_string (models.py:731-737): arg-max labels joined, then lstrip("<sos>") / rstrip("<eos>")
+    (character-SET strips, as the reference applies them)."""
+    return "".join([S[c] for c in onehot_uv.max(dim=1)[1]]).lstrip("<sos>").rstrip("<eos>")
+
+
+def init_seq2seq_state_dict(cfg, num_labels):
+    """Parameters of the seq2seq head in the reference's construction order (models.py:720-725: Seq2SeqEncoder GRUs;
+    Seq2SeqDecoder: embed, attention key / query / value, GRUCells, initial_state (randn), linear)."""
+    sd = {}
+    out_dim = cfg.word_rnn_num_hidden[-1] * (2 if cfg.word_rnn_bidirectional else 1)
+    for i in range(cfg.num_intent_encoder_layers):
+        for k, v in _gru_init(out_dim, cfg.intent_encoder_dim, True).items():
+            sd["encoder.layers.%d.%s" % (3 * i, k)] = v
+        out_dim = 2 * cfg.intent_encoder_dim
+    Dd, Kd, Vd = cfg.intent_decoder_dim, cfg.intent_decoder_key_dim, cfg.intent_decoder_value_dim
+    sd["decoder.embed.weight"], sd["decoder.embed.bias"] = _linear_init(num_labels, Dd)
+    for name, (i, o) in (("key", (2 * cfg.intent_encoder_dim, Kd)), ("query", (Dd, Kd)), ("value", (2 * cfg.intent_encoder_dim, Vd))):
+        w, b = _linear_init(i, o)
+        sd["decoder.attention.%s_linear.weight" % name], sd["decoder.attention.%s_linear.bias" % name] = w, b
+    for l in range(cfg.num_intent_decoder_layers):
+        m = torch.nn.GRUCell(input_size=(Dd + Vd) if l == 0 else Dd, hidden_size=Dd)
+        for k, v in m.state_dict().items():
+            sd["decoder.rnn.layers.%d.%s" % (2 * l, k)] = v.detach().clone()
+    sd["decoder.initial_state"] = torch.randn(cfg.num_intent_decoder_layers, Dd)
+    sd["decoder.linear.weight"], sd["decoder.linear.bias"] = _linear_init(Dd, num_labels)
+    return sd
+
+
+def draw_seq2seq_masks(cfg, x_bt, U, seed):
+    """Keep-masks of one train-mode seq2seq forward in torch-CPU's draw order: encoder stack (draw_dropout_masks
+    without the intent layers), the Seq2SeqEncoder dropouts (B,T,C) in memory order (T,B,C), then per decoding
+    step and decoder layer a (B, decoder_dim) mask.  Same generator stream as torch.manual_seed(seed)."""
+    g = torch.Generator().manual_seed(seed)
+    B, T = x_bt.shape
+    L = T
+    for c in range(len(cfg.cnn_N_filt)):
+        k = cfg.cnn_len_filt[c]
+        L = (L + 2 * (k // 2) - k) // cfg.cnn_stride[c] + 1
+        L = -(-L // cfg.cnn_max_pool_len[c])
+    masks = {}
+    for prefix, hidden, bi, drops, lens in (("phone", cfg.phone_rnn_num_hidden, cfg.phone_rnn_bidirectional, cfg.phone_rnn_drop, cfg.phone_downsample_len),
+                                            ("word", cfg.word_rnn_num_hidden, cfg.word_rnn_bidirectional, cfg.word_rnn_drop, cfg.word_downsample_len)):
+        for r, H in enumerate(hidden):
+            C = H * (2 if bi else 1)
+            if drops[r] > 0:
+                masks["%s_dropout%d" % (prefix, r)] = torch.empty(L, B, C).bernoulli_(1 - drops[r], generator=g).transpose(0, 1)
+            L = -(-L // lens[r])
+    for i in range(cfg.num_intent_encoder_layers):
+        masks["intent_encoder_dropout%d" % i] = torch.empty(L, B, 2 * cfg.intent_encoder_dim).bernoulli_(0.5, generator=g).transpose(0, 1)
+    for u in range(U):
+        for l in range(cfg.num_intent_decoder_layers):
+            masks["decoder_dropout_u%d_l%d" % (u, l)] = torch.empty(B, cfg.intent_decoder_dim).bernoulli_(0.5, generator=g)
+    return masks

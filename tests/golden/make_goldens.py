@@ -19,6 +19,8 @@ Fixtures:
   g5_tiny_model.npz     reduced-size Model: full state_dict, x, y, eval & train-mode loss/acc/logits
                         and every parameter gradient (train mode: dropout masks by seed)
   g5_tiny_asr.npz       reduced-size PretrainedModel.forward (ASR losses) + grads
+  g7_seq2seq_{a,b}.npz  tiny seq2seq Model (config.seq2seq): teacher-forced loss, log p(y|x), every gradient (eval and
+                        train mode by seed), beam-search scores / label sequences / decoded strings
   g6_full_model.npz     no_unfreezing.cfg architecture, seed 1234, x=randn(16,16000): state_dict
                         SHA-256 per tensor (weights are re-drawn, not stored), eval logits/loss/acc,
                         train-mode loss + grad digests, one Trainer.train step (post-Adam digests,
@@ -302,6 +304,65 @@ def g5():
             if p.grad is not None:
                 out[tag + "grad." + k] = npd(p.grad)
     np.savez_compressed(os.path.join(OUT, "g5_tiny_asr.npz"), **out)
+
+
+def seq2seq_cfg(**kw):
+    labels = ["<sos>"] + list("abcdefgh {}:'") + ["<eos>"]
+    c = tiny_cfg(seq2seq=True, intent_encoder_dim=12, num_intent_encoder_layers=1, intent_decoder_dim=20,
+                 num_intent_decoder_layers=2, intent_decoder_key_dim=10, intent_decoder_value_dim=14)
+    c.Sy_intent = labels
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def g7():
+    """seq2seq head (reference models.py:381-651, :720-725, :825-828, :848-851, :866-874): tiny Model with
+    config.seq2seq = True.  Teacher-forced loss / per-utterance log-probabilities and every gradient in eval mode and
+    in train mode (dropout masks by torch seed), the beam search of predict_intents (width 4, 200 steps) and the
+    decoded strings; a two-encoder-layer / three-decoder-layer variant for the loss."""
+    for tag, kw in (("a", {}), ("b", {"num_intent_encoder_layers": 2, "num_intent_decoder_layers": 3})):
+        torch.manual_seed(70 + len(kw))
+        cfg = seq2seq_cfg(**kw)
+        model = ref_models.Model(cfg)
+        V = len(cfg.Sy_intent)
+        B, U = 3, 7
+        x = 0.1 * torch.randn(B, 1800)
+        idx = torch.randint(1, V - 1, (B, U))
+        idx[:, 0] = 0
+        idx[0, 5:] = V - 1
+        idx[2, 6:] = V - 1
+        y = ref_data.one_hot(idx, V)
+        out = {"x": npd(x), "y_idx": npd(idx), "labels_json": np.frombuffer(json.dumps(cfg.Sy_intent).encode(), dtype=np.uint8)}
+        for k, v in model.state_dict().items():
+            out["sd." + k] = npd(v)
+        out["sd_keys_json"] = np.frombuffer(json.dumps(list(model.state_dict().keys())).encode(), dtype=np.uint8)
+        for mode, seed in (("eval", 0), ("train91", 91)):
+            model.zero_grad()
+            if mode == "eval":
+                model.eval()
+            else:
+                model.train()
+                torch.manual_seed(seed)
+            loss, acc = model(x, y)
+            loss.backward()
+            out[mode + ".loss"], out[mode + ".acc"] = npd(loss), npd(acc)
+            for k, p_ in model.named_parameters():
+                if p_.grad is not None:
+                    out[mode + ".grad." + k] = npd(p_.grad)
+        model.eval()
+        with torch.no_grad():
+            enc = model.encoder(model.pretrained_model.compute_features(x))
+            out["eval.encoder_out"] = npd(enc)
+            out["eval.log_p"] = npd(model.decoder(enc, y))
+            if tag == "a":
+                scores, beam = model.predict_intents(x)
+                out["beam.scores"] = npd(scores)
+                out["beam.idx"] = npd(beam.max(dim=3)[1]).astype(np.int16)      # (4, B, 200) label indices
+                out["beam.strings_json"] = np.frombuffer(json.dumps(model.decode_intents(x)).encode(), dtype=np.uint8)
+                out["truth_strings_json"] = np.frombuffer(
+                    json.dumps([model.one_hot_to_string(y[i], cfg.Sy_intent) for i in range(B)]).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, "g7_seq2seq_%s.npz" % tag), **out)
 
 
 CFG_NO_UNFREEZING = "no_unfreezing.cfg"
@@ -635,7 +696,7 @@ def g11():
 
 if __name__ == "__main__":
     only = os.environ.get("GOLDEN_ONLY")
-    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
     for k, fn in fns.items():
         if only is None or k in only.split(","):
             fn()

@@ -213,3 +213,70 @@ def test_g6_full_size_init_reproduction_and_forward():
             np.testing.assert_allclose(got[2:], ref[2:], atol=2e-4 * max(np.abs(ref[2:]).max(), 1e-6), err_msg=k)
             n += 1
     assert n >= 40
+
+
+# ---- seq2seq head (fixture g7: tiny Model with config.seq2seq, generated from the imported reference) ----------
+def seq2seq_cfg(d, **kw):
+    c = tiny_cfg(seq2seq=True, intent_encoder_dim=12, num_intent_encoder_layers=1, intent_decoder_dim=20,
+                 num_intent_decoder_layers=2, intent_decoder_key_dim=10, intent_decoder_value_dim=14)
+    c.Sy_intent = json.loads(bytes(d["labels_json"]).decode())
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def one_hot(idx, V):
+    y = torch.zeros(idx.shape[0], idx.shape[1], V)
+    y.scatter_(2, idx.unsqueeze(2), 1.0)
+    return y
+
+
+@pytest.mark.parametrize("tag,kw", [("a", {}), ("b", {"num_intent_encoder_layers": 2, "num_intent_decoder_layers": 3})])
+def test_g7_seq2seq_loss_grads_and_init(tag, kw):
+    d = load("g7_seq2seq_%s.npz" % tag)
+    cfg = seq2seq_cfg(d, **kw)
+    V = len(cfg.Sy_intent)
+    x, idx = T(d["x"]), T(d["y_idx"]).long()
+    y = one_hot(idx, V)
+    for mode in ("eval", "train91"):
+        sd = {k[3:]: T(v).requires_grad_() for k, v in d.items() if k.startswith("sd.")}
+        masks = None if mode == "eval" else O.draw_seq2seq_masks(cfg, x, idx.shape[1], seed=91)
+        loss, log_p = O.seq2seq_forward(sd, x, y, cfg, masks)
+        loss.backward()
+        assert abs(loss.item() - float(d[mode + ".loss"])) < 3e-6 * max(1.0, abs(float(d[mode + ".loss"]))), mode
+        if mode == "eval":
+            np.testing.assert_allclose(log_p.detach().numpy(), d["eval.log_p"], atol=2e-5)
+        n = 0
+        for k, v in sd.items():
+            key = mode + ".grad." + k
+            if key in d:
+                np.testing.assert_allclose(v.grad.numpy(), d[key], atol=2e-5 * max(1e-3, np.abs(d[key]).max()), err_msg=k)
+                n += 1
+        assert n >= 40
+    # the parameter set and its construction order (RNG consumption): the head's keys follow the encoder's
+    keys = json.loads(bytes(d["sd_keys_json"]).decode())
+    torch.manual_seed(70 + len(kw))                                 # the generator's seed for this variant
+    O.init_pretrained_state_dict(cfg)                               # the encoder draws first (models.py:661)
+    head = O.init_seq2seq_state_dict(cfg, V)
+    want = [k for k in keys if not k.startswith("pretrained_model.")]
+    assert sorted(head.keys()) == sorted(want)
+    for k in want:
+        assert np.array_equal(head[k].numpy(), d["sd." + k]), k     # same draws in the same order
+
+
+def test_g7_seq2seq_beam_search_and_strings():
+    d = load("g7_seq2seq_a.npz")
+    cfg = seq2seq_cfg(d)
+    V = len(cfg.Sy_intent)
+    sd = {k[3:]: T(v) for k, v in d.items() if k.startswith("sd.")}
+    with torch.no_grad():
+        st = O.encoder_stages(sd, T(d["x"]), cfg, prefix="pretrained_model.")
+        enc = O.seq2seq_encoder(sd, st["features"], cfg)
+        np.testing.assert_allclose(enc.numpy(), d["eval.encoder_out"], atol=2e-6)
+        scores, beam = O.seq2seq_infer(sd, enc, cfg, V, beam=4, max_len=200)
+    np.testing.assert_allclose(scores.numpy(), d["beam.scores"], rtol=2e-5, atol=2e-4)
+    assert np.array_equal(beam.max(dim=3)[1].numpy(), d["beam.idx"])
+    strings = [O.one_hot_to_string(beam[0, i], cfg.Sy_intent) for i in range(beam.shape[1])]
+    assert strings == json.loads(bytes(d["beam.strings_json"]).decode())
+    truth = [O.one_hot_to_string(one_hot(T(d["y_idx"]).long(), V)[i], cfg.Sy_intent) for i in range(3)]
+    assert truth == json.loads(bytes(d["truth_strings_json"]).decode())
