@@ -195,19 +195,27 @@ def read_wav(path):
     return x, fs
 
 
+def one_hot(letters, S):
+    """letters (B, U) int64 label indices -> (B, U, S) float32 one-hot rows (reference data.py:331-342)."""
+    out = torch.zeros(letters.shape[0], letters.shape[1], S)
+    out.scatter_(2, letters.long().unsqueeze(2), 1.0)
+    return out
+
+
 class CollateWavsSLU:
     """list of (waveform, [action, object, location]) -> (x (B, T_max) float32 zero-padded at the end,
-    y_intent (B, 3) int64), as reference data.py:344-376 (non-seq2seq branch).  The batch is assembled
-    directly in ONE buffer instead of per-row pad + stack; the DataLoader pins it (pin_memory=True, in
-    the parent process — never in a forked worker) so that the H2D copy of the look-ahead slots is
-    asynchronous."""
+    y_intent (B, 3) int64), as reference data.py:344-376.  seq2seq: the labels are <sos> ... <eos> index
+    sequences, padded with <eos> to the longest of the batch and returned one-hot, (B, U_max, num_labels) float32
+    (data.py:363-376).  The batch is assembled directly in ONE buffer instead of per-row pad + stack; the DataLoader
+    pins it (pin_memory=True, in the parent process — never in a forked worker) so that the H2D copy of the
+    look-ahead slots is asynchronous."""
 
     def __init__(self, Sy_intent, seq2seq, pad_multiple=None):
-        if seq2seq:
-            raise NotImplementedError("seq2seq collation (reference data.py:363-376) is out of scope")
         self.Sy_intent = Sy_intent
         self.num_labels = len(self.Sy_intent)
         self.seq2seq = seq2seq
+        if self.seq2seq:
+            self.EOS = self.Sy_intent.index("<eos>")
         # Opt-in (SLU_PAD_TO_MULTIPLE=n samples): round T_max up to a multiple of n so that ragged real
         # data falls into a few batch shapes (the look-ahead super-batches and hipGraphs are per shape).
         # Off by default: the extra trailing zeros are seen by the recurrences, i.e. it is not the
@@ -221,6 +229,12 @@ class CollateWavsSLU:
         x = torch.zeros(len(batch), T, dtype=torch.float32)
         for i, (xi, _) in enumerate(batch):
             x[i, :len(xi)] = torch.as_tensor(np.asarray(xi), dtype=torch.float32)
+        if self.seq2seq:
+            U = max(len(yi) for _, yi in batch)
+            idx = torch.full((len(batch), U), self.EOS, dtype=torch.int64)
+            for i, (_, yi) in enumerate(batch):
+                idx[i, :len(yi)] = torch.as_tensor(list(yi), dtype=torch.int64)
+            return x, one_hot(idx, self.num_labels)
         y = torch.tensor([list(yi) for _, yi in batch], dtype=torch.int64)
         return x, y
 
@@ -314,11 +328,13 @@ class SLUDataset(torch.utils.data.Dataset):
         self.augment = False
         self.SNRs = [0, 5, 10, 15, 20]
         self.seq2seq = config.seq2seq
-        if self.seq2seq:
-            raise NotImplementedError("seq2seq datasets (reference data.py:318-326) are out of scope")
         # label lookup and paths as plain lists: no per-item DataFrame indexing in the workers
         self._paths = [os.path.join(base_path, p) for p in df["path"].tolist()]
-        self._values = list(zip(df["action"].tolist(), df["object"].tolist(), df["location"].tolist()))
+        if self.seq2seq:
+            self._values = [str(v) for v in df["semantics"].tolist()]
+            self._index = {c: i for i, c in enumerate(self.Sy_intent)}       # label -> index (list.index per char otherwise)
+        else:
+            self._values = list(zip(df["action"].tolist(), df["object"].tolist(), df["location"].tolist()))
         collate = CollateWavsSLU(self.Sy_intent, self.seq2seq)
         pin = torch.cuda.is_available()
         # Data parallelism (`shard`: the training split only): every rank draws a disjoint 1/world of the
@@ -349,6 +365,9 @@ class SLUDataset(torch.utils.data.Dataset):
     def __getitem__(self, idx):
         idx = idx % len(self._paths)
         x, _fs = read_wav(self._paths[idx])
+        if self.seq2seq:                         # <sos> + the characters of the semantics string + <eos> (data.py:322-326)
+            y_intent = [self._index["<sos>"]] + [self._index[c] for c in self._values[idx]] + [self._index["<eos>"]]
+            return x, y_intent
         # a slot value that never occurs in the training split raises KeyError here, as in the reference
         y_intent = [self.Sy_intent[slot][v] for slot, v in zip(("action", "object", "location"), self._values[idx])]
         return x, y_intent
@@ -370,6 +389,44 @@ class SyntheticSLUDataset(SLUDataset):
             if pin and torch.cuda.is_available():
                 x, y = x.pin_memory(), y.pin_memory()
             batches.append((x, y))
+        self.batches = batches
+        self.loader = _SyntheticLoader(batches)
+
+    def __len__(self):
+        return sum(len(b[0]) for b in self.batches)
+
+    def __getitem__(self, idx):
+        bs = len(self.batches[0][0])
+        x, y = self.batches[idx // bs]
+        return x[idx % bs], y[idx % bs]
+
+
+SYNTHETIC_SEQ2SEQ_LABELS = ["<sos>"] + list("abcdefghijklmnopqrstuvwxyz {}:'|,_") + ["<eos>"]
+
+
+class SyntheticSeq2SeqDataset(SLUDataset):
+    """Synthetic seq2seq SLU dataset: `.loader` yields (x (B,T) float32, y (B,U,num_labels) one-hot float32) like
+    CollateWavsSLU's seq2seq branch (reference data.py:363-376): noise waveforms, random label strings of 3..U-2
+    characters between <sos> and <eos>, padded with <eos>."""
+
+    def __init__(self, num_batches, batch_size, num_samples, max_len=24, seed=1234, Sy_intent=None):
+        g = torch.Generator().manual_seed(seed)
+        self.Sy_intent = Sy_intent or list(SYNTHETIC_SEQ2SEQ_LABELS)
+        self.seq2seq = True
+        V = len(self.Sy_intent)
+        sos, eos = self.Sy_intent.index("<sos>"), self.Sy_intent.index("<eos>")
+        inner = [i for i in range(V) if i not in (sos, eos)]
+        batches = []
+        for _ in range(num_batches):
+            x = 0.1 * torch.randn(batch_size, num_samples, generator=g)
+            idx = torch.full((batch_size, max_len), eos, dtype=torch.int64)
+            idx[:, 0] = sos
+            lens = torch.randint(3, max_len - 1, (batch_size,), generator=g)
+            pick = torch.randint(0, len(inner), (batch_size, max_len), generator=g)
+            for b in range(batch_size):
+                n = int(lens[b])
+                idx[b, 1:1 + n] = torch.tensor([inner[int(k)] for k in pick[b, :n]])
+            batches.append((x, one_hot(idx, V)))
         self.batches = batches
         self.loader = _SyntheticLoader(batches)
 
@@ -586,12 +643,14 @@ def get_SLU_datasets(config):
         mk = lambda n, seed: SyntheticSLUDataset(n, bs, ns, config.values_per_slot, seed=seed,
                                                  Sy_intent=config.Sy_intent)
         rank = _world()[0]                                  # every rank its own training batches
+        if config.seq2seq:
+            config.Sy_intent = list(SYNTHETIC_SEQ2SEQ_LABELS)
+            mk = lambda n, seed: SyntheticSeq2SeqDataset(n, bs, ns, seed=seed, Sy_intent=config.Sy_intent)
         return (mk(nb, config.seed + 1000003 * rank), mk(max(1, nb // 4), config.seed + 1),
                 mk(max(1, nb // 4), config.seed + 2))
-    if config.seq2seq:
-        raise NotImplementedError("seq2seq datasets (reference data.py:143-146, 201-208) are out of scope")
     base_path = config.slu_path
-    csv = lambda name: pd.read_csv(os.path.join(base_path, "data", name))
+    sfx = "_seq2seq" if config.seq2seq else ""          # reference data.py:139-146, 182-187
+    csv = lambda name: pd.read_csv(os.path.join(base_path, "data", name.replace(".csv", sfx + ".csv")))
     synthetic_train_df = csv("synthetic_data.csv")
     real_train_df = csv("train_data.csv")
     have_spk = "speakerId" in list(real_train_df) and "speakerId" in list(synthetic_train_df)
@@ -617,14 +676,23 @@ def get_SLU_datasets(config):
     valid_df = csv("valid_data.csv")
     test_df = csv("test_data.csv")
 
-    Sy_intent = {"action": {}, "object": {}, "location": {}}
-    values_per_slot = []
-    for slot in ["action", "object", "location"]:
-        slot_values = Counter(train_df[slot])          # first-appearance order, like the reference
-        for idx, value in enumerate(slot_values):
-            Sy_intent[slot][value] = idx
-        values_per_slot.append(len(slot_values))
-    config.values_per_slot = values_per_slot
+    if not config.seq2seq:
+        Sy_intent = {"action": {}, "object": {}, "location": {}}
+        values_per_slot = []
+        for slot in ["action", "object", "location"]:
+            slot_values = Counter(train_df[slot])          # first-appearance order, like the reference
+            for idx, value in enumerate(slot_values):
+                Sy_intent[slot][value] = idx
+            values_per_slot.append(len(slot_values))
+        config.values_per_slot = values_per_slot
+    else:
+        # output alphabet: <sos>, every character of the training semantics + string.printable, <eos> (reference
+        # data.py:201-208).  The reference orders the characters by iterating a Python set — an order that changes
+        # from process to process (string hashing is salted), so its checkpoints only decode within one process;
+        # here the set is SORTED: the same alphabet, a reproducible index assignment.
+        import string
+        chars = set("".join(str(v) for v in train_df["semantics"].tolist()) + string.printable)
+        Sy_intent = ["<sos>"] + sorted(chars) + ["<eos>"]
     config.Sy_intent = Sy_intent
 
     def wordings(path):

@@ -19,8 +19,8 @@ gfx950 (libslu_hip.so, C ABI in include/slu_hip.h) instead of ATen:
 The `phoneme_layers` / `word_layers` / `intent_layers` ModuleLists keep the reference's indices
 (so checkpoints interchange) and still work layer-by-layer, but `compute_features`, `forward`
 and `predict_intents` run the fused stage plan.  There is no CPU path: without a gfx950 device
-the forward methods raise.  The seq2seq head (models.py:381-651) is outside the hot path and is
-not provided.
+the forward methods raise.  The seq2seq head (models.py:381-651: Seq2SeqEncoder, Attention, DecoderRNN,
+Seq2SeqDecoder with beam search) is provided on the same kernels (ops.Seq2SeqDecoderFn).
 """
 import os
 import sys
@@ -82,7 +82,10 @@ def _dropout_args(name, site, p, training, cnn=False):
     return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.current * 16 + site
 
 
-_SITE_BASE = {"phone": 0, "word": 4, "intent": 8, "cnn": 12}     # 16 dropout sites per step (Philox offset)
+# 16 dropout sites per step (Philox offset).  The seq2seq head replaces the intent stack, so its encoder layers take
+# the intent sites (at most 3 layers) and the decoder's per-step dropouts share site 11 (element index = step, layer, b, j)
+_SITE_BASE = {"phone": 0, "word": 4, "intent": 8, "cnn": 12, "intent_encoder": 8}
+_DECODER_SITE = 11
 
 
 def _site(module, idx):
@@ -341,6 +344,213 @@ class Abs(torch.nn.Module):
 def _named(layer, name):
     layer.name = name
     return layer
+
+
+# ------------------------------------------------------------------------------------------------
+# seq2seq intent head (reference models.py:381-651): same class / attribute / state_dict names; every contraction,
+# the GRUCell gates, the attention and the log-softmax pick run on the HIP kernels (ops.Seq2SeqDecoderFn and
+# ops.decoder_step); the beam bookkeeping (top-k, re-ordering of hypotheses) is host-side torch as in the reference.
+# ------------------------------------------------------------------------------------------------
+class Seq2SeqEncoder(torch.nn.Module):
+    """Stack of bidirectional GRU layers, each followed by RNNSelect and Dropout(0.5) (reference models.py:381-416)."""
+
+    def __init__(self, input_dim, num_layers, encoder_dim):
+        super().__init__()
+        if num_layers > 3:
+            raise NotImplementedError("Seq2SeqEncoder: at most 3 layers (dropout-stream sites 8-10 of a step)")
+        layers, self._stages = [], []
+        out_dim = input_dim
+        for idx in range(num_layers):
+            gru = _named(GRU(input_size=out_dim, hidden_size=encoder_dim, batch_first=True, bidirectional=True),
+                         "intent_encoder_rnn%d" % idx)
+            layers.append(gru)
+            out_dim = 2 * encoder_dim
+            layers.append(_named(RNNSelect(), "intent_encoder_rnn_select%d" % idx))
+            layers.append(_named(torch.nn.Dropout(p=0.5), "intent_encoder_dropout%d" % idx))
+            self._stages.append(_RnnStage(gru, "intent_encoder_dropout%d" % idx, 0.5, "none", 1))
+        self.layers = torch.nn.ModuleList(layers)
+
+    def run_time_major(self, h, training):
+        for st in self._stages:
+            h = st.run(h, training)
+        return h
+
+    def forward(self, x):
+        """(B, T, C) -> (B, T, 2 * encoder_dim)"""
+        _require_device(x)
+        _DropoutState.current = next_rng_step()
+        return self.run_time_major(x.transpose(0, 1), self.training).transpose(0, 1)
+
+
+class Attention(torch.nn.Module):
+    """Dot-product attention of one decoder state over the encoder states (reference models.py:418-438)."""
+
+    def __init__(self, encoder_dim, decoder_dim, key_dim, value_dim):
+        super().__init__()
+        self.scale_factor = torch.sqrt(torch.tensor(key_dim).float())
+        self.key_linear = torch.nn.Linear(encoder_dim, key_dim)
+        self.query_linear = torch.nn.Linear(decoder_dim, key_dim)
+        self.value_linear = torch.nn.Linear(encoder_dim, value_dim)
+        self.softmax = torch.nn.Softmax(dim=1)
+
+    def forward(self, encoder_states, decoder_state):
+        """encoder_states (B, T, encoder_dim), decoder_state (B, decoder_dim) -> (B, value_dim); inference helper
+        (no gradient path: training goes through Seq2SeqDecoder.forward's fused Function)."""
+        _require_device(encoder_states)
+        with torch.no_grad():
+            B, T, C = encoder_states.shape
+            enc = encoder_states.transpose(0, 1).contiguous().view(T * B, C)
+            keys = _ops.gemm(enc, self.key_linear.weight.t(), self.key_linear.bias).view(T, B, -1)
+            values = _ops.gemm(enc, self.value_linear.weight.t(), self.value_linear.bias).view(T, B, -1)
+            q = _ops.gemm(decoder_state.contiguous(), self.query_linear.weight.t(), self.query_linear.bias)
+            ctx = torch.empty(B, values.shape[2], dtype=torch.float32, device=enc.device)
+            w = torch.empty(B, T, dtype=torch.float32, device=enc.device)
+            _ops.attention_fwd(keys, values, q, ctx, w, 1.0 / float(self.scale_factor))
+        return ctx
+
+
+class DecoderRNN(torch.nn.Module):
+    """Stacked GRUCells with Dropout between them (reference models.py:440-485).  The cells are parameter holders
+    with torch.nn.GRUCell's names / shapes / initialisation; the arithmetic is ops.decoder_step's."""
+
+    def __init__(self, num_decoder_layers, num_decoder_hidden, input_size, dropout):
+        super().__init__()
+        layers = []
+        self.num_layers = num_decoder_layers
+        for index in range(num_decoder_layers):
+            cell = torch.nn.GRUCell(input_size=input_size if index == 0 else num_decoder_hidden,
+                                    hidden_size=num_decoder_hidden)
+            layers.append(_named(cell, "gru%d" % index))
+            layers.append(_named(torch.nn.Dropout(p=dropout), "dropout%d" % index))
+        self.layers = torch.nn.ModuleList(layers)
+        self.dropout = dropout
+
+    def cells(self):
+        return [l for l in self.layers if isinstance(l, torch.nn.GRUCell)]
+
+
+def sort_beam(beam_extensions, beam_extension_scores, beam_pointers):
+    """Order the candidate extensions of every utterance by score, descending (reference models.py:487-502).
+    Lists of W tensors (B, V) / (B) / (B) -> stacked (W, B, V), (W, B), (W, B)."""
+    ext, sc, ptr = torch.stack(beam_extensions), torch.stack(beam_extension_scores), torch.stack(beam_pointers)
+    sc = sc.view(len(beam_pointers), -1)
+    order = sc.sort(dim=0, descending=True)[1]
+    cols = torch.arange(sc.shape[1], device=sc.device)
+    return ext[order, cols], sc[order, cols], ptr[order, cols]
+
+
+class Seq2SeqDecoder(torch.nn.Module):
+    """Attention-based decoder for seq2seq SLU (reference models.py:504-651)."""
+
+    def __init__(self, num_labels, num_layers, encoder_dim, decoder_dim, key_dim, value_dim, SOS=0):
+        super().__init__()
+        embedding_dim = decoder_dim
+        self.embed = torch.nn.Linear(num_labels, embedding_dim)
+        self.attention = Attention(encoder_dim * 2, decoder_dim, key_dim, value_dim)
+        self.rnn = DecoderRNN(num_layers, decoder_dim, embedding_dim + value_dim, dropout=0.5)
+        self.initial_state = torch.nn.Parameter(torch.randn(num_layers, decoder_dim))
+        self.linear = torch.nn.Linear(decoder_dim, num_labels)
+        self.log_softmax = torch.nn.LogSoftmax(dim=1)
+        self.SOS = SOS
+
+    def _params(self):
+        """(names, tensors) in ops.Seq2SeqDecoderFn's argument order."""
+        a = self.attention
+        items = [("embed.weight", self.embed.weight), ("embed.bias", self.embed.bias),
+                 ("key.weight", a.key_linear.weight), ("key.bias", a.key_linear.bias),
+                 ("query.weight", a.query_linear.weight), ("query.bias", a.query_linear.bias),
+                 ("value.weight", a.value_linear.weight), ("value.bias", a.value_linear.bias)]
+        for l, cell in enumerate(self.rnn.cells()):
+            items += [("w_ih%d" % l, cell.weight_ih), ("w_hh%d" % l, cell.weight_hh),
+                      ("b_ih%d" % l, cell.bias_ih), ("b_hh%d" % l, cell.bias_hh)]
+        items += [("initial_state", self.initial_state), ("linear.weight", self.linear.weight),
+                  ("linear.bias", self.linear.bias)]
+        return tuple(n for n, _ in items), [t for _, t in items]
+
+    def teacher_forced(self, enc_tm, y):
+        """enc_tm time-major (T, B, 2 * encoder_dim), y (B, U, num_labels) -> (loss_acc (2) = [-mean log p, 0],
+        log_p (B)) on the current dropout step (models._DropoutState)."""
+        p = self.rnn.dropout if self.training else 0.0
+        masks, seed, offset, offset_dev = None, 0, 0, None
+        if p > 0.0:
+            if _DropoutState.masks is not None:
+                masks = _DropoutState.masks
+            else:
+                seed = (_DropoutState.seed if _DropoutState.seed is not None else torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+                if _DropoutState.current_dev is not None:
+                    offset, offset_dev = _DECODER_SITE, _DropoutState.current_dev
+                else:
+                    offset = _DropoutState.current * 16 + _DECODER_SITE
+        names, tensors = self._params()
+        return _ops.Seq2SeqDecoderFn.apply(enc_tm, y, (names, self.SOS, p, masks, seed, offset, offset_dev), *tensors)
+
+    def forward(self, encoder_outputs, y, y_lengths=None):
+        """encoder_outputs (B, T, 2 * encoder_dim), y (B, U, num_labels) one-hot, padded with <eos> -> log p(y|x) (B)
+        (reference models.py:519-557; y_lengths is unused there too)."""
+        _require_device(encoder_outputs)
+        _DropoutState.current = next_rng_step()
+        _, log_p = self.teacher_forced(encoder_outputs.transpose(0, 1), y)
+        return log_p
+
+    def infer(self, encoder_outputs, Sy, B=4, debug=False, y_lengths=None):
+        """Beam search of width B for argmax_y log p(y|x) (reference models.py:559-651; B = 1 is greedy search).
+        -> (beam_scores (B, batch), beam (B, batch, U, |Sy|) one-hot), U = 200 or max(y_lengths).
+        All B hypotheses of all utterances advance in ONE batched decoder step on the HIP kernels (rows w * batch +
+        b); the first input is the all-zero vector and only hypothesis 0 is expanded at the first step, as in the
+        reference.  Candidate selection is host-side torch (top-k per hypothesis, then the B best of the B * B)."""
+        _require_device(encoder_outputs)
+        dev = encoder_outputs.device
+        W, bsz, V = B, encoder_outputs.shape[0], len(Sy)
+        U = 200 if y_lengths is None else max(y_lengths)
+        names, tensors = self._params()
+        P = {n: t.detach() for n, t in zip(names, tensors)}
+        Kd, Vd = P["key.weight"].shape[0], P["value.weight"].shape[0]
+        P["inv_scale"] = 1.0 / float(self.attention.scale_factor)
+        Lc, Dd = P["initial_state"].shape
+        E = P["embed.weight"].shape[0]
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            enc = encoder_outputs.detach().float().transpose(0, 1).contiguous()          # (T, bsz, C)
+            T = enc.shape[0]
+            enc2 = enc.view(T * bsz, -1)
+            # keys / values once, replicated per hypothesis: row w * bsz + b of the step batch reads utterance b
+            keys = _ops.gemm(enc2, P["key.weight"].t(), P["key.bias"]).view(T, 1, bsz, Kd).expand(T, W, bsz, Kd).reshape(T, W * bsz, Kd)
+            values = _ops.gemm(enc2, P["value.weight"].t(), P["value.bias"]).view(T, 1, bsz, Vd).expand(T, W, bsz, Vd).reshape(T, W * bsz, Vd)
+            R = W * bsz
+            state, state_next = f(R, Lc, Dd), f(R, Lc, Dd)
+            _ops.broadcast_rows(P["initial_state"].contiguous().view(-1), state.view(R, Lc * Dd))
+            y_prev = torch.zeros(R, V, dtype=torch.float32, device=dev)
+            q, inp0, att_w, logits = f(R, Kd), f(R, E + Vd), f(R, T), f(R, V)
+            gi, gh, lse, sink = f(R, 3 * Dd), f(R, 3 * Dd), f(R), f(R)
+            drop = [f(R, Dd) for _ in range(Lc - 1)]
+            hyp = torch.zeros(W, bsz, U, dtype=torch.int64, device=dev)
+            scores = torch.zeros(W, bsz, dtype=torch.float32, device=dev)
+            cols = torch.arange(bsz, device=dev)
+            zeros_y = torch.zeros(R, V, dtype=torch.float32, device=dev)
+            for u in range(U):
+                _ops.decoder_step(P, keys, values, state, state_next, y_prev, q, inp0, att_w, gi, gh, None, drop, logits, u,
+                                  (0.0, None, 0, 0, None, R * Dd))
+                _ops.logsoftmax_dot_fwd(logits, zeros_y, sink, lse)                     # lse only (y = 0)
+                top_s, top_i = logits.topk(W, dim=1)                                    # log_softmax keeps the order
+                cand = (top_s - lse.unsqueeze(1)).view(W, bsz, W) + scores.unsqueeze(2)  # [src hypothesis, b, extension]
+                if u == 0:
+                    cand[1:] = float("-inf")
+                flat = cand.permute(1, 0, 2).reshape(bsz, W * W)                        # candidate order: src major
+                best, pick = flat.sort(dim=1, descending=True)
+                best, pick = best[:, :W].t().contiguous(), pick[:, :W].t()              # (W, bsz)
+                src, ext = pick // W, pick % W
+                label = top_i.view(W, bsz, W)[src, cols.unsqueeze(0), ext]              # (W, bsz)
+                hyp = hyp[src, cols.unsqueeze(0)]
+                hyp[:, :, u] = label
+                scores = best
+                state = state_next.view(W, bsz, Lc, Dd)[src, cols.unsqueeze(0)].reshape(R, Lc, Dd)
+                y_prev = torch.zeros(R, V, dtype=torch.float32, device=dev)
+                y_prev.scatter_(1, label.reshape(R, 1), 1.0)
+                if debug:
+                    print("step %d | best score of utterance 0: %1.2f" % (u, scores[0, 0].item()))
+            beam = torch.zeros(W, bsz, U, V, dtype=torch.float32, device=dev)
+            beam.scatter_(3, hyp.unsqueeze(3), 1.0)
+        return scores, beam
 
 
 # ------------------------------------------------------------------------------------------------
@@ -656,8 +866,8 @@ def is_frozen(layer):
 
 
 class Model(torch.nn.Module):
-    """End-to-end SLU model: pre-trained encoder + intent module (reference models.py:653-874,
-    fixed-length multi-slot output; the seq2seq variant is not part of this package)."""
+    """End-to-end SLU model: pre-trained encoder + intent module (reference models.py:653-874): fixed-length
+    multi-slot output, or (config.seq2seq) the attention decoder over output characters."""
 
     def __init__(self, config):
         super().__init__()
@@ -675,10 +885,20 @@ class Model(torch.nn.Module):
         if config.pretraining_type != 0:
             self.freeze_all_layers()
         self.seq2seq = config.seq2seq
-        if self.seq2seq:
-            raise NotImplementedError("the seq2seq decoder head (reference models.py:381-651) is outside "
-                                      "the MI355X hot path of this package")
         out_dim = config.word_rnn_num_hidden[-1] * (2 if config.word_rnn_bidirectional else 1)
+        if self.seq2seq:
+            # character-level decoder instead of the fixed slots (reference models.py:718-725)
+            self.intent_layers = []
+            self.SOS = config.Sy_intent.index("<sos>")
+            self.num_labels = len(config.Sy_intent)
+            self.encoder = Seq2SeqEncoder(out_dim, config.num_intent_encoder_layers, config.intent_encoder_dim)
+            self.decoder = Seq2SeqDecoder(self.num_labels, config.num_intent_decoder_layers, config.intent_encoder_dim,
+                                          config.intent_decoder_dim, config.intent_decoder_key_dim,
+                                          config.intent_decoder_value_dim, self.SOS)
+            self._intent_stages = self.encoder._stages
+            if self.is_cuda:
+                self.cuda()
+            return
         self.values_per_slot = config.values_per_slot
         self.num_values_total = sum(self.values_per_slot)
         intent_layers, self._intent_stages = [], []
@@ -765,18 +985,35 @@ class Model(torch.nn.Module):
             h = pm.run_stages(h, n_stages, len(pm._stages()))
             for st in self._intent_stages:
                 h = st.run(h, self.training)
+            if self.seq2seq:                       # teacher-forced decoder on the same dropout step
+                loss_acc, _ = self.decoder.teacher_forced(h, y_intent.to(h.device))
         finally:
             _DropoutState.current_dev = None
+        if self.seq2seq:
+            # loss = -mean log p(y|x); the reference returns a host zero for the accuracy (models.py:825-828)
+            self.last_loss_acc = loss_acc
+            return loss_acc[0], torch.tensor([0.])
         cls = self.intent_layers[-2]
         loss, acc, _, _ = _ops.IntentHeadFn.apply(h, cls.weight, cls.bias, y_intent.to(h.device),
                                                   tuple(self.values_per_slot))
+        self.last_loss_acc = _ops.IntentHeadFn.last_loss_acc
         return loss, acc
 
-    def forward(self, x, y_intent):
+    def forward(self, x, y_intent, *, rng_step=None, n_prefix=0):
         """x (B,T), y_intent (B,num_slots) -> (loss = sum of per-slot CE, acc = all slots right)
-        (reference models.py:797-823); classifier, max over time, CE and accuracy are one fused op."""
-        x = self.pretrained_model._to_device(x)[0]
-        return self.forward_from(x, 0, y_intent, next_rng_step())
+        (reference models.py:797-823); classifier, max over time, CE and accuracy are one fused op.
+        seq2seq: y_intent (B,U,num_labels) one-hot -> (-mean log p(y|x), host zero) (models.py:825-828).
+        Keyword-only extras (not in the reference) for training.Trainer: rng_step = the dropout-stream index of this
+        forward (None = the next one; or a 1-element int64 CUDA tensor holding step * 16 for captured steps),
+        n_prefix > 0: x is the output of the first n_prefix encoder stages (look-ahead pipeline)."""
+        if n_prefix == 0:
+            x = self.pretrained_model._to_device(x)[0]
+        return self.forward_from(x, n_prefix, y_intent, next_rng_step() if rng_step is None else rng_step)
+
+    def one_hot_to_string(self, input, S):
+        """input (T, |S|) one-hot rows, S list of labels -> the string (reference models.py:731-737; the strips are
+        character-set strips, as the reference applies them)."""
+        return "".join([S[c] for c in input.max(dim=1)[1]]).lstrip("<sos>").rstrip("<eos>")
 
     def eval_group(self, xs, ys):
         """Evaluation (no dropout, no autograd) of several equally-shaped batches in ONE pass through the
@@ -804,6 +1041,8 @@ class Model(torch.nn.Module):
     def predict_intents(self, x):
         """-> (intent_logits (B, num_values_total), predicted_intent (B, num_slots)) (models.py:830-846)"""
         h = self._intent_features_tm(x).contiguous()
+        if self.seq2seq:                                         # beam search, width 4 (models.py:848-851)
+            return self.decoder.infer(h.transpose(0, 1), self.Sy_intent, B=4)
         cls = self.intent_layers[-2]
         _, logits, pred, _, _ = _ops.cls_maxpool_ce_fwd(h.detach(), cls.weight.detach(), cls.bias.detach(), None,
                                                         tuple(self.values_per_slot), False)
@@ -813,6 +1052,8 @@ class Model(torch.nn.Module):
         """-> list (batch) of lists (slots) of slot-value strings (reference models.py:853-865)."""
         _, pred = self.predict_intents(x)
         pred = pred.cpu()
+        if self.seq2seq:                                         # best hypothesis of every utterance (models.py:866-874)
+            return [self.one_hot_to_string(pred[0, i], self.Sy_intent) for i in range(pred.shape[1])]
         inverse = [{idx: value for value, idx in self.Sy_intent[slot].items()} for slot in self.Sy_intent]
         return [[inverse[s][int(row[s])] for s in range(len(inverse)) if int(row[s]) in inverse[s]]
                 for row in pred]

@@ -936,3 +936,204 @@ class GRULayerFn(torch.autograd.Function):
             grads[6] = dbp[1, :3 * H]
         _Fork.join(dev)
         return tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# seq2seq intent decoder (reference models.py:418-557): step kernels + one autograd Function with a manual BPTT
+# ------------------------------------------------------------------------------------------------
+def gru_cell_fwd(gi, gh, h_prev, h_out, save, drop_out, mask, p, seed, offset, offset_dev, idx_base):
+    L = _lib.load()
+    B, H = h_prev.shape
+    assert gi.is_contiguous() and gh.is_contiguous() and h_prev.stride(1) == 1 and h_out.stride(1) == 1
+    _lib.check(L.slu_gru_cell_fwd(gi.data_ptr(), gh.data_ptr(), h_prev.data_ptr(), h_prev.stride(0), h_out.data_ptr(),
+                                  h_out.stride(0), _ptr(save), _ptr(drop_out), _ptr(mask), float(p), int(seed), int(offset),
+                                  _ptr(offset_dev), int(idx_base), B, H, _stream()), "slu_gru_cell_fwd")
+
+
+def gru_cell_bwd(d_h, d_drop, save, h_prev, d_gi, d_gh, d_h_prev, mask, p, seed, offset, offset_dev, idx_base):
+    L = _lib.load()
+    B, H = h_prev.shape
+    _lib.check(L.slu_gru_cell_bwd(d_h.data_ptr(), d_h.stride(0), _ptr(d_drop), save.data_ptr(), h_prev.data_ptr(),
+                                  h_prev.stride(0), d_gi.data_ptr(), d_gh.data_ptr(), d_h_prev.data_ptr(), d_h_prev.stride(0),
+                                  _ptr(mask), float(p), int(seed), int(offset), _ptr(offset_dev), int(idx_base), B, H,
+                                  _stream()), "slu_gru_cell_bwd")
+
+
+def attention_fwd(keys, values, query, ctx, weights, inv_scale):
+    """keys (T, B, Kd) / values (T, B, Vd) time-major contiguous; query (B, Kd), ctx (B, Vd) row-strided views."""
+    L = _lib.load()
+    T, B, Kd = keys.shape
+    Vd = values.shape[2]
+    _lib.check(L.slu_attention_fwd(keys.data_ptr(), keys.stride(0), keys.stride(1), values.data_ptr(), values.stride(0),
+                                   values.stride(1), query.data_ptr(), query.stride(0), ctx.data_ptr(), ctx.stride(0),
+                                   weights.data_ptr(), float(inv_scale), B, T, Kd, Vd, _stream()), "slu_attention_fwd")
+
+
+def attention_bwd(keys, values, query, d_ctx, weights, d_keys, d_values, d_query, inv_scale):
+    L = _lib.load()
+    T, B, Kd = keys.shape
+    Vd = values.shape[2]
+    assert d_keys.stride() == keys.stride() and d_values.stride() == values.stride()
+    _lib.check(L.slu_attention_bwd(keys.data_ptr(), keys.stride(0), keys.stride(1), values.data_ptr(), values.stride(0),
+                                   values.stride(1), query.data_ptr(), query.stride(0), d_ctx.data_ptr(), d_ctx.stride(0),
+                                   weights.data_ptr(), d_keys.data_ptr(), d_values.data_ptr(), d_query.data_ptr(),
+                                   d_query.stride(0), float(inv_scale), B, T, Kd, Vd, _stream()), "slu_attention_bwd")
+
+
+def logsoftmax_dot_fwd(logits, y_u, logp_acc, lse):
+    L = _lib.load()
+    B, V = logits.shape
+    assert logits.is_contiguous() and y_u.stride(1) == 1
+    _lib.check(L.slu_logsoftmax_dot_fwd(logits.data_ptr(), y_u.data_ptr(), y_u.stride(0), logp_acc.data_ptr(), _ptr(lse),
+                                        B, V, _stream()), "slu_logsoftmax_dot_fwd")
+
+
+def logsoftmax_dot_bwd(logits, y_u, lse, g, d_logits):
+    L = _lib.load()
+    B, V = logits.shape
+    _lib.check(L.slu_logsoftmax_dot_bwd(logits.data_ptr(), y_u.data_ptr(), y_u.stride(0), lse.data_ptr(), g.data_ptr(), 1,
+                                        d_logits.data_ptr(), B, V, _stream()), "slu_logsoftmax_dot_bwd")
+
+
+def broadcast_rows(src, dst2d):
+    L = _lib.load()
+    rows, n = dst2d.shape
+    assert src.numel() == n and src.is_contiguous() and dst2d.stride(1) == 1
+    _lib.check(L.slu_broadcast_rows_f32(src.data_ptr(), dst2d.data_ptr(), dst2d.stride(0), rows, n, _stream()),
+               "slu_broadcast_rows_f32")
+
+
+def decoder_step(P, keys, values, state_prev, state_next, y_prev, q, inp0, att_w, gi, gh, save, drop, logits, step,
+                 drop_cfg):
+    """One decoding step (models.py:528-536) on the HIP kernels, shared by the teacher-forced forward and the beam
+    search: attention on the top layer's state, embedding of the previous label, the GRUCell stack (+ dropout between
+    the cells), output logits.  P: parameter dict (detached tensors); state_* (B, L, Dd); save / drop: per-layer
+    buffers or None (inference); drop_cfg = (p, masks or None, seed, offset, offset_dev, B * Dd)."""
+    Lc, Dd = state_prev.shape[1], state_prev.shape[2]
+    E = P["embed.weight"].shape[0]
+    p, masks, seed, offset, offset_dev, bd = drop_cfg
+    gemm(state_prev[:, Lc - 1], P["query.weight"].t(), P["query.bias"], out=q)
+    attention_fwd(keys, values, q, inp0[:, E:], att_w, P["inv_scale"])
+    gemm(y_prev, P["embed.weight"].t(), P["embed.bias"], out=inp0[:, :E])
+    x_in = inp0
+    for l in range(Lc):
+        gemm(x_in, P["w_ih%d" % l].t(), P["b_ih%d" % l], out=gi)
+        gemm(state_prev[:, l], P["w_hh%d" % l].t(), P["b_hh%d" % l], out=gh)
+        last = l == Lc - 1
+        mask = None if (masks is None or last) else masks["decoder_dropout_u%d_l%d" % (step, l)]
+        gru_cell_fwd(gi, gh, state_prev[:, l], state_next[:, l], None if save is None else save[l],
+                     None if last else drop[l], mask, 0.0 if last else p, seed, offset, offset_dev,
+                     (step * Lc + l) * bd)
+        if not last:
+            x_in = drop[l]
+    gemm(state_next[:, Lc - 1], P["linear.weight"].t(), P["linear.bias"], out=logits)
+
+
+class Seq2SeqDecoderFn(torch.autograd.Function):
+    """Seq2SeqDecoder.forward (reference models.py:504-557) + the loss of Model.forward's seq2seq branch (:825-828):
+    teacher-forced log p(y | x) of every utterance and loss = -mean.  enc time-major (T, B, 2 * encoder_dim); y
+    (B, U, V) float (one-hot rows, padded with <eos>).  One autograd node for the whole decoder: the backward is a
+    hand-written BPTT over the U steps on the same kernels (every Linear's weight gradient is ONE GEMM over the
+    (U * B)-row history).  Returns (loss_acc (2) = [loss, 0], log_p (B)); only loss_acc[0] carries a gradient."""
+    NAMES = None    # set per call: parameter names in argument order
+
+    @staticmethod
+    def forward(ctx, enc, y, meta, *params):
+        names, SOS, p, masks, seed, offset, offset_dev = meta
+        P = {n: t.detach() for n, t in zip(names, params)}
+        dev = enc.device
+        enc = _f32c(enc, "encoder output")
+        y = _f32c(y.to(dev), "y")
+        T, B, E2 = enc.shape
+        _, U, V = y.shape
+        Lc = sum(1 for n in names if n.startswith("w_ih"))
+        Dd = P["w_hh0"].shape[1]
+        E, Kd, Vd = P["embed.weight"].shape[0], P["key.weight"].shape[0], P["value.weight"].shape[0]
+        P["inv_scale"] = 1.0 / float(torch.sqrt(torch.tensor(Kd).float()))          # models.py:421
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        enc2 = enc.view(T * B, E2)
+        keys = gemm(enc2, P["key.weight"].t(), P["key.bias"]).view(T, B, Kd)
+        values = gemm(enc2, P["value.weight"].t(), P["value.bias"]).view(T, B, Vd)
+        state = f(U + 1, B, Lc, Dd)
+        broadcast_rows(P["initial_state"].contiguous().view(-1), state[0].view(B, Lc * Dd))
+        yprev = f(U, B, V)                                   # the label fed at step u: <sos>, then y[:, u - 1]
+        yprev[0].zero_()
+        yprev[0, :, SOS] = 1.0
+        if U > 1:
+            yprev[1:].copy_(y[:, :U - 1].transpose(0, 1))
+        q, att_w, inp0 = f(U, B, Kd), f(U, B, T), f(U, B, E + Vd)
+        save = f(U, Lc, 4, B, Dd)
+        drop = f(max(Lc - 1, 1), U, B, Dd)
+        logits, lse = f(U, B, V), f(U, B)
+        logp = torch.zeros(B, dtype=torch.float32, device=dev)
+        gi, gh = f(B, 3 * Dd), f(B, 3 * Dd)
+        dcfg = (p, masks, seed, offset, offset_dev, B * Dd)
+        for u in range(U):
+            decoder_step(P, keys, values, state[u], state[u + 1], yprev[u], q[u], inp0[u], att_w[u], gi, gh, save[u],
+                         [drop[l][u] for l in range(Lc - 1)], logits[u], u, dcfg)
+            logsoftmax_dot_fwd(logits[u], y[:, u], logp, lse[u])
+        loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
+        L = _lib.load()
+        _lib.check(L.slu_neg_mean_f32(logp.data_ptr(), loss_acc.data_ptr(), B, _stream()), "slu_neg_mean_f32")
+        ctx.meta = (names, p, masks, seed, offset, offset_dev, (T, B, E2, U, V, Lc, Dd, E, Kd, Vd), P["inv_scale"])
+        ctx.save_for_backward(enc, y, yprev, keys, values, state, q, att_w, inp0, save, drop, logits, lse, *params)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(logp)
+        return loss_acc, logp
+
+    @staticmethod
+    def backward(ctx, d_loss_acc, _d_logp):
+        names, p, masks, seed, offset, offset_dev, dims, inv_scale = ctx.meta
+        T, B, E2, U, V, Lc, Dd, E, Kd, Vd = dims
+        n_par = len(names)
+        if d_loss_acc is None:
+            return (None,) * (3 + n_par)
+        saved = ctx.saved_tensors
+        enc, y, yprev, keys, values, state, q, att_w, inp0, save, drop, logits, lse = saved[:13]
+        P = {n: t.detach() for n, t in zip(names, saved[13:])}
+        dev = enc.device
+        L = _lib.load()
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        g = _f32c(d_loss_acc.float(), "d_loss")                       # (2): only [0] matters
+        dlogp = f(B)
+        _lib.check(L.slu_fill_scaled_f32(dlogp.data_ptr(), B, g.data_ptr(), -1.0 / B, _stream()), "slu_fill_scaled_f32")
+        d_state = torch.zeros(B, Lc, Dd, dtype=torch.float32, device=dev)
+        d_keys, d_values = torch.zeros_like(keys), torch.zeros_like(values)
+        d_gi, d_gh = f(Lc, U, B, 3 * Dd), f(Lc, U, B, 3 * Dd)
+        d_logits, d_q, d_inp0 = f(U, B, V), f(U, B, Kd), f(U, B, E + Vd)
+        d_x = f(B, Dd)                                              # gradient w.r.t. the dropped input of layer l + 1
+        for u in range(U - 1, -1, -1):
+            logsoftmax_dot_bwd(logits[u], y[:, u], lse[u], dlogp, d_logits[u])
+            gemm(d_logits[u], P["linear.weight"], out=d_state[:, Lc - 1], accumulate=True)
+            for l in range(Lc - 1, -1, -1):
+                last = l == Lc - 1
+                mask = None if (masks is None or last) else masks["decoder_dropout_u%d_l%d" % (u, l)]
+                gru_cell_bwd(d_state[:, l], None if last else d_x, save[u, l], state[u][:, l], d_gi[l, u], d_gh[l, u],
+                             d_state[:, l], mask, 0.0 if last else p, seed, offset, offset_dev, (u * Lc + l) * B * Dd)
+                gemm(d_gh[l, u], P["w_hh%d" % l], out=d_state[:, l], accumulate=True)
+                gemm(d_gi[l, u], P["w_ih%d" % l], out=d_x if l > 0 else d_inp0[u])
+            attention_bwd(keys, values, q[u], d_inp0[u][:, E:], att_w[u], d_keys, d_values, d_q[u], inv_scale)
+            gemm(d_q[u], P["query.weight"], out=d_state[:, Lc - 1], accumulate=True)
+        grads = {}
+        st_prev = state[:U].view(U * B, Lc * Dd)                     # rows (u, b): the state BEFORE step u
+        st_next = state[1:].view(U * B, Lc * Dd)
+        top = slice((Lc - 1) * Dd, Lc * Dd)
+        dl2, dq2, di2 = d_logits.view(U * B, V), d_q.view(U * B, Kd), d_inp0.view(U * B, E + Vd)
+        grads["linear.weight"], grads["linear.bias"] = gemm(dl2.t(), st_next[:, top]), colsum(dl2)
+        grads["query.weight"], grads["query.bias"] = gemm(dq2.t(), st_prev[:, top]), colsum(dq2)
+        grads["embed.weight"], grads["embed.bias"] = gemm(di2[:, :E].t(), yprev.view(U * B, V)), colsum(di2[:, :E])
+        for l in range(Lc):
+            gi2, gh2 = d_gi[l].view(U * B, 3 * Dd), d_gh[l].view(U * B, 3 * Dd)
+            x_l = inp0.view(U * B, E + Vd) if l == 0 else drop[l - 1].view(U * B, Dd)
+            grads["w_ih%d" % l], grads["b_ih%d" % l] = gemm(gi2.t(), x_l), colsum(gi2)
+            grads["w_hh%d" % l], grads["b_hh%d" % l] = gemm(gh2.t(), st_prev[:, l * Dd:(l + 1) * Dd]), colsum(gh2)
+        grads["initial_state"] = colsum(d_state.view(B, Lc * Dd)).view(Lc, Dd)
+        dk2, dv2, enc2 = d_keys.view(T * B, Kd), d_values.view(T * B, Vd), enc.view(T * B, E2)
+        grads["key.weight"], grads["key.bias"] = gemm(dk2.t(), enc2), colsum(dk2)
+        grads["value.weight"], grads["value.bias"] = gemm(dv2.t(), enc2), colsum(dv2)
+        d_enc = None
+        if ctx.needs_input_grad[0]:
+            d_enc = gemm(dk2, P["key.weight"])
+            gemm(dv2, P["value.weight"], out=d_enc, accumulate=True)
+            d_enc = d_enc.view(T, B, E2)
+        return (d_enc, None, None) + tuple(grads[n] if ctx.needs_input_grad[3 + i] else None for i, n in enumerate(names))

@@ -167,11 +167,12 @@ class Trainer:
                 loss = phoneme_loss + word_loss
             return [phoneme_loss, word_loss, phoneme_acc, word_acc], loss
         x, y_intent = batch
+        # through model.__call__ (forward hooks / wrappers keep working); rng_step is a keyword-only extra of this
+        # package's Model.forward
         if rng_step is None:
             intent_loss, intent_acc = self.model(x, y_intent)
         else:
-            intent_loss, intent_acc = self.model.forward_from(self.model.pretrained_model._to_device(x)[0], 0,
-                                                              y_intent, rng_step)
+            intent_loss, intent_acc = self.model(x, y_intent, rng_step=rng_step)
         return [intent_loss, intent_acc], intent_loss
 
     def lookahead_depth(self, train, asr):
@@ -255,11 +256,16 @@ class Trainer:
         def forward(ins, rng):
             ops.IntentHeadFn.epoch_sums = sums
             try:
-                loss, _ = self.model.forward_from(ins[0], n_prefix, ins[1], rng)
+                loss, _ = self.model(ins[0], ins[1], rng_step=rng, n_prefix=n_prefix)
             finally:
                 ops.IntentHeadFn.epoch_sums = None
-            return ops.IntentHeadFn.last_loss_acc, loss          # (2,) float32 [loss, acc]
+            return self.model.last_loss_acc, loss                # (2,) float32 [loss, acc]
         return forward
+
+    def _fused_sums(self):
+        """Can the epoch statistics be accumulated inside the step's own kernels?  (the intent head's launch does it;
+        the seq2seq decoder's loss is accumulated by the loop instead)"""
+        return hasattr(self.model, "pretrained_model") and not getattr(self.model, "seq2seq", False)
 
     def _sums_buffer(self):
         """Persistent float64 (4) device tensor: the running B-weighted sums of the step metrics of one epoch
@@ -296,9 +302,9 @@ class Trainer:
             self._full_stream = torch.cuda.Stream(dev)
         main = self._full_stream
         main.wait_stream(outer)
-        fused = sums is not None and hasattr(self.model, "pretrained_model")
+        fused = sums is not None and self._fused_sums()
         if hasattr(self.model, "pretrained_model"):
-            pm, forward = self.model.pretrained_model, self._slu_forward(0, sums)
+            pm, forward = self.model.pretrained_model, self._slu_forward(0, sums if fused else None)
         else:
             pm, forward = self.model, self._asr_forward
         # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it) and to
@@ -321,6 +327,8 @@ class Trainer:
 
     def _iterate(self, loader, train, asr, accumulate=False):
         """Yields ([metric tensors], batch_size) per batch, doing the optimisation step when `train`.
+        NOTE for consumers: the metrics of a hipGraph-captured step are ONE static device buffer that the next replay
+        overwrites — read (or .clone()) them before advancing the generator, as _run does at print intervals.
         accumulate: also keep the epoch statistics on the device — self.epoch_sums[:n] (float64, zeroed here)
         receives batch_size * metrics of every batch, inside the step's own kernels where they are captured
         (no per-step accumulation launch); the consumer reads it when the generator is exhausted."""
@@ -330,6 +338,7 @@ class Trainer:
             sums.zero_()
         depth, n_prefix = self.lookahead_depth(train, asr)
         group_eval = (not train and not asr and hasattr(self.model, "eval_group") and not models_masks_injected()
+                      and not getattr(self.model, "seq2seq", False)
                       and all(p.is_cuda for p in self.model.parameters())
                       and _lookahead_env() not in (0, 1))
         if group_eval:
@@ -397,7 +406,8 @@ class Trainer:
             slot.stream.wait_stream(main)
         use_graph = pipeline.graphs_enabled()
         step_graphs = use_graph and self._graphable()
-        forward = self._slu_forward(n_prefix, sums if step_graphs else None)
+        fused = step_graphs and self._fused_sums()
+        forward = self._slu_forward(n_prefix, sums if fused else None)
         trainable = _param_signature(self.model)
         # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so a run that
         # fits in two super-batches is split 60 : 40 — the second, smaller one (its encoder runs beside the first
@@ -464,11 +474,11 @@ class Trainer:
                             key = (tuple(feats.shape), tuple(y.shape), n_prefix, trainable, sums is not None)
                             vals = self._graph_step(key, [feats, y], steps[k], forward, main)
                         else:
-                            loss, acc = self.model.forward_from(feats, n_prefix, y, steps[k])
+                            loss, acc = self.model(feats, y, rng_step=steps[k], n_prefix=n_prefix)
                             self._step(loss)
                             vals = [loss, acc]
-                            if sums is not None:
-                                self._accumulate(sums, vals, len(batch[0]))
+                        if sums is not None and not fused:
+                            self._accumulate(sums, vals, len(batch[0]))
                         if k == len(group) - 1:
                             slot.consumed = torch.cuda.Event()
                             slot.consumed.record(main)
@@ -499,6 +509,17 @@ class Trainer:
         # runs NOW — the current stream returns to the caller's and it waits for the training stream
         # the batch_size-weighted sums of the metrics (reference training.py:100-104) stay on the device:
         # self.epoch_sums, filled by the step loop itself (inside the captured step's kernels where it can)
+        seq2seq = not asr and getattr(self.model, "seq2seq", False)
+        batches_seen = []
+        if seq2seq:                      # the decoded strings need the batch the step consumed
+            def tee(loader):
+                for b in loader:
+                    batches_seen.append(b)
+                    del batches_seen[:-64]
+                    yield b
+            src = it
+            it = tee(src)
+        string_acc = 0.0
         with contextlib.closing(self._iterate(it, train, asr, accumulate=True)) as steps:
             for idx, (vals, batch_size) in enumerate(steps):
                 num_examples += batch_size
@@ -506,7 +527,37 @@ class Trainer:
                     step_vals = vals if torch.is_tensor(vals) else [v.detach().reshape(()) for v in vals]
                     for n, v in zip(names, [float(v) for v in step_vals]):   # one host sync per print interval
                         print(n + ": " + str(v))
-        return self._epoch_means(self.epoch_sums[:len(names)].tolist(), num_examples, dev)
+                    if seq2seq:          # reference training.py:103-112: show one decoded utterance
+                        self._say_seq2seq_sample(batches_seen, batch_size)
+                if seq2seq and not train and self.epoch > 1:
+                    # reference training.py:158-164: from the third epoch on the test accuracy is the fraction of
+                    # utterances whose beam-search string equals the label string
+                    x, y = next(b for b in reversed(batches_seen) if len(b[0]) == batch_size)
+                    guess = self.model.decode_intents(x)
+                    truth = [self.model.one_hot_to_string(y[i], self.model.Sy_intent) for i in range(batch_size)]
+                    hit = sum(g == t for g, t in zip(guess, truth)) / batch_size
+                    string_acc += hit * batch_size
+                    self._say("acc: " + str(hit))
+                    self._say("guess: " + guess[0])
+                    self._say("truth: " + truth[0])
+        means = self._epoch_means(self.epoch_sums[:len(names)].tolist() + [string_acc], num_examples, dev)
+        if seq2seq and not train:
+            means[1] = means[1] + means[-1]          # intent_acc += string accuracy (the model's own acc is 0)
+        return means[:len(names)]
+
+    def _say_seq2seq_sample(self, batches_seen, batch_size):
+        x, y = next(b for b in reversed(batches_seen) if len(b[0]) == batch_size)
+        import models
+        was_training = self.model.training
+        step = models._DropoutState.step          # the sample must not shift the training run's dropout streams
+        self.model.eval()
+        try:
+            print("seq2seq output")
+            print("guess: " + self.model.decode_intents(x[:1])[0])
+            print("truth: " + self.model.one_hot_to_string(y[0].cpu(), self.model.Sy_intent))
+        finally:
+            self.model.train(was_training)
+            models._DropoutState.step = step
 
     # -- reference API -----------------------------------------------------------------------------
     def train(self, dataset, print_interval=100):

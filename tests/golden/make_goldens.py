@@ -583,6 +583,45 @@ def g10():
             res[name] = entry
         finally:
             shutil.rmtree(root)
+    # seq2seq variant (reference data.py:143-146, 186-187, 201-208, 318-326): the output alphabet is built from a Python
+    # set, i.e. its ORDER changes from process to process; the fixture pins the set, the <sos>/<eos> positions and the
+    # label sequences as strings
+    root = tempfile.mkdtemp()
+    try:
+        fx.make_fsc_tree(root, seed=11, seq2seq=True)
+        cfg = tiny_cfg(folder=root)
+        cfg.slu_path = root
+        cfg.seq2seq = True
+        cfg.training_batch_size = 4
+        for k in ("real_speaker_subset_percentage", "synthetic_speaker_subset_percentage",
+                  "real_dataset_subset_percentage", "synthetic_dataset_subset_percentage"):
+            setattr(cfg, k, 1.0)
+        cfg.train_wording_path = cfg.test_wording_path = None
+        cfg.dataset_upsample_factor = 1
+        np.random.seed(0)
+        stdout, sys.stdout = sys.stdout, io.StringIO()
+        try:
+            tr, va, te = ref_data.get_SLU_datasets(cfg)
+        finally:
+            sys.stdout = stdout
+        Sy = cfg.Sy_intent
+        entry = {"alphabet_sorted": sorted(Sy[1:-1]), "first": Sy[0], "last": Sy[-1], "len": [len(tr), len(va), len(te)],
+                 "train_paths": [str(v) for v in tr.df.path.tolist()], "items": []}
+        for i in (0, 5, len(tr.df) - 1):
+            x, y = tr[i]
+            entry["items"].append({"idx": i, "n": int(len(x)), "labels": [Sy[k] for k in y]})
+        res["seq2seq"] = entry
+    finally:
+        shutil.rmtree(root)
+    labels = ["<sos>"] + list("abc{}' :") + ["<eos>"]
+    coll = ref_data.CollateWavsSLU(labels, True)
+    rs = np.random.RandomState(6)
+    batch = [(rs.randn(n).astype(np.float32), [0] + [int(rs.randint(1, 9)) for _ in range(u)] + [9])
+             for n, u in ((7, 3), (12, 6), (3, 1))]
+    x, y = coll(batch)
+    res["collate_seq2seq"] = {"labels": labels, "lens": [7, 12, 3], "ulens": [3, 6, 1], "seed": 6, "x": npd(x).tolist(),
+                              "y_idx": npd(y.max(dim=2)[1]).tolist(), "y_shape": list(y.shape), "y_sum": float(y.sum()),
+                              "y_dtype": str(y.dtype)}
     # collate: ragged float32 waveforms -> zero-padded batch
     coll = ref_data.CollateWavsSLU({"action": {}, "object": {}, "location": {}}, False)
     rs = np.random.RandomState(5)

@@ -29,8 +29,14 @@ def _rows(rs, split, n, speakers, with_speaker):
     return pd.DataFrame(rows)
 
 
-def make_fsc_tree(root, seed=0, with_speaker=True, sizes=(23, 11, 7, 5)):
-    """root/data/{train,synthetic,valid,test}_data.csv + root/wavs/... ; returns {split: DataFrame}."""
+def semantics_of(row):
+    """The seq2seq label string of a row (the *_seq2seq.csv splits of the reference carry a `semantics` column)."""
+    return "{'action': '%s', 'object': '%s', 'location': '%s'}" % (row["action"], row["object"], row["location"])
+
+
+def make_fsc_tree(root, seed=0, with_speaker=True, sizes=(23, 11, 7, 5), seq2seq=False):
+    """root/data/{train,synthetic,valid,test}_data.csv + root/wavs/... ; returns {split: DataFrame}.
+    seq2seq: also write the *_data_seq2seq.csv splits (same rows + a `semantics` column)."""
     rs = np.random.RandomState(seed)
     speakers = ["spk%02d" % i for i in range(6)]
     os.makedirs(os.path.join(root, "data"), exist_ok=True)
@@ -38,6 +44,10 @@ def make_fsc_tree(root, seed=0, with_speaker=True, sizes=(23, 11, 7, 5)):
     for split, n in zip(("train", "synthetic", "valid", "test"), sizes):
         df = _rows(rs, split, n, speakers, with_speaker)
         df.to_csv(os.path.join(root, "data", "%s_data.csv" % split))        # FSC csvs carry an unnamed index column
+        if seq2seq:
+            d2 = df.copy()
+            d2["semantics"] = [semantics_of(r) for _, r in df.iterrows()]
+            d2.to_csv(os.path.join(root, "data", "%s_data_seq2seq.csv" % split))
         for p in df.path:
             full = os.path.join(root, p)
             os.makedirs(os.path.dirname(full), exist_ok=True)

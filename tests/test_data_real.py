@@ -51,6 +51,43 @@ def test_get_slu_datasets_matches_reference(name, tmp_path, capsys, monkeypatch)
         assert float(np.float64(x).sum()) == it["sum"]
 
 
+def test_seq2seq_datasets_match_reference(tmp_path, capsys, monkeypatch):
+    """config.seq2seq (reference data.py:143-146, 186-187, 201-208, 318-326): the *_seq2seq.csv splits, the output
+    alphabet (the reference's set of characters; its order is hash-salted there, sorted here), <sos> ... <eos> label
+    sequences."""
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=11, seq2seq=True)
+    cfg = _config(root, {})
+    cfg.seq2seq = True
+    np.random.seed(0)
+    tr, va, te = data.get_SLU_datasets(cfg)
+    capsys.readouterr()
+    g = GOLD["seq2seq"]
+    Sy = cfg.Sy_intent
+    assert Sy[0] == g["first"] == "<sos>" and Sy[-1] == g["last"] == "<eos>"
+    assert Sy[1:-1] == g["alphabet_sorted"]
+    assert [len(tr), len(va), len(te)] == g["len"]
+    assert [str(p) for p in tr.df.path.tolist()] == g["train_paths"]
+    for it in g["items"]:
+        x, y = tr[it["idx"]]
+        assert len(x) == it["n"] and [Sy[k] for k in y] == it["labels"]
+    x, y = next(iter(tr.loader))
+    assert y.dtype == torch.float32 and y.dim() == 3 and y.shape[2] == len(Sy) and float(y.sum()) == y.shape[0] * y.shape[1]
+    assert torch.equal(y[:, 0].argmax(1), torch.zeros(y.shape[0], dtype=torch.int64))          # <sos> first
+
+
+def test_seq2seq_collate_matches_reference():
+    g = GOLD["collate_seq2seq"]
+    rs = np.random.RandomState(g["seed"])
+    batch = [(rs.randn(n).astype(np.float32), [0] + [int(rs.randint(1, 9)) for _ in range(u)] + [9])
+             for n, u in zip(g["lens"], g["ulens"])]
+    x, y = data.CollateWavsSLU(g["labels"], True)(batch)
+    assert torch.equal(x, torch.tensor(g["x"], dtype=torch.float32))
+    assert list(y.shape) == g["y_shape"] and str(y.dtype) == g["y_dtype"] and float(y.sum()) == g["y_sum"]
+    assert y.max(dim=2)[1].tolist() == g["y_idx"]                                              # <eos> padding
+
+
 def test_collate_matches_reference():
     g = GOLD["collate"]
     rs = np.random.RandomState(g["seed"])

@@ -105,10 +105,13 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
         assert torch.equal(v, sd[k]), k
 
 
-def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path):
-    """One look-ahead super-batch (12 x 64 = 768 utterances of 3 s: 4-sequence recurrence kernels at the size
-    the bench launches them) through the frozen encoder with the oracle's dropout masks, against the CPU
-    oracle's encoder (models.py:349-361): features within 1e-4."""
+@pytest.mark.parametrize("n_utt", [1280, 768])
+def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, n_utt):
+    """One look-ahead super-batch through the frozen encoder with the oracle's dropout masks, against the CPU oracle's
+    encoder (models.py:349-361), features within 1e-4.  1280 = 20 x 64 utterances of 3 s is exactly what bench.py's
+    default launches: split-precision convolutions, the 96-row panel GEMM (M = 150 x 1280 = 192 000 rows >= 131 072,
+    K = 256), the tiled GEMM for the shorter layers, the row-panel GEMM for K = 60 and the 16-sequence bf16x3
+    recurrence on 80 tiles x 2 directions; 768 = a 12-batch super-batch (all launches below the panel threshold)."""
     import models
     cfg = _full_cfg(tmp_path)
     torch.manual_seed(1)
@@ -118,21 +121,21 @@ def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path):
     model = models.Model(cfg)
     model.train()
     g = torch.Generator().manual_seed(7)
-    x = 0.1 * torch.randn(768, 48000, generator=g)
+    x = 0.1 * torch.randn(n_utt, 48000, generator=g)
     masks = O.draw_dropout_masks(cfg, x, seed=11, include_intent=False)
     models.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
     try:
         n = model.frozen_prefix_len()
         assert n == 7
-        feats = model.prefix_features(x.cuda(), n, 1)              # (19, 768, 256) time-major
+        feats = model.prefix_features(x.cuda(), n, 1)              # (19, n_utt, 256) time-major
         torch.cuda.synchronize()
     finally:
         models.set_dropout_masks(None)
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     with torch.no_grad():
-        ref = O.encoder_stages(pre, x, cfg, masks, explicit_gru=False)["features"]       # (768, 19, 256)
+        ref = O.encoder_stages(pre, x, cfg, masks, explicit_gru=False)["features"]       # (n_utt, 19, 256)
     err = (feats.transpose(0, 1).cpu() - ref).abs().max().item()
-    print("super-batch (768 x 3 s) encoder features max-abs deviation vs oracle: %.3e" % err)
+    print("super-batch (%d x 3 s) encoder features max-abs deviation vs oracle: %.3e" % (n_utt, err))
     assert err <= 1e-4
 
 

@@ -387,3 +387,46 @@ def test_ten_second_utterances_vs_oracle(models_mod, tmp_path):
         if sdg[k].grad is not None:
             scale = max(sdg[k].grad.abs().max().item(), 1e-6)
             assert maxerr(p.grad, sdg[k].grad) <= 3e-4 * scale, k
+
+
+def test_full_size_asr_pretraining_step_vs_oracle(models_mod, tmp_path):
+    """BASELINE.json configs[2]: the full PretrainedModel (Sinc + 2 conv + 4 biGRU layers, phoneme head 42, word head
+    VOCABULARY 10 000) forward + backward at B = 64 x 3 s with injected dropout masks against O.asr_forward
+    (reference models.py:291-331): both losses and accuracies, every gradient (float64 Sinc parameters included)."""
+    cfg = full_cfg(tmp_path, pretraining_type=2)
+    torch.manual_seed(31)
+    pm = models_mod.PretrainedModel(cfg)
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in pm.state_dict().items()}
+    g = torch.Generator().manual_seed(32)
+    B, T = 64, 48000
+    x = 0.1 * torch.randn(B, T, generator=g)
+    Tp, Tw = -(-T // 640), -(-T // 2560)
+    yp = torch.randint(0, cfg.num_phonemes, (B, Tp), generator=g)
+    yw = torch.randint(0, cfg.vocabulary_size, (B, Tw), generator=g)
+    yp[torch.rand(B, Tp, generator=g) < 0.1] = -1
+    yw[torch.rand(B, Tw, generator=g) < 0.1] = -1
+    masks = O.draw_dropout_masks(cfg, x, seed=33, include_intent=False)
+    models_mod.set_dropout_masks(masks_to_cuda(masks))
+    try:
+        pm.train()
+        pl, wl, pa, wa = pm(x, yp, yw)
+        (pl + wl).backward()
+        torch.cuda.synchronize()
+    finally:
+        models_mod.set_dropout_masks(None)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    rpl, rwl, rpa, rwa = O.asr_forward(sd, x, yp, yw, cfg, masks, explicit_gru=False)
+    (rpl + rwl).backward()
+    assert abs(pl.item() - rpl.item()) <= 1e-4 and abs(wl.item() - rwl.item()) <= 1e-4, (pl.item(), rpl.item(), wl.item(), rwl.item())
+    assert abs(pa.item() - rpa.item()) <= 1e-6 and abs(wa.item() - rwa.item()) <= 1e-6
+    worst, n = (0.0, ""), 0
+    for k, p in pm.named_parameters():
+        ref = sd[k].grad
+        assert ref is not None and p.grad is not None, k
+        assert p.grad.dtype == ref.dtype, k
+        e = maxerr(p.grad, ref) / max(ref.abs().max().item(), 1e-9)
+        worst = max(worst, (e, k))
+        n += 1
+    print("full-size ASR step: losses %.5f / %.5f (oracle %.5f / %.5f), %d gradients, worst relative deviation %.2e (%s)"
+          % (pl.item(), wl.item(), rpl.item(), rwl.item(), n, worst[0], worst[1]))
+    assert worst[0] <= 2e-4, worst

@@ -134,14 +134,39 @@ def test_bad_downsample_method_exits_like_the_reference(capsys):
     assert "downsampling method must be one of" in capsys.readouterr().out
 
 
-def test_seq2seq_head_is_explicitly_out_of_scope(tmp_path, no_gpu):
-    import models
-    with pytest.raises(NotImplementedError, match="seq2seq"):
-        models.Model(_cfg(tmp_path, pretraining_type=0, seq2seq=True))
-
-
 def test_decode_intents_mapping(tmp_path, no_gpu, monkeypatch):
     import models
     model = models.Model(_cfg(tmp_path, pretraining_type=0))
     monkeypatch.setattr(model, "predict_intents", lambda x: (None, torch.tensor([[1, 13, 0], [5, 0, 3]])))
     assert model.decode_intents(None) == [["a1", "o13", "l0"], ["a5", "o0", "l3"]]
+
+
+@pytest.mark.parametrize("tag,kw", [("a", {}), ("b", {"num_intent_encoder_layers": 2, "num_intent_decoder_layers": 3})])
+def test_seq2seq_state_dict_is_bit_identical_to_the_reference_under_the_same_seed(tmp_path, no_gpu, tag, kw):
+    """Model(config.seq2seq): same state_dict keys IN ORDER, shapes and — under the fixture's seed — the same values
+    as the reference's Model (g7), i.e. the same modules constructed in the same order (models.py:720-725); layer
+    names of the seq2seq encoder / decoder as the reference sets them."""
+    import models
+    d = dict(np.load(os.path.join(G, "g7_seq2seq_%s.npz" % tag)))
+    labels = json.loads(bytes(d["labels_json"]).decode())
+    cfg = O.OracleConfig(cnn_N_filt=[8, 6, 6], cnn_len_filt=[41, 5, 3], cnn_stride=[10, 1, 1],
+                         phone_rnn_num_hidden=[16, 16], word_rnn_num_hidden=[16, 16], intent_rnn_num_hidden=[16],
+                         vocabulary_size=50, num_phonemes=11, values_per_slot=[3, 4, 2], pretraining_type=0,
+                         seq2seq=True, intent_encoder_dim=12, num_intent_encoder_layers=1, intent_decoder_dim=20,
+                         num_intent_decoder_layers=2, intent_decoder_key_dim=10, intent_decoder_value_dim=14)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    cfg.folder, cfg.Sy_intent, cfg.starting_unfreezing_index = str(tmp_path), labels, 1
+    torch.manual_seed(70 + len(kw))
+    model = models.Model(cfg)
+    sd = model.state_dict()
+    assert list(sd.keys()) == json.loads(bytes(d["sd_keys_json"]).decode())
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), d["sd." + k]), k
+    assert model.seq2seq and model.SOS == 0 and model.num_labels == len(labels) and model.intent_layers == []
+    assert [l.name for l in model.encoder.layers][:3] == ["intent_encoder_rnn0", "intent_encoder_rnn_select0", "intent_encoder_dropout0"]
+    assert [l.name for l in model.decoder.rnn.layers][:4] == ["gru0", "dropout0", "gru1", "dropout1"]
+    assert float(model.decoder.attention.scale_factor) == float(torch.sqrt(torch.tensor(10).float()))
+    with pytest.raises(Exception, match="no CPU fallback|GPU"):
+        model(torch.zeros(2, 1800), torch.zeros(2, 3, len(labels)))
+    assert model.one_hot_to_string(torch.eye(len(labels))[[0, 3, 4, len(labels) - 1]], labels) == labels[3] + labels[4]
