@@ -419,14 +419,24 @@ def test_full_size_asr_pretraining_step_vs_oracle(models_mod, tmp_path):
     (rpl + rwl).backward()
     assert abs(pl.item() - rpl.item()) <= 1e-4 and abs(wl.item() - rwl.item()) <= 1e-4, (pl.item(), rpl.item(), wl.item(), rwl.item())
     assert abs(pa.item() - rpa.item()) <= 1e-6 and abs(wa.item() - rwa.item()) <= 1e-6
+    # LeakyReLU kinks: a convolution output within fp32 round-off of ZERO may land on either side of the kink in two
+    # correct fp32 evaluations (this draw has one: conv1 at (33, ch 1, frame 95) is -1.3e-7 in the oracle, +2.2e-7 on
+    # the GPU), and its upstream gradient then differs by the slope ratio 1 : 0.2 in BOTH implementations' own right.
+    # One such element among 1.15 M moves the (tiny, heavily cancelling) Sinc-parameter gradients by ~1e-3 and nothing
+    # else measurably; parameters UPSTREAM of a kink-adjacent element get the wider bound, everything else 2e-4.
+    with torch.no_grad():
+        st = O.encoder_stages({k: v.detach() for k, v in sd.items()}, x, cfg, masks, explicit_gru=False, upto="phoneme_features")
+    kink_stage = max([c for c in (1, 2) if int((st["conv%d" % c].abs() < 1e-6).sum()) > 0], default=0)
+    upstream = {0: (), 1: ("phoneme_layers.0.",), 2: ("phoneme_layers.0.", "phoneme_layers.5.")}[kink_stage]
     worst, n = (0.0, ""), 0
     for k, p in pm.named_parameters():
         ref = sd[k].grad
         assert ref is not None and p.grad is not None, k
         assert p.grad.dtype == ref.dtype, k
         e = maxerr(p.grad, ref) / max(ref.abs().max().item(), 1e-9)
+        assert e <= (3e-3 if k.startswith(upstream) and upstream else 2e-4), (k, e, kink_stage)
         worst = max(worst, (e, k))
         n += 1
-    print("full-size ASR step: losses %.5f / %.5f (oracle %.5f / %.5f), %d gradients, worst relative deviation %.2e (%s)"
-          % (pl.item(), wl.item(), rpl.item(), rwl.item(), n, worst[0], worst[1]))
-    assert worst[0] <= 2e-4, worst
+    print("full-size ASR step: losses %.5f / %.5f (oracle %.5f / %.5f), %d gradients, worst relative deviation %.2e (%s); "
+          "conv outputs within 1e-6 of the LeakyReLU kink up to stage conv%d"
+          % (pl.item(), wl.item(), rpl.item(), rwl.item(), n, worst[0], worst[1], kink_stage))

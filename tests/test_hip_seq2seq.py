@@ -67,7 +67,9 @@ def check_grads(model, ref_of, rel):
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
             continue
         assert p.grad is not None, k
-        scale = max(ref.abs().max().item(), 1e-6)
+        # floor: the softmax over frames is invariant to a constant added to every score, so the key bias gradient is
+        # zero in exact arithmetic — in both implementations it is pure round-off (1e-8 against gradients of 1e-2..1)
+        scale = max(ref.abs().max().item(), 1e-4)
         e = maxerr(p.grad, ref) / scale
         assert e <= rel, "%s: relative deviation %.3e" % (k, e)
         worst = max(worst, (e, k))
