@@ -35,7 +35,7 @@ struct GemmBfParams {
 // W (N x K, row stride ldw) fp32 -> packed bf16 planes in B-fragment order, zero beyond N / K
 template <int NS>
 __global__ void __launch_bounds__(256)
-gemm_bf_pack_kernel(const float* __restrict__ W, long long ldw, uint4* __restrict__ wp, int N, int K, int KC, int NT) {
+gemm_bf_pack_kernel(const float* __restrict__ W, long long ldw, long long w_cs, uint4* __restrict__ wp, int N, int K, int KC, int NT) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // (kc, nt, lane)
   if (idx >= KC * NT * 64) return;
   const int lane = idx & 63, nt = (idx >> 6) % NT, kc = (idx >> 6) / NT;
@@ -43,7 +43,7 @@ gemm_bf_pack_kernel(const float* __restrict__ W, long long ldw, uint4* __restric
   unsigned short h[NS][8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float v = (n < N && k0 + e < K) ? W[(long long)n * ldw + k0 + e] : 0.0f;
+    const float v = (n < N && k0 + e < K) ? W[(long long)n * ldw + (long long)(k0 + e) * w_cs] : 0.0f;
     unsigned short s[NS];
     split_bf16<NS>(v, s);
 #pragma unroll
@@ -444,7 +444,7 @@ extern "C" size_t slu_gemm_bf16_pack_bytes(int64_t N, int64_t K, int nsplit) {
   return (size_t)nsplit * cdiv(K, 32) * cdiv(N, 16) * 64 * sizeof(uint4);
 }
 
-extern "C" int slu_gemm_bf16_pack(const float* W, int64_t ldw, void* packed, int64_t N, int64_t K, int nsplit,
+extern "C" int slu_gemm_bf16_pack(const float* W, int64_t ldw, int64_t w_cs, void* packed, int64_t N, int64_t K, int nsplit,
                                   void* stream) {
   SLU_REQUIRE(W && packed && N > 0 && K > 0, "slu_gemm_bf16_pack: bad argument");
   SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_gemm_bf16_pack: nsplit must be 1 or 3");
@@ -452,10 +452,10 @@ extern "C" int slu_gemm_bf16_pack(const float* W, int64_t ldw, void* packed, int
   const int total = KC * NT * 64;
   if (nsplit == 3)
     hipLaunchKernelGGL(gemm_bf_pack_kernel<3>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W,
-                       (long long)ldw, (uint4*)packed, (int)N, (int)K, KC, NT);
+                       (long long)ldw, (long long)w_cs, (uint4*)packed, (int)N, (int)K, KC, NT);
   else
     hipLaunchKernelGGL(gemm_bf_pack_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W,
-                       (long long)ldw, (uint4*)packed, (int)N, (int)K, KC, NT);
+                       (long long)ldw, (long long)w_cs, (uint4*)packed, (int)N, (int)K, KC, NT);
   SLU_CHECK_LAUNCH("gemm_bf_pack_kernel");
   return SLU_OK;
 }

@@ -25,6 +25,8 @@ struct WconvBfParams {
   const uint4* wp;      // packed filters [plane][KC][NT][64]
   const float* bias;    // (c_out) or null
   float* out;
+  unsigned char* route;     // null, or (B, l_out, c_out): pool pick | sign << 1, as wconv_fwd_kernel writes it (trainable
+                            // blocks in bf16 mode: bf16 forward, exact fp32 backward through slu_wconv_bwd_*)
   unsigned short* planes;   // null, or NS bf16 planes of (l_out * Bn) x Kp_out (time-major rows f * Bn + b, zero padded
   long long plane;          // columns): the split-precision activation format the next frozen GRU layer's GEMM reads
   int Kp_out, Bn;
@@ -213,9 +215,11 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
       if (c >= p.c_out) continue;
       const float bias = p.bias ? p.bias[c] : 0.0f;
       float v[4];
+      bool neg[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float t = acc[m][n][r] + bias;
+        neg[r] = t < 0.0f;
         v[r] = p.do_abs ? fabsf(t) : t;
       }
       if (p.pool == 2) {
@@ -224,8 +228,13 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
           const int f0 = fbase + 2 * h;
           if (f0 >= p.l_conv) continue;
           const bool has1 = (f0 + 1) < p.l_conv;                // ceil_mode: last window may be partial
-          const float pooled = (has1 && v[2 * h + 1] > v[2 * h]) ? v[2 * h + 1] : v[2 * h];
+          const bool pick1 = has1 && v[2 * h + 1] > v[2 * h];
+          const float pooled = pick1 ? v[2 * h + 1] : v[2 * h];
           p.out[(size_t)b * p.out_sb + (long long)(f0 >> 1) * p.out_sl + c] = pooled > 0.0f ? pooled : pooled * p.slope;
+          if (p.route) {
+            const bool sgn = pick1 ? neg[2 * h + 1] : neg[2 * h];
+            p.route[((size_t)b * p.l_out + (f0 >> 1)) * p.c_out + c] = (unsigned char)((pick1 ? 1 : 0) | (sgn ? 2 : 0));
+          }
         }
       } else {
 #pragma unroll
@@ -233,6 +242,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
           const int f = fbase + r;
           if (f >= p.l_conv) continue;
           p.out[(size_t)b * p.out_sb + (long long)f * p.out_sl + c] = v[r] > 0.0f ? v[r] : v[r] * p.slope;
+          if (p.route) p.route[((size_t)b * p.l_out + f) * p.c_out + c] = (unsigned char)(neg[r] ? 2 : 0);
         }
       }
     }
@@ -284,7 +294,7 @@ extern "C" size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, in
 }
 
 extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows,
-                                  const float* weight, const float* bias, float* out, int64_t B,
+                                  const float* weight, const float* bias, float* out, uint8_t* route, int64_t B,
                                   int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t,
                                   int do_abs, int pool, float slope, int64_t out_sb, int64_t out_sl,
                                   void* out_planes, int64_t out_plane_stride,
@@ -322,7 +332,8 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
     SLU_CHECK_LAUNCH("bf_wconv_pack_kernel");
   }
   WconvBfParams p;
-  p.in = in; p.wp = wp; p.bias = bias; p.out = out;
+  p.in = in; p.wp = wp; p.bias = bias; p.out = out; p.route = route;
+  SLU_REQUIRE(!route || (out && !out_planes), "slu_wconv_fwd_bf16: route goes with the fp32 output");
   p.in_tab = in_table; p.tab_rows = (int)(in_table ? table_rows : 1);
   p.planes = (unsigned short*)out_planes; p.plane = out_plane_stride; p.Kp_out = (int)(cdiv(c_out, 32) * 32); p.Bn = (int)B;
   if (out_planes) {

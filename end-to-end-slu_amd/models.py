@@ -102,7 +102,8 @@ def contraction_nsplit(frozen):
       3  fp32 values as three bf16 terms, six bf16 MFMA products (fp32-class, csrc/slu_bf16.h) — FROZEN layers
          (default; SLU_FROZEN_MATH=fp32 switches it off);
       1  plain bf16 operands, fp32 accumulation and gate math — every layer when SLU_DTYPE=bf16
-         (BASELINE configs[4]: bf16 weights / activations; gradients stay fp32)."""
+         (BASELINE configs[4]: weights and activations enter every forward contraction and the data-gradient
+         contractions as bf16 — ops.bf16_mode; weight gradients, master weights and Adam stay fp32)."""
     if os.environ.get("SLU_DTYPE", "f32") == "bf16":
         return 1
     if frozen and os.environ.get("SLU_FROZEN_MATH", "bf16x3") != "fp32":
@@ -592,9 +593,9 @@ class _ConvStage:
         slope = self.slope if fused_pool else 1.0
         # FROZEN block with nothing to differentiate: the convolution on the split-precision kernels, outside
         # autograd (same decision in the pipelined and the sequential loop: it depends on requires_grad only)
+        # (a TRAINABLE block in bf16 mode takes bf16 operands inside ops.SincBlockFn / ConvBlockFn: forward on the bf16
+        # kernel with the route bits, fp32 backward)
         nsplit = contraction_nsplit(True) if not any(q.requires_grad for q in self.parameters()) else 0
-        if os.environ.get("SLU_DTYPE", "f32") == "bf16" and not nsplit:
-            nsplit = 0                                 # trainable convolutions stay exact fp32 in bf16 mode
         c_in = 1 if (self.is_sinc or h.dim() == 2) else h.shape[2]
         k_t = self.conv.Filt_dim if self.is_sinc else self.conv.kernel_size
         if (nsplit and fused_pool and not h.requires_grad

@@ -16,6 +16,14 @@ from . import lib as _lib
 METHODS = {"none": 0, "avg": 1, "max": 2}
 
 
+def bf16_mode():
+    """SLU_DTYPE=bf16 (BASELINE configs[4]): every forward contraction — convolutions, GRU input projections and
+    recurrences — and the data-gradient contractions of the backward pass take bf16 operands on
+    v_mfma_f32_16x16x32_bf16 with fp32 accumulation; weight gradients (k-major operands, up to 32 000-row reductions),
+    gate / loss math, master weights and Adam stay fp32."""
+    return os.environ.get("SLU_DTYPE", "f32") == "bf16"
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -307,12 +315,13 @@ def split_bf16(x2d, nsplit):
 
 
 def gemm_bf16_pack(w, nsplit):
-    """(N, K) fp32 weights -> bf16 planes in MFMA B-fragment order (opaque byte tensor)."""
+    """(N, K) fp32 weights — any strides, e.g. the .t() view of a weight — -> bf16 planes in MFMA B-fragment order
+    (opaque byte tensor)."""
     L = _lib.load()
     N, K = w.shape
-    assert w.dtype == torch.float32 and w.stride(1) == 1
+    assert w.dtype == torch.float32
     packed = torch.empty(L.slu_gemm_bf16_pack_bytes(N, K, nsplit), dtype=torch.uint8, device=w.device)
-    _lib.check(L.slu_gemm_bf16_pack(w.data_ptr(), w.stride(0), packed.data_ptr(), N, K, nsplit, _stream()),
+    _lib.check(L.slu_gemm_bf16_pack(w.data_ptr(), w.stride(0), w.stride(1), packed.data_ptr(), N, K, nsplit, _stream()),
                "slu_gemm_bf16_pack")
     return packed
 
@@ -383,7 +392,7 @@ def wconv_bf16_planes_ok(c_out, pool):
 
 
 def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit, out_planes=False,
-                   pack_cache=None):
+                   pack_cache=None, want_route=False):
     """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in).
     out_planes: return a SplitAct (time-major rows, bf16 planes) for the next frozen GRU layer instead of fp32.
     pack_cache: a dict of the caller's (one per frozen block and weight version): the packed filters are built by
@@ -403,7 +412,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
         assert time_major and wconv_bf16_planes_ok(c_out, pool)
         planes = torch.empty(nsplit, l_out * B, round_up(c_out, 32), dtype=torch.bfloat16, device=x.device)
         ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
-        _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, B, l_in, c_in, c_out,
+        _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, None, B, l_in, c_in, c_out,
                                         k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
                                         planes.stride(0), ws.data_ptr(), wsb, valid, nsplit, _stream()), "slu_wconv_fwd_bf16")
         return SplitAct(planes, l_out, B, c_out)
@@ -414,10 +423,11 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
         out = torch.empty(B, l_out, c_out, dtype=torch.float32, device=x.device)
         sb, sl = l_out * c_out, c_out
     ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
-    _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), out.data_ptr(), B, l_in, c_in, c_out,
-                                    k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
+    route = torch.empty(B, l_out, c_out, dtype=torch.uint8, device=x.device) if want_route else None
+    _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(route), B, l_in,
+                                    c_in, c_out, k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
                                     valid, nsplit, _stream()), "slu_wconv_fwd_bf16")
-    return out
+    return (out, route, l_conv) if want_route else out
 
 
 def _wconv_pack_ws(L, cache, c_out, c_in, k_t, nsplit, device):
@@ -748,8 +758,15 @@ class SincBlockFn(torch.autograd.Function):
         B, T = x.shape
         filters = sinc_filters(b1, band, filt_dim, fs)
         need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        out, route, l_conv = wconv_fwd(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, do_abs,
-                                       pool, slope, time_major, need and (do_abs or pool != 1))
+        if bf16_mode() and pool in (1, 2) and wconv_bf16_supported(1, stride, pool, filt_dim, 1):
+            # bf16 operands on the MFMA (waveform and filterbank rounded to bf16), the epilogue and the route bits as
+            # the fp32 kernel's; the backward below is the exact fp32 one on the saved fp32 input
+            res = wconv_fwd_bf16(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, do_abs, pool, slope, time_major, 1,
+                                 want_route=need and (do_abs or pool != 1))
+            out, route, l_conv = res if isinstance(res, tuple) else (res, None, conv_out_len(T, filt_dim, stride))
+        else:
+            out, route, l_conv = wconv_fwd(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, do_abs,
+                                           pool, slope, time_major, need and (do_abs or pool != 1))
         ctx.cfg = (B, T, filt_dim, fs, stride, pool, slope, time_major, l_conv, do_abs)
         if need:
             ctx.save_for_backward(x, b1, band, out, route)
@@ -775,8 +792,14 @@ class ConvBlockFn(torch.autograd.Function):
         B, l_in, c_in = x.shape
         x = x.contiguous()
         need_route = (pool != 1 or do_abs) and any(ctx.needs_input_grad[:3])
-        out, route, l_conv = wconv_fwd(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope,
-                                       time_major, need_route)
+        k_t = weight.shape[2]
+        if bf16_mode() and pool in (1, 2) and wconv_bf16_supported(c_in, stride, pool, k_t, 1) and weight.shape[0] <= 128:
+            res = wconv_fwd_bf16(x, weight.detach(), None if bias is None else bias.detach(), B, l_in, c_in, stride, do_abs,
+                                 pool, slope, time_major, 1, want_route=need_route)
+            out, route, l_conv = res if isinstance(res, tuple) else (res, None, conv_out_len(l_in, k_t, stride))
+        else:
+            out, route, l_conv = wconv_fwd(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope,
+                                           time_major, need_route)
         ctx.cfg = (B, l_in, c_in, stride, do_abs, pool, slope, time_major, l_conv)
         ctx.save_for_backward(x, weight, out, route)
         ctx.has_bias = bias is not None
@@ -799,9 +822,25 @@ class ConvBlockFn(torch.autograd.Function):
             if stride != 1:
                 raise NotImplementedError("data gradient of a strided Conv1d layer is not implemented "
                                           "(only the first CNN layer of the reference is strided)")
-            dx = wconv_bwd_data(d_conv, weight, B, l_in)
+            if bf16_mode() and wconv_bf16_supported(c_out, 1, 1, k_t, 1) and c_in <= 128:
+                # data gradient = the same windowed contraction with the filters transposed and reversed in time, on
+                # bf16 operands (the flip / transpose is a 72 KB copy)
+                w_t = weight.detach().transpose(0, 1).flip(2).contiguous()
+                dx = wconv_fwd_bf16(d_conv, w_t, None, B, l_conv, c_out, 1, False, 1, 1.0, False, 1)
+            else:
+                dx = wconv_bwd_data(d_conv, weight, B, l_in)
         _Fork.join(dev)
         return dx, dW, db, None, None, None, None, None
+
+
+def _gru_dx(g2, w_ih, T, B, I, H, D):
+    """dx = d_gx W_ih (K = D * 3H): exact fp32 MFMA, or — bf16 mode, I a multiple of 64 — bf16 operands on the
+    split-precision GEMM (d_gx rounded to bf16 planes, W_ih^T packed in fragment order in place)."""
+    if bf16_mode() and I % 64 == 0 and split_path_supported(H, D):
+        planes = split_bf16(g2, 1)
+        packed = gemm_bf16_pack(w_ih.t(), 1)                # (N = I, K = D*3H) view of the stacked weight
+        return gemm_bf16(planes, packed, None, I, D * 3 * H).view(T, B, I)
+    return gemm(g2, w_ih).view(T, B, I)
 
 
 class GRULayerFn(torch.autograd.Function):
@@ -895,7 +934,7 @@ class GRULayerFn(torch.autograd.Function):
                 if ng[8 + 2 * d]:
                     grads[8 + 2 * d] = dbp[d, 3 * H:]
             if ng[0]:
-                grads[0] = gemm(g2, w_ih).view(T, B, I)
+                grads[0] = _gru_dx(g2, w_ih, T, B, I, H, D)
             if ng[5]:
                 grads[5] = dbp[0, :3 * H]
             if D == 2 and ng[6]:
@@ -929,7 +968,7 @@ class GRULayerFn(torch.autograd.Function):
             if ng[bpos]:
                 grads[bpos] = dbp[d, 3 * H:]
         if ng[0]:                                          # dx = d_gx W_ih (both directions, K = D*3H)
-            grads[0] = gemm(g2, w_ih).view(T, B, I)
+            grads[0] = _gru_dx(g2, w_ih, T, B, I, H, D)
         if ng[5]:
             grads[5] = dbp[0, :3 * H]
         if D == 2 and ng[6]:

@@ -154,7 +154,8 @@ int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t 
 int slu_split_bf16(const float* x, int64_t ldx, void* planes, int64_t plane_stride, int64_t rows, int64_t K,
                    int nsplit, void* stream);
 size_t slu_gemm_bf16_pack_bytes(int64_t N, int64_t K, int nsplit);
-int slu_gemm_bf16_pack(const float* W, int64_t ldw, void* packed, int64_t N, int64_t K, int nsplit, void* stream);
+int slu_gemm_bf16_pack(const float* W, int64_t ldw, int64_t w_cs, void* packed, int64_t N, int64_t K, int nsplit,
+                       void* stream);      /* W[n][k] at W + n * ldw + k * w_cs: a weight or its transpose, in place */
 int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, const void* w_packed,
                   const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int nsplit,
                   void* stream);
@@ -167,11 +168,13 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
  * in_table != NULL: a DEVICE array of ceil(B / table_rows) base pointers; batch row b is read from
  * in_table[b / table_rows] + (b % table_rows) * l_in * c_in instead of in + b * l_in * c_in — a look-ahead super-batch
  * reads its batches where they lie instead of a concatenated copy (`in` is then ignored).
+ * route (NULL, or as slu_wconv_fwd's, with the fp32 `out`): the block is TRAINABLE and runs its forward on bf16
+ * operands (nsplit = 1, BASELINE configs[4]); the backward is slu_wconv_bwd_act / _bwd_weight / _bwd_data as usual.
  * packed_valid != 0: `workspace` still holds the filter pack a previous call built from these very weights (a frozen
  * block: the caller keeps the workspace per weight version) — the pack launch is skipped.                           */
 size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t, int nsplit);
 int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows, const float* weight,
-                       const float* bias, float* out, int64_t B,
+                       const float* bias, float* out, uint8_t* route, int64_t B,
                        int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t, int do_abs,
                        int pool, float slope, int64_t out_sb, int64_t out_sl, void* out_planes,
                        int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,

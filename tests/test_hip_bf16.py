@@ -123,6 +123,103 @@ def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):
     assert total >= 0.97 and worst >= 0.9                      # bounds set empirically (measured 0.985 / 0.963)
 
 
+def test_bf16_mode_at_configs4_shape_vs_fp32_oracle(tmp_path, monkeypatch):
+    """BASELINE configs[4] at ITS shape: 10 s utterances (GRU lengths 1000 / 500 / 250 / 125 / 63), B = 32 per GPU, every
+    layer trainable (unfreeze_all_layers end state), SLU_DTYPE=bf16 — bf16 operands in every forward contraction
+    (Sinc / conv blocks, input projections, recurrences) and in the data-gradient contractions, fp32 accumulation, gate
+    math, weight gradients.  The reference is fp32 only (models.py:190-286), so the yardstick is the fp32 oracle with
+    the same dropout masks: predicted intents identical, eval logits / train loss within the bound bf16's 2^-9 operand
+    rounding gives over 1000 recurrent steps (measured, printed), gradients pointing the same way tensor by tensor."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import slu_oracle as O
+    import data
+    import models
+    from slu_hip import ops as _ops
+    cfg = O.OracleConfig(pretraining_type=0)
+    cfg.folder = str(tmp_path)
+    cfg.starting_unfreezing_index = 1
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    torch.manual_seed(6)
+    monkeypatch.setenv("SLU_DTYPE", "bf16")
+    assert _ops.bf16_mode()
+    model = models.Model(cfg)
+    sd = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    B, T = 32, 160000
+    x = 0.1 * torch.randn(B, T, generator=g)
+    y = torch.stack([torch.randint(0, n, (B,), generator=g) for n in cfg.values_per_slot], dim=1)
+    masks = O.draw_dropout_masks(cfg, x, seed=22)
+    models.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
+    calls = {"conv_bf16": 0, "gemm_bf16": 0}
+    real_conv, real_gemm = _ops.wconv_fwd_bf16, _ops.gemm_bf16
+    monkeypatch.setattr(_ops, "wconv_fwd_bf16", lambda *a, **k: (calls.__setitem__("conv_bf16", calls["conv_bf16"] + 1), real_conv(*a, **k))[1])
+    monkeypatch.setattr(_ops, "gemm_bf16", lambda *a, **k: (calls.__setitem__("gemm_bf16", calls["gemm_bf16"] + 1), real_gemm(*a, **k))[1])
+    try:
+        model.train()
+        loss, acc = model(x, y)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        models.set_dropout_masks(None)
+    # 3 conv forwards + 2 conv data gradients; 5 input projections + 4 GRU data gradients (I = 256; the first layer's I = 60 stays fp32)
+    assert calls == {"conv_bf16": 5, "gemm_bf16": 9}, calls
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    rloss, racc, rlogits, rpred = O.slu_forward(sd, x, y, cfg, masks, explicit_gru=False)
+    rloss.backward()
+    model.eval()
+    with torch.no_grad():
+        logits, pred = model.predict_intents(x)
+        _, _, elogits, epred = O.slu_forward({k: v.detach() for k, v in sd.items()}, x, y, cfg, None, explicit_gru=False)
+    dev = (logits.cpu() - elogits).abs().max().item()
+    margin = torch.stack([t.topk(2)[0] for t in elogits.split(cfg.values_per_slot, dim=1)], 0)
+    margin = (margin[..., 0] - margin[..., 1]).min().item()
+    print("bf16 mode, 32 x 10 s: eval logits max-abs deviation vs fp32 oracle %.3e (logit range %.2f, smallest top-2 margin %.3e); "
+          "train loss %.5f vs %.5f" % (dev, elogits.abs().max().item(), margin, loss.item(), rloss.item()))
+    assert (pred.cpu() != epred).sum().item() == 0 or dev >= 0.5 * margin       # a decision may only move where the margin is inside the bf16 error
+    assert dev <= 3e-2 and abs(loss.item() - rloss.item()) <= 3e-2
+    worst, worst_name, dots, na, nb = 1.0, "", 0.0, 0.0, 0.0
+    for k, p in model.named_parameters():
+        if sd[k].grad is None or p.grad is None:
+            continue
+        a, b = p.grad.cpu().double().flatten(), sd[k].grad.double().flatten()
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        if cos < worst:
+            worst, worst_name = cos, k
+        dots, na, nb = dots + (a @ b).item(), na + (a @ a).item(), nb + (b @ b).item()
+    total = dots / (na ** 0.5 * nb ** 0.5)
+    print("bf16 mode, 32 x 10 s: gradient cosine vs fp32 oracle: whole model %.5f, worst tensor %.5f (%s)" % (total, worst, worst_name))
+    assert total >= 0.97 and worst >= 0.85
+
+
+@pytest.mark.parametrize("case", ["sinc", "conv1"])
+def test_wconv_bf16_route_equals_fp32_kernel(ops, case):
+    """The route bits (pool pick, sign) the bf16 convolution kernel writes for TRAINABLE blocks in bf16 mode equal the
+    exact kernel's wherever the two forward results agree on the decision (pre-activations further than the bf16
+    error from a tie / from zero): the backward (slu_wconv_bwd_act) reads them."""
+    torch.manual_seed(5)
+    if case == "sinc":
+        B, l_in, c_in, c_out, k, stride, do_abs, pool = 4, 15930, 1, 80, 401, 80, True, 2
+        x = (0.1 * torch.randn(B, l_in)).cuda()
+        w = (torch.randn(c_out, 1, k) * 0.05).cuda()
+        bias = None
+    else:
+        B, l_in, c_in, c_out, k, stride, do_abs, pool = 5, 301, 80, 60, 5, 1, False, 1
+        x = torch.randn(B, l_in, c_in).abs().cuda()
+        w = (torch.randn(c_out, c_in, k) * 0.05).cuda()
+        bias = (torch.randn(c_out) * 0.1).cuda()
+    ref, route_ref, l_conv = ops.wconv_fwd(x, w, bias, B, l_in, c_in, stride, do_abs, pool, 0.2, False, True)
+    out, route, l_conv2 = ops.wconv_fwd_bf16(x, w, bias, B, l_in, c_in, stride, do_abs, pool, 0.2, False, 1, want_route=True)
+    torch.cuda.synchronize()
+    assert l_conv == l_conv2 and route.shape == route_ref.shape and route.dtype == torch.uint8
+    agree = (route == route_ref).float().mean().item()
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    print("wconv bf16 route (%s): %.3f %% of the route bytes equal the exact kernel's; output deviation %.2e of the range" % (case, 100 * agree, err))
+    assert agree >= 0.97 and err <= 2e-2
+    # the exact-fp32 backward accepts the bf16 forward's (out, route)
+    d = ops.wconv_bwd_act(torch.ones_like(out), out, route, B, l_conv, c_out, do_abs, pool, 0.2, False)
+    assert torch.isfinite(d).all() and tuple(d.shape) == (B, l_conv, c_out)
+
+
 @pytest.mark.parametrize("case", ["sinc", "sinc_odd", "conv1", "conv2", "conv2_tm"])
 @pytest.mark.parametrize("nsplit", [3, 1])
 def test_wconv_bf16_vs_exact_fp32_kernel(ops, case, nsplit):
