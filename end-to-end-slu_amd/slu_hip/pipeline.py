@@ -89,6 +89,10 @@ class PrefixSlot:
         self.consumed = None       # event: the main stream is done with this slot's last output
         self.signature = None      # versions of the frozen parameters the graphs were captured with
         self.capture_failures = 0
+        # host batches: their H2D copies run on a stream of their own, AHEAD of the compute (which is serialised
+        # behind the previous super-batch): the copy of super-batch n + 1 overlaps the kernels of super-batch n
+        self.copy_stream = torch.cuda.Stream(device)
+        self.last_done = None      # event: this slot's previous super-batch has finished (its static input is free)
 
     def invalidate(self):
         self.graphs = {}
@@ -102,10 +106,11 @@ class PrefixSlot:
         was tried: its kernels are latency-bound at that size, 2.85 ms either way.)
         Returns (features of the concatenated batch, event recorded when they are complete)."""
         B, T = xs[0].shape
+        host = not all(x.is_cuda for x in xs)
         with torch.cuda.stream(self.stream):
             if self.consumed is not None:
                 self.stream.wait_event(self.consumed)
-            if after is not None:
+            if after is not None and not host:
                 self.stream.wait_event(after)
             feats = None
             if use_graph:
@@ -124,16 +129,35 @@ class PrefixSlot:
                         # offset (adjacent words of one buffer) in ONE launch instead of one copy per batch
                         ops.store_u64(self.words, [x.data_ptr() for x in xs] + [0] * (self.MAX_TABLE - len(xs)) + [step0 * 16])
                     else:
-                        self._fill(x_static, xs)
+                        self._copy_in(x_static, xs, host, after)
                         self.rng.fill_(step0 * 16)
                     graph.replay()
             if feats is None:
                 x_cat = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
-                self._fill(x_cat, xs)
+                self._copy_in(x_cat, xs, host, after)
                 feats = model.prefix_features(x_cat, n_prefix, step0, sub_batch=B if len(xs) > 1 else 0)
             done = torch.cuda.Event()
             done.record(self.stream)
+            self.last_done = done
         return feats, done
+
+    def _copy_in(self, dst, xs, host, after):
+        """Fill the super-batch's input.  Device batches: plain copies on this slot's stream.  Host (pinned) batches: on
+        the copy stream, as soon as this slot's previous super-batch has released the buffer — not behind `after`
+        (the OTHER slot's super-batch, which is computing right now); the compute then waits for the copy and `after`."""
+        if not host:
+            self._fill(dst, xs)
+            return
+        cs = self.copy_stream
+        cs.wait_stream(self.stream)                  # dst's allocation / the consumed-wait enqueued so far
+        if self.last_done is not None:
+            cs.wait_event(self.last_done)
+        with torch.cuda.stream(cs):
+            self._fill(dst, xs)
+        dst.record_stream(cs)
+        self.stream.wait_stream(cs)
+        if after is not None:
+            self.stream.wait_event(after)
 
     @staticmethod
     def _fill(x_cat, xs):

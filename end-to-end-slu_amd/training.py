@@ -451,7 +451,11 @@ class Trainer:
             feats, done = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
                                    after=last_done[0])
             last_done[0] = done
-            pending.append((group, feats, done, steps, slot))
+            # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
+            # versions, so that a loader that recycles its device buffers is caught instead of silently training on
+            # whatever the buffer holds by then (batches must stay unchanged until consumed)
+            versions = [b[0]._version if b[0].is_cuda else None for b in group]
+            pending.append((group, feats, done, steps, slot, versions))
             return True
 
         # The consumer's per-step work (metric accumulation in _run) runs with `main` as the current
@@ -462,7 +466,13 @@ class Trainer:
                 for _ in self._slots:
                     launch_next()
                 while pending:
-                    group, feats_cat, done, steps, slot = pending.popleft()
+                    group, feats_cat, done, steps, slot, versions = pending.popleft()
+                    for b, v in zip(group, versions):
+                        if v is not None and b[0]._version != v:
+                            raise RuntimeError(
+                                "a device-resident input batch was modified in place while its look-ahead super-batch was "
+                                "still reading it (the loader recycles device buffers): hand over fresh tensors per batch, "
+                                "host batches, or set SLU_ROW_TABLE=0 / SLU_LOOKAHEAD=0")
                     B = group[0][0].shape[0]
                     for k, batch in enumerate(group):
                         if k == 0:

@@ -376,3 +376,60 @@ def test_bucketed_real_data_forms_super_batches(tmp_path, monkeypatch):
     assert results["0"][0] == results["3"][0]
     for k, v in results["0"][1].items():
         assert torch.equal(v, results["3"][1][k]), k
+
+
+def test_host_batches_and_recycled_device_buffers_in_the_lookahead_pipeline(tmp_path, monkeypatch):
+    """(1) Pinned HOST batches (a CPU DataLoader: reference models.py:351-352 moves each batch inside the step) go
+    through the look-ahead pipeline with their H2D copies on the slots' copy streams and give the device-resident
+    run's losses bit for bit.  (2) A loader that RECYCLES a device buffer (overwrites a batch tensor in place while its
+    super-batch may still be reading it through the row-pointer table) is detected and refused, not trained on."""
+    sys.path.insert(0, PKG)
+    import data
+    import models
+    import training
+    cfg = O.OracleConfig(cnn_N_filt=[16, 12, 12], cnn_len_filt=[101, 5, 5], cnn_stride=[20, 1, 1],
+                         phone_rnn_num_hidden=[32, 32], word_rnn_num_hidden=[32, 32],
+                         intent_rnn_num_hidden=[32], vocabulary_size=60, num_phonemes=20, pretraining_type=2)
+    cfg.folder = str(tmp_path)
+    cfg.training_lr = 0.003
+    cfg.starting_unfreezing_index = 1
+    cfg.unfreezing_type = 0
+    cfg.Sy_intent = data.synthetic_Sy_intent(cfg.values_per_slot)
+    os.makedirs(tmp_path / "pretraining")
+    os.makedirs(tmp_path / "training")
+    torch.manual_seed(1)
+    torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
+    ds = data.SyntheticSLUDataset(3, 8, 6000, cfg.values_per_slot, seed=5)
+    monkeypatch.setenv("SLU_LOOKAHEAD", "3")
+
+    def run(loader):
+        torch.manual_seed(2)
+        model = models.Model(cfg)
+        models.set_dropout_seed(7)
+        trainer = training.Trainer(model, cfg)
+        model.train()
+        losses = [float(v[0]) for v, _ in trainer._iterate(loader, True, False)]
+        torch.cuda.synchronize()
+        return losses
+
+    dev = [tuple(t.cuda() for t in b) for b in ds.batches]
+    host = [tuple(t.pin_memory() for t in b) for b in ds.batches]
+    order = [i % 3 for i in range(15)]
+    want = run([dev[i] for i in order])
+    assert run([host[i] for i in order]) == want
+
+    class Recycling:
+        """yields the SAME device tensor for every batch, refilled in place"""
+        def __init__(self):
+            self.buf = torch.empty_like(dev[0][0])
+
+        def __len__(self):
+            return len(order)
+
+        def __iter__(self):
+            for i in order:
+                self.buf.copy_(dev[i][0])
+                yield self.buf, dev[i][1]
+
+    with pytest.raises(RuntimeError, match="modified in place"):
+        run(Recycling())
