@@ -427,6 +427,8 @@ class Trainer:
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
             nonlocal launched
             group = [carry.pop()] if carry else []
+            ver = lambda b: b[0]._version if b[0].is_cuda else None
+            versions = [ver(b) for b in group]                 # tensor version of every batch WHEN IT WAS READ
             cap = [1 << 30]
 
             def width():
@@ -443,6 +445,7 @@ class Trainer:
                     carry.append(batch)
                     break
                 group.append(batch)
+                versions.append(ver(batch))
             if not group:
                 return False
             slot = self._slots[launched % len(self._slots)]
@@ -454,7 +457,6 @@ class Trainer:
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on
             # whatever the buffer holds by then (batches must stay unchanged until consumed)
-            versions = [b[0]._version if b[0].is_cuda else None for b in group]
             pending.append((group, feats, done, steps, slot, versions))
             return True
 
