@@ -45,12 +45,14 @@ BATCH = 64
 SECONDS = 3
 FS = 16000
 CFG = {"no_unfreezing": "no_unfreezing_synthetic.cfg", "unfreeze_all": "unfreeze_all_layers_synthetic.cfg",
-       "asr_pretrain": "unfreeze_all_layers_synthetic.cfg"}
+       "asr_pretrain": "unfreeze_all_layers_synthetic.cfg", "seq2seq": "seq2seq_synthetic.cfg"}
 WORKLOAD_TEXT = {
     "no_unfreezing": "experiments/no_unfreezing.cfg SLU train step (frozen SincNet/conv/biGRU encoder in train "
                      "mode + intent biGRU trained): fwd + 3-slot CE + bwd + grad all-reduce + Adam",
     "unfreeze_all": "SLU train step with every encoder layer unfrozen (unfreeze_all_layers end state): fwd + CE "
                     "+ full bwd + grad all-reduce + Adam",
+    "seq2seq": "seq2seq SLU train step (experiments/all_real_seq2seq.cfg sizes: frozen encoder + intent biGRU encoder 128 + "
+               "2-layer attention decoder 256 over ~35 output characters, 24 teacher-forced steps): fwd + loss + bwd + Adam",
     "asr_pretrain": "ASR pre-training step of the full PretrainedModel (BASELINE configs[2]): fwd + phoneme/word "
                     "CE heads (vocabulary 10 000) + full bwd + grad all-reduce + Adam"}
 
@@ -781,7 +783,7 @@ def main():
         if default_line:
             note("host-input point")
             out["host_inputs"] = host_inputs_point(model, trainer, batches, max(args.steps, 256), asr)
-        if world == 1 and not args.no_cpu_baseline and not asr:
+        if world == 1 and not args.no_cpu_baseline and not asr and args.workload != "seq2seq":
             note("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)
         if default_line:
@@ -792,7 +794,7 @@ def main():
             common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--seconds", str(args.seconds)]
             out["exact_fp32"] = side_run(common, {"SLU_FROZEN_MATH": "fp32"})
             short = ["--steps", "40", "--warmup", "10", "--batch", str(args.batch), "--seconds", str(args.seconds)]
-            out["other_workloads"] = {w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain")}
+            out["other_workloads"] = {w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain", "seq2seq")}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

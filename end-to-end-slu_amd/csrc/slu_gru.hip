@@ -16,6 +16,7 @@
 //     step ahead.
 // The backward kernel mirrors this with W_hh consumed transposed (dh_{t-1} += dG W_hh).
 #include "slu_common.h"
+#include <stdlib.h>
 #include <cstdlib>
 
 namespace slu {
@@ -37,7 +38,15 @@ struct GruFwdParams {
   float* out;             // (T, B, D*H)
   float* reserve;         // [D][T][NBT][NW][5][64][4] or null
   int T, B, D;
+#ifdef SLU_GRU_PROBE
+  int dbg;                // ablation mask of the probe build (tools/gru_probe.py): never compiled into the product
+#endif
 };
+#ifdef SLU_GRU_PROBE
+#define SLU_DBG(bit) (p.dbg & (bit))
+#else
+#define SLU_DBG(bit) 0
+#endif
 
 template <int H>
 __global__ void __launch_bounds__(H * 4)
@@ -235,7 +244,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     float ngr[2], ngz[2], ngn[2];
-    if (s + 1 < T) {
+    if (s + 1 < T && !SLU_DBG(1)) {
       const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -257,6 +266,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
       }
     }
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
+    if (!SLU_DBG(16))
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int kb = (q / 4) * 32 + (q % 4);
@@ -283,19 +293,24 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     float rr[2], zz[2], nn[2], qq[2], hn[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
+      if (SLU_DBG(8)) {      // probe: gate math without the transcendentals
+        rr[e] = 0.5f + 0.01f * (gr[e] + (hr[e] + bhr)); zz[e] = 0.5f + 0.01f * (gz[e] + (hz[e] + bhz));
+        qq[e] = hq[e] + bhn; nn[e] = 0.01f * (gn[e] + rr[e] * qq[e]);
+      } else {
       rr[e] = act_sigmoid(gr[e] + (hr[e] + bhr));
       zz[e] = act_sigmoid(gz[e] + (hz[e] + bhz));
       qq[e] = hq[e] + bhn;
       nn[e] = act_tanh(gn[e] + rr[e] * qq[e]);
+      }
       hn[e] = (1.0f - zz[e]) * nn[e] + zz[e] * hprev[e];
     }
     float* __restrict__ hnext = &hbuf[cur ^ 1][0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       hnext[(2 * half + e) * LD + j] = hn[e];
-      if (rowok[e]) outd[(size_t)t * out_ts + grow[e] * D * H] = hn[e];
+      if (rowok[e] && !SLU_DBG(2)) outd[(size_t)t * out_ts + grow[e] * D * H] = hn[e];
     }
-    if (p.reserve) {
+    if (p.reserve && !SLU_DBG(4)) {
       float* __restrict__ rs = p.reserve + ((((size_t)dir * T + t) * NBT16) * NW16 + rsv_wave) * (5 * 256) + rsv_lane;
       *reinterpret_cast<float2*>(rs + 0 * 256) = make_float2(rr[0], rr[1]);
       *reinterpret_cast<float2*>(rs + 1 * 256) = make_float2(zz[0], zz[1]);
@@ -713,6 +728,9 @@ extern "C" int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const flo
   GruFwdParams p;
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
   p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+#ifdef SLU_GRU_PROBE
+  { const char* e = getenv("SLU_GRU_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (!gru_persistent(H)) return gru_step_fwd(gx, p.w_hh, p.b_hh, out, reserve, T, B, H, D, st);
   if (gru_use_seq4(B, H, D)) {

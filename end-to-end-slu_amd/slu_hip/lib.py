@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libslu_hip.so")
+# SLU_HIP_LIB: another build of the same ABI (the probe build of tools/gru_probe.py); the product never sets it
+LIB_PATH = os.environ.get("SLU_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libslu_hip.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int
