@@ -89,9 +89,21 @@ class PrefixSlot:
         self.consumed = None       # event: the main stream is done with this slot's last output
         self.signature = None      # versions of the frozen parameters the graphs were captured with
         self.capture_failures = 0
-        # host batches: their H2D copies run on a stream of their own, AHEAD of the compute (which is serialised
-        # behind the previous super-batch): the copy of super-batch n + 1 overlaps the kernels of super-batch n
-        self.copy_stream = torch.cuda.Stream(device)
+        # host batches: optionally their H2D copies run on a stream of their own, AHEAD of the compute (which is
+        # serialised behind the previous super-batch): the copy of super-batch n + 1 overlaps the kernels of super-batch n
+        # Measured (tools/host_inputs_probe.py, round 3): OFF by default.  With the copies on a stream of their own the
+        # H2D rate drops to ~17 GB/s while the other slot's kernels run (33 GB/s on an idle device), and the loop gets
+        # SLOWER (0.73 vs 0.56 ms/step; any CU mask for the copy stream: 16 / 32 / 160 CUs or none) than with the copies
+        # serialised on the slot's own stream — the host-input path is PCIe-bound either way.  SLU_COPY_CUS=n > 0 enables
+        # the separate copy stream on the top n CUs of the look-ahead partition (>= its size: unmasked).
+        n_copy = int(os.environ.get("SLU_COPY_CUS", "0"))
+        total = n_compute_units(device)
+        if n_copy <= 0:
+            self.copy_stream = None
+        elif n > 0 and n_copy < total - n:
+            self.copy_stream = cu_range_stream(device, total - n_copy, n_copy)
+        else:
+            self.copy_stream = torch.cuda.Stream(device)
         self.last_done = None      # event: this slot's previous super-batch has finished (its static input is free)
 
     def invalidate(self):
@@ -145,7 +157,9 @@ class PrefixSlot:
         """Fill the super-batch's input.  Device batches: plain copies on this slot's stream.  Host (pinned) batches: on
         the copy stream, as soon as this slot's previous super-batch has released the buffer — not behind `after`
         (the OTHER slot's super-batch, which is computing right now); the compute then waits for the copy and `after`."""
-        if not host:
+        if not host or self.copy_stream is None:
+            if host and after is not None:
+                self.stream.wait_event(after)
             self._fill(dst, xs)
             return
         cs = self.copy_stream

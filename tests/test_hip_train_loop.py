@@ -417,6 +417,9 @@ def test_host_batches_and_recycled_device_buffers_in_the_lookahead_pipeline(tmp_
     order = [i % 3 for i in range(15)]
     want = run([dev[i] for i in order])
     assert run([host[i] for i in order]) == want
+    monkeypatch.setenv("SLU_COPY_CUS", "16")                 # the opt-in separate copy stream (CU-masked)
+    assert run([host[i] for i in order]) == want
+    monkeypatch.delenv("SLU_COPY_CUS")
 
     class Recycling:
         """yields the SAME device tensor for every batch, refilled in place"""
