@@ -269,8 +269,18 @@ colsum_kernel(const float* __restrict__ X, long long rs, float* __restrict__ out
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
   float s = 0.0f;
-  if (n < N)
-    for (int m = w; m < M; m += 4) s += X[(long long)m * rs + n];
+  if (n < N) {
+    // eight independent partial sums per thread: eight loads in flight instead of one dependent load per iteration
+    // (a 1536-row sum took 70 us as a 384-step chain of L2 round trips); fixed order, deterministic
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int m = w;
+    for (; m + 28 < M; m += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += X[(long long)(m + 4 * u) * rs + n];
+    }
+    for (; m < M; m += 4) a[0] += X[(long long)m * rs + n];
+    s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
   red[w][lane] = s;
   __syncthreads();
   if (w == 0 && n < N) {

@@ -1047,13 +1047,17 @@ def decoder_step(P, keys, values, state_prev, state_next, y_prev, q, inp0, att_w
     """One decoding step (models.py:528-536) on the HIP kernels, shared by the teacher-forced forward and the beam
     search: attention on the top layer's state, embedding of the previous label, the GRUCell stack (+ dropout between
     the cells), output logits.  P: parameter dict (detached tensors); state_* (B, L, Dd); save / drop: per-layer
-    buffers or None (inference); drop_cfg = (p, masks or None, seed, offset, offset_dev, B * Dd)."""
+    buffers or None (inference); drop_cfg = (p, masks or None, seed, offset, offset_dev, B * Dd).
+    y_prev None: the embedding half of inp0 is already filled; logits None: the caller computes them later (teacher
+    forcing knows every input label up front and needs the logits only after the loop: both become ONE GEMM over all
+    steps instead of one small launch per step)."""
     Lc, Dd = state_prev.shape[1], state_prev.shape[2]
     E = P["embed.weight"].shape[0]
     p, masks, seed, offset, offset_dev, bd = drop_cfg
     gemm(state_prev[:, Lc - 1], P["query.weight"].t(), P["query.bias"], out=q)
     attention_fwd(keys, values, q, inp0[:, E:], att_w, P["inv_scale"])
-    gemm(y_prev, P["embed.weight"].t(), P["embed.bias"], out=inp0[:, :E])
+    if y_prev is not None:
+        gemm(y_prev, P["embed.weight"].t(), P["embed.bias"], out=inp0[:, :E])
     x_in = inp0
     for l in range(Lc):
         gemm(x_in, P["w_ih%d" % l].t(), P["b_ih%d" % l], out=gi)
@@ -1065,7 +1069,8 @@ def decoder_step(P, keys, values, state_prev, state_next, y_prev, q, inp0, att_w
                      (step * Lc + l) * bd)
         if not last:
             x_in = drop[l]
-    gemm(state_next[:, Lc - 1], P["linear.weight"].t(), P["linear.bias"], out=logits)
+    if logits is not None:
+        gemm(state_next[:, Lc - 1], P["linear.weight"].t(), P["linear.bias"], out=logits)
 
 
 class Seq2SeqDecoderFn(torch.autograd.Function):
@@ -1095,11 +1100,11 @@ class Seq2SeqDecoderFn(torch.autograd.Function):
         values = gemm(enc2, P["value.weight"].t(), P["value.bias"]).view(T, B, Vd)
         state = f(U + 1, B, Lc, Dd)
         broadcast_rows(P["initial_state"].contiguous().view(-1), state[0].view(B, Lc * Dd))
-        yprev = f(U, B, V)                                   # the label fed at step u: <sos>, then y[:, u - 1]
-        yprev[0].zero_()
-        yprev[0, :, SOS] = 1.0
-        if U > 1:
-            yprev[1:].copy_(y[:, :U - 1].transpose(0, 1))
+        ycat = f(U + 1, B, V)                                # time-major labels behind a <sos> row:
+        ycat[0].zero_()                                      #   yprev[u] = ycat[u]     = the label fed at step u
+        ycat[0, :, SOS] = 1.0                                #   y_tm[u]  = ycat[u + 1] = the label scored at step u
+        ycat[1:].copy_(y.transpose(0, 1))
+        yprev, y_tm = ycat[:U], ycat[1:]
         q, att_w, inp0 = f(U, B, Kd), f(U, B, T), f(U, B, E + Vd)
         save = f(U, Lc, 4, B, Dd)
         drop = f(max(Lc - 1, 1), U, B, Dd)
@@ -1107,15 +1112,23 @@ class Seq2SeqDecoderFn(torch.autograd.Function):
         logp = torch.zeros(B, dtype=torch.float32, device=dev)
         gi, gh = f(B, 3 * Dd), f(B, 3 * Dd)
         dcfg = (p, masks, seed, offset, offset_dev, B * Dd)
+        # teacher forcing: the embeddings of ALL steps' input labels in one GEMM (rows (u, b)), straight into inp0
+        gemm(yprev.view(U * B, V), P["embed.weight"].t(), P["embed.bias"], out=inp0.view(U * B, E + Vd)[:, :E])
         for u in range(U):
-            decoder_step(P, keys, values, state[u], state[u + 1], yprev[u], q[u], inp0[u], att_w[u], gi, gh, save[u],
-                         [drop[l][u] for l in range(Lc - 1)], logits[u], u, dcfg)
-            logsoftmax_dot_fwd(logits[u], y[:, u], logp, lse[u])
+            decoder_step(P, keys, values, state[u], state[u + 1], None, q[u], inp0[u], att_w[u], gi, gh, save[u],
+                         [drop[l][u] for l in range(Lc - 1)], None, u, dcfg)
+        # ... and the output layer of all steps in one GEMM over the state history; the per-step scores are then added
+        # in step order (the reference's running sum, models.py:540)
+        top = slice((Lc - 1) * Dd, Lc * Dd)
+        gemm(state[1:].view(U * B, Lc * Dd)[:, top], P["linear.weight"].t(), P["linear.bias"], out=logits.view(U * B, V))
+        lp = torch.zeros(U, B, dtype=torch.float32, device=dev)               # log p(y_u | ...) of every (step, utterance)
+        logsoftmax_dot_fwd(logits.view(U * B, V), y_tm.reshape(U * B, V), lp.view(-1), lse.view(-1))
+        colsum(lp, out=logp)                                                  # log p(y | x) = sum over the steps
         loss_acc = torch.zeros(2, dtype=torch.float32, device=dev)
         L = _lib.load()
         _lib.check(L.slu_neg_mean_f32(logp.data_ptr(), loss_acc.data_ptr(), B, _stream()), "slu_neg_mean_f32")
         ctx.meta = (names, p, masks, seed, offset, offset_dev, (T, B, E2, U, V, Lc, Dd, E, Kd, Vd), P["inv_scale"])
-        ctx.save_for_backward(enc, y, yprev, keys, values, state, q, att_w, inp0, save, drop, logits, lse, *params)
+        ctx.save_for_backward(enc, ycat, yprev, keys, values, state, q, att_w, inp0, save, drop, logits, lse, *params)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(logp)
         return loss_acc, logp
@@ -1128,26 +1141,30 @@ class Seq2SeqDecoderFn(torch.autograd.Function):
         if d_loss_acc is None:
             return (None,) * (3 + n_par)
         saved = ctx.saved_tensors
-        enc, y, yprev, keys, values, state, q, att_w, inp0, save, drop, logits, lse = saved[:13]
+        enc, ycat, yprev, keys, values, state, q, att_w, inp0, save, drop, logits, lse = saved[:13]
+        y_tm = ycat[1:]
         P = {n: t.detach() for n, t in zip(names, saved[13:])}
         dev = enc.device
         L = _lib.load()
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         g = _f32c(d_loss_acc.float(), "d_loss")                       # (2): only [0] matters
-        dlogp = f(B)
-        _lib.check(L.slu_fill_scaled_f32(dlogp.data_ptr(), B, g.data_ptr(), -1.0 / B, _stream()), "slu_fill_scaled_f32")
+        dlogp = f(U * B)                                             # d loss / d log p(y_u | ...) = -g / B for every row
+        _lib.check(L.slu_fill_scaled_f32(dlogp.data_ptr(), U * B, g.data_ptr(), -1.0 / B, _stream()), "slu_fill_scaled_f32")
         d_state = torch.zeros(B, Lc, Dd, dtype=torch.float32, device=dev)
         d_keys, d_values = torch.zeros_like(keys), torch.zeros_like(values)
         d_gi, d_gh = f(Lc, U, B, 3 * Dd), f(Lc, U, B, 3 * Dd)
         d_logits, d_q, d_inp0 = f(U, B, V), f(U, B, Kd), f(U, B, E + Vd)
         d_x = f(B, Dd)                                              # gradient w.r.t. the dropped input of layer l + 1
+        # every step's d loss / d logits, and its way into the top layer's state, in ONE GEMM over all steps (the loop then
+        # adds slice u where the reference's graph adds it: as an extra gradient of the top cell's output at step u)
+        logsoftmax_dot_bwd(logits.view(U * B, V), y_tm.reshape(U * B, V), lse.view(-1), dlogp, d_logits.view(U * B, V))
+        g_top = gemm(d_logits.view(U * B, V), P["linear.weight"]).view(U, B, Dd)
         for u in range(U - 1, -1, -1):
-            logsoftmax_dot_bwd(logits[u], y[:, u], lse[u], dlogp, d_logits[u])
-            gemm(d_logits[u], P["linear.weight"], out=d_state[:, Lc - 1], accumulate=True)
             for l in range(Lc - 1, -1, -1):
                 last = l == Lc - 1
                 mask = None if (masks is None or last) else masks["decoder_dropout_u%d_l%d" % (u, l)]
-                gru_cell_bwd(d_state[:, l], None if last else d_x, save[u, l], state[u][:, l], d_gi[l, u], d_gh[l, u],
+                # top cell: d_drop = this step's logits gradient (keep-factor 1: there is no dropout after the last cell)
+                gru_cell_bwd(d_state[:, l], g_top[u] if last else d_x, save[u, l], state[u][:, l], d_gi[l, u], d_gh[l, u],
                              d_state[:, l], mask, 0.0 if last else p, seed, offset, offset_dev, (u * Lc + l) * B * Dd)
                 gemm(d_gh[l, u], P["w_hh%d" % l], out=d_state[:, l], accumulate=True)
                 gemm(d_gi[l, u], P["w_ih%d" % l], out=d_x if l > 0 else d_inp0[u])
