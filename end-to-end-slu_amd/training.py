@@ -473,8 +473,8 @@ class Trainer:
                         if v is not None and b[0]._version != v:
                             raise RuntimeError(
                                 "a device-resident input batch was modified in place while its look-ahead super-batch was "
-                                "still reading it (the loader recycles device buffers): hand over fresh tensors per batch, "
-                                "host batches, or set SLU_ROW_TABLE=0 / SLU_LOOKAHEAD=0")
+                                "still reading it (the loader recycles device buffers): hand over fresh tensors per batch or "
+                                "host batches, or set SLU_LOOKAHEAD=0")
                     B = group[0][0].shape[0]
                     for k, batch in enumerate(group):
                         if k == 0:
