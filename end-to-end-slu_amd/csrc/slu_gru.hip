@@ -257,7 +257,10 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     }
 
     float af[NQ];
-    {
+    if (SLU_DBG(32 | 64)) {       // probe: no LDS read (values from registers: wrong results, timing only)
+#pragma unroll
+      for (int v = 0; v < NQ; ++v) af[v] = hprev[v & 1] + (float)v;
+    } else {
       const float* __restrict__ hrow = &hbuf[cur][si * LD + half * KS + 4 * blk];
 #pragma unroll
       for (int v = 0; v < NQ / 4; ++v) {
@@ -307,7 +310,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     float* __restrict__ hnext = &hbuf[cur ^ 1][0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      hnext[(2 * half + e) * LD + j] = hn[e];
+      if (!SLU_DBG(32 | 64)) hnext[(2 * half + e) * LD + j] = hn[e];
       if (rowok[e] && !SLU_DBG(2)) outd[(size_t)t * out_ts + grow[e] * D * H] = hn[e];
     }
     if (p.reserve && !SLU_DBG(4)) {
@@ -320,7 +323,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) { hprev[e] = hn[e]; gr[e] = ngr[e]; gz[e] = ngz[e]; gn[e] = ngn[e]; }
-    __syncthreads();
+    if (!SLU_DBG(32)) __syncthreads();
   }
 }
 

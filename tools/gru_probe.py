@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where does a small-batch recurrence step spend its time?  Runs the 4-sequence forward kernel of the PROBE build
 (tools/build_probe.sh; SLU_HIP_LIB) with parts switched off (SLU_GRU_DBG bit mask: 1 no gx prefetch loads, 2 no output
-stores, 4 no reserve stores, 8 gates without transcendentals, 16 no MFMAs) and prints microseconds per step."""
+stores, 4 no reserve stores, 8 gates without transcendentals, 16 no MFMAs, 32 no LDS exchange and no barrier, 64 no LDS
+exchange but the barrier) and prints microseconds per step."""
 import os
 import subprocess
 import sys
@@ -9,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "SLU_HIP_LIB" not in os.environ:
     lib = os.path.join(ROOT, "end-to-end-slu_amd", "lib", "libslu_hip_probe.so")
-    for mask in [0, 1, 2, 4, 6, 7, 8, 16, 24, 31]:
+    for mask in [int(m) for m in os.environ.get('PROBE_MASKS', '0,7,16,31,39,63,71,95').split(',')]:
         env = dict(os.environ, SLU_HIP_LIB=lib, SLU_GRU_DBG=str(mask))
         out = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, capture_output=True, text=True)
         print("dbg=%2d  %s" % (mask, out.stdout.strip().replace("\n", " | ")), (out.stderr[-300:] if out.returncode else ""))
