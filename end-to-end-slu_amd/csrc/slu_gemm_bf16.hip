@@ -531,3 +531,168 @@ extern "C" int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64
   SLU_CHECK_LAUNCH("gemm_bf_kernel");
   return SLU_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TN GEMM on bf16 operands for the weight gradients of BASELINE configs[4] (SLU_DTYPE=bf16):
+//     C (M x N) = A^T B,   A (K x M), B (K x N) fp32 row-major (k is the SLOW index of both: d_gx / d_gh and x / h_prev
+//     as the BPTT and the forward pass leave them), K = T * B rows up to tens of thousands.
+// The bf16 MFMA wants 8 consecutive k per lane, so a chunk of 32 k-rows is read with coalesced float4 loads (a row of 64
+// m / n values is 256 contiguous bytes), rounded to bf16 in registers and written to LDS TRANSPOSED ([m][k], 80-byte rows):
+// a fragment is then one ds_read_b128.  64 x 64 output tile per workgroup, 2 x 2 waves of 32 x 32, fp32 accumulation;
+// the next chunk's global loads are in flight during the MFMAs (register prefetch, LDS double buffer, one barrier per
+// chunk).  Split-K over gridDim.z into a workspace [KS][M][N], summed in fixed order by gemm_tn_bf16_reduce_kernel
+// (deterministic).  Operand traffic comes from L2 / MALL (each operand is re-read by the other dimension's tiles).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace slu {
+
+constexpr int TNB_T = 64;          // tile edge (M and N)
+constexpr int TNB_K = 32;          // k rows per chunk
+constexpr int TNB_LD = 40;         // bf16 elements per LDS row: 32 + 8 padding (80 bytes, 16-byte aligned fragments)
+
+struct TnBfParams {
+  const float* A; long long lda;
+  const float* B; long long ldb;
+  float* out; long long ldc;       // C (KS == 1) or the workspace slab base (row stride N)
+  long long slab;                  // elements between split slabs (M * N), 0 when KS == 1
+  int M, N, K, k_per_split;
+};
+
+__device__ __forceinline__ void tnb_stage(unsigned short* __restrict__ s, const float4& v0, const float4& v1, int c4, int kr) {
+  // rows c4 .. c4 + 3 of the transposed tile, k columns kr and kr + 16
+  s[(c4 + 0) * TNB_LD + kr] = f32_to_bf16_rne(v0.x); s[(c4 + 1) * TNB_LD + kr] = f32_to_bf16_rne(v0.y);
+  s[(c4 + 2) * TNB_LD + kr] = f32_to_bf16_rne(v0.z); s[(c4 + 3) * TNB_LD + kr] = f32_to_bf16_rne(v0.w);
+  s[(c4 + 0) * TNB_LD + kr + 16] = f32_to_bf16_rne(v1.x); s[(c4 + 1) * TNB_LD + kr + 16] = f32_to_bf16_rne(v1.y);
+  s[(c4 + 2) * TNB_LD + kr + 16] = f32_to_bf16_rne(v1.z); s[(c4 + 3) * TNB_LD + kr + 16] = f32_to_bf16_rne(v1.w);
+}
+
+__global__ void __launch_bounds__(256)
+gemm_tn_bf16_kernel(const TnBfParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned short sA[2][TNB_T * TNB_LD];
+  __shared__ __attribute__((aligned(16))) unsigned short sB[2][TNB_T * TNB_LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m0 = blockIdx.y * TNB_T, n0 = blockIdx.x * TNB_T;
+  const int k_begin = blockIdx.z * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int kr = tid >> 4, c4 = (tid & 15) * 4;                  // loader: k rows kr, kr + 16; columns c4 .. c4 + 3
+  const float* __restrict__ Ap = p.A + m0 + c4;
+  const float* __restrict__ Bp = p.B + n0 + c4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto load = [&](int k0, float4& a0, float4& a1, float4& b0, float4& b1) {
+    const int ka = k0 + kr, kb = k0 + kr + 16;
+    a0 = ka < k_end ? *reinterpret_cast<const float4*>(Ap + (long long)ka * p.lda) : zero;
+    a1 = kb < k_end ? *reinterpret_cast<const float4*>(Ap + (long long)kb * p.lda) : zero;
+    b0 = ka < k_end ? *reinterpret_cast<const float4*>(Bp + (long long)ka * p.ldb) : zero;
+    b1 = kb < k_end ? *reinterpret_cast<const float4*>(Bp + (long long)kb * p.ldb) : zero;
+  };
+
+  float4 a0, a1, b0, b1;
+  load(k_begin, a0, a1, b0, b1);
+  tnb_stage(sA[0], a0, a1, c4, kr);
+  tnb_stage(sB[0], b0, b1, c4, kr);
+  __syncthreads();
+
+  const int wm = w >> 1, wn = w & 1;
+  const int i = lane & 15, kg = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += TNB_K) {
+    const bool more = k0 + TNB_K < k_end;
+    if (more) load(k0 + TNB_K, a0, a1, b0, b1);                 // in flight during this chunk's MFMAs
+    uint4 fa[2], fb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      fa[mt] = *reinterpret_cast<const uint4*>(&sA[buf][(wm * 32 + mt * 16 + i) * TNB_LD + kg * 8]);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+      fb[nt] = *reinterpret_cast<const uint4*>(&sB[buf][(wn * 32 + nt * 16 + i) * TNB_LD + kg * 8]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma_bf16(fa[mt], fb[nt], acc[mt][nt]);
+    if (more) {
+      tnb_stage(sA[buf ^ 1], a0, a1, c4, kr);
+      tnb_stage(sB[buf ^ 1], b0, b1, c4, kr);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // D[row = 4 * kg + r][col = i] of each 16 x 16 tile: rows index m (the A operand), columns n
+  float* __restrict__ out = p.out + (size_t)blockIdx.z * p.slab;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + mt * 16 + 4 * kg + r, n = n0 + wn * 32 + nt * 16 + i;
+        out[(size_t)m * p.ldc + n] = acc[mt][nt][r];
+      }
+}
+
+__global__ void __launch_bounds__(256)
+gemm_tn_bf16_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long long ldc, int M, int N, int KS) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx - (long long)m * N);
+  float s = 0.0f;
+  for (int k = 0; k < KS; ++k) s += ws[(size_t)k * M * N + idx];
+  C[(long long)m * ldc + n] = s;
+}
+
+static void tnb_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper) {
+  const int64_t tiles = (M / TNB_T) * (N / TNB_T);
+  int64_t ks = 512 / tiles;                       // a function of the shape only (bit-reproducible on any stream)
+  const int64_t max_ks = cdiv(K, 256);            // >= 256 k rows per split
+  if (ks > max_ks) ks = max_ks;
+  if (ks < 1) ks = 1;
+  const int64_t per = cdiv(cdiv(K, ks), TNB_K) * TNB_K;
+  *kper = (int)per;
+  *KS = (int)cdiv(K, per);
+}
+
+}  // namespace slu
+
+extern "C" size_t slu_gemm_tn_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || M % slu::TNB_T || N % slu::TNB_T) return 0;
+  int KS, kper;
+  slu::tnb_plan(M, N, K, &KS, &kper);
+  return KS > 1 ? (size_t)KS * M * N * sizeof(float) : 0;
+}
+
+extern "C" int slu_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                                int64_t M, int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  SLU_REQUIRE(A && B && C, "slu_gemm_tn_bf16: null pointer");
+  SLU_REQUIRE(M > 0 && N > 0 && K > 0 && K < (1LL << 31), "slu_gemm_tn_bf16: bad size");
+  if (M % TNB_T || N % TNB_T)
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_bf16: M = %lld and N = %lld must be multiples of %d", (long long)M, (long long)N, TNB_T);
+  if ((lda | ldb) & 3 || ((uintptr_t)A & 15) || ((uintptr_t)B & 15))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_bf16: lda / ldb must be multiples of 4 and A / B 16-byte aligned");
+  int KS, kper;
+  tnb_plan(M, N, K, &KS, &kper);
+  TnBfParams p;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = (int)M; p.N = (int)N; p.K = (int)K; p.k_per_split = kper;
+  if (KS > 1) {
+    const size_t need = (size_t)KS * M * N * sizeof(float);
+    if (!workspace || workspace_bytes < need)
+      SLU_FAIL(SLU_ERR_WORKSPACE, "slu_gemm_tn_bf16: workspace too small (%zu < %zu)", workspace_bytes, need);
+    p.out = reinterpret_cast<float*>(workspace); p.ldc = N; p.slab = M * N;
+  } else {
+    p.out = C; p.ldc = ldc; p.slab = 0;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)(N / TNB_T), (unsigned)(M / TNB_T), (unsigned)KS), dim3(256), 0, st, p);
+  SLU_CHECK_LAUNCH("gemm_tn_bf16_kernel");
+  if (KS > 1) {
+    hipLaunchKernelGGL(gemm_tn_bf16_reduce_kernel, dim3((unsigned)cdiv(M * N, 256)), dim3(256), 0, st,
+                       (const float*)workspace, C, (long long)ldc, (int)M, (int)N, KS);
+    SLU_CHECK_LAUNCH("gemm_tn_bf16_reduce_kernel");
+  }
+  return SLU_OK;
+}

@@ -62,6 +62,8 @@ SIGNATURES = {
     "slu_gemm_bf16_pack_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "slu_gemm_bf16_pack": (c_int, [vp, c_i64, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gemm_bf16": (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
+    "slu_gemm_tn_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "slu_gemm_tn_bf16": (c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i64, c_i64, vp, c_sz, vp]),
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
                                    c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp]),

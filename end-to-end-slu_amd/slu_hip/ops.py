@@ -18,9 +18,9 @@ METHODS = {"none": 0, "avg": 1, "max": 2}
 
 def bf16_mode():
     """SLU_DTYPE=bf16 (BASELINE configs[4]): every forward contraction — convolutions, GRU input projections and
-    recurrences — and the data-gradient contractions of the backward pass take bf16 operands on
-    v_mfma_f32_16x16x32_bf16 with fp32 accumulation; weight gradients (k-major operands, up to 32 000-row reductions),
-    gate / loss math, master weights and Adam stay fp32."""
+    recurrences — and the backward contractions of the GRU layers (data gradients, and the weight gradients of layers
+    with more than TN_SMALL_ROWS rows on slu_gemm_tn_bf16) take bf16 operands on v_mfma_f32_16x16x32_bf16 with fp32
+    accumulation; convolution weight gradients, BPTT gate math, loss math, master weights and Adam stay fp32."""
     return os.environ.get("SLU_DTYPE", "f32") == "bf16"
 
 
@@ -833,6 +833,37 @@ class ConvBlockFn(torch.autograd.Function):
         return dx, dW, db, None, None, None, None, None
 
 
+def gemm_tn_bf16_ok(a, b):
+    """Shapes slu_gemm_tn_bf16 takes: A (K, M), B (K, N) fp32 views with unit column stride."""
+    return (a.dtype == b.dtype == torch.float32 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
+            and a.shape[1] % 64 == 0 and b.shape[1] % 64 == 0 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gemm_tn_bf16(a, b, out=None):
+    """out (M, N) = a^T b with a (K, M), b (K, N) rounded to bf16 on the way into the MFMA, fp32 accumulation:
+    the weight gradients of a GRU layer in bf16 mode (slu_gemm_tn_bf16)."""
+    L = _lib.load()
+    K, M = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    assert out.stride(1) == 1
+    wsb = L.slu_gemm_tn_bf16_workspace_bytes(M, N, K)
+    ws = _workspace(wsb, a.device) if wsb else None
+    _lib.check(L.slu_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                  M, N, K, _ptr(ws), wsb, _stream()), "slu_gemm_tn_bf16")
+    return out
+
+
+def _wgrad(a, b, out):
+    """out = a^T b (a (K, M) gradients, b (K, N) activations): bf16 operands in bf16 mode where the kernel takes the
+    shape, else the exact fp32 GEMM on the transposed view."""
+    if bf16_mode() and gemm_tn_bf16_ok(a, b):
+        return gemm_tn_bf16(a, b, out)
+    return gemm(a.t(), b, out=out)
+
+
 def _gru_dx(g2, w_ih, T, B, I, H, D):
     """dx = d_gx W_ih (K = D * 3H): exact fp32 MFMA, or — bf16 mode, I a multiple of 64 — bf16 operands on the
     split-precision GEMM (d_gx rounded to bf16 planes, W_ih^T packed in fragment order in place)."""
@@ -945,7 +976,7 @@ class GRULayerFn(torch.autograd.Function):
         if ng[3] or ng[4]:                                 # dW_ih = d_gx^T x, one GEMM for both directions
             dW = torch.empty(D * 3 * H, I, dtype=torch.float32, device=dev)
             with _Fork(dev, 0):
-                gemm(g2.t(), x2, out=dW)
+                _wgrad(g2, x2, dW)
             grads[3] = dW[:3 * H]
             if D == 2:
                 grads[4] = dW[3 * H:]
@@ -961,7 +992,7 @@ class GRULayerFn(torch.autograd.Function):
                         ga, hp = hd[:n], r2[B:, H:]
                     dWh = torch.empty(3 * H, H, dtype=torch.float32, device=dev)
                     with _Fork(dev, 1 + d):
-                        gemm(ga.t(), hp, out=dWh)
+                        _wgrad(ga, hp, dWh)
                     grads[wpos] = dWh
                 else:
                     grads[wpos] = torch.zeros(3 * H, H, dtype=torch.float32, device=dev)

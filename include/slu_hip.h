@@ -160,6 +160,15 @@ int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, con
                   const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int nsplit,
                   void* stream);
 
+/* C (M x N, row stride ldc) = A^T B on bf16 operands (fp32 accumulation): A (K x M, row stride lda), B (K x N, ldb) fp32
+ * with k as the slow index of both — the weight gradients d_gx^T x / d_gh^T h_prev of a GRU layer under SLU_DTYPE=bf16
+ * (BASELINE configs[4]; the reference's autograd GEMMs of nn.GRU, models.py:232/:262/:686).  The operands are rounded to
+ * bf16 while they are staged (transposed) in LDS.  M and N multiples of 64, lda / ldb multiples of 4, 16-byte aligned
+ * bases; deterministic split-K through the caller's workspace (slu_gemm_tn_bf16_workspace_bytes, 0 = none needed).   */
+size_t slu_gemm_tn_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int slu_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
+                     int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+
 /* slu_wconv_fwd for a FROZEN CNN block on the split-precision MFMA path (no `route`: forward only).  Needs
  * stride_t * c_in % 8 == 0 for c_in == 1, stride_t == 1 otherwise (channels are padded to a multiple of 8).
  * out_planes != NULL (pool == 1): the result goes straight into the split-precision activation format instead of

@@ -49,6 +49,31 @@ def test_gemm_bf16_vs_float64(ops, M, N, K, nsplit):
     assert err <= (4e-7 if nsplit == 3 else 2e-2)
 
 
+@pytest.mark.parametrize("K,M,N", [(32000, 768, 256), (9568, 384, 128), (300, 64, 64), (4097, 128, 192), (31, 64, 128)])
+def test_gemm_tn_bf16_vs_float64(ops, K, M, N):
+    """slu_gemm_tn_bf16 (weight gradients in bf16 mode): C = A^T B with k-major fp32 operands rounded to bf16 in the
+    staging, fp32 accumulation, deterministic split-K — against float64 on the bf16-rounded operands (exact up to fp32
+    accumulation) and on the fp32 operands (the bf16 bound), incl. column-slice views (row stride > width)."""
+    torch.manual_seed(K + M)
+    abig = torch.randn(K + 3, M + 64, device="cuda")
+    bbig = torch.randn(K + 3, N + 128, device="cuda")
+    a, b = abig[3:, 64:], bbig[:K, 128:]                       # offset / strided views, 16-byte aligned
+    assert ops.gemm_tn_bf16_ok(a, b)
+    out = ops.gemm_tn_bf16(a, b)
+    out2 = ops.gemm_tn_bf16(a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)                              # deterministic
+    ar, br = a.to(torch.bfloat16).double(), b.to(torch.bfloat16).double()
+    ref_r = ar.t() @ br
+    ref = a.double().t() @ b.double()
+    scale = (a.abs().double().t() @ b.abs().double()).max().item()
+    e_r = (out.double() - ref_r).abs().max().item() / scale
+    e = (out.double() - ref).abs().max().item() / scale
+    print("gemm_tn_bf16 K=%d M=%d N=%d: %.2e of sum|a||b| vs the bf16-rounded operands, %.2e vs fp32 operands" % (K, M, N, e_r, e))
+    assert e_r <= 2e-6 and e <= 1e-2
+    assert not ops.gemm_tn_bf16_ok(a[:, :60], b)
+
+
 @pytest.mark.parametrize("T,B,H", [(40, 64, 128), (23, 37, 128), (9, 5, 64), (300, 768, 128)])
 @pytest.mark.parametrize("nsplit", [3, 1])
 def test_gru_bf16_vs_exact_fp32_kernel(ops, T, B, H, nsplit):
@@ -150,8 +175,9 @@ def test_bf16_mode_at_configs4_shape_vs_fp32_oracle(tmp_path, monkeypatch):
     y = torch.stack([torch.randint(0, n, (B,), generator=g) for n in cfg.values_per_slot], dim=1)
     masks = O.draw_dropout_masks(cfg, x, seed=22)
     models.set_dropout_masks({k: v.cuda() for k, v in masks.items()})
-    calls = {"conv_bf16": 0, "gemm_bf16": 0}
-    real_conv, real_gemm = _ops.wconv_fwd_bf16, _ops.gemm_bf16
+    calls = {"conv_bf16": 0, "gemm_bf16": 0, "tn_bf16": 0}
+    real_conv, real_gemm, real_tn = _ops.wconv_fwd_bf16, _ops.gemm_bf16, _ops.gemm_tn_bf16
+    monkeypatch.setattr(_ops, "gemm_tn_bf16", lambda *a, **k: (calls.__setitem__("tn_bf16", calls["tn_bf16"] + 1), real_tn(*a, **k))[1])
     monkeypatch.setattr(_ops, "wconv_fwd_bf16", lambda *a, **k: (calls.__setitem__("conv_bf16", calls["conv_bf16"] + 1), real_conv(*a, **k))[1])
     monkeypatch.setattr(_ops, "gemm_bf16", lambda *a, **k: (calls.__setitem__("gemm_bf16", calls["gemm_bf16"] + 1), real_gemm(*a, **k))[1])
     try:
@@ -161,8 +187,11 @@ def test_bf16_mode_at_configs4_shape_vs_fp32_oracle(tmp_path, monkeypatch):
         torch.cuda.synchronize()
     finally:
         models.set_dropout_masks(None)
-    # 3 conv forwards + 2 conv data gradients; 5 input projections + 4 GRU data gradients (I = 256; the first layer's I = 60 stays fp32)
-    assert calls == {"conv_bf16": 5, "gemm_bf16": 9}, calls
+    # 3 conv forwards + 2 conv data gradients; 5 input projections + 4 GRU data gradients (I = 256; the first layer's
+    # I = 60 stays fp32); weight gradients on the TN bf16 kernel: dW_hh of both directions of the three layers with more
+    # than 4096 rows (1000 / 500 / 250 steps x 32) + dW_ih of the two of them with I = 256 (the 4000- and 2016-row
+    # layers take the batched fp32 launch)
+    assert calls == {"conv_bf16": 5, "gemm_bf16": 9, "tn_bf16": 8}, calls
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
     rloss, racc, rlogits, rpred = O.slu_forward(sd, x, y, cfg, masks, explicit_gru=False)
     rloss.backward()
