@@ -205,7 +205,8 @@ def test_bf16_mode_at_configs4_shape_vs_fp32_oracle(tmp_path, monkeypatch):
     print("bf16 mode, 32 x 10 s: eval logits max-abs deviation vs fp32 oracle %.3e (logit range %.2f, smallest top-2 margin %.3e); "
           "train loss %.5f vs %.5f" % (dev, elogits.abs().max().item(), margin, loss.item(), rloss.item()))
     assert (pred.cpu() != epred).sum().item() == 0 or dev >= 0.5 * margin       # a decision may only move where the margin is inside the bf16 error
-    assert dev <= 3e-2 and abs(loss.item() - rloss.item()) <= 3e-2
+    # measured on MI355X: 3.3e-4 / 3e-5; the bounds leave a factor of ~6 (bf16 rounding is data dependent)
+    assert dev <= 2e-3 and abs(loss.item() - rloss.item()) <= 1e-3
     worst, worst_name, dots, na, nb = 1.0, "", 0.0, 0.0, 0.0
     for k, p in model.named_parameters():
         if sd[k].grad is None or p.grad is None:
@@ -217,7 +218,7 @@ def test_bf16_mode_at_configs4_shape_vs_fp32_oracle(tmp_path, monkeypatch):
         dots, na, nb = dots + (a @ b).item(), na + (a @ a).item(), nb + (b @ b).item()
     total = dots / (na ** 0.5 * nb ** 0.5)
     print("bf16 mode, 32 x 10 s: gradient cosine vs fp32 oracle: whole model %.5f, worst tensor %.5f (%s)" % (total, worst, worst_name))
-    assert total >= 0.97 and worst >= 0.85
+    assert total >= 0.999 and worst >= 0.99                 # measured 0.99968 / 0.9974 (the float64 Sinc parameters)
 
 
 @pytest.mark.parametrize("case", ["sinc", "conv1"])
