@@ -317,6 +317,7 @@ VARIANTS = {
                                     intent_downsample_type=["max"], intent_downsample_len=[2]),
     "unidirectional": dict(phone_rnn_bidirectional=False, word_rnn_bidirectional=False, intent_rnn_bidirectional=False),
     "wide_pool_fallback": dict(cnn_max_pool_len=[3, 1, 1]),
+    "wide_pools_everywhere": dict(cnn_max_pool_len=[3, 4, 3], cnn_act=["leaky_relu", "relu", "leaky_relu"]),
     "two_intent_layers_three_phone": dict(intent_rnn_num_hidden=[16, 32], intent_rnn_drop=[0.5, 0.25],
                                           intent_downsample_type=["none", "avg"], intent_downsample_len=[1, 2],
                                           phone_rnn_num_hidden=[16, 32, 16], phone_downsample_len=[2, 1, 2],
