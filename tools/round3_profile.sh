@@ -25,4 +25,7 @@ for t in default unfrozen cfg4 seq2seq; do
   python tools/rocprof_summary.py $f 50 --by-shape > $O/${t}_kernel_stats_by_shape.txt
   rm -rf $O/trace_$t
 done
+python tools/inloop_json.py $O/default_kernel_stats_by_shape.txt > $O/inloop_kernel_us.json
+if [ -f end-to-end-slu_amd/lib/libslu_hip_probe.so ]; then timeout 300 python tools/gru_probe.py > $O/gru_probe.txt 2>&1; fi
+timeout 400 python tools/host_inputs_probe.py 0 16 999 > $O/host_inputs_probe.txt 2>&1
 head -16 $O/default_kernel_stats.txt | cut -c1-150
