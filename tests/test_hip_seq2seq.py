@@ -388,3 +388,32 @@ def test_pool_act_and_multi_kernels_vs_torch():
     ops.scale_multi(srcs[:5], s)
     for a, b in zip(srcs[:5], before):
         assert torch.equal(a, b * s)
+
+
+def test_main_train_seq2seq_cfg(tmp_path):
+    """The reference's driver flow with a seq2seq cfg (`seq2seq=True`, the six seq2seq hyper-parameters): main.py
+    --pretrain --train on synthetic data — read_config, seq2seq datasets, Model with the decoder head, three epochs
+    (the last one's validation decodes with beam search: training.py:158-164), checkpoints with the decoder's keys."""
+    import subprocess
+    import sys
+    PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "end-to-end-slu_amd")
+    os.makedirs(tmp_path / "experiments")
+    text = open(os.path.join(PKG, "experiments", "seq2seq_synthetic.cfg")).read()
+    text = text.replace("asr_path=synthetic:8x64x36000", "asr_path=synthetic:2x8x16000")
+    text = text.replace("slu_path=synthetic:8x64x48000", "slu_path=synthetic:4x4x16000")
+    text = text.replace("training_num_epochs=2", "training_num_epochs=3")
+    (tmp_path / "experiments" / "s2s.cfg").write_text(text.replace("seq2seq_synthetic", "s2s"))
+    env = dict(os.environ, PYTHONPATH=PKG)
+    r = subprocess.run([sys.executable, os.path.join(PKG, "main.py"), "--pretrain", "--train",
+                        "--config_path=experiments/s2s.cfg"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = r.stdout
+    assert "seq2seq output" in out and "guess: " in out and "truth: " in out          # the decoded sample at the print interval
+    assert "========= Test results =========" in out
+    sd = torch.load(tmp_path / "experiments" / "s2s" / "training" / "model_state.pth", map_location="cpu")
+    assert "decoder.initial_state" in sd and "encoder.layers.0.weight_ih_l0" in sd and "decoder.rnn.layers.2.weight_hh" in sd
+    assert not any(k.startswith("intent_layers") for k in sd)
+    tlog = open(tmp_path / "experiments" / "s2s" / "training" / "log.csv").read().splitlines()
+    assert tlog[0] == ",intent_loss,intent_acc,set" and len(tlog) == 1 + 3 * 2 + 1
+    losses = [float(line.split(",")[1]) for line in tlog[1:]]
+    assert all(np.isfinite(v) for v in losses)
