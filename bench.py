@@ -145,6 +145,44 @@ def host_topology():
     return info
 
 
+def cpu_baseline_seq2seq(config, batch, samples, max_len=24, budget_s=20.0):
+    """The CPU oracle on the seq2seq workload: frozen encoder (train mode), seq2seq encoder + attention decoder
+    trained — forward, loss, backward, Adam (torch-CPU restatement of reference models.py:381-557, 825-828)."""
+    from oracle import slu_oracle as O
+    import data
+    threads = max(1, min(torch.get_num_threads(), 64))
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    labels = list(data.SYNTHETIC_SEQ2SEQ_LABELS)
+    V = len(labels)
+    sd = {"pretrained_model." + k: v for k, v in O.init_pretrained_state_dict(config).items()}
+    head = O.init_seq2seq_state_dict(config, V)
+    for v in head.values():
+        v.requires_grad_()
+    sd.update(head)
+    opt = torch.optim.Adam(list(head.values()), lr=1e-3)
+    ds = data.SyntheticSeq2SeqDataset(1, batch, samples, max_len=max_len, seed=1234, Sy_intent=labels)
+    x, y = ds.batches[0]
+
+    def step():
+        masks = O.draw_seq2seq_masks(config, x, y.shape[1], seed=1)
+        opt.zero_grad()
+        loss, _ = O.seq2seq_forward(sd, x, y, config, masks, explicit_gru=False, SOS=labels.index("<sos>"))
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < budget_s * 0.6 and n < 40):
+        step()
+        n += 1
+    rate = n * batch / (time.perf_counter() - t0)
+    return {"value": round(rate, 2), "unit": "utterances/s", "cores": threads, "kind": "port", "host": host_topology(),
+            "sample": "%d seq2seq train steps (after 1 warm-up) of B=%d x %d s, %d teacher-forced steps, on %d torch-CPU threads "
+                      "(oracle: ATen GRU encoder, explicit attention decoder)" % (n, batch, samples // FS, max_len, threads)}
+
+
 def cpu_baseline(config, batch, samples, budget_s=20.0):
     """The CPU oracle (torch-CPU restatement of the reference path, ATen GRU like the reference) on
     the same workload: train-mode forward + backward of the trainable part + Adam, on the host's cores."""
@@ -783,9 +821,10 @@ def main():
         if default_line:
             note("host-input point")
             out["host_inputs"] = host_inputs_point(model, trainer, batches, max(args.steps, 256), asr)
-        if world == 1 and not args.no_cpu_baseline and not asr and args.workload != "seq2seq":
+        if world == 1 and not args.no_cpu_baseline and not asr:
             note("cpu baseline")
-            out["cpu_baseline"] = cpu_baseline(config, args.batch, samples)
+            out["cpu_baseline"] = (cpu_baseline_seq2seq(config, args.batch, samples) if args.workload == "seq2seq"
+                                   else cpu_baseline(config, args.batch, samples))
         if default_line:
             # fresh processes (their own graphs / environment); this process' model is released first
             del model, trainer, batches

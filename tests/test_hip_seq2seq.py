@@ -196,12 +196,14 @@ def test_seq2seq_at_reference_cfg_sizes_vs_oracle(models_mod, tmp_path):
     assert n >= 60
 
 
-def test_decoder_step_kernels_vs_torch():
-    """slu_gru_cell_*, slu_attention_*, slu_logsoftmax_dot_* against torch autograd (float64 where it matters)."""
+@pytest.mark.parametrize("B,H,I,Tn,Kd,Vd,V", [(37, 52, 29, 23, 100, 200, 102), (1, 5, 3, 1, 7, 9, 4), (64, 256, 456, 63, 100, 200, 102),
+                                              (3, 300, 8, 130, 260, 33, 1000)])
+def test_decoder_step_kernels_vs_torch(B, H, I, Tn, Kd, Vd, V):
+    """slu_gru_cell_*, slu_attention_*, slu_logsoftmax_dot_* against torch autograd (float64 where it matters), incl.
+    degenerate sizes (one utterance, one encoder frame, widths that are no multiple of a wave) and the reference cfgs'."""
     from slu_hip import lib, ops
     lib.require_gfx950()
     torch.manual_seed(0)
-    B, H, I = 37, 52, 29
     cell = torch.nn.GRUCell(I, H).double()
     x = torch.randn(B, I, dtype=torch.float64, requires_grad=True)
     h = torch.randn(B, 3, H, dtype=torch.float64, requires_grad=True)          # strided state slice [:, 1]
@@ -234,7 +236,7 @@ def test_decoder_step_kernels_vs_torch():
     ops.gru_cell_fwd(gi, gh, hc[:, 1], h_out[:, 0], None, d2, None, 0.5, 77, 19, None, 5 * B * H)
     assert torch.equal(d1, d2)
     kept = (d1 != 0).float().mean().item()
-    assert 0.4 < kept < 0.6
+    assert 0.4 < kept < 0.6 or B * H < 500
     keep = (d1 != 0).float()
     assert maxerr(d1, h_out[:, 0] * keep * 2.0) <= 1e-6
     ops.gru_cell_bwd(d_state[:, 0], gd_.float().cuda(), save, hc[:, 1], d_gi, d_gh, d_state[:, 1], None, 0.5, 77, 19, None, 5 * B * H)
@@ -242,7 +244,6 @@ def test_decoder_step_kernels_vs_torch():
     assert maxerr(d_state[:, 1], d_state[:, 0]) <= 1e-6
 
     # attention: time-major keys / values, strided query and context
-    Tn, Kd, Vd = 23, 100, 200
     keys = torch.randn(Tn, B, Kd, dtype=torch.float64, requires_grad=True)
     values = torch.randn(Tn, B, Vd, dtype=torch.float64, requires_grad=True)
     q = torch.randn(B, Kd, dtype=torch.float64, requires_grad=True)
@@ -265,7 +266,6 @@ def test_decoder_step_kernels_vs_torch():
     assert maxerr(dk - 1.0, keys.grad) <= 2e-5 and maxerr(dv - 1.0, values.grad) <= 2e-5 and maxerr(dq, q.grad) <= 2e-5
 
     # log-softmax + label pick
-    V = 102
     logits = (3.0 * torch.randn(B, V, dtype=torch.float64)).requires_grad_()
     yall = one_hot(torch.randint(0, V, (B, 4)), V)
     lp = (torch.log_softmax(logits, dim=1) * yall[:, 2].double()).sum(1)
