@@ -602,6 +602,116 @@ int colsum_two_stage(const float* X, int64_t rs, float* out, int64_t M, int64_t 
   return SLU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Grouped small-M GEMMs in ONE launch (the seq2seq decoder's per-step products: 64 utterances x a few hundred
+// columns x K <= 768, reference models.py:427-485): up to four independent problems
+//     C_q (M x N_q) = [C_q +] A_q (M x K_q, k fast) * op(B_q) + bias_q,
+//     op(B) = B^T for mode 0 (B is (N x K), k fast: a Linear / GRUCell weight as stored), B for mode 1 (B is (K x N),
+//     n fast: the same weights in the data-gradient products).
+// These launches are latency-bound, so the kernel is built around ONE memory round trip: a 64 x 16 output tile per
+// workgroup, EIGHT waves that split K in 16-wide chunks (wave w takes chunks w, w + 8, ...), every load of a pass of
+// eight chunks per wave issued before the first MFMA (operands straight from global memory / L2: a 16-byte A load per
+// lane and m-tile feeds four k steps — the MFMA's k index is remapped so that lane group kg owns k = 4 kg .. 4 kg + 3
+// of a chunk), exact fp32 MFMA (v_mfma_f32_16x16x4_f32), cross-wave reduction in LDS in fixed wave order (deterministic),
+// bias / accumulate in the epilogue.  K % 4 == 0, lda % 4 == 0, 16-byte aligned A (and B, ldb % 4 == 0, for mode 0).
+// ---------------------------------------------------------------------------------------------------------------------
+struct SmallProblem {
+  const float* A; const float* B; float* C; const float* bias;
+  long long lda, ldb, ldc;
+  int M, N, K, mode, accumulate;
+  int tiles_n, tile_end;      // column tiles; exclusive prefix of (m tiles x n tiles)
+};
+struct SmallArgs { SmallProblem p[4]; int count; };
+
+constexpr int SM_WAVES = 8;
+constexpr int SM_CHUNKS = 8;    // chunks of 16 k per wave and pass
+
+__global__ void __launch_bounds__(SM_WAVES * 64)
+gemm_small_batched_kernel(const SmallArgs a) {
+  __shared__ float red[SM_WAVES][64 * 16];
+  int q = 0;
+  while (q + 1 < a.count && (int)blockIdx.x >= a.p[q].tile_end) ++q;
+  const SmallProblem& P = a.p[q];
+  const int t = blockIdx.x - (q ? a.p[q - 1].tile_end : 0);
+  const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 16;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kg = lane >> 4;
+  const int nchunks = (P.K + 15) >> 4;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // row pointers (clamped: rows / columns outside the problem read a valid address and are masked to zero)
+  const float* arow[4];
+  float amask[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + mt * 16 + i;
+    amask[mt] = m < P.M ? 1.0f : 0.0f;
+    arow[mt] = P.A + (long long)min(m, P.M - 1) * P.lda;
+  }
+  const int n = n0 + i;
+  const float bmask = n < P.N ? 1.0f : 0.0f;
+  const int nc = min(n, P.N - 1);
+
+  for (int c0 = w; c0 < nchunks; c0 += SM_WAVES * SM_CHUNKS) {
+    float4 fa[SM_CHUNKS][4];
+    float4 fb[SM_CHUNKS];
+#pragma unroll
+    for (int u = 0; u < SM_CHUNKS; ++u) {
+      const int c = c0 + u * SM_WAVES;
+      const int k = c * 16 + 4 * kg;                       // this lane's four k of the chunk
+      const bool ok = c < nchunks && k < P.K;              // K % 4 == 0: a lane's four k are all in or all out
+      const int kc = ok ? k : 0;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float4 v = *reinterpret_cast<const float4*>(arow[mt] + kc);
+        const float f = ok ? amask[mt] : 0.0f;
+        fa[u][mt] = make_float4(v.x * f, v.y * f, v.z * f, v.w * f);
+      }
+      float4 b;
+      if (P.mode == 0) {
+        b = *reinterpret_cast<const float4*>(P.B + (long long)nc * P.ldb + kc);
+      } else {
+        const float* bp = P.B + (long long)kc * P.ldb + nc;
+        b = make_float4(bp[0], bp[P.ldb], bp[2 * P.ldb], bp[3 * P.ldb]);
+      }
+      const float f = ok ? bmask : 0.0f;
+      fb[u] = make_float4(b.x * f, b.y * f, b.z * f, b.w * f);
+    }
+#pragma unroll
+    for (int u = 0; u < SM_CHUNKS; ++u) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        acc[mt] = mfma16(fa[u][mt].x, fb[u].x, acc[mt]);
+        acc[mt] = mfma16(fa[u][mt].y, fb[u].y, acc[mt]);
+        acc[mt] = mfma16(fa[u][mt].z, fb[u].z, acc[mt]);
+        acc[mt] = mfma16(fa[u][mt].w, fb[u].w, acc[mt]);
+      }
+    }
+  }
+  // D[row = 4 kg + r][col = i] of m-tile mt -> red[w][(mt * 16 + 4 kg + r) * 16 + i]
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][(mt * 16 + 4 * kg + r) * 16 + i] = acc[mt][r];
+  __syncthreads();
+  for (int e = tid; e < 64 * 16; e += SM_WAVES * 64) {
+    float s = red[0][e];
+#pragma unroll
+    for (int v = 1; v < SM_WAVES; ++v) s += red[v][e];
+    const int m = m0 + (e >> 4), nn = n0 + (e & 15);
+    if (m < P.M && nn < P.N) {
+      if (P.bias) s += P.bias[nn];
+      float* c = P.C + (long long)m * P.ldc + nn;
+      *c = P.accumulate ? *c + s : s;
+    }
+  }
+}
+
 static void split_plan(int64_t M, int64_t N, int64_t K, int* KS, int* kper, int* wt) {
   // measured on MI355X: the 64-tile wins or ties up to 8192^2 x 1024 (more waves per SIMD hide the
   // per-k-tile latency chain; L2 absorbs the extra operand re-reads); 128-tiles only pay off when
@@ -744,5 +854,34 @@ extern "C" int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t 
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream,
                      X, (long long)x_rs, out, (int)M, (int)N, accumulate);
   SLU_CHECK_LAUNCH("colsum_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_gemm_small_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                      const int* mode, float* const* C, const int64_t* ldc, const float* const* bias,
+                                      const int* accumulate, const int64_t* M, const int64_t* N, const int64_t* K,
+                                      int64_t count, void* stream) {
+  SLU_REQUIRE(A && lda && B && ldb && mode && C && ldc && bias && accumulate && M && N && K, "slu_gemm_small_batched: null pointer");
+  SLU_REQUIRE(count >= 1 && count <= 4, "slu_gemm_small_batched: 1..4 problems per call");
+  SmallArgs a;
+  int tiles = 0;
+  for (int q = 0; q < (int)count; ++q) {
+    SLU_REQUIRE(A[q] && B[q] && C[q] && M[q] > 0 && N[q] > 0 && K[q] > 0, "slu_gemm_small_batched: bad problem %d", q);
+    SLU_REQUIRE(M[q] < (1LL << 24) && N[q] < (1LL << 24) && K[q] < (1LL << 24), "slu_gemm_small_batched: size overflow");
+    SLU_REQUIRE(mode[q] == 0 || mode[q] == 1, "slu_gemm_small_batched: mode must be 0 (B is N x K) or 1 (B is K x N)");
+    if ((K[q] & 3) || (lda[q] & 3) || ((uintptr_t)A[q] & 15) || (mode[q] == 0 && ((ldb[q] & 3) || ((uintptr_t)B[q] & 15))))
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_small_batched: problem %d needs K %% 4 == 0, lda (ldb for mode 0) %% 4 == 0 and "
+               "16-byte aligned operands", q);
+    SmallProblem& P = a.p[q];
+    P.A = A[q]; P.B = B[q]; P.C = C[q]; P.bias = bias[q];
+    P.lda = lda[q]; P.ldb = ldb[q]; P.ldc = ldc[q];
+    P.M = (int)M[q]; P.N = (int)N[q]; P.K = (int)K[q]; P.mode = mode[q]; P.accumulate = accumulate[q];
+    P.tiles_n = (int)cdiv(N[q], 16);
+    tiles += (int)(cdiv(M[q], 64) * P.tiles_n);
+    P.tile_end = tiles;
+  }
+  a.count = (int)count;
+  hipLaunchKernelGGL(gemm_small_batched_kernel, dim3((unsigned)tiles), dim3(SM_WAVES * 64), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("gemm_small_batched_kernel");
   return SLU_OK;
 }

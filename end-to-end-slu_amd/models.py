@@ -522,7 +522,7 @@ class Seq2SeqDecoder(torch.nn.Module):
             _ops.broadcast_rows(P["initial_state"].contiguous().view(-1), state.view(R, Lc * Dd))
             y_prev = torch.zeros(R, V, dtype=torch.float32, device=dev)
             q, inp0, att_w, logits = f(R, Kd), f(R, E + Vd), f(R, T), f(R, V)
-            gi, gh, lse, sink = f(R, 3 * Dd), f(R, 3 * Dd), f(R), f(R)
+            gi, gh, lse, sink = f(R, 3 * Dd), f(Lc, R, 3 * Dd), f(R), f(R)
             drop = [f(R, Dd) for _ in range(Lc - 1)]
             hyp = torch.zeros(W, bsz, U, dtype=torch.int64, device=dev)
             scores = torch.zeros(W, bsz, dtype=torch.float32, device=dev)

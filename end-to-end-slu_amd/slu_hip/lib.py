@@ -75,6 +75,7 @@ SIGNATURES = {
     "slu_comm_allreduce_f64": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_destroy": (c_int, [vp]),
     "slu_gemm_tn_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp]),
+    "slu_gemm_small_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "slu_gru_bias_tiles": (c_i64, [c_i64, c_i64, c_i64, c_i64]),

@@ -200,6 +200,48 @@ def gemm(a, b, bias=None, out=None, accumulate=False):
     return out
 
 
+def _small_ok(a, b, mode):
+    return (a.dtype == b.dtype == torch.float32 and a.dim() == b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+            and a.shape[1] % 4 == 0 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0
+            and (mode == 1 or (b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0)))
+
+
+def gemm_small_batched(problems):
+    """problems: [(A (M, K), B, bias or None, C (M, N), mode, accumulate)] — mode 0: B is (N, K) (C = A B^T + bias), mode 1:
+    B is (K, N) (C = A B + bias); row-strided fp32 views with unit column stride.  Up to four problems per launch of
+    slu_gemm_small_batched (latency-bound small-M products); shapes the kernel does not take go through gemm()."""
+    import ctypes
+    L = _lib.load()
+    batch = []
+
+    def flush():
+        if not batch:
+            return
+        n = len(batch)
+        vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        arr = lambda ty, vals: (ty * n)(*vals)
+        _lib.check(L.slu_gemm_small_batched(
+            arr(vp, [p[0].data_ptr() for p in batch]), arr(i64, [p[0].stride(0) for p in batch]),
+            arr(vp, [p[1].data_ptr() for p in batch]), arr(i64, [p[1].stride(0) for p in batch]),
+            arr(ci, [p[4] for p in batch]), arr(vp, [p[3].data_ptr() for p in batch]), arr(i64, [p[3].stride(0) for p in batch]),
+            arr(vp, [_ptr(p[2]) or None for p in batch]), arr(ci, [int(p[5]) for p in batch]),
+            arr(i64, [p[0].shape[0] for p in batch]), arr(i64, [p[3].shape[1] for p in batch]), arr(i64, [p[0].shape[1] for p in batch]),
+            n, _stream()), "slu_gemm_small_batched")
+        batch.clear()
+
+    for A, B, bias, C, mode, acc in problems:
+        assert C.stride(1) == 1 and C.shape[0] == A.shape[0]
+        assert (B.shape == (C.shape[1], A.shape[1])) if mode == 0 else (B.shape == (A.shape[1], C.shape[1]))
+        if _small_ok(A, B, mode):
+            batch.append((A, B, bias, C, mode, acc))
+            if len(batch) == 4:
+                flush()
+        else:
+            flush()
+            gemm(A, B.t() if mode == 0 else B, bias, out=C, accumulate=bool(acc))
+    flush()
+
+
 def stage_inputs(pairs, set_tensor=None, set_value=0):
     """One launch refreshing static input buffers: pairs = [(dst contiguous, src)] with src contiguous or strided
     along dim 0 only; optionally set_tensor[0] = set_value (int64).  Returns the pairs it could not take."""
@@ -1085,23 +1127,26 @@ def decoder_step(P, keys, values, state_prev, state_next, y_prev, q, inp0, att_w
     Lc, Dd = state_prev.shape[1], state_prev.shape[2]
     E = P["embed.weight"].shape[0]
     p, masks, seed, offset, offset_dev, bd = drop_cfg
-    gemm(state_prev[:, Lc - 1], P["query.weight"].t(), P["query.bias"], out=q)
+    # everything that depends on the previous state only, in ONE grouped launch: the attention query and every cell's
+    # hidden-to-hidden product (gh is (Lc, B, 3 Dd))
+    group = [(state_prev[:, Lc - 1], P["query.weight"], P["query.bias"], q, 0, 0)]
+    group += [(state_prev[:, l], P["w_hh%d" % l], P["b_hh%d" % l], gh[l], 0, 0) for l in range(Lc)]
+    gemm_small_batched(group)
     attention_fwd(keys, values, q, inp0[:, E:], att_w, P["inv_scale"])
     if y_prev is not None:
         gemm(y_prev, P["embed.weight"].t(), P["embed.bias"], out=inp0[:, :E])
     x_in = inp0
     for l in range(Lc):
-        gemm(x_in, P["w_ih%d" % l].t(), P["b_ih%d" % l], out=gi)
-        gemm(state_prev[:, l], P["w_hh%d" % l].t(), P["b_hh%d" % l], out=gh)
+        gemm_small_batched([(x_in, P["w_ih%d" % l], P["b_ih%d" % l], gi, 0, 0)])
         last = l == Lc - 1
         mask = None if (masks is None or last) else masks["decoder_dropout_u%d_l%d" % (step, l)]
-        gru_cell_fwd(gi, gh, state_prev[:, l], state_next[:, l], None if save is None else save[l],
+        gru_cell_fwd(gi, gh[l], state_prev[:, l], state_next[:, l], None if save is None else save[l],
                      None if last else drop[l], mask, 0.0 if last else p, seed, offset, offset_dev,
                      (step * Lc + l) * bd)
         if not last:
             x_in = drop[l]
     if logits is not None:
-        gemm(state_next[:, Lc - 1], P["linear.weight"].t(), P["linear.bias"], out=logits)
+        gemm_small_batched([(state_next[:, Lc - 1], P["linear.weight"], P["linear.bias"], logits, 0, 0)])
 
 
 class Seq2SeqDecoderFn(torch.autograd.Function):
@@ -1141,7 +1186,7 @@ class Seq2SeqDecoderFn(torch.autograd.Function):
         drop = f(max(Lc - 1, 1), U, B, Dd)
         logits, lse = f(U, B, V), f(U, B)
         logp = torch.zeros(B, dtype=torch.float32, device=dev)
-        gi, gh = f(B, 3 * Dd), f(B, 3 * Dd)
+        gi, gh = f(B, 3 * Dd), f(Lc, B, 3 * Dd)
         dcfg = (p, masks, seed, offset, offset_dev, B * Dd)
         # teacher forcing: the embeddings of ALL steps' input labels in one GEMM (rows (u, b)), straight into inp0
         gemm(yprev.view(U * B, V), P["embed.weight"].t(), P["embed.bias"], out=inp0.view(U * B, E + Vd)[:, :E])
@@ -1197,10 +1242,11 @@ class Seq2SeqDecoderFn(torch.autograd.Function):
                 # top cell: d_drop = this step's logits gradient (keep-factor 1: there is no dropout after the last cell)
                 gru_cell_bwd(d_state[:, l], g_top[u] if last else d_x, save[u, l], state[u][:, l], d_gi[l, u], d_gh[l, u],
                              d_state[:, l], mask, 0.0 if last else p, seed, offset, offset_dev, (u * Lc + l) * B * Dd)
-                gemm(d_gh[l, u], P["w_hh%d" % l], out=d_state[:, l], accumulate=True)
-                gemm(d_gi[l, u], P["w_ih%d" % l], out=d_x if l > 0 else d_inp0[u])
+                # one grouped launch: the recurrent part of d h_{u-1} (accumulated) and the gradient of the cell's input
+                gemm_small_batched([(d_gh[l, u], P["w_hh%d" % l], None, d_state[:, l], 1, 1),
+                                    (d_gi[l, u], P["w_ih%d" % l], None, d_x if l > 0 else d_inp0[u], 1, 0)])
             attention_bwd(keys, values, q[u], d_inp0[u][:, E:], att_w[u], d_keys, d_values, d_q[u], inv_scale)
-            gemm(d_q[u], P["query.weight"], out=d_state[:, Lc - 1], accumulate=True)
+            gemm_small_batched([(d_q[u], P["query.weight"], None, d_state[:, Lc - 1], 1, 1)])
         grads = {}
         st_prev = state[:U].view(U * B, Lc * Dd)                     # rows (u, b): the state BEFORE step u
         st_next = state[1:].view(U * B, Lc * Dd)

@@ -138,6 +138,15 @@ int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* 
                         int64_t count, const float* rowsum_src, int64_t rowsum_rows, int64_t rowsum_cols,
                         float* rowsum_dst, void* stream);
 /* out[n] = [out[n] if accumulate] + sum_m X[m*x_rs + n]   (bias gradients)                       */
+/* Up to four independent SMALL-M products in one launch (latency-bound shapes: the seq2seq decoder's per-step Linear /
+ * GRUCell products and their data gradients, models.py:427-485): C_q (M x N) = [C_q +] A_q (M x K, row stride lda, k fast)
+ * * op(B_q) + bias_q; mode 0: B is (N x K) with row stride ldb (a weight as stored, C = A B^T), mode 1: B is (K x N) with
+ * row stride ldb (C = A B).  Exact fp32 MFMA, eight waves split K, deterministic.  K % 4 == 0, lda % 4 == 0, A 16-byte
+ * aligned (also B and ldb for mode 0).  Arrays are HOST arrays of `count` entries; bias[q] may be NULL.              */
+int slu_gemm_small_batched(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                           const int* mode, float* const* C, const int64_t* ldc, const float* const* bias,
+                           const int* accumulate, const int64_t* M, const int64_t* N, const int64_t* K, int64_t count,
+                           void* stream);
 int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,
                    int accumulate, void* stream);
 

@@ -417,3 +417,45 @@ def test_main_train_seq2seq_cfg(tmp_path):
     assert tlog[0] == ",intent_loss,intent_acc,set" and len(tlog) == 1 + 3 * 2 + 1
     losses = [float(line.split(",")[1]) for line in tlog[1:]]
     assert all(np.isfinite(v) for v in losses)
+
+
+def test_gemm_small_batched_vs_float64():
+    """slu_gemm_small_batched: grouped small-M products (both operand layouts, bias, accumulate, ragged M / N, strided
+    views, K that is no multiple of the 16-wide chunk or of the 128-wide wave round) against float64; shapes the kernel
+    refuses take the generic GEMM inside the same call."""
+    from slu_hip import lib, ops
+    lib.require_gfx950()
+    torch.manual_seed(1)
+    dev = "cuda"
+    cases = [(64, 768, 456, 0), (64, 768, 256, 0), (64, 100, 256, 0), (64, 256, 768, 1), (64, 456, 768, 1), (64, 256, 100, 1),
+             (37, 50, 20, 0), (1, 16, 4, 1), (130, 33, 1028, 0), (12, 60, 36, 1), (5, 7, 34, 0)]
+    problems, refs = [], []
+    for M, N, K, mode in cases:
+        A = torch.randn(M + 1, K + 4, device=dev)[1:, 4:]                       # row-strided view, 16-byte aligned start
+        Bm = torch.randn(N, K, device=dev) if mode == 0 else torch.randn(K, N + 3, device=dev)[:, :N]
+        bias = torch.randn(N, device=dev) if (M + N) % 2 else None
+        acc = (M % 3 == 0)
+        Cbig = torch.randn(M, N + 5, device=dev)
+        C = Cbig[:, :N]
+        ref = A.double() @ (Bm.double().t() if mode == 0 else Bm.double())
+        if bias is not None:
+            ref = ref + bias.double()
+        if acc:
+            ref = ref + C.double()
+        problems.append((A, Bm, bias, C, mode, acc))
+        refs.append((ref, Cbig, N, (A.abs().double() @ (Bm.abs().double().t() if mode == 0 else Bm.abs().double())).max().item()))
+    assert ops._small_ok(problems[0][0], problems[0][1], 0) and not ops._small_ok(problems[-1][0], problems[-1][1], 0)
+    untouched = [r[1][:, r[2]:].clone() for r in refs]
+    ops.gemm_small_batched(problems)
+    torch.cuda.synchronize()
+    for (A, Bm, bias, C, mode, acc), (ref, Cbig, N, scale), keep in zip(problems, refs, untouched):
+        err = (C.double() - ref).abs().max().item() / scale
+        assert err <= 2e-6, (tuple(A.shape), N, mode, err)
+        assert torch.equal(Cbig[:, N:], keep)                                    # nothing written outside the (M, N) block
+    # deterministic
+    C1 = torch.empty(64, 768, device=dev)
+    C2 = torch.empty(64, 768, device=dev)
+    A, Bm = problems[0][0], problems[0][1]
+    ops.gemm_small_batched([(A, Bm, None, C1, 0, 0)])
+    ops.gemm_small_batched([(A, Bm, None, C2, 0, 0)])
+    assert torch.equal(C1, C2)
