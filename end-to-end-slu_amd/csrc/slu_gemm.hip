@@ -624,9 +624,9 @@ struct SmallProblem {
 struct SmallArgs { SmallProblem p[4]; int count; };
 
 constexpr int SM_WAVES = 8;
-constexpr int SM_CHUNKS = 8;    // chunks of 16 k per wave and pass
+constexpr int SM_CHUNKS = 4;    // chunks of 16 k per wave and pass (8 waves x 4 x 16 = 512 k per pass)
 
-__global__ void __launch_bounds__(SM_WAVES * 64)
+__global__ void __launch_bounds__(SM_WAVES * 64, 4)       // two workgroups per CU (<= 128 VGPRs)
 gemm_small_batched_kernel(const SmallArgs a) {
   __shared__ float red[SM_WAVES][64 * 16];
   int q = 0;
@@ -658,13 +658,17 @@ gemm_small_batched_kernel(const SmallArgs a) {
   const int nc = min(n, P.N - 1);
 
   for (int c0 = w; c0 < nchunks; c0 += SM_WAVES * SM_CHUNKS) {
+    // chunks this wave really has in this pass (wave-uniform): the others cost neither loads nor MFMAs (a first
+    // version issued all of them masked: 10 us per workgroup whatever K)
+    const int nv = min(SM_CHUNKS, (nchunks - c0 + SM_WAVES - 1) / SM_WAVES);
     float4 fa[SM_CHUNKS][4];
     float4 fb[SM_CHUNKS];
 #pragma unroll
     for (int u = 0; u < SM_CHUNKS; ++u) {
+      if (u >= nv) break;
       const int c = c0 + u * SM_WAVES;
       const int k = c * 16 + 4 * kg;                       // this lane's four k of the chunk
-      const bool ok = c < nchunks && k < P.K;              // K % 4 == 0: a lane's four k are all in or all out
+      const bool ok = k < P.K;                             // K % 4 == 0: a lane's four k are all in or all out
       const int kc = ok ? k : 0;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -684,13 +688,16 @@ gemm_small_batched_kernel(const SmallArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < SM_CHUNKS; ++u) {
+      if (u >= nv) break;
+      // k sub-step outermost: the four m-tiles are four independent accumulator chains
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        acc[mt] = mfma16(fa[u][mt].x, fb[u].x, acc[mt]);
-        acc[mt] = mfma16(fa[u][mt].y, fb[u].y, acc[mt]);
-        acc[mt] = mfma16(fa[u][mt].z, fb[u].z, acc[mt]);
-        acc[mt] = mfma16(fa[u][mt].w, fb[u].w, acc[mt]);
-      }
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(fa[u][mt].x, fb[u].x, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(fa[u][mt].y, fb[u].y, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(fa[u][mt].z, fb[u].z, acc[mt]);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(fa[u][mt].w, fb[u].w, acc[mt]);
     }
   }
   // D[row = 4 kg + r][col = i] of m-tile mt -> red[w][(mt * 16 + 4 kg + r) * 16 + i]
