@@ -15,6 +15,7 @@
 //     72 x 16 = 1152 cycles per wave, 2304 per SIMD (two waves) for SIXTEEN sequences, against 1536 cycles for
 //     FOUR sequences on the fp32 4x4x1 kernel: 2.7x the sequences per CU-cycle.
 #include "slu_bf16.h"
+#include <stdlib.h>
 
 namespace slu {
 
@@ -25,7 +26,16 @@ __device__ __forceinline__ float bf_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+#ifdef SLU_GRU_PROBE
+#define SLU_BDBG(bit) (p.dbg & (bit))
+#else
+#define SLU_BDBG(bit) 0
+#endif
+
 struct GruBfParams {
+#ifdef SLU_GRU_PROBE
+  int dbg;                // ablation mask of the probe build (tools/gru_probe.py): never compiled into the product
+#endif
   const float* gx;        // (T, B, D*3H)
   const float* w_hh[2];   // (3H, H) fp32
   const float* b_hh[2];   // (3H)
@@ -116,7 +126,10 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     float ngr[4], ngz[4], ngn[4];
-    {
+    if (SLU_BDBG(1)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ngr[r] = gr[r]; ngz[r] = gz[r]; ngn[r] = gn[r]; }
+    } else {
       const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -128,6 +141,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!SLU_BDBG(16))
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       uint4 fa[NS];                     // (W_hh takes 144 of the 256 registers: one fragment set at a time)
@@ -144,10 +158,15 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     float hn[4], rr[4], zz[4], nn[4], qq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (SLU_BDBG(8)) {       // probe: gate math without the transcendentals
+        rr[r] = 0.5f + 0.01f * (gr[r] + (acc[0][r] + bhr)); zz[r] = 0.5f + 0.01f * (gz[r] + (acc[1][r] + bhz));
+        qq[r] = acc[2][r] + bhn; nn[r] = 0.01f * (gn[r] + rr[r] * qq[r]);
+      } else {
       rr[r] = bf_sigmoid(gr[r] + (acc[0][r] + bhr));
       zz[r] = bf_sigmoid(gz[r] + (acc[1][r] + bhz));
       qq[r] = acc[2][r] + bhn;
       nn[r] = bf_tanh(gn[r] + rr[r] * qq[r]);
+      }
       hn[r] = (1.0f - zz[r]) * nn[r] + zz[r] * hprev[r];
     }
     if (p.reserve) {      // trainable layer (bf16 forward, fp32 BPTT): the gates the exact BPTT kernels read
@@ -163,10 +182,17 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       unsigned short sp[NS];
-      split_bf16<NS>(hn[r], sp);
+      if (SLU_BDBG(32)) {      // probe: one rounding instead of the NS-way split
+        sp[0] = f32_to_bf16_rne(hn[r]);
 #pragma unroll
-      for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<unsigned short*>(hnext + pl * (16 * ROWB) + h_off[r]) = sp[pl];
-      if (o_off[r] >= 0) outd[(size_t)t * out_ts + o_off[r]] = hn[r];
+        for (int pl = 1; pl < NS; ++pl) sp[pl] = 0;
+      } else {
+        split_bf16<NS>(hn[r], sp);
+      }
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl)
+        if (!SLU_BDBG(64)) *reinterpret_cast<unsigned short*>(hnext + pl * (16 * ROWB) + h_off[r]) = sp[pl];
+      if (o_off[r] >= 0 && !SLU_BDBG(2)) outd[(size_t)t * out_ts + o_off[r]] = hn[r];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hprev[r] = hn[r]; gr[r] = ngr[r]; gz[r] = ngz[r]; gn[r] = ngn[r]; }
@@ -189,6 +215,9 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
     SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_bf16: hidden size %lld not instantiated (64, 128)", (long long)H);
   SLU_REQUIRE(cdiv(B, 16) <= 65535 && B * D * 3 * H < (1LL << 31), "slu_gru_seq_fwd_bf16: B too large");
   GruBfParams p;
+#ifdef SLU_GRU_PROBE
+  { const char* e = getenv("SLU_GRU_DBG"); p.dbg = e ? atoi(e) : 0; }
+#endif
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
   p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
   dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);

@@ -22,6 +22,16 @@ from slu_hip import ops  # noqa: E402
 from bench_kernels import timeit  # noqa: E402
 
 H, D = 128, 2
+if os.environ.get("PROBE_KERNEL") == "bf":
+    # the split-precision recurrence of the frozen layers at the super-batch size (bits: 1 no gx loads, 2 no output
+    # stores, 8 gates without transcendentals, 16 no MFMAs, 32 one rounding instead of the 3-way split, 64 no LDS stores)
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    for B, T in ((1280, 150), (64, 150)):
+        gx = torch.randn(T, B, 2 * 3 * H, device="cuda")
+        f, _ = timeit(lambda: ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, 3), reps=3)
+        print("bf16x3 B=%d T=%d: %.3f us/step" % (B, T, f / T))
+    sys.exit(0)
 wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
 bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
 for B, T in ((64, 300), (32, 1000)):
