@@ -186,18 +186,16 @@ attention_bwd_kernel(const AttBwdArgs a) {
   for (int v = tid; v < a.Vd; v += 256) dc[v] = a.d_ctx[(size_t)b * a.ld_dctx + v];
   for (int t = tid; t < a.T; t += 256) wt[t] = a.weights[(size_t)b * a.T + t];
   __syncthreads();
-  for (int t = w; t < a.T; t += 4) {          // d a_t = <values[b,t], d_ctx>
+  for (int t = w; t < a.T; t += 4) {          // d a_t = <values[b,t], d_ctx>; d_values[b,t] += a_t d_ctx
     const size_t o = (size_t)t * a.v_t + (size_t)b * a.v_b;
+    const float at = wt[t];
     float acc = 0.0f;
-    for (int v = lane; v < a.Vd; v += 64) acc = fmaf(a.values[o + v], dc[v], acc);
+    for (int v = lane; v < a.Vd; v += 64) {
+      acc = fmaf(a.values[o + v], dc[v], acc);
+      a.d_values[o + v] += at * dc[v];
+    }
     acc = wave_sum(acc);
     if (lane == 0) ds[t] = acc;
-  }
-  // d_values[b,t,v] += a_t d_ctx[v]: all (t, v) pairs spread over the workgroup, independent read-modify-writes
-  // (as a per-frame loop inside the dot product above every frame paid its own memory round trip: 13.9 us per launch)
-  for (int e = tid; e < a.T * a.Vd; e += 256) {
-    const int t = e / a.Vd, v = e - t * a.Vd;
-    a.d_values[(size_t)t * a.v_t + (size_t)b * a.v_b + v] += wt[t] * dc[v];
   }
   __syncthreads();
   float dot = 0.0f;
@@ -206,18 +204,13 @@ attention_bwd_kernel(const AttBwdArgs a) {
   __syncthreads();
   for (int t = tid; t < a.T; t += 256) ds[t] = wt[t] * (ds[t] - dot) * a.inv_scale;     // d score_t
   __syncthreads();
-  for (int e = tid; e < a.T * a.Kd; e += 256) {          // d_keys[b,t,k] += d score_t * q[k]
-    const int t = e / a.Kd, k = e - t * a.Kd;
-    a.d_keys[(size_t)t * a.s_t + (size_t)b * a.s_b + k] += ds[t] * q[k];
-  }
-  for (int k = tid; k < a.Kd; k += 256) {                 // d_query[k] = sum_t d score_t * keys[b,t,k] (frames in order)
+  for (int k = tid; k < a.Kd; k += 256) {
     float acc = 0.0f;
-    for (int t0 = 0; t0 < a.T; t0 += 8) {
-      float kv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) kv[u] = a.keys[(size_t)min(t0 + u, a.T - 1) * a.s_t + (size_t)b * a.s_b + k];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc = (t0 + u < a.T) ? fmaf(ds[t0 + u], kv[u], acc) : acc;
+    const float qk = q[k];
+    for (int t = 0; t < a.T; ++t) {
+      const size_t o = (size_t)t * a.s_t + (size_t)b * a.s_b + k;
+      acc = fmaf(ds[t], a.keys[o], acc);
+      a.d_keys[o] += ds[t] * qk;
     }
     a.d_query[(size_t)b * a.ld_dq + k] = acc;
   }
