@@ -69,7 +69,7 @@ def _check(ranks, single, world, comm):
     # Adam normalises by |g|: where a gradient entry is ~0 the two summation orders may differ in sign, which moves
     # that parameter by up to 2 lr = 6e-3 per step (absolute), twelve steps here — a gross error (a missing or doubled
     # reduction) would show as O(1) and in the losses below
-    assert worst <= 5e-2
+    assert worst <= 5e-3               # measured 9e-6 with two ranks
     for (acc1, loss1), (accn, lossn) in zip(single["epochs"], a["epochs"]):
         assert abs(loss1 - lossn) <= 1e-3 * max(1.0, abs(loss1))
 
