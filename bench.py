@@ -313,7 +313,8 @@ def _timed_graph(fn, stream, reps=20):
     return ms
 
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (fp16: the same rate)
+MFMA_PRODUCTS = {1: 1.0, 2: 3.0, 3: 6.0}     # 16-bit MFMA products issued per algorithmic product, by split scheme
 PEAK_HBM_TBS = 8.0                 # HBM3E spec (6.3 TB/s achievable per the same guide)
 
 
@@ -355,7 +356,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             ns = models.contraction_nsplit(True) if conv_frozen else (1 if ops.bf16_mode() else 0)
             if ns and ops.wconv_bf16_supported(C, stride, pool, k, ns):
                 ms = _timed_graph(lambda: ops.wconv_fwd_bf16(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, ns), stream)
-                name, mult, peak = "wconv_bf_fwd_kernel<%d>" % ns, (6.0 if ns == 3 else 1.0), PEAK_BF16_MFMA_TFLOPS
+                name, mult, peak = "wconv_bf_fwd_kernel<%d>" % ns, MFMA_PRODUCTS[ns], PEAK_BF16_MFMA_TFLOPS
             else:
                 ms = _timed_graph(lambda: ops.wconv_fwd(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, False), stream)
                 name, mult, peak = "wconv_fwd_kernel", 1.0, PEAK_FP32_MFMA_TFLOPS
@@ -382,7 +383,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             gx = torch.randn(T, B, N, device=dev)
             if ns:
                 planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
-                mult = 6.0 if ns == 3 else 1.0
+                mult = MFMA_PRODUCTS[ns]
                 ms = _timed_graph(lambda: ops.gemm_bf16(planes, packed, b_ih, N, I), stream)
                 kc = ops.round_up(I, 32) // 32
                 # K <= 64: the row-panel kernel (A resident in LDS, HBM-write bound); else the tiled kernel
@@ -393,7 +394,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                 else:
                     gemm_name = "gemm_bf_kernel<%d>" % ns
                 rows.setdefault(gemm_name, []).append(
-                    {"shape": "M=%d N=%d K=%d input projection, %d bf16 plane(s) (%s)" % (T * B, N, I, ns, where),
+                    {"shape": "M=%d N=%d K=%d input projection, %d 16-bit plane(s) (%s)" % (T * B, N, I, ns, where),
                      "flops": 2.0 * T * B * N * I, "ms": ms, "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
                      "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + 2.0 * ns * N * ops.round_up(I, 32) + 4.0 * T * B * N})
                 ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
@@ -470,6 +471,10 @@ def dtype_label():
     if models.contraction_nsplit(False) == 1:
         return ("bf16 (operands of every forward contraction - convolutions, input projections, recurrences - and of the "
                 "data-gradient contractions on bf16 MFMA; fp32 accumulation, gate math, weight gradients, master weights, Adam)")
+    if models.contraction_nsplit(True) == 2:
+        return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
+                "operands split into 2 fp16 terms (22-bit significand), 3 fp16 MFMA products, fp32 accumulation - "
+                "fp32-class: same deviation from float64 as an fp32 fmaf chain, parity <= 1e-4)")
     if models.contraction_nsplit(True) == 3:
         return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
                 "operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation - fp32-class, parity <= 1e-4)")

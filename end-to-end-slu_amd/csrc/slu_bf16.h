@@ -1,16 +1,25 @@
-// bf16 MFMA building blocks shared by the split-precision kernels (slu_gemm_bf16.hip, slu_gru_bf16.hip,
-// slu_wconv_bf16.hip).
+// Low-precision-MFMA building blocks shared by the split-precision kernels (slu_gemm_bf16.hip, slu_gru_bf16.hip,
+// slu_wconv_bf16.hip, slu_pool.hip).  A "split scheme" NS writes every fp32 operand as NS 16-bit terms
+// ("planes") and forms the contraction from a few 16-bit MFMA products with fp32 accumulation:
 //
-// Split precision.  An fp32 value x is written as x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1),
-// x3 = bf16(x - x1 - x2): three 8-bit significands cover fp32's 24 bits, i.e. the triple is (barring
-// underflow) EXACT.  A product a*b is then the sum of nine bf16 x bf16 products; the three with combined
-// order >= 5 — (2,3), (3,2), (3,3) — are below 2^-24 |a b| and are dropped, the other six are formed by
-// v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulation).  Six bf16 MFMAs cost 6/16 of one fp32
-// MFMA of the same shape, so an "fp32-class" contraction runs at up to 2.67x the fp32 MFMA rate with an
-// error of a few 2^-24 per product (same class as the fp32 fmaf chain; tests hold it to the same 1e-4).
+// NS = 3, "bf16x3".  x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): three 8-bit
+//   significands cover fp32's 24 bits, i.e. the triple is (barring underflow) EXACT.  A product a*b is then the sum of
+//   nine bf16 x bf16 products; the three with combined order >= 5 — (2,3), (3,2), (3,3) — are below 2^-24 |a b| and are
+//   dropped, the other six are formed by v_mfma_f32_16x16x32_bf16: 6/16 of the fp32-MFMA cycles.  bf16 has fp32's
+//   exponent: no range restriction.
+// NS = 2, "f16x2" (default of the frozen stages).  x = hi + 2^-11 lo with hi = fp16(x) and lo = fp16(2^11 (x - hi)):
+//   two 11-bit significands = 22 bits, |x - hi - 2^-11 lo| <= 2^-22 |x|.  Of the four products hi_a hi_b goes to one
+//   accumulator, hi_a lo_b + lo_a hi_b (both carry the factor 2^11) to a second one, lo_a lo_b (<= 2^-22 |a b|) is
+//   dropped; the result is acc0 + 2^-11 acc1.  THREE v_mfma_f32_16x16x32_f16 — 3/16 of the fp32-MFMA cycles, half of
+//   bf16x3 — for an error of <= 3 * 2^-22 per product in the worst case; measured (tests/test_hip_bf16.py): 1e-7 of
+//   sum |a b| against float64 for the GEMMs — torch's fp32 GEMM: 2e-7 — and the fp32 kernels' own round-off over a
+//   300-step recurrence.  Scaling lo by 2^11 keeps it in fp16's NORMAL range
+//   whenever hi is; values below fp16's smallest normal (6.1e-5) get hi = 0 and are carried by lo alone (11 bits,
+//   absolute error <= 1.5e-8) so that nothing depends on how the MFMA treats fp16 denormals.  Range: |x| < 65504
+//   (fp16's largest finite value; beyond it hi is infinite and the result NaN — SLU_FROZEN_MATH=bf16x3 has no limit).
 // NS = 1 is plain bf16 (BASELINE configs[4]: bf16 weights / activations, fp32 accumulation).
 //
-// Activations travel between the frozen stages as NS planes of bf16, plane p = element-wise x_{p+1},
+// Activations travel between the frozen stages as NS planes of 16-bit terms, plane p = element-wise term p,
 // rows padded with zeros to a multiple of 32 columns (one MFMA k-chunk).
 #pragma once
 #include "slu_common.h"
@@ -19,15 +28,31 @@ namespace slu {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// the product pairs (plane of A, plane of B) kept for a given split count
-template <int NS> struct SplitPairs;
-template <> struct SplitPairs<1> { static constexpr int N = 1; static constexpr int A[1] = {0}; static constexpr int B[1] = {0}; };
-template <> struct SplitPairs<3> {
-  static constexpr int N = 6;
-  // small terms first: the accumulation order adds the corrections before the dominant product
-  static constexpr int A[6] = {1, 2, 0, 1, 0, 0};
-  static constexpr int B[6] = {1, 0, 2, 0, 1, 0};
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// The products kept by a split scheme: q-th product = (plane PA(q) of A) x (plane PB(q) of B), added to accumulator
+// ACC(q).  Small terms first: the accumulation order adds the corrections before the dominant product.
+template <int NS> struct Split;
+template <> struct Split<1> {
+  static constexpr int NPAIR = 1, NACC = 1;
+  static __device__ __host__ constexpr int PA(int) { return 0; }
+  static __device__ __host__ constexpr int PB(int) { return 0; }
+  static __device__ __host__ constexpr int ACC(int) { return 0; }
 };
+template <> struct Split<3> {
+  static constexpr int NPAIR = 6, NACC = 1;      // (1,1) (2,0) (0,2) (1,0) (0,1) (0,0)
+  static __device__ __host__ constexpr int PA(int q) { return (0x001021 >> (4 * q)) & 15; }
+  static __device__ __host__ constexpr int PB(int q) { return (0x010201 >> (4 * q)) & 15; }
+  static __device__ __host__ constexpr int ACC(int) { return 0; }
+};
+template <> struct Split<2> {
+  static constexpr int NPAIR = 3, NACC = 2;      // (1,0) (0,1) -> accumulator 1 (scaled 2^11); (0,0) -> accumulator 0
+  static __device__ __host__ constexpr int PA(int q) { return q == 0 ? 1 : 0; }
+  static __device__ __host__ constexpr int PB(int q) { return q == 1 ? 1 : 0; }
+  static __device__ __host__ constexpr int ACC(int q) { return q == 2 ? 0 : 1; }
+};
+constexpr float F16X2_LO_SCALE = 2048.0f, F16X2_LO_INV = 1.0f / 2048.0f;
+constexpr float F16_MIN_NORMAL = 6.103515625e-05f;
 
 // round to nearest even on the gfx950 conversion unit (v_cvt_pk_bf16_f32: one instruction instead of the
 // five-instruction integer sequence; the splits are VALU-bound in the recurrence and the staging loops)
@@ -50,8 +75,43 @@ __device__ __forceinline__ void split_bf16(float x, unsigned short (&h)[NS]) {
   }
 }
 
+// x -> (hi, lo) fp16 terms of the f16x2 scheme: x ~= hi + 2^-11 lo (see the header comment)
+__device__ __forceinline__ void split_f16x2(float x, unsigned short (&h)[2]) {
+  const float hi = __builtin_fabsf(x) >= F16_MIN_NORMAL ? (float)(_Float16)x : 0.0f;
+  h[0] = __builtin_bit_cast(unsigned short, (_Float16)hi);                              // exact
+  h[1] = __builtin_bit_cast(unsigned short, (_Float16)((x - hi) * F16X2_LO_SCALE));     // x - hi is exact
+}
+
+// the NS terms of scheme NS
+template <int NS>
+__device__ __forceinline__ void split_terms(float x, unsigned short (&h)[NS]) {
+  if constexpr (NS == 2) split_f16x2(x, h);
+  else split_bf16<NS>(x, h);
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// one 16 x 16 x 32 product of scheme NS's element type
+template <int NS>
+__device__ __forceinline__ f32x4 mfma_split(const uint4& a, const uint4& b, f32x4 c) {
+  if constexpr (NS == 2) return mfma_f16(a, b, c);
+  else return mfma_bf16(a, b, c);
+}
+// the result of scheme NS from its accumulators (a1 is ignored when the scheme has one)
+template <int NS>
+__device__ __forceinline__ f32x4 split_result(const f32x4& a0, const f32x4& a1) {
+  if constexpr (NS == 2) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(a1[e], F16X2_LO_INV, a0[e]);
+    return r;
+  } else {
+    return a0;
+  }
 }
 
 // LDS image of a (rows x 32) bf16 operand tile: 64 bytes (four 16-byte slots) per row, dense; slot kg of

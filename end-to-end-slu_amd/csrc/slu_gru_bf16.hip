@@ -1,8 +1,9 @@
 // Split-precision persistent GRU recurrence (forward only, no saved gates) for FROZEN layers:
 // torch.nn.GRU semantics (models.py:232/:262: h0 = 0, gates [r; z; n], optional reverse direction), the
 // hidden x hidden contraction on v_mfma_f32_16x16x32_bf16 with W_hh and h_{t-1} each split into NS bf16
-// terms (slu_bf16.h): NS = 3 keeps six products (fp32-class result at 6/16 of the fp32-MFMA cycles),
-// NS = 1 is plain bf16 (BASELINE configs[4]).
+// 16-bit terms (slu_bf16.h): NS = 3 (bf16x3) keeps six products (fp32-class result at 6/16 of the fp32-MFMA cycles),
+// NS = 2 (f16x2: two fp16 terms, v_mfma_f32_16x16x32_f16) three products (fp32-class at 3/16), NS = 1 is plain bf16
+// (BASELINE configs[4]).
 //
 // Geometry = gru_seq_fwd_kernel's: grid (16-sequence tile) x (direction), H/16 waves, wave w owns hidden
 // units [16w, 16w+16) of all three gates, so each lane ends up with r, z, n of the same (sequence, unit) and
@@ -51,7 +52,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   constexpr int KC = H / 32;          // 32-wide k-chunks
   constexpr int ROWB = H * 2;         // bytes per LDS row (one sequence, one plane)
   constexpr int SLOTS = H / 8;        // 16-byte slots per row
-  constexpr int NPAIR = NS == 1 ? 1 : 6;
+  typedef Split<NS> SP;
   __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][NS][16 * ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +75,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
         const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         unsigned short s[8][NS];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split_bf16<NS>(v[e], s[e]);
+        for (int e = 0; e < 8; ++e) split_terms<NS>(v[e], s[e]);
 #pragma unroll
         for (int pl = 0; pl < NS; ++pl) {
           uint4 o;
@@ -137,10 +138,13 @@ gru_bf_fwd_kernel(const GruBfParams p) {
         ngr[r] = g[0]; ngz[r] = g[H]; ngn[r] = g[2 * H];
       }
     }
-    // one accumulator chain per gate: three independent chains per wave, two waves per SIMD
-    f32x4 acc[3];
+    // one accumulator chain per gate (two for f16x2: the 2^11-scaled cross terms): three or six independent
+    // chains per wave, two waves per SIMD
+    f32x4 accs[SP::NACC][3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) accs[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (!SLU_BDBG(16))
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -148,12 +152,15 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
       for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
 #pragma unroll
-      for (int q = 0; q < NPAIR; ++q) {
-        const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15;
+      for (int q = 0; q < SP::NPAIR; ++q) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = mfma_bf16(fa[pa], wb[g][c][pb], acc[g]);
+        for (int g = 0; g < 3; ++g)
+          accs[SP::ACC(q)][g] = mfma_split<NS>(fa[SP::PA(q)], wb[g][c][SP::PB(q)], accs[SP::ACC(q)][g]);
       }
     }
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = split_result<NS>(accs[0][g], accs[SP::NACC - 1][g]);
 
     float hn[4], rr[4], zz[4], nn[4], qq[4];
 #pragma unroll
@@ -187,7 +194,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
         for (int pl = 1; pl < NS; ++pl) sp[pl] = 0;
       } else {
-        split_bf16<NS>(hn[r], sp);
+        split_terms<NS>(hn[r], sp);
       }
 #pragma unroll
       for (int pl = 0; pl < NS; ++pl)
@@ -210,7 +217,7 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
   SLU_REQUIRE(gx && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd_bf16: null pointer");
   SLU_REQUIRE(D == 1 || (D == 2 && w_hh_rev && b_hh_rev), "slu_gru_seq_fwd_bf16: D must be 1 or 2 (with reverse weights)");
   SLU_REQUIRE(T > 0 && B > 0, "slu_gru_seq_fwd_bf16: non-positive T or B");
-  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_gru_seq_fwd_bf16: nsplit must be 1 or 3");
+  SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_gru_seq_fwd_bf16: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   if (H != 64 && H != 128)
     SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_bf16: hidden size %lld not instantiated (64, 128)", (long long)H);
   SLU_REQUIRE(cdiv(B, 16) <= 65535 && B * D * 3 * H < (1LL << 31), "slu_gru_seq_fwd_bf16: B too large");
@@ -224,9 +231,11 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
   hipStream_t st = (hipStream_t)stream;
   if (H == 128) {
     if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 3>), grid, dim3(512), 0, st, p);
+    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 1>), grid, dim3(512), 0, st, p);
   } else {
     if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 3>), grid, dim3(256), 0, st, p);
+    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 2>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 1>), grid, dim3(256), 0, st, p);
   }
   SLU_CHECK_LAUNCH("gru_bf_fwd_kernel");

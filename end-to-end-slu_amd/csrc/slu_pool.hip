@@ -128,8 +128,8 @@ __device__ __forceinline__ float4 keep_scale4(const PoolParams& q, uint64_t off_
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
-// grid: x over B*C/4 quads, y over output frames.  NS = 0: fp32 output y; NS = 1 / 3: the output goes straight
-// into the split-precision activation format (NS bf16 planes of (T_out*B) x C, plane stride `plane` elements)
+// grid: x over B*C/4 quads, y over output frames.  NS = 0: fp32 output y; NS = 1 / 2 / 3: the output goes straight
+// into the split-precision activation format (NS 16-bit planes of (T_out*B) x C, plane stride `plane` elements)
 // that the next frozen layer's input-projection GEMM reads (slu_gemm_bf16): no fp32 round trip, no split pass.
 template <int NS>
 __global__ void __launch_bounds__(256)
@@ -165,7 +165,7 @@ dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, uns
   } else {
     constexpr int NP = NS == 0 ? 1 : NS;
     unsigned short h[4][NP];
-    split_bf16<NP>(acc.x, h[0]); split_bf16<NP>(acc.y, h[1]); split_bf16<NP>(acc.z, h[2]); split_bf16<NP>(acc.w, h[3]);
+    split_terms<NP>(acc.x, h[0]); split_terms<NP>(acc.y, h[1]); split_terms<NP>(acc.z, h[2]); split_terms<NP>(acc.w, h[3]);
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
       *reinterpret_cast<uint2*>(planes + (size_t)pl * plane + to * row + col) =
@@ -312,7 +312,7 @@ extern "C" int slu_dropout_pool_fwd_planes(const float* x, const float* mask, in
                                            void* planes, int64_t plane_stride, int nsplit, int64_t T, int64_t B,
                                            int64_t C, void* stream) {
   SLU_REQUIRE(x && planes, "slu_dropout_pool_fwd_planes: null pointer");
-  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_dropout_pool_fwd_planes: nsplit must be 1 or 3");
+  SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_dropout_pool_fwd_planes: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   PoolParams q;
   int rc = pool_fill(q, "slu_dropout_pool_fwd_planes", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
@@ -320,12 +320,10 @@ extern "C" int slu_dropout_pool_fwd_planes(const float* x, const float* mask, in
     SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_dropout_pool_fwd_planes: needs C %% 32 == 0 (got %lld), aligned buffers, T_out <= 65535", (long long)C);
   SLU_REQUIRE(plane_stride >= (int64_t)q.T_out * B * C, "slu_dropout_pool_fwd_planes: plane stride too small");
   dim3 grid((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out);
-  if (nsplit == 3)
-    hipLaunchKernelGGL(dropout_pool_fwd4_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
-                       (unsigned short*)planes, (long long)plane_stride, q);
-  else
-    hipLaunchKernelGGL(dropout_pool_fwd4_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr,
-                       (unsigned short*)planes, (long long)plane_stride, q);
+#define SLU_DPP(NS_) hipLaunchKernelGGL(dropout_pool_fwd4_kernel<NS_>, grid, dim3(256), 0, (hipStream_t)stream, x, (float*)nullptr, \
+                                        (unsigned short*)planes, (long long)plane_stride, q)
+  if (nsplit == 3) SLU_DPP(3); else if (nsplit == 2) SLU_DPP(2); else SLU_DPP(1);
+#undef SLU_DPP
   SLU_CHECK_LAUNCH("dropout_pool_fwd4_kernel(planes)");
   return SLU_OK;
 }

@@ -56,7 +56,7 @@ bf_wconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int c_
     const int k = q / c_pad, ci = q - k * c_pad;
     const float v = (c < c_out && k < k_t && ci < c_in) ? w[((size_t)c * c_in + ci) * k_t + k] : 0.0f;
     unsigned short sp[NS];
-    split_bf16<NS>(v, sp);
+    split_terms<NS>(v, sp);
 #pragma unroll
     for (int p = 0; p < NS; ++p) h[p][e] = sp[p];
   }
@@ -81,7 +81,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* lds = reinterpret_cast<unsigned short*>(smem);     // [NS][nrows][Sp]
   constexpr int F = 64 * MT;                      // frames per workgroup
-  constexpr int NPAIR = NS == 1 ? 1 : 6;
+  typedef Split<NS> SP;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
@@ -126,8 +126,8 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
       for (int j = 0; j < U; ++j) {
         if (off[j] < 0) continue;
         unsigned short a[NS], c[NS];
-        split_bf16<NS>(v0[j], a);
-        split_bf16<NS>(v1[j], c);
+        split_terms<NS>(v0[j], a);
+        split_terms<NS>(v1[j], c);
 #pragma unroll
         for (int pl = 0; pl < NS; ++pl)
           *reinterpret_cast<unsigned*>(lds + pl * plane + off[j]) = a[pl] | ((unsigned)c[pl] << 16);
@@ -136,11 +136,13 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   }
   __syncthreads();
 
-  f32x4 acc[RT][CT];
+  f32x4 accs[SP::NACC][RT][CT];
 #pragma unroll
-  for (int m = 0; m < RT; ++m)
+  for (int a = 0; a < SP::NACC; ++a)
 #pragma unroll
-    for (int n = 0; n < CT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+      for (int n = 0; n < CT; ++n) accs[a][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int i = lane & 15, kg = lane >> 4;
   // tap chunk (kc, kg) starts at padded tap q = kc*32 + kg*8: LDS row offset q / S, column q % S (multiple of 8)
@@ -170,12 +172,12 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
       for (int m = 0; m < RT; ++m) fa[pl][m] = *reinterpret_cast<const uint4*>(lds + pl * plane + abase[m] + aoff);
     __builtin_amdgcn_sched_barrier(0);             // next chunk's filter loads and this chunk's fragments issued HERE
 #pragma unroll
-    for (int q = 0; q < NPAIR; ++q) {
-      const int pa = NS == 1 ? 0 : (0x001021 >> (4 * q)) & 15, pb = NS == 1 ? 0 : (0x010201 >> (4 * q)) & 15;
+    for (int q = 0; q < SP::NPAIR; ++q) {
 #pragma unroll
       for (int m = 0; m < RT; ++m)
 #pragma unroll
-        for (int n = 0; n < CT; ++n) acc[m][n] = mfma_bf16(fa[pa][m], fb[pb][n], acc[m][n]);
+        for (int n = 0; n < CT; ++n)
+          accs[SP::ACC(q)][m][n] = mfma_split<NS>(fa[SP::PA(q)][m], fb[SP::PB(q)][n], accs[SP::ACC(q)][m][n]);
     }
     qm += 32;
     while (qm >= p.S) { qm -= p.S; ++qd; }
@@ -184,6 +186,12 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
 #pragma unroll
       for (int n = 0; n < CT; ++n) fb[pl][n] = fbn[pl][n];
   }
+
+  f32x4 acc[RT][CT];
+#pragma unroll
+  for (int m = 0; m < RT; ++m)
+#pragma unroll
+    for (int n = 0; n < CT; ++n) acc[m][n] = split_result<NS>(accs[0][m][n], accs[SP::NACC - 1][m][n]);
 
   // ---- epilogue: bias, abs, max-pool over frame pairs, LeakyReLU, strided store (as wconv_fwd_kernel) ----
 #pragma unroll
@@ -205,7 +213,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
           t = p.do_abs ? fabsf(t) : t;
           t = real ? (t > 0.0f ? t : t * p.slope) : 0.0f;
           unsigned short sp[NS];
-          split_bf16<NS>(t, sp);
+          split_terms<NS>(t, sp);
 #pragma unroll
           for (int pl = 0; pl < NS; ++pl)
             p.planes[(size_t)pl * p.plane + ((size_t)f * p.Bn + b) * p.Kp_out + c] = sp[pl];
@@ -303,7 +311,7 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   SLU_REQUIRE(!in_table || (table_rows >= 1 && table_rows <= B), "slu_wconv_fwd_bf16: bad table_rows");
   SLU_REQUIRE(B > 0 && l_in > 0 && c_in > 0 && c_out > 0 && k_t > 0 && stride_t > 0, "slu_wconv_fwd_bf16: non-positive size");
   SLU_REQUIRE(pool == 1 || pool == 2, "slu_wconv_fwd_bf16: pool must be 1 or 2 (got %d)", pool);
-  SLU_REQUIRE(nsplit == 1 || nsplit == 3, "slu_wconv_fwd_bf16: nsplit must be 1 or 3");
+  SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_wconv_fwd_bf16: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   SLU_REQUIRE(B <= 65535, "slu_wconv_fwd_bf16: B must be <= 65535");
   const int64_t c_pad = bf_c_pad(c_in);
   const int64_t S = stride_t * c_pad, S_real = stride_t * c_in;
@@ -323,12 +331,10 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   uint4* wp = reinterpret_cast<uint4*>(workspace);
   if (!packed_valid) {     // else: the workspace still holds the pack of these very filters (frozen block, caller's cache)
     const int total = (int)(KC * NT * 64);
-    if (nsplit == 3)
-      hipLaunchKernelGGL(bf_wconv_pack_kernel<3>, dim3((total + 255) / 256), dim3(256), 0, st, weight, wp, (int)c_out,
-                         (int)c_in, (int)c_pad, (int)k_t, NT, (int)KC);
-    else
-      hipLaunchKernelGGL(bf_wconv_pack_kernel<1>, dim3((total + 255) / 256), dim3(256), 0, st, weight, wp, (int)c_out,
-                         (int)c_in, (int)c_pad, (int)k_t, NT, (int)KC);
+#define SLU_WPACK(NS_) hipLaunchKernelGGL(bf_wconv_pack_kernel<NS_>, dim3((total + 255) / 256), dim3(256), 0, st, weight, wp, \
+                                          (int)c_out, (int)c_in, (int)c_pad, (int)k_t, NT, (int)KC)
+    if (nsplit == 3) SLU_WPACK(3); else if (nsplit == 2) SLU_WPACK(2); else SLU_WPACK(1);
+#undef SLU_WPACK
     SLU_CHECK_LAUNCH("bf_wconv_pack_kernel");
   }
   WconvBfParams p;
@@ -359,5 +365,6 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   }
   if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_fwd_bf16: window of %zu bytes exceeds the 160 KiB LDS", lds);
   dim3 grid((unsigned)cdiv(l_conv, F), (unsigned)B);
-  return nsplit == 3 ? bf_launch_nt<3>(MT, NT, grid, lds, st, p) : bf_launch_nt<1>(MT, NT, grid, lds, st, p);
+  return nsplit == 3 ? bf_launch_nt<3>(MT, NT, grid, lds, st, p)
+       : nsplit == 2 ? bf_launch_nt<2>(MT, NT, grid, lds, st, p) : bf_launch_nt<1>(MT, NT, grid, lds, st, p);
 }

@@ -99,16 +99,25 @@ def _site(module, idx):
 def contraction_nsplit(frozen):
     """Arithmetic of the forward contractions of a GRU layer (input projection and recurrence):
       0  exact fp32 MFMA — trainable layers (default);
-      3  fp32 values as three bf16 terms, six bf16 MFMA products (fp32-class, csrc/slu_bf16.h) — FROZEN layers
-         (default; SLU_FROZEN_MATH=fp32 switches it off);
+      2  "f16x2": fp32 values as two fp16 terms (22-bit significand), three fp16 MFMA products, two fp32
+         accumulators (fp32-class: the deviation from float64 equals an fp32 fmaf chain's, csrc/slu_bf16.h; values
+         up to 65504) — FROZEN layers (default);
+      3  "bf16x3": three bf16 terms, six bf16 MFMA products (fp32-class, no range limit) — FROZEN layers with
+         SLU_FROZEN_MATH=bf16x3; SLU_FROZEN_MATH=fp32 switches the split schemes off (0);
       1  plain bf16 operands, fp32 accumulation and gate math — every layer when SLU_DTYPE=bf16
          (BASELINE configs[4]: weights and activations enter every forward contraction and the data-gradient
          contractions as bf16 — ops.bf16_mode; weight gradients, master weights and Adam stay fp32)."""
     if os.environ.get("SLU_DTYPE", "f32") == "bf16":
         return 1
-    if frozen and os.environ.get("SLU_FROZEN_MATH", "bf16x3") != "fp32":
-        return 3
+    if frozen:
+        mode = os.environ.get("SLU_FROZEN_MATH", "f16x2")
+        if mode not in _FROZEN_MATH:
+            raise ValueError("SLU_FROZEN_MATH=%r: expected one of %s" % (mode, sorted(_FROZEN_MATH)))
+        return _FROZEN_MATH[mode]
     return 0
+
+
+_FROZEN_MATH = {"f16x2": 2, "bf16x3": 3, "fp32": 0}
 
 
 def _require_device(t):
@@ -273,7 +282,7 @@ class GRU(torch.nn.Module):
         return self._ih_storage
 
     def split_frozen(self):
-        """nsplit (1 / 3) when this layer runs FROZEN on the split-precision kernels, else 0."""
+        """nsplit (1 / 2 / 3) when this layer runs FROZEN on the split-precision kernels, else 0."""
         if any(q.requires_grad for q in self.parameters()):
             return 0
         nsplit = contraction_nsplit(True)

@@ -62,8 +62,9 @@ SIGNATURES = {
     "slu_gemm_bf16_pack_bytes": (c_sz, [c_i64, c_i64, c_int]),
     "slu_gemm_bf16_pack": (c_int, [vp, c_i64, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gemm_bf16": (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
+    "slu_gemm_bf16_a32": (c_int, [vp, c_i64, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
     "slu_gemm_tn_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
-    "slu_gemm_tn_bf16": (c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i64, c_i64, vp, c_sz, vp]),
+    "slu_gemm_tn_bf16": (c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp, c_sz, vp]),
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
                                    c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp]),
@@ -97,7 +98,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 4          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

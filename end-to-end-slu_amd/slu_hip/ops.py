@@ -24,6 +24,31 @@ def bf16_mode():
     return os.environ.get("SLU_DTYPE", "f32") == "bf16"
 
 
+_TRAIN_MATH = {"split": (2, 3), "bf16x3": (3, 3), "fp32": (0, 0)}
+
+
+def train_nsplit(grad=False):
+    """Split scheme (csrc/slu_bf16.h) of the GEMM-shaped contractions of TRAINABLE layers — GRU input projections, their
+    data and weight gradients, the convolution blocks' data gradients, the ASR heads' products (SLU_TRAIN_MATH):
+      "split" (default): products of activations and weights (grad=False) on f16x2 — fp32 operands as two fp16 terms,
+          three fp16 MFMA products, 3/16 of the fp32-MFMA cycles; products with a GRADIENT operand (grad=True: d_gx W,
+          d_gx^T x, ...) on bf16x3 — three bf16 terms, six products, 6/16 — because gradient entries are far below
+          fp16's smallest normal number (softmax gradients of a 10 000-word head: 1e-7), where f16x2 keeps 11 bits
+          only; bf16 has fp32's exponent.  Both are fp32-class: 1e-7 of sum |a b| against float64 (tests/test_hip_bf16.py);
+      "bf16x3": bf16x3 for both;   "fp32": exact fp32 MFMA everywhere;
+      SLU_DTYPE=bf16 (BASELINE configs[4]) overrides: plain bf16 operands (1).
+    Always exact fp32: the recurrences (forward and BPTT) — bf16 mode's forward recurrences excepted —, the FORWARD pass of
+    trainable convolution blocks (|.| and LeakyReLU have kinks: the sign of a pre-activation within round-off of zero
+    decides a whole gradient term, and the exact kernel keeps those decisions where the reference's are), the convolutions'
+    weight gradients, every reduction, the loss and the optimizer."""
+    if bf16_mode():
+        return 1
+    mode = os.environ.get("SLU_TRAIN_MATH", "split")
+    if mode not in _TRAIN_MATH:
+        raise ValueError("SLU_TRAIN_MATH=%r: expected one of %s" % (mode, sorted(_TRAIN_MATH)))
+    return _TRAIN_MATH[mode][1 if grad else 0]
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -340,25 +365,31 @@ class PoolActFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-# -- split-precision (bf16 MFMA) path of the frozen stages: see csrc/slu_bf16.h --------------------------
+# -- split-precision (16-bit MFMA) path of the frozen stages: see csrc/slu_bf16.h ------------------------
 def round_up(n, m):
     return -(-n // m) * m
 
 
+def plane_dtype(nsplit):
+    """Element type of the planes of split scheme `nsplit`: 2 = f16x2 (two fp16 terms), 1 / 3 = bf16 terms."""
+    return torch.float16 if nsplit == 2 else torch.bfloat16
+
+
 def split_bf16(x2d, nsplit):
-    """fp32 (rows, K) with unit column stride -> (nsplit, rows, round_up(K, 32)) bf16 planes, zero padded."""
+    """fp32 (rows, K) with unit column stride -> (nsplit, rows, round_up(K, 32)) planes of 16-bit terms, zero padded
+    (nsplit 1 / 3: bf16 terms, 2: the fp16 pair of the f16x2 scheme)."""
     L = _lib.load()
     rows, K = x2d.shape
     assert x2d.dtype == torch.float32 and x2d.stride(1) == 1
-    planes = torch.empty(nsplit, rows, round_up(K, 32), dtype=torch.bfloat16, device=x2d.device)
+    planes = torch.empty(nsplit, rows, round_up(K, 32), dtype=plane_dtype(nsplit), device=x2d.device)
     _lib.check(L.slu_split_bf16(x2d.data_ptr(), x2d.stride(0), planes.data_ptr(), planes.stride(0), rows, K,
                                 nsplit, _stream()), "slu_split_bf16")
     return planes
 
 
 def gemm_bf16_pack(w, nsplit):
-    """(N, K) fp32 weights — any strides, e.g. the .t() view of a weight — -> bf16 planes in MFMA B-fragment order
-    (opaque byte tensor)."""
+    """(N, K) fp32 weights — any strides, e.g. the .t() view of a weight — -> the scheme's 16-bit planes in MFMA
+    B-fragment order (opaque byte tensor)."""
     L = _lib.load()
     N, K = w.shape
     assert w.dtype == torch.float32
@@ -377,6 +408,34 @@ def gemm_bf16(planes, packed, bias, N, K, out=None):
     _lib.check(L.slu_gemm_bf16(planes.data_ptr(), planes.stride(0), ld, packed.data_ptr(), _ptr(bias), out.data_ptr(),
                                out.stride(0), M, N, K, nsplit, _stream()), "slu_gemm_bf16")
     return out
+
+
+def gemm_a32_ok(a, N, K):
+    """Shapes slu_gemm_bf16_a32 takes: a (M, K) fp32 with unit column stride, 16-byte aligned rows; N, K % 4 == 0."""
+    return (a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and a.stride(0) % 4 == 0 and a.stride(0) >= K
+            and a.data_ptr() % 16 == 0 and N % 4 == 0 and K % 4 == 0)
+
+
+def gemm_a32(a, packed, bias, N, nsplit, out=None):
+    """out (M, N) fp32 = a W^T + bias with the fp32 matrix a (M, K) split on the fly inside the kernel and W packed by
+    gemm_bf16_pack (W (N, K) or a transposed view of a weight): the GEMMs of trainable layers (slu_gemm_bf16_a32)."""
+    L = _lib.load()
+    M, K = a.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _lib.check(L.slu_gemm_bf16_a32(a.data_ptr(), a.stride(0), packed.data_ptr(), _ptr(bias), out.data_ptr(), out.stride(0),
+                                   M, N, K, nsplit, _stream()), "slu_gemm_bf16_a32")
+    return out
+
+
+def gemm_nt(a, w, bias=None, out=None, grad=False):
+    """a (M, K) @ w^T (w (N, K), any strides) + bias in the arithmetic of the trainable layers (train_nsplit; grad: a
+    is a gradient): the split-precision kernel where the shape allows it, else the exact fp32 GEMM."""
+    ns = train_nsplit(grad)
+    N, K = w.shape
+    if ns and a.is_cuda and gemm_a32_ok(a, N, K) and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0)):
+        return gemm_a32(a, gemm_bf16_pack(w.detach(), ns), bias, N, ns, out)
+    return gemm(a, w.t(), bias, out=out)
 
 
 def wconv_bf16_supported(c_in, stride, pool, k_t=None, nsplit=3):
@@ -452,7 +511,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     l_out = -(-l_conv // pool)
     if out_planes:
         assert time_major and wconv_bf16_planes_ok(c_out, pool)
-        planes = torch.empty(nsplit, l_out * B, round_up(c_out, 32), dtype=torch.bfloat16, device=x.device)
+        planes = torch.empty(nsplit, l_out * B, round_up(c_out, 32), dtype=plane_dtype(nsplit), device=x.device)
         ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
         _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, None, B, l_in, c_in, c_out,
                                         k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
@@ -501,7 +560,7 @@ def dropout_pool_fwd_planes(x, mask, p, seed, offset, method, factor, nsplit, of
     L = _lib.load()
     T, B, C = x.shape
     T_out = -(-T // factor)
-    planes = torch.empty(nsplit, T_out * B, C, dtype=torch.bfloat16, device=x.device)
+    planes = torch.empty(nsplit, T_out * B, C, dtype=plane_dtype(nsplit), device=x.device)
     mp, mst, msb = _mask_args(mask, T, B, C)
     _lib.check(L.slu_dropout_pool_fwd_planes(x.data_ptr(), mp, mst, msb, float(p), int(seed), int(offset),
                                              _ptr(offset_dev), int(sub_batch), 16, METHODS[method], factor,
@@ -760,7 +819,7 @@ class FrameHeadFn(torch.autograd.Function):
         if y_tm.dtype != torch.int64 or y_tm.numel() != T * B:
             raise TypeError("FrameHeadFn: y must be int64 of shape (B, T)")
         need = any(ctx.needs_input_grad[:3])
-        logits = gemm(hn, weight.t(), bias)
+        logits = gemm_nt(hn, weight, bias)                         # train_nsplit arithmetic
         row_stats = torch.empty(2 * T * B, dtype=torch.float32, device=h.device)
         out3 = torch.empty(3, dtype=torch.float32, device=h.device)
         _lib.check(L.slu_frame_ce_fwd(logits.data_ptr(), y_tm.data_ptr(), T * B, V, -1, int(need),
@@ -782,9 +841,9 @@ class FrameHeadFn(torch.autograd.Function):
         g = d_loss.float()
         dh = dW = db = None
         if ctx.needs_input_grad[0]:
-            dh = gemm(d_logits, weight).view(T, B, C)
+            dh = gemm_nt(d_logits, weight.t(), grad=True).view(T, B, C)
         if ctx.needs_input_grad[1]:
-            dW = gemm(d_logits.t(), hn)
+            dW = _wgrad(d_logits, hn, None)
         if ctx.needs_input_grad[2]:
             db = colsum(d_logits)
         scale_multi([t for t in (dh, dW, db) if t is not None], g)      # d loss upstream (a device scalar), one launch
@@ -800,10 +859,11 @@ class SincBlockFn(torch.autograd.Function):
         B, T = x.shape
         filters = sinc_filters(b1, band, filt_dim, fs)
         need = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        if bf16_mode() and pool in (1, 2) and wconv_bf16_supported(1, stride, pool, filt_dim, 1):
+        ns = 1 if bf16_mode() else 0           # the forward pass of a TRAINABLE block is exact fp32 (train_nsplit: kinks)
+        if ns and pool in (1, 2) and wconv_bf16_supported(1, stride, pool, filt_dim, ns):
             # bf16 operands on the MFMA (waveform and filterbank rounded to bf16), the epilogue and the route bits as
             # the fp32 kernel's; the backward below is the exact fp32 one on the saved fp32 input
-            res = wconv_fwd_bf16(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, do_abs, pool, slope, time_major, 1,
+            res = wconv_fwd_bf16(x, filters.view(-1, 1, filt_dim), None, B, T, 1, stride, do_abs, pool, slope, time_major, ns,
                                  want_route=need and (do_abs or pool != 1))
             out, route, l_conv = res if isinstance(res, tuple) else (res, None, conv_out_len(T, filt_dim, stride))
         else:
@@ -835,9 +895,10 @@ class ConvBlockFn(torch.autograd.Function):
         x = x.contiguous()
         need_route = (pool != 1 or do_abs) and any(ctx.needs_input_grad[:3])
         k_t = weight.shape[2]
-        if bf16_mode() and pool in (1, 2) and wconv_bf16_supported(c_in, stride, pool, k_t, 1) and weight.shape[0] <= 128:
+        ns = 1 if bf16_mode() else 0           # the forward pass of a TRAINABLE block is exact fp32 (train_nsplit: kinks)
+        if ns and pool in (1, 2) and wconv_bf16_supported(c_in, stride, pool, k_t, ns) and weight.shape[0] <= 128:
             res = wconv_fwd_bf16(x, weight.detach(), None if bias is None else bias.detach(), B, l_in, c_in, stride, do_abs,
-                                 pool, slope, time_major, 1, want_route=need_route)
+                                 pool, slope, time_major, ns, want_route=need_route)
             out, route, l_conv = res if isinstance(res, tuple) else (res, None, conv_out_len(l_in, k_t, stride))
         else:
             out, route, l_conv = wconv_fwd(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope,
@@ -864,11 +925,12 @@ class ConvBlockFn(torch.autograd.Function):
             if stride != 1:
                 raise NotImplementedError("data gradient of a strided Conv1d layer is not implemented "
                                           "(only the first CNN layer of the reference is strided)")
-            if bf16_mode() and wconv_bf16_supported(c_out, 1, 1, k_t, 1) and c_in <= 128:
+            ns = train_nsplit(True)
+            if ns and wconv_bf16_supported(c_out, 1, 1, k_t, ns) and c_in <= 128:
                 # data gradient = the same windowed contraction with the filters transposed and reversed in time, on
-                # bf16 operands (the flip / transpose is a 72 KB copy)
+                # split-precision operands (the flip / transpose is a 72 KB copy)
                 w_t = weight.detach().transpose(0, 1).flip(2).contiguous()
-                dx = wconv_fwd_bf16(d_conv, w_t, None, B, l_conv, c_out, 1, False, 1, 1.0, False, 1)
+                dx = wconv_fwd_bf16(d_conv, w_t, None, B, l_conv, c_out, 1, False, 1, 1.0, False, ns)
             else:
                 dx = wconv_bwd_data(d_conv, weight, B, l_in)
         _Fork.join(dev)
@@ -878,13 +940,13 @@ class ConvBlockFn(torch.autograd.Function):
 def gemm_tn_bf16_ok(a, b):
     """Shapes slu_gemm_tn_bf16 takes: A (K, M), B (K, N) fp32 views with unit column stride."""
     return (a.dtype == b.dtype == torch.float32 and a.shape[0] == b.shape[0] and a.stride(1) == 1 and b.stride(1) == 1
-            and a.shape[1] % 64 == 0 and b.shape[1] % 64 == 0 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
+            and a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
             and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
-def gemm_tn_bf16(a, b, out=None):
-    """out (M, N) = a^T b with a (K, M), b (K, N) rounded to bf16 on the way into the MFMA, fp32 accumulation:
-    the weight gradients of a GRU layer in bf16 mode (slu_gemm_tn_bf16)."""
+def gemm_tn_bf16(a, b, out=None, nsplit=1):
+    """out (M, N) = a^T b with a (K, M), b (K, N) split (nsplit 2 / 3) or rounded to bf16 (1) on the way into the MFMA,
+    fp32 accumulation: the weight gradients of the trainable layers (slu_gemm_tn_bf16)."""
     L = _lib.load()
     K, M = a.shape
     N = b.shape[1]
@@ -894,26 +956,23 @@ def gemm_tn_bf16(a, b, out=None):
     wsb = L.slu_gemm_tn_bf16_workspace_bytes(M, N, K)
     ws = _workspace(wsb, a.device) if wsb else None
     _lib.check(L.slu_gemm_tn_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
-                                  M, N, K, _ptr(ws), wsb, _stream()), "slu_gemm_tn_bf16")
+                                  M, N, K, nsplit, _ptr(ws), wsb, _stream()), "slu_gemm_tn_bf16")
     return out
 
 
 def _wgrad(a, b, out):
-    """out = a^T b (a (K, M) gradients, b (K, N) activations): bf16 operands in bf16 mode where the kernel takes the
-    shape, else the exact fp32 GEMM on the transposed view."""
-    if bf16_mode() and gemm_tn_bf16_ok(a, b):
-        return gemm_tn_bf16(a, b, out)
+    """out = a^T b (a (K, M) gradients, b (K, N) activations) in the arithmetic of the trainable layers (train_nsplit):
+    the split-precision TN kernel where it takes the shape, else the exact fp32 GEMM on the transposed view."""
+    ns = train_nsplit(True)
+    if ns and gemm_tn_bf16_ok(a, b) and (out is None or out.stride(1) == 1):
+        return gemm_tn_bf16(a, b, out, ns)
     return gemm(a.t(), b, out=out)
 
 
 def _gru_dx(g2, w_ih, T, B, I, H, D):
-    """dx = d_gx W_ih (K = D * 3H): exact fp32 MFMA, or — bf16 mode, I a multiple of 64 — bf16 operands on the
-    split-precision GEMM (d_gx rounded to bf16 planes, W_ih^T packed in fragment order in place)."""
-    if bf16_mode() and I % 64 == 0 and split_path_supported(H, D):
-        planes = split_bf16(g2, 1)
-        packed = gemm_bf16_pack(w_ih.t(), 1)                # (N = I, K = D*3H) view of the stacked weight
-        return gemm_bf16(planes, packed, None, I, D * 3 * H).view(T, B, I)
-    return gemm(g2, w_ih).view(T, B, I)
+    """dx = d_gx W_ih (K = D * 3H) in the arithmetic of the trainable layers (train_nsplit): d_gx split on the fly, W_ih^T
+    packed in fragment order in place — or the exact fp32 MFMA GEMM."""
+    return gemm_nt(g2, w_ih.t(), grad=True).view(T, B, I)     # (N = I, K = D*3H) view of the stacked weight
 
 
 class GRULayerFn(torch.autograd.Function):
@@ -942,7 +1001,7 @@ class GRULayerFn(torch.autograd.Function):
             gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
             raw, reserve = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, need)
         else:
-            gx = gemm(x.view(T * B, I), w_ih.t(), b_ih)                   # (T*B, D*3H)
+            gx = gemm_nt(x.view(T * B, I), w_ih, b_ih)                    # (T*B, D*3H); train_nsplit arithmetic
             raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
         offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
         if p == 0.0 and (factor == 1):

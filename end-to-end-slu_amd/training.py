@@ -14,7 +14,9 @@ moves the model to the CPU for its seq2seq beam search, training.py:150,166, and
 CPU-only host); under torch.distributed only rank 0 prints, logs and writes checkpoints.
 """
 import contextlib
+import math
 import os
+import warnings
 
 import pandas as pd
 import torch
@@ -553,6 +555,12 @@ class Trainer:
                     self._say("guess: " + guess[0])
                     self._say("truth: " + truth[0])
         means = self._epoch_means(self.epoch_sums[:len(names)].tolist() + [string_acc], num_examples, dev)
+        if not all(math.isfinite(float(m)) for m in means[:len(names)]):
+            import models
+            if models.contraction_nsplit(True) == 2:
+                warnings.warn("non-finite epoch metrics: the frozen stages run on the f16x2 split scheme, whose operands "
+                              "must stay below 65504 in magnitude (fp16 range) — if the waveforms are not scaled to "
+                              "[-1, 1] set SLU_FROZEN_MATH=bf16x3 (no range limit) or fp32")
         if seq2seq and not train:
             means[1] = means[1] + means[-1]          # intent_acc += string accuracy (the model's own acc is 0)
         return means[:len(names)]

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 3
+#define SLU_ABI_VERSION 4
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -150,14 +150,20 @@ int slu_gemm_small_batched(const float* const* A, const int64_t* lda, const floa
 int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,
                    int accumulate, void* stream);
 
-/* -------- split-precision (bf16 MFMA) path of the FROZEN encoder stages ---------------------------------
- * An fp32 value x = x1 + x2 + x3 (three bf16 terms, exact); a product keeps the six bf16 x bf16 terms above
- * 2^-24 |a b| (v_mfma_f32_16x16x32_bf16, fp32 accumulation): fp32-class results at 6/16 of the fp32-MFMA
- * cycle count.  nsplit = 3 selects that, nsplit = 1 plain bf16 (BASELINE configs[4]).  Activations between
- * the stages are `nsplit` planes of bf16 (rows x ld, ld = round_up(K, 32), zero padded), plane p at
- * planes + p * plane_stride (in bf16 elements).
+/* -------- split-precision (16-bit MFMA) path of the FROZEN encoder stages --------------------------------
+ * `nsplit` selects the scheme (csrc/slu_bf16.h):
+ *   3  "bf16x3": x = x1 + x2 + x3 (three bf16 terms, exact); a product keeps the six bf16 x bf16 terms above
+ *      2^-24 |a b| (v_mfma_f32_16x16x32_bf16, fp32 accumulation): fp32-class at 6/16 of the fp32-MFMA cycles, no
+ *      range limit;
+ *   2  "f16x2": x = hi + 2^-11 lo (two fp16 terms, 22-bit significand); hi hi on one fp32 accumulator, hi lo + lo hi
+ *      on a second one, result acc0 + 2^-11 acc1 (v_mfma_f32_16x16x32_f16): fp32-class (<= 3 * 2^-22 per product
+ *      worst case, measured 1e-7 of sum |a b| against float64: an fp32 fmaf chain's deviation) at 3/16 of the fp32-MFMA cycles; |x| < 65504, values
+ *      below 6.1e-5 carry 11 bits (absolute error <= 1.5e-8);
+ *   1  plain bf16 (BASELINE configs[4]).
+ * Activations between the stages are `nsplit` planes of 16-bit terms (rows x ld, ld = round_up(K, 32), zero padded),
+ * plane p at planes + p * plane_stride (in 16-bit elements).
  *   slu_split_bf16     fp32 (rows x K, row stride ldx) -> planes (entry into the format)
- *   slu_gemm_bf16_pack W (N x K) fp32 -> packed bf16 planes in MFMA B-fragment order (once per weight)
+ *   slu_gemm_bf16_pack W (N x K) fp32 -> packed planes in MFMA B-fragment order (once per weight)
  *   slu_gemm_bf16      C (M x N fp32, row stride ldc) = A W^T + bias: the input projection x W_ih^T + b_ih of
  *                      nn.GRU (models.py:232/:262) for frozen layers; N must be a multiple of 64           */
 int slu_split_bf16(const float* x, int64_t ldx, void* planes, int64_t plane_stride, int64_t rows, int64_t K,
@@ -168,20 +174,27 @@ int slu_gemm_bf16_pack(const float* W, int64_t ldw, int64_t w_cs, void* packed, 
 int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64_t lda, const void* w_packed,
                   const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int nsplit,
                   void* stream);
+/* The same product with A given as plain fp32 (M x K, k fast, row stride lda) and split on the fly inside the kernel —
+ * the GEMMs of TRAINABLE layers, whose operands are produced by exact-fp32 kernels a moment earlier: the forward
+ * projection x W_ih^T + b_ih and the data gradient d_gx W_ih (pack W_ih^T in place with w_cs / ldw swapped).  N, K, lda,
+ * ldc multiples of 4, A and C 16-byte aligned; N need not be a multiple of 64.                                          */
+int slu_gemm_bf16_a32(const float* A, int64_t lda, const void* w_packed, const float* bias, float* C, int64_t ldc,
+                      int64_t M, int64_t N, int64_t K, int nsplit, void* stream);
 
-/* C (M x N, row stride ldc) = A^T B on bf16 operands (fp32 accumulation): A (K x M, row stride lda), B (K x N, ldb) fp32
- * with k as the slow index of both — the weight gradients d_gx^T x / d_gh^T h_prev of a GRU layer under SLU_DTYPE=bf16
- * (BASELINE configs[4]; the reference's autograd GEMMs of nn.GRU, models.py:232/:262/:686).  The operands are rounded to
- * bf16 while they are staged (transposed) in LDS.  M and N multiples of 64, lda / ldb multiples of 4, 16-byte aligned
+/* C (M x N, row stride ldc) = A^T B on split-precision operands (fp32 accumulation): A (K x M, row stride lda), B (K x N,
+ * ldb) fp32 with k as the slow index of both — the weight gradients d_gx^T x / d_gh^T h_prev of a GRU layer (the
+ * reference's autograd GEMMs of nn.GRU, models.py:232/:262/:686): nsplit = 2 (f16x2, fp32-class: the default of trainable
+ * layers, SLU_TRAIN_MATH), 1 (bf16: SLU_DTYPE=bf16, BASELINE configs[4]) or 3.  The operands are split / rounded while they
+ * are staged (transposed) in LDS.  M and N multiples of 4, lda / ldb multiples of 4, 16-byte aligned
  * bases; deterministic split-K through the caller's workspace (slu_gemm_tn_bf16_workspace_bytes, 0 = none needed).   */
 size_t slu_gemm_tn_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int slu_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-                     int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+                     int64_t N, int64_t K, int nsplit, void* workspace, size_t workspace_bytes, void* stream);
 
 /* slu_wconv_fwd for a FROZEN CNN block on the split-precision MFMA path (no `route`: forward only).  Needs
  * stride_t * c_in % 8 == 0 for c_in == 1, stride_t == 1 otherwise (channels are padded to a multiple of 8).
  * out_planes != NULL (pool == 1): the result goes straight into the split-precision activation format instead of
- * `out` — nsplit bf16 planes (plane stride out_plane_stride elements) of (l_out * B) x round_up(c_out, 32), rows in
+ * `out` — nsplit 16-bit planes (plane stride out_plane_stride elements) of (l_out * B) x round_up(c_out, 32), rows in
  * time-major order l * B + b, zero padded columns — which slu_gemm_bf16 reads (no fp32 round trip, no slu_split_bf16).
  * in_table != NULL: a DEVICE array of ceil(B / table_rows) base pointers; batch row b is read from
  * in_table[b / table_rows] + (b % table_rows) * l_in * c_in instead of in + b * l_in * c_in — a look-ahead super-batch
@@ -198,7 +211,7 @@ int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t ta
                        int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,
                        void* stream);
 /* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
- * W_hh (3 gates x nsplit bf16 planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
+ * W_hh (3 gates x nsplit 16-bit planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
  * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)
  * back-propagates through a bf16 forward (BASELINE configs[4]: bf16 forward contractions, fp32 gradients).     */
 int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
@@ -254,7 +267,7 @@ int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_
                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                          int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, float* y,
                          int64_t T, int64_t B, int64_t C, void* stream);
-/* The same, writing the result straight into the split-precision activation format (nsplit bf16 planes of
+/* The same, writing the result straight into the split-precision activation format (nsplit 16-bit planes of
  * (T_out*B) x C, see slu_split_bf16) read by the next frozen layer's slu_gemm_bf16.  C % 32 == 0.             */
 int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st, int64_t m_sb, float p,
                                 uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t sub_batch,

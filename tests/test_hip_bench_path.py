@@ -1,6 +1,6 @@
 """GPU parity of the EXACT path bench.py times (BASELINE.json configs[3] at full size: no_unfreezing
 architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 20 batches (1280 sequences, split-precision
-bf16x3 MFMA input projections and 16-sequence recurrence kernels for the frozen layers, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
+(f16x2) MFMA input projections and 16-sequence recurrence kernels for the frozen layers, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
 step, against (1) the plain sequential eager loop, bit for bit, and (2) the CPU oracle (<= 1e-4).
 
 Chain proven here:  oracle == HIP kernels at super-batch size (mask-in)  and  sequential eager ==
@@ -105,14 +105,15 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
         assert torch.equal(v, sd[k]), k
 
 
-@pytest.mark.parametrize("n_utt", [1280, 768])
-def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, n_utt):
+@pytest.mark.parametrize("n_utt,math", [(1280, "f16x2"), (768, "f16x2"), (768, "bf16x3")])
+def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, monkeypatch, n_utt, math):
     """One look-ahead super-batch through the frozen encoder with the oracle's dropout masks, against the CPU oracle's
     encoder (models.py:349-361), features within 1e-4.  1280 = 20 x 64 utterances of 3 s is exactly what bench.py's
     default launches: split-precision convolutions, the 96-row panel GEMM (M = 150 x 1280 = 192 000 rows >= 131 072,
-    K = 256), the tiled GEMM for the shorter layers, the row-panel GEMM for K = 60 and the 16-sequence bf16x3
-    recurrence on 80 tiles x 2 directions; 768 = a 12-batch super-batch (all launches below the panel threshold)."""
+    K = 256), the tiled GEMM for the shorter layers, the row-panel GEMM for K = 60 and the 16-sequence split-precision
+    (f16x2) recurrence on 80 tiles x 2 directions; 768 = a 12-batch super-batch (all launches below the panel threshold)."""
     import models
+    monkeypatch.setenv("SLU_FROZEN_MATH", math)
     cfg = _full_cfg(tmp_path)
     torch.manual_seed(1)
     pre = O.init_pretrained_state_dict(cfg)
@@ -135,18 +136,19 @@ def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, n_utt):
     with torch.no_grad():
         ref = O.encoder_stages(pre, x, cfg, masks, explicit_gru=False)["features"]       # (n_utt, 19, 256)
     err = (feats.transpose(0, 1).cpu() - ref).abs().max().item()
-    print("super-batch (%d x 3 s) encoder features max-abs deviation vs oracle: %.3e" % (n_utt, err))
+    print("super-batch (%d x 3 s, %s) encoder features max-abs deviation vs oracle: %.3e" % (n_utt, math, err))
     assert err <= 1e-4
 
 
-@pytest.mark.parametrize("tile", ["bf16x3", "4", "16"])
+@pytest.mark.parametrize("tile", ["f16x2", "bf16x3", "4", "16"])
 def test_recurrence_at_super_batch_size_vs_oracle(tile, monkeypatch):
     """The GRU layer at B = 768, T = 300, I = 60, H = 128, both directions (phone_rnn0 of a super-batch) against
     the oracle's GRU (torch.nn.GRU semantics, models.py:232): the split-precision path the bench runs for
-    frozen layers (slu_gemm_bf16 + slu_gru_seq_fwd_bf16, three bf16 terms) and the exact-fp32 kernels forced
-    onto 4- and 16-sequence workgroups."""
+    frozen layers (slu_gemm_bf16 + slu_gru_seq_fwd_bf16: two fp16 terms — the default — or three bf16 terms) and the
+    exact-fp32 kernels forced onto 4- and 16-sequence workgroups."""
     from slu_hip import ops
-    if tile != "bf16x3":
+    ns = {"f16x2": 2, "bf16x3": 3}.get(tile, 0)
+    if not ns:
         monkeypatch.setenv("SLU_GRU_TILE", tile)
     T, B, I, H = 300, 768, 60, 128
     torch.manual_seed(3)
@@ -164,10 +166,10 @@ def test_recurrence_at_super_batch_size_vs_oracle(tile, monkeypatch):
     xt = x.transpose(0, 1).contiguous().cuda()
     w_ih = torch.cat([d["weight_ih_l0"], d["weight_ih_l0_reverse"]])
     b_ih = torch.cat([d["bias_ih_l0"], d["bias_ih_l0_reverse"]])
-    if tile == "bf16x3":
-        gx = ops.gemm_bf16(ops.split_bf16(xt.view(T * B, I), 3), ops.gemm_bf16_pack(w_ih, 3), b_ih, 6 * H, I)
+    if ns:
+        gx = ops.gemm_bf16(ops.split_bf16(xt.view(T * B, I), ns), ops.gemm_bf16_pack(w_ih, ns), b_ih, 6 * H, I)
         out, _ = ops.gru_seq_fwd_bf16(gx, d["weight_hh_l0"], d["weight_hh_l0_reverse"], d["bias_hh_l0"],
-                                      d["bias_hh_l0_reverse"], T, B, H, 2, 3)
+                                      d["bias_hh_l0_reverse"], T, B, H, 2, ns)
     else:
         gx = ops.gemm(xt.view(T * B, I), w_ih.t(), b_ih)
         out, _ = ops.gru_seq_fwd(gx, d["weight_hh_l0"], d["weight_hh_l0_reverse"], d["bias_hh_l0"],
@@ -215,3 +217,35 @@ def test_captured_asr_pretraining_step_equals_eager(tmp_path, monkeypatch):
     assert len(set(results["0"][0][:, 0].tolist())) == 10
     for k, v in results["0"][1].items():
         assert torch.equal(v, results["1"][1][k]), k
+
+
+@pytest.mark.parametrize("scale", [1e-3, 0.1, 30.0])
+def test_split_schemes_hold_fp32_class_over_the_input_dynamic_range(tmp_path, monkeypatch, scale):
+    """f16x2 (the default of the frozen stages) has fp16's exponent range: quiet recordings (amplitude 1e-3: most
+    samples below fp16's smallest normal in the first convolution) and loud ones (30: far beyond [-1, 1]) must still give
+    encoder features within fp32 round-off of the exact-fp32 kernels, like bf16x3 (no range limit).  Eval mode (no
+    dropout), full-size architecture, 16 x 3 s."""
+    import models
+    cfg = _full_cfg(tmp_path)
+    torch.manual_seed(1)
+    pre = O.init_pretrained_state_dict(cfg)
+    torch.save(pre, tmp_path / "pretraining" / "model_state.pth")
+    torch.manual_seed(2)
+    model = models.Model(cfg)
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    x = (scale * torch.randn(16, 48000, generator=g)).cuda()
+    n = model.frozen_prefix_len()
+    feats = {}
+    with torch.no_grad():
+        for math in ("fp32", "f16x2", "bf16x3"):
+            monkeypatch.setenv("SLU_FROZEN_MATH", math)
+            feats[math] = model.prefix_features(x, n, 1).clone()
+    torch.cuda.synchronize()
+    ref = feats["fp32"]
+    span = ref.abs().max().item()
+    for math in ("f16x2", "bf16x3"):
+        assert torch.isfinite(feats[math]).all()
+        err = (feats[math] - ref).abs().max().item()
+        print("input amplitude %g, %s: max-abs deviation from the exact-fp32 kernels %.3e (feature range %.3f)" % (scale, math, err, span))
+        assert err <= 2e-5 * max(span, 1.0)
