@@ -30,20 +30,24 @@ _TRAIN_MATH = {"split": (2, 3), "bf16x3": (3, 3), "fp32": (0, 0)}
 def train_nsplit(grad=False):
     """Split scheme (csrc/slu_bf16.h) of the GEMM-shaped contractions of TRAINABLE layers — GRU input projections, their
     data and weight gradients, the convolution blocks' data gradients, the ASR heads' products (SLU_TRAIN_MATH):
-      "split" (default): products of activations and weights (grad=False) on f16x2 — fp32 operands as two fp16 terms,
+      "fp32" (default): exact fp32 MFMA everywhere;
+      "split": products of activations and weights (grad=False) on f16x2 — fp32 operands as two fp16 terms,
           three fp16 MFMA products, 3/16 of the fp32-MFMA cycles; products with a GRADIENT operand (grad=True: d_gx W,
           d_gx^T x, ...) on bf16x3 — three bf16 terms, six products, 6/16 — because gradient entries are far below
           fp16's smallest normal number (softmax gradients of a 10 000-word head: 1e-7), where f16x2 keeps 11 bits
           only; bf16 has fp32's exponent.  Both are fp32-class: 1e-7 of sum |a b| against float64 (tests/test_hip_bf16.py);
-      "bf16x3": bf16x3 for both;   "fp32": exact fp32 MFMA everywhere;
+      "bf16x3": bf16x3 for both;
       SLU_DTYPE=bf16 (BASELINE configs[4]) overrides: plain bf16 operands (1).
+    "split" measured on MI355X (B = 64, 3 s, same box): unfreeze_all 2.73 vs 2.79 ms/step, ASR pre-training 3.43 vs
+    3.05 (the 10 000-word head's products do not suit the 128 x 64 tiles) — the weight-gradient GEMMs run beside the
+    next layer's BPTT and the recurrences dominate the step, so it stays opt-in.
     Always exact fp32: the recurrences (forward and BPTT) — bf16 mode's forward recurrences excepted —, the FORWARD pass of
     trainable convolution blocks (|.| and LeakyReLU have kinks: the sign of a pre-activation within round-off of zero
     decides a whole gradient term, and the exact kernel keeps those decisions where the reference's are), the convolutions'
     weight gradients, every reduction, the loss and the optimizer."""
     if bf16_mode():
         return 1
-    mode = os.environ.get("SLU_TRAIN_MATH", "split")
+    mode = os.environ.get("SLU_TRAIN_MATH", "fp32")
     if mode not in _TRAIN_MATH:
         raise ValueError("SLU_TRAIN_MATH=%r: expected one of %s" % (mode, sorted(_TRAIN_MATH)))
     return _TRAIN_MATH[mode][1 if grad else 0]

@@ -25,21 +25,23 @@ def cu_split(device=None):
     """CUs [0, n) of the device are reserved for the trainable part of the step, the look-ahead
     super-batches get the rest.  Without the partition the big frozen-prefix kernels keep every CU
     busy and each of the ~25 small, latency-bound kernels of the trainable part waits for workgroup
-    slots (measured: the two streams then take almost the SUM of their times).  Default: three eighths of
-    the device (96 of 256 CUs = 12 per XCD; the mask bits interleave over the 8 XCDs, odd counts per XCD split CU
-    pairs between the partitions and are markedly slower).  Round 2, after the trainable step shrank to ten
-    launches (bench.py, same box): 64 CUs + 16-batch super-batches 265-267 k utt/s, 96 CUs + 20-batch super-batches
-    (one recurrence workgroup per look-ahead CU) 278-281 k; 80 / 88 / 104 / 112 / 128 CUs: 268 / 236-277 / 208-228 /
-    208-240 / 223 k.  SLU_CU_SPLIT=n overrides, 0 = off."""
+    slots (measured: the two streams then take almost the SUM of their times).  Default: half of the device
+    (128 of 256 CUs = 16 per XCD; the mask bits interleave over the 8 XCDs, odd counts per XCD split CU pairs between the
+    partitions and are markedly slower) with 16-batch super-batches (one recurrence workgroup per look-ahead CU).
+    Round 3, with the frozen stages on the f16x2 scheme (their share of a step fell from 0.20 to 0.145 ms, the trainable
+    part's ten launches became the longer side; tools/cu_split_sweep.sh, 512 steps, same box, CUs + batches -> k utt/s):
+    96 + 20: 296-299, 112 + 16: 311, 128 + 16: 316-321, 128 + 12: 303, 144 + 14: 226, 160 + 12: 257, 80 + 22: 272,
+    64 + 24: 253 (the driver's 20-step command: 200 / 192 / 197 / 199 / 188 / 185).  Round 2 (bf16x3 frozen stages):
+    96 + 20 was the optimum (278-281; 128: 223).  SLU_CU_SPLIT=n overrides, 0 = off."""
     v = os.environ.get("SLU_CU_SPLIT", "auto")
     if v != "auto":
         return int(v)
     if not torch.cuda.is_available():
         return 0
     n = n_compute_units(torch.cuda.current_device() if device is None else device)
-    # three eighths, rounded to whole CU PAIRS per XCD (a multiple of 16: the mask bits interleave over 8 XCDs and an
-    # odd count per XCD splits a pair between the partitions); 256 CUs -> 96, other parts their nearest even share
-    return max(16, (3 * n // 8) // 16 * 16) if n >= 32 else 0
+    # one half, rounded to whole CU PAIRS per XCD (a multiple of 16: the mask bits interleave over 8 XCDs and an
+    # odd count per XCD splits a pair between the partitions); 256 CUs -> 128, other parts their nearest even share
+    return max(16, (n // 2) // 16 * 16) if n >= 32 else 0
 
 
 _CU_MASK_BROKEN = [False]

@@ -1,5 +1,5 @@
 """GPU parity of the EXACT path bench.py times (BASELINE.json configs[3] at full size: no_unfreezing
-architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 20 batches (1280 sequences, split-precision
+architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 16 batches (1024 sequences, split-precision
 (f16x2) MFMA input projections and 16-sequence recurrence kernels for the frozen layers, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
 step, against (1) the plain sequential eager loop, bit for bit, and (2) the CPU oracle (<= 1e-4).
 
@@ -88,10 +88,10 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k
 
-    # the bench.py default: automatic look-ahead width (20 batches = 1280 sequences) + graphs
+    # the bench.py default: automatic look-ahead width (16 batches = 1024 sequences) + graphs
     tr, losses, sd = _run_training(cfg, loader, monkeypatch, "auto", "1", n_steps)
     import training
-    assert training._lookahead_width(-1, 64) == 20
+    assert training._lookahead_width(-1, 64) == 16
     stats = tr.graph_stats()
     assert stats["step_graphs"] == 1 and stats["capture_failures"] == 0
     assert all(len([g for g in slot.graphs.values() if g is not None]) >= 1 for slot in tr._slots)
@@ -105,13 +105,14 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
         assert torch.equal(v, sd[k]), k
 
 
-@pytest.mark.parametrize("n_utt,math", [(1280, "f16x2"), (768, "f16x2"), (768, "bf16x3")])
+@pytest.mark.parametrize("n_utt,math", [(1024, "f16x2"), (1280, "f16x2"), (768, "bf16x3")])
 def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, monkeypatch, n_utt, math):
     """One look-ahead super-batch through the frozen encoder with the oracle's dropout masks, against the CPU oracle's
-    encoder (models.py:349-361), features within 1e-4.  1280 = 20 x 64 utterances of 3 s is exactly what bench.py's
-    default launches: split-precision convolutions, the 96-row panel GEMM (M = 150 x 1280 = 192 000 rows >= 131 072,
+    encoder (models.py:349-361), features within 1e-4.  1024 = 16 x 64 utterances of 3 s is exactly what bench.py's
+    default launches: split-precision convolutions, the 96-row panel GEMM (M = 150 x 1024 = 153 600 rows >= 131 072,
     K = 256), the tiled GEMM for the shorter layers, the row-panel GEMM for K = 60 and the 16-sequence split-precision
-    (f16x2) recurrence on 80 tiles x 2 directions; 768 = a 12-batch super-batch (all launches below the panel threshold)."""
+    (f16x2) recurrence on 64 tiles x 2 directions; 1280 = the 20-batch super-batch of the 96 + 160 CU partition (rounds
+    1-2); 768 = a 12-batch super-batch (all launches below the panel threshold), on the bf16x3 scheme."""
     import models
     monkeypatch.setenv("SLU_FROZEN_MATH", math)
     cfg = _full_cfg(tmp_path)
