@@ -10,6 +10,7 @@
 // the first V threads.  V = 24 and T = 19 for the reference architecture: this is latency-bound
 // glue, fused to replace ~35 small ATen launches per training step by 4.
 #include "slu_common.h"
+#include "slu_philox.h"
 
 #include <algorithm>
 
@@ -33,6 +34,14 @@ struct HeadParams {
   unsigned int* ticket;    // zero-initialised device word (zero again afterwards) or null: separate reduce launch
   int T, B, C, V, S;
   int w_in_lds;            // 0: the classifier rows are read from L2 (T x C + V x C does not fit the LDS)
+  int vec;                 // 1: C % 4 == 0 and 16-byte aligned h / W: float4 staging
+  // fused Dropout of the layer below (nn.Dropout after the last intent GRU, models.py:700; vec only): h is the GRU's raw
+  // output, element (t, b, c) is multiplied by its keep factor of the Philox stream (seed, offset [+ *offset_dev]) —
+  // the mask slu_dropout_pool_fwd would draw — and the dropped rows go to h_drop (the backward pass reads them)
+  float drop_p, drop_scale;
+  unsigned long long seed, offset;
+  const unsigned long long* offset_dev;
+  float* h_drop;           // (T, B, C) or null
   int slot_begin[HEAD_MAX_SLOTS + 1];
 };
 
@@ -82,7 +91,44 @@ head_fwd_kernel(const HeadParams p) {
   // store (48 in flight: the whole staging costs one memory round trip; on the training stream's small CU
   // partition, beside the look-ahead kernels' traffic, a round trip is 2-3 us and a load -> store chain per
   // batch of 4 or 8 elements cost 20-30 us here)
-  {
+  if (p.vec) {
+    // four consecutive channels per thread and load (float4): a quarter of the load instructions of the scalar path
+    // below, and one Philox block per load when the dropout is fused
+    const int C4 = C >> 2;
+    const int nh = T * C4, nw = p.w_in_lds ? V * C4 : 0;
+    const float thr = 1.0f - p.drop_p;
+    const unsigned long long off = p.offset + (p.offset_dev ? *p.offset_dev : 0ull);
+    constexpr int U = 13;
+    for (int base = 0; base < nh + nw; base += HEAD_THREADS * U) {
+      float4 v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int idx = base + j * HEAD_THREADS + tid;
+        const bool ok = idx < nh + nw, isw = idx >= nh;
+        const int e = ok ? (isw ? idx - nh : idx) : 0;
+        const int row = e / C4, c = (e - row * C4) * 4;
+        const float* src = (ok && isw) ? p.W + (size_t)row * C + c : p.h + ((size_t)row * p.B + b) * C + c;
+        v[j] = *reinterpret_cast<const float4*>(src);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int idx = base + j * HEAD_THREADS + tid;
+        const bool ok = idx < nh + nw, isw = idx >= nh;
+        const int e = ok ? (isw ? idx - nh : idx) : 0;
+        const int row = e / C4, c = (e - row * C4) * 4;
+        if (!ok) continue;
+        float4 x = v[j];
+        if (!isw && p.drop_p > 0.0f) {
+          const size_t g = ((size_t)row * p.B + b) * C + c;                 // element index of the (T, B, C) tensor
+          const float4 k = philox_keep4(p.seed, off, g, thr, p.drop_scale);
+          x = make_float4(x.x * k.x, x.y * k.y, x.z * k.z, x.w * k.w);
+          if (p.h_drop) *reinterpret_cast<float4*>(p.h_drop + g) = x;
+        }
+        float* dst = sh + (isw ? T + row : row) * LD + c;                   // sw = sh + T * LD; rows of C + 1 floats
+        dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+      }
+    }
+  } else {
     const int nh = T * C, nw = p.w_in_lds ? V * C : 0;
     constexpr int U = 48;
     for (int base = 0; base < nh + nw; base += HEAD_THREADS * U) {
@@ -213,10 +259,16 @@ head_fwd_kernel(const HeadParams p) {
 // d_h[t][b][c] = g * sum_v [t == argmax_t[b][v]] d_logits[b][v] W[v][c]
 // One workgroup per utterance; thread c owns column c of a (T x C) LDS accumulator and adds, for
 // each classifier output v, d_logits[v] * W[v][c] into the row of v's arg-max time step.
+struct HeadDrop {          // the fused dropout of slu_cls_maxpool_ce_fwd (p = 0: none)
+  float p, scale;
+  unsigned long long seed, offset;
+  const unsigned long long* offset_dev;
+};
+
 __device__ __forceinline__ void
 head_bwd_dh_body(char* smem, const int b, const float* __restrict__ d_logits, const int* __restrict__ argmax_t,
                  const float* __restrict__ W, const float* __restrict__ gscale,
-                 float* __restrict__ d_h, int T, int B, int C, int V) {
+                 float* __restrict__ d_h, int T, int B, int C, int V, const HeadDrop& dr) {
   float* acc = reinterpret_cast<float*>(smem);          // [T][C]
   __shared__ float s_dl[HEAD_THREADS];
   __shared__ int s_at[HEAD_THREADS];
@@ -228,6 +280,20 @@ head_bwd_dh_body(char* smem, const int b, const float* __restrict__ d_logits, co
   for (int c = tid; c < C; c += HEAD_THREADS)
     for (int v = 0; v < V; ++v) acc[s_at[v] * C + c] = fmaf(s_dl[v], W[(size_t)v * C + c], acc[s_at[v] * C + c]);
   __syncthreads();
+  if (dr.p > 0.0f) {
+    // the gradient w.r.t. the GRU's RAW output: times the keep factors the forward pass applied (C % 4 == 0)
+    const int C4 = C >> 2;
+    const float thr = 1.0f - dr.p;
+    const unsigned long long off = dr.offset + (dr.offset_dev ? *dr.offset_dev : 0ull);
+    for (int idx = tid; idx < T * C4; idx += HEAD_THREADS) {
+      const int t = idx / C4, c = (idx - t * C4) * 4;
+      const size_t g = ((size_t)t * B + b) * C + c;
+      const float4 k = philox_keep4(dr.seed, off, g, thr, dr.scale);
+      const float* a = acc + t * C + c;
+      *reinterpret_cast<float4*>(d_h + g) = make_float4(a[0] * k.x, a[1] * k.y, a[2] * k.z, a[3] * k.w);
+    }
+    return;
+  }
   for (int idx = tid; idx < T * C; idx += HEAD_THREADS) {
     const int t = idx / C, c = idx - t * C;
     d_h[((size_t)t * B + b) * C + c] = acc[idx];
@@ -319,10 +385,11 @@ head_bwd_dw_body(char* smem, const int v, const float* __restrict__ d_logits, co
 __global__ void __launch_bounds__(HEAD_THREADS)
 head_bwd_kernel(const float* __restrict__ d_logits, const int* __restrict__ argmax_t, const float* __restrict__ h,
                 const float* __restrict__ W, const float* __restrict__ gscale, float* __restrict__ d_h,
-                float* __restrict__ d_W, float* __restrict__ d_bias, int n_dh, int T, int B, int C, int V) {
+                float* __restrict__ d_W, float* __restrict__ d_bias, int n_dh, int T, int B, int C, int V,
+                const HeadDrop dr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < n_dh)
-    head_bwd_dh_body(smem, blockIdx.x, d_logits, argmax_t, W, gscale, d_h, T, B, C, V);
+    head_bwd_dh_body(smem, blockIdx.x, d_logits, argmax_t, W, gscale, d_h, T, B, C, V, dr);
   else
     head_bwd_dw_body(smem, (int)blockIdx.x - n_dh, d_logits, argmax_t, h, gscale, d_W, d_bias, T, B, C, V);
 }
@@ -335,9 +402,11 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
                                       const int64_t* y, const int64_t* values_per_slot,
                                       int64_t num_slots, float* logits, int32_t* argmax_t,
                                       int64_t* pred, float* d_logits, float* row_stats,
-                                      float* loss_acc, double* epoch_sums, uint32_t* ticket, int64_t T, int64_t B, int64_t C,
-                                      void* stream) {
+                                      float* loss_acc, double* epoch_sums, uint32_t* ticket, float drop_p,
+                                      uint64_t drop_seed, uint64_t drop_offset, const uint64_t* drop_offset_dev,
+                                      float* h_drop, int64_t T, int64_t B, int64_t C, void* stream) {
   SLU_REQUIRE(h && weight && bias && logits && argmax_t && pred && values_per_slot, "slu_cls_maxpool_ce_fwd: null pointer");
+  SLU_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "slu_cls_maxpool_ce_fwd: dropout probability must be in [0, 1)");
   SLU_REQUIRE(num_slots >= 1 && num_slots <= HEAD_MAX_SLOTS, "slu_cls_maxpool_ce_fwd: 1..%d slots supported", HEAD_MAX_SLOTS);
   SLU_REQUIRE(!y || (row_stats && loss_acc), "slu_cls_maxpool_ce_fwd: row_stats / loss_acc required with labels");
   SLU_REQUIRE(T > 0 && B > 0 && C > 0, "slu_cls_maxpool_ce_fwd: non-positive size");
@@ -346,6 +415,13 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
   p.pred = (long long*)pred; p.d_logits = d_logits; p.row_stats = row_stats;
   p.loss_acc = loss_acc; p.epoch_sums = y ? epoch_sums : nullptr; p.ticket = (unsigned int*)ticket;
   p.T = (int)T; p.B = (int)B; p.C = (int)C; p.S = (int)num_slots;
+  p.vec = ((C & 3) == 0 && (((uintptr_t)h | (uintptr_t)weight | (uintptr_t)h_drop) & 15) == 0) ? 1 : 0;
+  if (drop_p > 0.0f && !p.vec)
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_cls_maxpool_ce_fwd: the fused dropout needs C %% 4 == 0 (got %lld) and 16-byte aligned "
+             "h / weight / h_drop", (long long)C);
+  p.drop_p = drop_p; p.drop_scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  p.seed = drop_seed; p.offset = drop_offset; p.offset_dev = (const unsigned long long*)drop_offset_dev;
+  p.h_drop = drop_p > 0.0f ? h_drop : nullptr;
   int V = 0;
   for (int s = 0; s < num_slots; ++s) { p.slot_begin[s] = V; V += (int)values_per_slot[s]; }
   p.slot_begin[num_slots] = V;
@@ -376,9 +452,16 @@ extern "C" int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const
 
 extern "C" int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const float* h,
                                       const float* weight, const float* grad_scale, float* d_h,
-                                      float* d_weight, float* d_bias, int64_t T, int64_t B,
+                                      float* d_weight, float* d_bias, float drop_p, uint64_t drop_seed,
+                                      uint64_t drop_offset, const uint64_t* drop_offset_dev, int64_t T, int64_t B,
                                       int64_t C, int64_t V, void* stream) {
   SLU_REQUIRE(d_logits && argmax_t && h && weight && grad_scale, "slu_cls_maxpool_ce_bwd: null pointer");
+  SLU_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "slu_cls_maxpool_ce_bwd: dropout probability must be in [0, 1)");
+  if (drop_p > 0.0f && d_h && ((C & 3) || ((uintptr_t)d_h & 15)))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_cls_maxpool_ce_bwd: the fused dropout needs C %% 4 == 0 and a 16-byte aligned d_h");
+  HeadDrop dr;
+  dr.p = drop_p; dr.scale = drop_p > 0.0f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  dr.seed = drop_seed; dr.offset = drop_offset; dr.offset_dev = (const unsigned long long*)drop_offset_dev;
   SLU_REQUIRE((d_weight == nullptr) == (d_bias == nullptr), "slu_cls_maxpool_ce_bwd: d_weight and d_bias go together");
   SLU_REQUIRE(C <= 1024, "slu_cls_maxpool_ce_bwd: C <= 1024");
   hipStream_t st = (hipStream_t)stream;
@@ -395,7 +478,7 @@ extern "C" int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argm
   }
   const int n_dh = d_h ? (int)B : 0;
   hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(n_dh + (d_weight ? V : 0))), dim3(HEAD_THREADS), lds, st,
-                     d_logits, argmax_t, h, weight, grad_scale, d_h, d_weight, d_bias, n_dh, (int)T, (int)B, (int)C, (int)V);
+                     d_logits, argmax_t, h, weight, grad_scale, d_h, d_weight, d_bias, n_dh, (int)T, (int)B, (int)C, (int)V, dr);
   SLU_CHECK_LAUNCH("head_bwd_kernel");
   return SLU_OK;
 }

@@ -36,4 +36,17 @@ __device__ __forceinline__ void philox_block(uint64_t seed, uint64_t offset, uin
 
 __device__ __forceinline__ float philox_to_uniform(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
+// dropout keep factors (scale or 0) of elements idx .. idx + 3 (idx % 4 == 0) of the stream (seed, offset): element e
+// is kept iff its uniform draw is below thr = 1 - p.  The one formula every kernel that applies or re-derives a mask uses.
+__device__ __forceinline__ float4 philox_keep4(uint64_t seed, uint64_t offset, uint64_t idx, float thr, float scale) {
+  uint32_t w[4];
+  philox_block(seed, offset, idx >> 2, w);
+  float4 o;
+  o.x = (philox_to_uniform(w[0]) < thr) ? scale : 0.0f;
+  o.y = (philox_to_uniform(w[1]) < thr) ? scale : 0.0f;
+  o.z = (philox_to_uniform(w[2]) < thr) ? scale : 0.0f;
+  o.w = (philox_to_uniform(w[3]) < thr) ? scale : 0.0f;
+  return o;
+}
+
 }  // namespace slu

@@ -113,17 +113,7 @@ __device__ __forceinline__ float4 keep_scale4(const PoolParams& q, uint64_t off_
     idx = ((uint64_t)t * q.B + b) * q.C + c;
   }
   // idx % 4 == 0 (C % 4 == 0, c % 4 == 0): the four words of one Philox block are elements idx .. idx+3
-  uint32_t cw[4] = {(uint32_t)(idx >> 2), (uint32_t)(idx >> 34), (uint32_t)off, (uint32_t)(off >> 32)};
-  uint32_t kw[2] = {(uint32_t)q.seed, (uint32_t)(q.seed >> 32)};
-#pragma unroll
-  for (int r = 0; r < 10; ++r) philox_round(cw, kw);
-  const float thr = 1.0f - q.p;
-  float4 o;
-  o.x = ((float)(cw[0] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
-  o.y = ((float)(cw[1] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
-  o.z = ((float)(cw[2] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
-  o.w = ((float)(cw[3] >> 8) * (1.0f / 16777216.0f) < thr) ? q.scale : 0.0f;
-  return o;
+  return philox_keep4(q.seed, off, idx, 1.0f - q.p, q.scale);
 }
 
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }

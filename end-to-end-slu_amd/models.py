@@ -993,7 +993,19 @@ class Model(torch.nn.Module):
             _DropoutState.current = rng_step
         try:
             h = pm.run_stages(h, n_stages, len(pm._stages()))
+            drop = None
             for st in self._intent_stages:
+                last = st is self._intent_stages[-1] and not self.seq2seq
+                if last:
+                    # the Dropout in front of the classifier is drawn inside the head kernels (same Philox stream, same
+                    # bits as the stand-alone launch; two launches fewer per step) where ops.head_dropout_fusable allows
+                    p, mask, seed, offset = _dropout_args(st.drop_name, st.site, st.p, self.training)
+                    if _ops.head_dropout_fusable(h, self.intent_layers[-2].weight, p, mask, st.method, st.factor):
+                        off, off_dev, sub = offset if isinstance(offset, tuple) else (offset, None, 0)
+                        if sub == 0:
+                            drop = (p, seed, off, off_dev)
+                            h = st.gru.run_time_major(h, 0.0, None, 0, 0, st.method, st.factor, False)
+                            continue
                 h = st.run(h, self.training)
             if self.seq2seq:                       # teacher-forced decoder on the same dropout step
                 loss_acc, _ = self.decoder.teacher_forced(h, y_intent.to(h.device))
@@ -1005,7 +1017,7 @@ class Model(torch.nn.Module):
             return loss_acc[0], torch.tensor([0.])
         cls = self.intent_layers[-2]
         loss, acc, _, _ = _ops.IntentHeadFn.apply(h, cls.weight, cls.bias, y_intent.to(h.device),
-                                                  tuple(self.values_per_slot))
+                                                  tuple(self.values_per_slot), drop)
         self.last_loss_acc = _ops.IntentHeadFn.last_loss_acc
         return loss, acc
 

@@ -93,8 +93,9 @@ SIGNATURES = {
     "slu_dropout_pool_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64,
                                      c_int, c_i64, vp, c_i64, c_i64, c_i64, vp]),
     "slu_cls_maxpool_ce_fwd": (c_int, [vp, vp, vp, vp, ctypes.POINTER(c_i64), c_i64, vp, vp, vp, vp, vp, vp, vp, vp,
-                                       c_i64, c_i64, c_i64, vp]),
-    "slu_cls_maxpool_ce_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
+                                       c_f32, c_u64, c_u64, vp, vp, c_i64, c_i64, c_i64, vp]),
+    "slu_cls_maxpool_ce_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_f32, c_u64, c_u64, vp, c_i64, c_i64, c_i64, c_i64,
+                                       vp]),
 }
 
 _lib = None

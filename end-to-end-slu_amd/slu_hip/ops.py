@@ -734,9 +734,11 @@ def _ticket(dev):
     return t
 
 
-def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad, epoch_sums=None):
-    """-> (loss_acc (2) or None, logits (B,V), pred (B,S), argmax_t (B,V) int32, d_logits or None)
-    epoch_sums: optional float64 (2) device tensor; B * (loss, acc) is added to it by the same launch."""
+def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad, epoch_sums=None, drop=None):
+    """-> (loss_acc (2) or None, logits (B,V), pred (B,S), argmax_t (B,V) int32, d_logits or None[, h_drop])
+    epoch_sums: optional float64 (2) device tensor; B * (loss, acc) is added to it by the same launch.
+    drop: None, or (p, seed, offset, offset_dev) — the Dropout in front of the classifier fused into this launch (h is
+    then the raw GRU output; the dropped activations are returned as a sixth value)."""
     import ctypes
     L = _lib.load()
     T, B, C = h.shape
@@ -750,13 +752,25 @@ def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad, epoch_sum
     row_stats = torch.empty(B, 2, dtype=torch.float32, device=dev) if y is not None else None
     loss_acc = torch.empty(2, dtype=torch.float32, device=dev) if y is not None else None
     vps = (ctypes.c_int64 * S)(*[int(v) for v in values_per_slot])
+    p, seed, offset, offset_dev = drop if drop else (0.0, 0, 0, None)
+    h_drop = torch.empty_like(h) if drop else None
     _lib.check(L.slu_cls_maxpool_ce_fwd(h.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(y), vps, S,
                                         logits.data_ptr(), argmax_t.data_ptr(), pred.data_ptr(), _ptr(d_logits),
                                         _ptr(row_stats), _ptr(loss_acc), _ptr(epoch_sums),
                                         _ptr(_ticket(dev)) if y is not None else 0,
+                                        float(p), int(seed), int(offset), _ptr(offset_dev), _ptr(h_drop),
                                         T, B, C, _stream()),
                "slu_cls_maxpool_ce_fwd")
+    if drop:
+        return loss_acc, logits, pred, argmax_t, d_logits, h_drop
     return loss_acc, logits, pred, argmax_t, d_logits
+
+
+def head_dropout_fusable(h, weight, p, mask, method, factor):
+    """The Dropout between the last intent GRU layer and the classifier can be drawn inside the head kernels: Philox
+    masks (no injected mask tensor), no Downsample, four-channel alignment."""
+    return (p > 0.0 and mask is None and factor == 1 and h.shape[-1] % 4 == 0 and h.is_contiguous()
+            and h.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and os.environ.get("SLU_FUSE_HEAD_DROPOUT", "1") != "0")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -770,16 +784,20 @@ class IntentHeadFn(torch.autograd.Function):
     epoch_sums = None       # float64 (2) device tensor while a training loop wants B * (loss, acc) accumulated in-kernel
 
     @staticmethod
-    def forward(ctx, h, weight, bias, y, values_per_slot):
+    def forward(ctx, h, weight, bias, y, values_per_slot, drop=None):
+        """drop: None, or (p, seed, offset, offset_dev): h is the RAW output of the last intent GRU layer and the
+        Dropout in front of the classifier (models.py:700) is drawn inside the head kernels (forward and backward)."""
         h = h.contiguous()
         y = y.contiguous()
         need = any(ctx.needs_input_grad[:3])
         sums = IntentHeadFn.epoch_sums
         if sums is not None:
             assert sums.dtype == torch.float64 and sums.numel() >= 2 and sums.is_contiguous() and sums.device == h.device
-        loss_acc, logits, pred, argmax_t, d_logits = cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, need, sums)
+        res = cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, need, sums, drop)
+        loss_acc, logits, pred, argmax_t, d_logits = res[:5]
+        ctx.drop = drop
         if need:
-            ctx.save_for_backward(h, weight, argmax_t, d_logits)
+            ctx.save_for_backward(res[5] if drop else h, weight, argmax_t, d_logits)
         ctx.set_materialize_grads(False)       # no zero-filled gradients for acc / logits / pred
         ctx.mark_non_differentiable(logits, pred)
         acc = loss_acc[1]
@@ -791,8 +809,9 @@ class IntentHeadFn(torch.autograd.Function):
     def backward(ctx, d_loss, _d_acc, _d_logits, _d_pred):
         L = _lib.load()
         if d_loss is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         h, weight, argmax_t, d_logits = ctx.saved_tensors
+        p, seed, offset, offset_dev = ctx.drop if ctx.drop else (0.0, 0, 0, None)
         T, B, C = h.shape
         V = weight.shape[0]
         g = d_loss.contiguous().float()
@@ -802,8 +821,9 @@ class IntentHeadFn(torch.autograd.Function):
         db = torch.empty(V, dtype=torch.float32, device=h.device) if need_w else None
         _lib.check(L.slu_cls_maxpool_ce_bwd(d_logits.data_ptr(), argmax_t.data_ptr(), h.data_ptr(),
                                             weight.data_ptr(), g.data_ptr(), _ptr(dh), _ptr(dW), _ptr(db),
+                                            float(p), int(seed), int(offset), _ptr(offset_dev),
                                             T, B, C, V, _stream()), "slu_cls_maxpool_ce_bwd")
-        return dh, dW, db, None, None
+        return dh, dW, db, None, None, None
 
 
 

@@ -303,17 +303,24 @@ int slu_pool_act_bwd(const float* dy, const float* y, const uint8_t* route, floa
  *   ticket: NULL, or a zero-initialised device uint32 of the caller's (zero again afterwards; one per stream
  *   that may run this call concurrently): the launch's last workgroup then reduces row_stats to loss_acc itself
  *   instead of a second one-workgroup launch (same summation, same bits).
+ *   drop_p > 0: the nn.Dropout between the last intent GRU and the classifier (models.py:700) is applied HERE — h is
+ *   the GRU's raw output, element (t,b,c) is multiplied by the keep factor of element (t*B + b)*C + c of the Philox
+ *   stream (drop_seed, drop_offset + *drop_offset_dev), i.e. the mask slu_dropout_pool_fwd draws for the same
+ *   arguments, and the dropped activations are written to h_drop (T,B,C) for the backward pass (no separate dropout
+ *   launches in the step).  Needs C % 4 == 0 and 16-byte aligned h / weight / h_drop.
  * Backward: d_h (T,B,C), d_weight (V,C), d_bias (V), all scaled by the device scalar *grad_scale;
- * d_h or the (d_weight, d_bias) pair may be NULL.                                                  */
+ * d_h or the (d_weight, d_bias) pair may be NULL.  h = the activations the classifier saw (h_drop of a fused
+ * forward); with drop_p > 0 (the forward's arguments) d_h is the gradient w.r.t. the GRU's RAW output.               */
 int slu_cls_maxpool_ce_fwd(const float* h, const float* weight, const float* bias, const int64_t* y,
                            const int64_t* values_per_slot, int64_t num_slots, float* logits,
                            int32_t* argmax_t, int64_t* pred, float* d_logits, float* row_stats,
-                           float* loss_acc, double* epoch_sums, uint32_t* ticket, int64_t T, int64_t B, int64_t C,
-                           void* stream);
+                           float* loss_acc, double* epoch_sums, uint32_t* ticket, float drop_p, uint64_t drop_seed,
+                           uint64_t drop_offset, const uint64_t* drop_offset_dev, float* h_drop, int64_t T, int64_t B,
+                           int64_t C, void* stream);
 int slu_cls_maxpool_ce_bwd(const float* d_logits, const int32_t* argmax_t, const float* h,
                            const float* weight, const float* grad_scale, float* d_h,
-                           float* d_weight, float* d_bias, int64_t T, int64_t B, int64_t C,
-                           int64_t V, void* stream);
+                           float* d_weight, float* d_bias, float drop_p, uint64_t drop_seed, uint64_t drop_offset,
+                           const uint64_t* drop_offset_dev, int64_t T, int64_t B, int64_t C, int64_t V, void* stream);
 
 /* -------- ASR pre-training heads: F.cross_entropy(logits, y, ignore_index) + frame accuracy ----------
  * (PretrainedModel.forward, models.py:291-331; the Linear layers are slu_gemm_f32 calls).

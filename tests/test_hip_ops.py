@@ -394,6 +394,39 @@ def test_intent_head_fused_vs_torch(ops, T, B, C, vps):
     assert torch.equal(lg3, lg2) and torch.equal(p3, p2)
 
 
+@pytest.mark.parametrize("T,B,C,vps", [(19, 64, 256, (6, 14, 4)), (5, 3, 64, (3, 4))])
+def test_intent_head_with_fused_dropout_equals_separate_dropout_launches(ops, T, B, C, vps):
+    """The Dropout between the last intent GRU layer and the classifier (models.py:700) drawn INSIDE the head kernels
+    (slu_cls_maxpool_ce_fwd / _bwd with drop_p > 0) against the stand-alone slu_dropout_pool_fwd / _bwd launches around the
+    same head: loss, accuracy, logits, predictions and every gradient bit for bit (same Philox stream, same products), also
+    with the dropout step read from device memory (the captured-step form)."""
+    g = torch.Generator().manual_seed(T + B)
+    V = sum(vps)
+    h = torch.randn(T, B, C, generator=g).cuda()
+    W = (torch.randn(V, C, generator=g) / C ** 0.5).cuda()
+    bias = torch.randn(V, generator=g).cuda()
+    y = torch.stack([torch.randint(0, n, (B,), generator=g) for n in vps], dim=1).cuda()
+    p, seed, step, site = 0.5, 1234567, 7, 8
+    # (a) separate launches
+    hd = ops.dropout_pool_fwd(h, None, p, seed, step * 16 + site, "none", 1).requires_grad_()
+    Wa, ba = W.clone().requires_grad_(), bias.clone().requires_grad_()
+    la, aa, lga, pa = ops.IntentHeadFn.apply(hd, Wa, ba, y, vps)
+    (la * 1.3).backward()
+    dh_a = ops.dropout_pool_bwd(hd.grad, h, None, p, seed, step * 16 + site, "none", 1)
+    assert 0.3 < (hd == 0).float().mean().item() < 0.7
+    # (b) fused, offset given directly and through a device word
+    for drop in ((p, seed, step * 16 + site, None), (p, seed, site, torch.tensor([step * 16], dtype=torch.int64, device="cuda"))):
+        hb, Wb, bb = h.clone().requires_grad_(), W.clone().requires_grad_(), bias.clone().requires_grad_()
+        lb, ab, lgb, pb = ops.IntentHeadFn.apply(hb, Wb, bb, y, vps, drop)
+        (lb * 1.3).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(lb, la) and torch.equal(ab, aa) and torch.equal(lgb, lga) and torch.equal(pb, pa)
+        assert torch.equal(hb.grad, dh_a)
+        assert torch.equal(Wb.grad, Wa.grad) and torch.equal(bb.grad, ba.grad)
+    assert not ops.head_dropout_fusable(h[:, :, :C - 1], W, p, None, "none", 1)
+    assert not ops.head_dropout_fusable(h, W, p, torch.ones(1), "none", 1) and not ops.head_dropout_fusable(h, W, p, None, "avg", 2)
+
+
 # ---------------------------------------------------------------------------------------------
 # Adam (slu_optim.hip) against torch.optim.Adam, the optimiser the reference constructs (training.py:19)
 # ---------------------------------------------------------------------------------------------

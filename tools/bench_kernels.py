@@ -123,7 +123,7 @@ def main():
         dh, dW, db = torch.empty_like(h), torch.empty_like(W), torch.empty_like(bias)
         s_ = lambda: torch.cuda.current_stream().cuda_stream
         medb, _ = timeit(lambda: L.slu_cls_maxpool_ce_bwd(dl.data_ptr(), am.data_ptr(), h.data_ptr(), W.data_ptr(), g.data_ptr(),
-                                                          dh.data_ptr(), dW.data_ptr(), db.data_ptr(), T, B, C, 24, s_()))
+                                                          dh.data_ptr(), dW.data_ptr(), db.data_ptr(), 0.0, 0, 0, None, T, B, C, 24, s_()))
         print("head fwd (+reduce): %6.1f us (min %5.1f) | bwd (dh + dW): %6.1f us" % (med, mn, medb))
 
 

@@ -51,6 +51,12 @@ L = _lib.load()
 dh, dWc, dbc = torch.empty_like(h), torch.empty_like(cw), torch.empty_like(cb)
 def head_bwd():
     _lib.check(L.slu_cls_maxpool_ce_bwd(d_logits.data_ptr(), argmax_t.data_ptr(), h.data_ptr(), cw.data_ptr(), one.data_ptr(),
-                                        dh.data_ptr(), dWc.data_ptr(), dbc.data_ptr(), T, B, D * H, V, st.cuda_stream), "bwd")
+                                        dh.data_ptr(), dWc.data_ptr(), dbc.data_ptr(), 0.0, 0, 0, None, T, B, D * H, V, st.cuda_stream), "bwd")
 print("head bwd (d_h + d_W in one launch): %.1f us" % (1e3 * _timed_graph(head_bwd, st)))
 print("dropout_pool fwd: %.1f us" % (1e3 * _timed_graph(lambda: ops.dropout_pool_fwd(out, None, 0.5, 1, 16, "none", 1), st)))
+drop = (0.5, 1, 16, None)
+print("head fwd with the dropout fused: %.1f us" % (1e3 * _timed_graph(lambda: ops.cls_maxpool_ce_fwd(h, cw, cb, y, (6, 14, 4), True, None, drop), st)))
+def head_bwd_drop():
+    _lib.check(L.slu_cls_maxpool_ce_bwd(d_logits.data_ptr(), argmax_t.data_ptr(), h.data_ptr(), cw.data_ptr(), one.data_ptr(),
+                                        dh.data_ptr(), dWc.data_ptr(), dbc.data_ptr(), 0.5, 1, 16, None, T, B, D * H, V, st.cuda_stream), "bwd")
+print("head bwd with the dropout fused: %.1f us" % (1e3 * _timed_graph(head_bwd_drop, st)))
