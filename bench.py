@@ -809,12 +809,12 @@ def main():
                 "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
                 "kernels": table[:6],
                 "note": "per kernel: sums over its distinct launch shapes in one look-ahead cycle (%d steps) of the "
-                        "algorithmic fp32 flops (mfma_tflops counts the bf16 MFMA products actually issued: 6 per fp32 "
-                        "product on the split-precision kernels) and of the algorithmic HBM bytes / sum of the average "
+                        "algorithmic fp32 flops (mfma_tflops counts the 16-bit MFMA products actually issued: 3 per fp32 "
+                        "product on the f16x2 kernels, 6 on bf16x3) and of the algorithmic HBM bytes / sum of the average "
                         "durations; each shape is launched 20x back to back (one hipGraph) on the CU-masked stream it "
                         "runs on during the timed steps (frozen stages: %d sequences on CUs [%d,%d); trainable stages: "
                         "%d sequences on CUs [0,%d)) between two HIP events on that stream.  Peaks are whole-chip: fp32 "
-                        "MFMA 157.3, dense bf16 MFMA 2500 TFLOP/s, HBM 8 TB/s; `frac` is against the kernel's binding one."
+                        "MFMA 157.3, dense bf16 / fp16 MFMA 2500 TFLOP/s, HBM 8 TB/s; `frac` is against the kernel's binding one."
                         % (width, args.batch * width, _cu_split(), _n_cus(), args.batch, _cu_split())}
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
@@ -837,6 +837,8 @@ def main():
             note("side runs")
             common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--seconds", str(args.seconds)]
             out["exact_fp32"] = side_run(common, {"SLU_FROZEN_MATH": "fp32"})
+            note("side run: frozen stages on bf16x3")
+            out["frozen_bf16x3"] = side_run(common, {"SLU_FROZEN_MATH": "bf16x3"})
             short = ["--steps", "40", "--warmup", "10", "--batch", str(args.batch), "--seconds", str(args.seconds)]
             out["other_workloads"] = {w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain", "seq2seq")}
         print(json.dumps(out), flush=True)

@@ -23,16 +23,21 @@ def pick(prefix, n_shapes):
     return sorted((r for r in rows if r["name"].startswith(prefix)), key=lambda r: -r["calls"])[:n_shapes]
 
 
-spec = {  # bench.py table name -> (name prefix in the trace, launch shapes per look-ahead cycle, launches per shape)
-    "gru_bf_fwd_kernel<128,3>": ("void slu::gru_bf_fwd_kernel<128, 3>", 1),          # the four T share one grid
-    "gemm_bf_panel96_kernel<3,8>": ("void slu::gemm_bf_panel96_kernel<3, 8>", 1),
-    "gemm_bf_kernel<3>": ("void slu::gemm_bf_kernel<3>", 2),
-    "gemm_bf_panel_kernel<3,2>": ("void slu::gemm_bf_panel_kernel<3, 2>", 1),
-    "wconv_bf_fwd_kernel<3>": ("void slu::wconv_bf_fwd_kernel<", 2),
-    "dropout_pool_fwd4_kernel<3>": ("void slu::dropout_pool_fwd4_kernel<3>", 3),
+spec = {  # bench.py table name -> (name prefix in the trace, launch shapes per look-ahead cycle)
     "gru_seq_fwd4_kernel<128>": ("void slu::gru_seq_fwd4_kernel<128>", 1),
     "gemm_f32_kernel<true,true,2>": ("void slu::gemm_f32_kernel<true, true, 2>", 1),
 }
+for ns in (2, 3):           # the split scheme of the frozen stages: f16x2 (default) / bf16x3
+    spec.update({
+        "gru_bf_fwd_kernel<128,%d>" % ns: ("void slu::gru_bf_fwd_kernel<128, %d>" % ns, 1),          # the four T share one grid
+        "gemm_bf_panel96_kernel<%d,8>" % ns: ("void slu::gemm_bf_panel96_kernel<%d, 8>" % ns, 1),
+        "gemm_bf_kernel<%d>" % ns: ("void slu::gemm_bf_kernel<%d>" % ns, 2),
+        "gemm_bf_panel_kernel<%d,2>" % ns: ("void slu::gemm_bf_panel_kernel<%d, 2>" % ns, 1),
+        "dropout_pool_fwd4_kernel<%d>" % ns: ("void slu::dropout_pool_fwd4_kernel<%d>" % ns, 3),
+    })
+    if any(r["name"].startswith("void slu::wconv_bf_fwd_kernel<") and (", %d, true>" % ns in r["name"] or ", %d, false>" % ns in r["name"])
+           for r in rows):
+        spec["wconv_bf_fwd_kernel<%d>" % ns] = ("void slu::wconv_bf_fwd_kernel<", 2)
 out = {"_comment": "average kernel durations inside the real pipelined loop (rocprofv3 --kernel-trace of `python bench.py`), "
                    "per launch shape, from " + path + "; bench.py divides roofline.frac_isolated by avg_us(in loop) / avg_us(isolated)"}
 for key, (prefix, n) in spec.items():

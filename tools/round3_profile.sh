@@ -1,31 +1,70 @@
 #!/bin/bash
-# Round-3 measurement pass (one gpurun call): bench lines, then rocprofv3 kernel traces of the bench.py command lines.
-# usage: tools/round3_profile.sh <tag>
+# Round-3 measurement pass (one gpurun call): bench lines, rocprofv3 kernel traces of the bench.py command lines, PMC
+# traffic of the dominant kernel.   usage: tools/round3_profile.sh <tag>
 TAG=${1:-r03}
 R=/root/repo
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 export SLU_BENCH_VERBOSE=1
-timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?"
+cd /tmp && export TMPDIR=/tmp
+B="--no-kernel-table --no-cpu-baseline --no-large-batch --no-side-runs"
+# the trace of the default command first: profiles/inloop_kernel_us.json feeds roofline.frac of the bench lines below
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o d -- python $R/bench.py $B > $O/bench_default_prof.json 2> $O/bench_default_prof.err
+cd $R
+f=$(find $O/trace_default -name "*kernel_trace.csv" | head -1)
+python tools/rocprof_summary.py $f 34 > $O/default_kernel_stats.txt
+python tools/rocprof_summary.py $f 50 --by-shape > $O/default_kernel_stats_by_shape.txt
+rm -rf $O/trace_default
+python tools/inloop_json.py $O/default_kernel_stats_by_shape.txt > $O/inloop_kernel_us.json
+sed -i "s#$O/#profiles/${TAG}_#" $O/inloop_kernel_us.json
+cp $O/inloop_kernel_us.json profiles/inloop_kernel_us.json
+# HBM traffic of the dominant kernel (separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KiB, FETCH x 2 on gfx950)
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/tools/run_one.py gru_bf 1024 2 > /dev/null 2>&1
+done
+cd $R
+python - <<PY > $O/pmc_gru_bf.txt 2>&1
+import csv, glob
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % c, recursive=True)
+    v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "gru_bf_fwd" in r["Kernel_Name"] and r["Counter_Name"] == c]
+    res[c] = sum(v) / len(v)
+    print(c, "launches", len(v), "mean KiB", res[c])
+T, B, H, D = 300, 1024, 128, 2
+alg = 4.0 * (T * B * D * 3 * H + T * B * D * H + D * 3 * H * H)
+tot = 2 * res["FETCH_SIZE"] * 1024 + res["WRITE_SIZE"] * 1024
+print("gru_bf_fwd_kernel<128,2> T=300 B=1024: fetch x 2 = %d B, write = %d B, total %d B; algorithmic %d B; ratio %.3f"
+      % (2 * res["FETCH_SIZE"] * 1024, res["WRITE_SIZE"] * 1024, tot, alg, tot / alg))
+PY
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+cat $O/pmc_gru_bf.txt
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?"
 timeout 400 python bench.py --no-cpu-baseline --no-large-batch --no-side-runs > $O/bench_512.json 2> $O/bench_512.err; echo "bench512 rc=$?"
 timeout 300 python bench.py --workload seq2seq --steps 40 --warmup 10 --no-side-runs > $O/bench_seq2seq.json 2> $O/bench_seq2seq.err; echo "seq2seq rc=$?"
 for d in bf16 f32; do
   timeout 300 python bench.py --dtype $d --workload unfreeze_all --seconds 10 --batch 32 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_cfg4_$d.json 2> $O/bench_cfg4_$d.err; echo "cfg4 $d rc=$?"
 done
-cd /tmp && export TMPDIR=/tmp
-B="--no-kernel-table --no-cpu-baseline --no-large-batch --no-side-runs"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_default -o d -- python $R/bench.py $B > $O/bench_default_prof.json 2> $O/bench_default_prof.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_unfrozen -o u -- python $R/bench.py $B --workload unfreeze_all --steps 100 --warmup 10 > $O/bench_unfrozen_prof.json 2> $O/bench_unfrozen_prof.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_cfg4 -o c -- python $R/bench.py $B --dtype bf16 --workload unfreeze_all --seconds 10 --batch 32 --steps 40 --warmup 10 > $O/bench_cfg4_prof.json 2> $O/bench_cfg4_prof.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_seq2seq -o s -- python $R/bench.py $B --workload seq2seq --steps 40 --warmup 10 > $O/bench_seq2seq_prof.json 2> $O/bench_seq2seq_prof.err
-cd $R
-for t in default unfrozen cfg4 seq2seq; do
-  f=$(find $O/trace_$t -name "*kernel_trace.csv" | head -1)
-  python tools/rocprof_summary.py $f 34 > $O/${t}_kernel_stats.txt
-  python tools/rocprof_summary.py $f 50 --by-shape > $O/${t}_kernel_stats_by_shape.txt
-  rm -rf $O/trace_$t
-done
-python tools/inloop_json.py $O/default_kernel_stats_by_shape.txt > $O/inloop_kernel_us.json
-if [ -f end-to-end-slu_amd/lib/libslu_hip_probe.so ]; then timeout 300 python tools/gru_probe.py > $O/gru_probe.txt 2>&1; fi
-timeout 400 python tools/host_inputs_probe.py 0 16 999 > $O/host_inputs_probe.txt 2>&1
+if [ "${TRACE_UNFROZEN:-1}" = "1" ]; then
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_unfrozen -o u -- python $R/bench.py $B --workload unfreeze_all --steps 100 --warmup 10 > $O/bench_unfrozen_prof.json 2> $O/bench_unfrozen_prof.err
+  cd $R
+  f=$(find $O/trace_unfrozen -name "*kernel_trace.csv" | head -1)
+  python tools/rocprof_summary.py $f 34 > $O/unfrozen_kernel_stats.txt
+  python tools/rocprof_summary.py $f 50 --by-shape > $O/unfrozen_kernel_stats_by_shape.txt
+  rm -rf $O/trace_unfrozen
+fi
 head -16 $O/default_kernel_stats.txt | cut -c1-150
+python - <<PY
+import json
+for f in ("bench_20", "bench_512", "bench_seq2seq", "bench_cfg4_bf16", "bench_cfg4_f32"):
+    try:
+        d = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1])
+        r = d.get("roofline") or {}
+        print(f, d["value"], d["ms_per_step"], d.get("steady_state"), {k: r.get(k) for k in ("kernel", "frac", "frac_isolated", "frac_in_loop", "prefix_traffic_over_8d", "traffic")})
+        for k in ("exact_fp32", "frozen_bf16x3", "host_inputs", "other_workloads", "cpu_baseline", "parity"):
+            if d.get(k): print("   ", k, json.dumps(d[k])[:300])
+    except Exception as e:
+        print(f, "ERR", e)
+PY

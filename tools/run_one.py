@@ -33,12 +33,13 @@ elif what in ("gemm_bf_ip0", "gemm_bf_ip1"):
     for _ in range(5):
         ops.gemm_bf16(planes, packed, bias, N, K, out=out)
 elif what == "gru_bf":
-    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1280), 128
+    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128
+    NS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     gx = torch.randn(T, B, 6 * H, device="cuda")
     wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
-        ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, 3)
+        ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS)
 elif what == "tn":
     # the intent layer's three weight gradients in one batched launch (T = 19, B = 64)
     T, B, I, H, D = 19, 64, 256, 128, 2
