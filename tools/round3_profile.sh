@@ -37,6 +37,18 @@ alg = 4.0 * (T * B * D * 3 * H + T * B * D * H + D * 3 * H * H)
 tot = 2 * res["FETCH_SIZE"] * 1024 + res["WRITE_SIZE"] * 1024
 print("gru_bf_fwd_kernel<128,2> T=300 B=1024: fetch x 2 = %d B, write = %d B, total %d B; algorithmic %d B; ratio %.3f"
       % (2 * res["FETCH_SIZE"] * 1024, res["WRITE_SIZE"] * 1024, tot, alg, tot / alg))
+import json
+j = json.load(open("profiles/pmc_traffic.json"))
+j["gru_bf_fwd_kernel<128,2>"] = {
+    "bytes_per_launch_mean_of_measured_shapes": round(tot),
+    "shapes": {"T=300 B=1024 H=128 D=2": {"fetch_x2_bytes": round(2 * res["FETCH_SIZE"] * 1024), "write_bytes": round(res["WRITE_SIZE"] * 1024),
+                                          "algorithmic_bytes": round(alg)}},
+    "traffic_over_algorithmic": round(tot / alg, 3),
+    "source": "profiles/${TAG}_pmc_gru_bf.txt",
+    "note": "the T=300 launch of the default 16-batch (1024-sequence) super-batch only; roofline.algorithmic_bytes_per_launch in the "
+            "bench line averages the four launch shapes (T = 300, 150, 75, 38)"}
+json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(j, open("$O/pmc_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 cat $O/pmc_gru_bf.txt
