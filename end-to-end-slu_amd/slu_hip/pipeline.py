@@ -117,7 +117,9 @@ class PrefixSlot:
         step0, step0+1, ...) on this slot's stream, after the event `after` (the previous super-batch:
         two super-batches side by side would only delay the one the training step is waiting for).
         (Replaying the FIRST super-batch of a run on an unmasked stream, while the training partition is still idle,
-        was tried: its kernels are latency-bound at that size, 2.85 ms either way.)
+        was tried twice: round 2 — 2.85 ms either way; round 3, f16x2 kernels, 12 batches on 256 instead of 128 CUs —
+        2.27 vs 2.48 ms for the super-batch, no change of the 20-step throughput (199.1 k utt/s both): its kernels are
+        latency-bound at that size.)
         Returns (features of the concatenated batch, event recorded when they are complete)."""
         B, T = xs[0].shape
         host = not all(x.is_cuda for x in xs)

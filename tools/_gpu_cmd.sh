@@ -1,9 +1,7 @@
-mkdir -p gpurun_out/r03_q; cd /root/repo
-for f in tests/test_hip_*.py; do
-  n=$(basename $f .py)
-  timeout 900 python -m pytest $f -q -m gpu -rP > gpurun_out/r03_q/$n.txt 2>&1
-  echo "$n: $(grep -E "passed|failed|error" gpurun_out/r03_q/$n.txt | tail -1)"
-  awk '/=+ FAILURES =+/{p=1} /=+ PASSES =+/{p=0} p && (/^_+ .* _+$/ || /^E    +(Assertion|assert)/)' gpurun_out/r03_q/$n.txt | cut -c1-220 | head -20
+mkdir -p gpurun_out/r03_r; cd /root/repo
+for w in 1 0; do echo "== SLU_WIDE_FILL=$w"; SLU_WIDE_FILL=$w python tools/pipeline_timeline.py --lookahead 16 --steps 20 2>&1 | grep -E "prefix|steps "; done | tee gpurun_out/r03_r/timeline_wide.txt
+for w in 1 0 1 0; do
+  v=$(SLU_WIDE_FILL=$w python bench.py --steps 20 --warmup 5 --no-kernel-table --no-cpu-baseline --no-large-batch --no-side-runs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['pipeline_fill_ms'], (d.get('steady_state') or {}).get('utterances_per_s'))")
+  echo "wide=$w: $v" | tee -a gpurun_out/r03_r/timeline_wide.txt
 done
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-timeout 300 python bench.py --gpus 2 --share-gpu --steps 10 --warmup 3 --no-side-runs --no-kernel-table --no-cpu-baseline --no-large-batch 2>&1 | tail -1 | cut -c1-400
+python -m pytest tests/test_hip_bench_path.py tests/test_hip_train_loop.py -q -m gpu 2>&1 | tail -2

@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 ev = lambda: torch.cuda.Event(enable_timing=True)
 prefix_marks, step_marks, group_sizes = [], [], []
 orig_slot_run = pipeline.PrefixSlot.run
-def slot_run(self, model_, xs, n_prefix, step0, use_graph, after=None):
+def slot_run(self, model_, xs, n_prefix, step0, use_graph, after=None, **kw):
     e0, e1, e2 = ev(), ev(), ev()
     with torch.cuda.stream(self.stream):
         if self.consumed is not None:
@@ -38,16 +38,19 @@ def slot_run(self, model_, xs, n_prefix, step0, use_graph, after=None):
             self.stream.wait_event(after)
         e0.record(self.stream)                 # dependencies satisfied: the copies start here
     orig_fill = pipeline.PrefixSlot._fill
+    filled = []
     def fill(x_cat, xs_):
         orig_fill(x_cat, xs_)
         e1.record(torch.cuda.current_stream())
+        filled.append(1)
     pipeline.PrefixSlot._fill = staticmethod(fill)
     try:
-        out = orig_slot_run(self, model_, xs, n_prefix, step0, use_graph, after)
+        out = orig_slot_run(self, model_, xs, n_prefix, step0, use_graph, after, **kw)
     finally:
         pipeline.PrefixSlot._fill = staticmethod(orig_fill)
+    (self.last_done and self.stream.wait_event(self.last_done))
     e2.record(self.stream)
-    prefix_marks.append((e0, e1, e2))
+    prefix_marks.append((e0, e1 if filled else e0, e2))       # batches read in place (row-pointer table): no copies
     group_sizes.append(list(xs))
     return out
 pipeline.PrefixSlot.run = slot_run
