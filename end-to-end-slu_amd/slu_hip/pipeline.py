@@ -66,8 +66,14 @@ def cu_range_stream(device, first, count, **stream_kw):
     return torch.cuda.Stream(device, **stream_kw)
 
 
+_N_CU = {}
+
+
 def n_compute_units(device):
-    return torch.cuda.get_device_properties(device).multi_processor_count
+    key = str(device)
+    if key not in _N_CU:                       # (asked once per batch by the look-ahead loop)
+        _N_CU[key] = torch.cuda.get_device_properties(device).multi_processor_count
+    return _N_CU[key]
 
 
 class PrefixSlot:

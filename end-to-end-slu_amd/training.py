@@ -433,11 +433,16 @@ class Trainer:
             versions = [ver(b) for b in group]                 # tensor version of every batch WHEN IT WAS READ
             cap = [1 << 30]
 
+            wcache = {}
+
             def width():
-                w = _lookahead_width(depth, len(group[0][0]))
-                if launched == 0 and n_run < 2 * w:
-                    cap[0] = max(2, -(-3 * n_run // 5))
-                return min(cap[0], w)
+                bs = len(group[0][0])
+                if bs not in wcache:
+                    w = _lookahead_width(depth, bs)
+                    if launched == 0 and n_run < 2 * w:
+                        cap[0] = max(2, -(-3 * n_run // 5))
+                    wcache[bs] = min(cap[0], w)
+                return wcache[bs]
             while not group or len(group) < width():
                 try:
                     batch = next(it)

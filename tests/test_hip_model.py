@@ -228,10 +228,13 @@ def test_baseline_config0_full_size_vs_reference(models_mod, tmp_path):
     assert a[0] == b[0] and a[3] == b[3] and abs(float(a[1]) - float(b[1])) <= 1e-4 and float(a[2]) == float(b[2])
 
 
-@pytest.mark.parametrize("B,seconds", [(64, 3), (5, 1)])
-def test_full_size_batch_vs_oracle(models_mod, tmp_path, B, seconds):
+@pytest.mark.parametrize("B,seconds,train_math", [(64, 3, "fp32"), (5, 1, "fp32"), (64, 3, "split")])
+def test_full_size_batch_vs_oracle(models_mod, tmp_path, monkeypatch, B, seconds, train_math):
     """BASELINE.json configs[2]/[3] shape: B=64 synthetic 3 s utterances through the whole SLU model,
-    eval logits and fully-unfrozen train-mode gradients against the CPU oracle."""
+    eval logits and fully-unfrozen train-mode gradients against the CPU oracle.  train_math = "split": the opt-in
+    SLU_TRAIN_MATH=split arithmetic of the trainable layers' GEMMs (f16x2 forward products, bf16x3 products with a
+    gradient operand: slu_gemm_bf16_a32 / slu_gemm_tn_bf16) must hold the SAME bounds as exact fp32."""
+    monkeypatch.setenv("SLU_TRAIN_MATH", train_math)
     meta = {"pretrain_seed": 11, "model_seed": 12}
     cfg, model = _full_model_from_seeds(models_mod, tmp_path, meta)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -273,7 +276,7 @@ def test_full_size_batch_vs_oracle(models_mod, tmp_path, B, seconds):
         e = maxerr(p.grad, sdg[k].grad) / scale
         worst = max(worst, e)
         assert e <= 2e-4, (k, e)
-    print("B=%d worst relative gradient deviation: %.3e" % (B, worst))
+    print("B=%d SLU_TRAIN_MATH=%s worst relative gradient deviation: %.3e" % (B, train_math, worst))
 
 
 def test_philox_dropout_training_step_runs_and_is_seeded(models_mod, tmp_path):

@@ -1,7 +1,5 @@
-mkdir -p gpurun_out/r03_r; cd /root/repo
-for w in 1 0; do echo "== SLU_WIDE_FILL=$w"; SLU_WIDE_FILL=$w python tools/pipeline_timeline.py --lookahead 16 --steps 20 2>&1 | grep -E "prefix|steps "; done | tee gpurun_out/r03_r/timeline_wide.txt
-for w in 1 0 1 0; do
-  v=$(SLU_WIDE_FILL=$w python bench.py --steps 20 --warmup 5 --no-kernel-table --no-cpu-baseline --no-large-batch --no-side-runs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['pipeline_fill_ms'], (d.get('steady_state') or {}).get('utterances_per_s'))")
-  echo "wide=$w: $v" | tee -a gpurun_out/r03_r/timeline_wide.txt
+mkdir -p gpurun_out/r03_s; cd /root/repo
+python -m pytest tests/test_hip_model.py tests/test_hip_train_loop.py -q -m gpu -rP > gpurun_out/r03_s/model.txt 2>&1; grep -E "passed|failed" gpurun_out/r03_s/model.txt | tail -1; grep -E "SLU_TRAIN_MATH" gpurun_out/r03_s/model.txt | head
+for i in 1 2 3; do
+  python bench.py --steps 20 --warmup 5 --no-kernel-table --no-cpu-baseline --no-large-batch --no-side-runs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['pipeline_fill_ms'], (d.get('steady_state') or {}).get('utterances_per_s'))"
 done
-python -m pytest tests/test_hip_bench_path.py tests/test_hip_train_loop.py -q -m gpu 2>&1 | tail -2
