@@ -36,3 +36,51 @@ def test_lookahead_width_rules(monkeypatch):
     assert 2 <= w <= 32
     if not torch.cuda.is_available():
         assert w == 32 and training._lookahead_width(-1, 4096) == 2    # clamps without a device (256 CUs assumed)
+
+
+def test_arithmetic_mode_switches(monkeypatch):
+    """SLU_FROZEN_MATH / SLU_TRAIN_MATH / SLU_DTYPE -> the split scheme of each class of contraction (csrc/slu_bf16.h):
+    frozen stages default to f16x2 (2), trainable GEMMs to exact fp32 (0); bf16 mode (BASELINE configs[4]) overrides both;
+    unknown values are rejected instead of silently running another arithmetic."""
+    import pytest
+    import models
+    from slu_hip import ops
+    for k in ("SLU_FROZEN_MATH", "SLU_TRAIN_MATH", "SLU_DTYPE"):
+        monkeypatch.delenv(k, raising=False)
+    assert models.contraction_nsplit(True) == 2 and models.contraction_nsplit(False) == 0
+    assert ops.train_nsplit() == 0 and ops.train_nsplit(True) == 0
+    monkeypatch.setenv("SLU_FROZEN_MATH", "bf16x3")
+    assert models.contraction_nsplit(True) == 3 and models.contraction_nsplit(False) == 0
+    monkeypatch.setenv("SLU_FROZEN_MATH", "fp32")
+    assert models.contraction_nsplit(True) == 0
+    monkeypatch.setenv("SLU_FROZEN_MATH", "fp16")
+    with pytest.raises(ValueError):
+        models.contraction_nsplit(True)
+    monkeypatch.setenv("SLU_TRAIN_MATH", "split")
+    assert ops.train_nsplit() == 2 and ops.train_nsplit(True) == 3      # gradient operands: fp32's exponent range
+    monkeypatch.setenv("SLU_TRAIN_MATH", "bf16x3")
+    assert ops.train_nsplit() == 3 and ops.train_nsplit(True) == 3
+    monkeypatch.setenv("SLU_TRAIN_MATH", "f16")
+    with pytest.raises(ValueError):
+        ops.train_nsplit()
+    monkeypatch.setenv("SLU_DTYPE", "bf16")
+    assert ops.bf16_mode() and ops.train_nsplit() == 1 and ops.train_nsplit(True) == 1
+    assert models.contraction_nsplit(True) == 1 and models.contraction_nsplit(False) == 1
+    assert ops.plane_dtype(2) == torch.float16 and ops.plane_dtype(3) == ops.plane_dtype(1) == torch.bfloat16
+
+
+def test_head_dropout_fusion_rule(monkeypatch):
+    """The Dropout in front of the classifier moves into the head kernels only for Philox masks (no injected mask
+    tensor), no Downsample, four-channel alignment; SLU_FUSE_HEAD_DROPOUT=0 switches it off."""
+    from slu_hip import ops
+    monkeypatch.delenv("SLU_FUSE_HEAD_DROPOUT", raising=False)
+    h, w = torch.zeros(19, 4, 256), torch.zeros(31, 256)
+    assert ops.head_dropout_fusable(h, w, 0.5, None, "none", 1)
+    assert ops.head_dropout_fusable(h, w, 0.5, None, "avg", 1)               # factor 1: the Downsample is the identity
+    assert not ops.head_dropout_fusable(h, w, 0.0, None, "none", 1)           # eval / p = 0: nothing to fuse
+    assert not ops.head_dropout_fusable(h, w, 0.5, torch.ones(1), "none", 1)  # the oracle's masks are injected
+    assert not ops.head_dropout_fusable(h, w, 0.5, None, "max", 2)
+    assert not ops.head_dropout_fusable(torch.zeros(19, 4, 30), torch.zeros(31, 30), 0.5, None, "none", 1)
+    assert not ops.head_dropout_fusable(h[:, :, ::2], w, 0.5, None, "none", 1)
+    monkeypatch.setenv("SLU_FUSE_HEAD_DROPOUT", "0")
+    assert not ops.head_dropout_fusable(h, w, 0.5, None, "none", 1)
