@@ -64,7 +64,7 @@ def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps):
 
 
 def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, monkeypatch):
-    """120 steps of B = 64 x 3 s: six 20-batch super-batches, three per look-ahead slot: each slot captures its shape
+    """120 steps of B = 64 x 3 s: seven 16-batch super-batches (+ one of 8), four per look-ahead slot: each slot captures its shape
     on the second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
     Per-step losses and final parameters must be bit-equal to the eager sequential loop."""
     import data
@@ -96,10 +96,12 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     assert stats["step_graphs"] == 1 and stats["capture_failures"] == 0
     assert all(len([g for g in slot.graphs.values() if g is not None]) >= 1 for slot in tr._slots)
     assert stats["prefix_graphs"] == 2
-    # every slot replayed its captured graph at least once (seen >= 3 for the 20-batch key)
+    # every slot replayed its captured graph at least once (seen >= 3 for the 16-batch key)
     assert all(max(slot.seen.values()) >= 3 for slot in tr._slots)
     from slu_hip import ops as _ops
-    assert all(isinstance(g[1], _ops.RowTable) for slot in tr._slots for g in slot.graphs.values() if g is not None)
+    import models
+    if models.contraction_nsplit(True):      # the split-precision first stage reads the batches in place (row-pointer table)
+        assert all(isinstance(g[1], _ops.RowTable) for slot in tr._slots for g in slot.graphs.values() if g is not None)
     assert losses == ref_losses
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k
