@@ -381,7 +381,20 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             wr = gru.weight_hh_l0_reverse.detach() if D == 2 else None
             br = gru.bias_hh_l0_reverse.detach() if D == 2 else None
             gx = torch.randn(T, B, N, device=dev)
-            if ns:
+            fused_in = bool(ns) and is_frozen and ops.gru_fused_input_ok(I, H, D, ns)
+            if fused_in:
+                # the first frozen GRU layer (K = 60): the recurrence computes x W_ih^T + b_ih itself (no projection
+                # launch, no gx round trip): flops of both contractions, bytes = the input planes + the output
+                planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
+                mult = MFMA_PRODUCTS[ns]
+                ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(None, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                               T, B, H, D, ns, False, fused=(planes, I, packed, b_ih)), stream)
+                rows.setdefault("gru_bf_fwd_kernel<%d,%d>" % (H, ns), []).append(
+                    {"shape": "T=%d B=%d H=%d D=%d K=%d fused input projection (%s)" % (T, B, H, D, I, where),
+                     "flops": 2.0 * B * H * 3 * H * D * T + 2.0 * T * B * N * I, "ms": ms,
+                     "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
+                     "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + 4.0 * (T * B * D * H + D * 3 * H * H) + 2.0 * ns * N * ops.round_up(I, 32)})
+            elif ns:
                 planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
                 mult = MFMA_PRODUCTS[ns]
                 ms = _timed_graph(lambda: ops.gemm_bf16(planes, packed, b_ih, N, I), stream)

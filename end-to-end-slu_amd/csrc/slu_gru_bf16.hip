@@ -37,7 +37,11 @@ struct GruBfParams {
 #ifdef SLU_GRU_PROBE
   int dbg;                // ablation mask of the probe build (tools/gru_probe.py): never compiled into the product
 #endif
-  const float* gx;        // (T, B, D*3H)
+  const float* gx;        // (T, B, D*3H); unused by the fused-input kernels
+  // fused input projection (KI > 0: K <= 32 KI input channels): x as NS planes of (T*B) x (32 KI) 16-bit terms
+  // (plane stride x_plane elements), W_ih packed by gemm_bf_pack_kernel for N = D*3H columns, b_ih (D*3H)
+  const unsigned short* xp; long long x_plane;
+  const uint4* wih; const float* b_ih;
   const float* w_hh[2];   // (3H, H) fp32
   const float* b_hh[2];   // (3H)
   float* out;             // (T, B, D*H)
@@ -45,7 +49,12 @@ struct GruBfParams {
   int T, B, D;
 };
 
-template <int H, int NS>
+// KI > 0: the input projection x_t W_ih^T + b_ih is computed HERE instead of being read as gx — for layers whose input has
+// at most 32 KI channels (the first GRU layer: K = 60) the wave's W_ih slice fits beside W_hh (3 gates x KI chunks x NS
+// planes = 48 registers for KI = 2 on f16x2; the registers that prefetched gx are free), the A fragments of x_t are read
+// straight from the previous stage's planes (one 16-byte load per chunk and plane, a step ahead), and the extra MFMAs do
+// not depend on h_{t-1}.  Saves the projection GEMM and the fp32 gx round trip (T*B*D*3H*8 bytes) of that layer.
+template <int H, int NS, int KI>
 __global__ void __launch_bounds__(H * 4)
 gru_bf_fwd_kernel(const GruBfParams p) {
   constexpr int NW = H / 16;          // waves
@@ -86,6 +95,52 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       }
   }
   const float bhr = p.b_hh[dir][j], bhz = p.b_hh[dir][H + j], bhn = p.b_hh[dir][2 * H + j];
+  // fused input projection: the wave's W_ih fragments (tile dir * 3H/16 + g * H/16 + w of the packed matrix) and biases
+  constexpr int KIA = KI > 0 ? KI : 1;
+  uint4 wi[3][KIA][NS];
+  float bir = 0.f, biz = 0.f, bin = 0.f;
+  if constexpr (KI > 0) {
+    const int NTI = p.D * 3 * NW;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < KI; ++c)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          wi[g][c][pl] = p.wih[(size_t)pl * KI * NTI * 64 + ((size_t)c * NTI + dir * 3 * NW + g * NW + w) * 64 + lane];
+    const float* bi = p.b_ih + (size_t)dir * 3 * H + j;
+    bir = bi[0]; biz = bi[H]; bin = bi[2 * H];
+  }
+  // x_t W_ih^T + b_ih for this lane's four (sequence, unit) pairs from the A fragments of x_t: the accumulation order
+  // of gemm_bf_panel_kernel (k-chunks outside, products inside), i.e. bit-identical to the gx the GEMM would write
+  auto xproj = [&](const uint4 (&xa)[KIA][NS], float (&o_r)[4], float (&o_z)[4], float (&o_n)[4]) {
+    f32x4 ax[SP::NACC][3];
+#pragma unroll
+    for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) ax[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KIA; ++c)
+#pragma unroll
+      for (int q = 0; q < SP::NPAIR; ++q)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+          ax[SP::ACC(q)][g] = mfma_split<NS>(xa[c][SP::PA(q)], wi[g][c][SP::PB(q)], ax[SP::ACC(q)][g]);
+    const f32x4 vr = split_result<NS>(ax[0][0], ax[SP::NACC - 1][0]), vz = split_result<NS>(ax[0][1], ax[SP::NACC - 1][1]),
+                vn = split_result<NS>(ax[0][2], ax[SP::NACC - 1][2]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { o_r[r] = vr[r] + bir; o_z[r] = vz[r] + biz; o_n[r] = vn[r] + bin; }
+  };
+  // A fragment of x_t for this lane: row (sequence) b0 + i (clamped), k slice kg of chunk c, plane pl
+  const int xrow = min(b0 + i, p.B - 1);
+  auto xload = [&](int t_, uint4 (&xa)[KIA][NS]) {
+    const unsigned short* base = p.xp + ((size_t)t_ * p.B + xrow) * (32 * KIA) + kg * 8;
+#pragma unroll
+    for (int c = 0; c < KIA; ++c)
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl)
+        xa[c][pl] = *reinterpret_cast<const uint4*>(base + (size_t)pl * p.x_plane + c * 32);
+  };
 
   for (int x = tid; x < 2 * NS * 16 * ROWB / 4; x += H * 4) reinterpret_cast<unsigned*>(&hbuf[0][0][0])[x] = 0u;   // h0 = 0
   float hprev[4] = {0.f, 0.f, 0.f, 0.f};
@@ -115,10 +170,16 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   float gr[4], gz[4], gn[4];
   {
     const int t0 = dir ? T - 1 : 0;
+    if constexpr (KI > 0) {
+      uint4 xa0[KIA][NS];
+      xload(t0, xa0);
+      xproj(xa0, gr, gz, gn);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* g = gxd + (size_t)t0 * gx_ts + g_off[r];
-      gr[r] = g[0]; gz[r] = g[H]; gn[r] = g[2 * H];
+      for (int r = 0; r < 4; ++r) {
+        const float* g = gxd + (size_t)t0 * gx_ts + g_off[r];
+        gr[r] = g[0]; gz[r] = g[H]; gn[r] = g[2 * H];
+      }
     }
   }
   __syncthreads();
@@ -127,11 +188,14 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     float ngr[4], ngz[4], ngn[4];
-    if (SLU_BDBG(1)) {
+    uint4 xan[KIA][NS];                                          // fused input: A fragments of the NEXT step's x
+    const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
+    if constexpr (KI > 0) {
+      xload(tn, xan);                                            // in flight during this step; multiplied at its end
+    } else if (SLU_BDBG(1)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ngr[r] = gr[r]; ngz[r] = gz[r]; ngn[r] = gn[r]; }
     } else {
-      const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float* g = gxd + (size_t)tn * gx_ts + g_off[r];
@@ -201,6 +265,9 @@ gru_bf_fwd_kernel(const GruBfParams p) {
         if (!SLU_BDBG(64)) *reinterpret_cast<unsigned short*>(hnext + pl * (16 * ROWB) + h_off[r]) = sp[pl];
       if (o_off[r] >= 0 && !SLU_BDBG(2)) outd[(size_t)t * out_ts + o_off[r]] = hn[r];
     }
+    // the next step's x W_ih^T + b_ih: independent of h.  (Issued before the gate math and interleaved with it by
+    // sched_group_barrier hints — one MFMA per six VALU instructions — the step took 2.2 us instead of 1.7: measured.)
+    if constexpr (KI > 0) xproj(xan, ngr, ngz, ngn);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hprev[r] = hn[r]; gr[r] = ngr[r]; gz[r] = ngz[r]; gn[r] = ngn[r]; }
     __syncthreads();
@@ -213,8 +280,20 @@ using namespace slu;
 
 extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
                                     const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
-                                    int64_t T, int64_t B, int64_t H, int64_t D, int nsplit, void* stream) {
-  SLU_REQUIRE(gx && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd_bf16: null pointer");
+                                    const void* x_planes, int64_t x_plane_stride, int64_t K, const void* w_ih_packed,
+                                    const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D, int nsplit,
+                                    void* stream) {
+  SLU_REQUIRE((gx || x_planes) && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd_bf16: null pointer");
+  const bool fused = x_planes != nullptr;
+  if (fused) {
+    SLU_REQUIRE(!gx && w_ih_packed && b_ih && !reserve, "slu_gru_seq_fwd_bf16: the fused input projection takes x_planes, "
+                "w_ih_packed and b_ih instead of gx, and no reserve (frozen layers only)");
+    if (!(nsplit == 2 && H == 128 && K >= 1 && K <= 64))
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_bf16: the fused input projection is instantiated for f16x2 (nsplit 2), "
+               "H = 128 and at most 64 input channels (got nsplit %d, H %lld, K %lld)", nsplit, (long long)H, (long long)K);
+    SLU_REQUIRE(x_plane_stride >= T * B * (cdiv(K, 32) * 32) && ((uintptr_t)x_planes & 15) == 0 && (x_plane_stride & 7) == 0,
+                "slu_gru_seq_fwd_bf16: x plane stride / alignment");
+  }
   SLU_REQUIRE(D == 1 || (D == 2 && w_hh_rev && b_hh_rev), "slu_gru_seq_fwd_bf16: D must be 1 or 2 (with reverse weights)");
   SLU_REQUIRE(T > 0 && B > 0, "slu_gru_seq_fwd_bf16: non-positive T or B");
   SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_gru_seq_fwd_bf16: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
@@ -225,18 +304,22 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
 #ifdef SLU_GRU_PROBE
   { const char* e = getenv("SLU_GRU_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
+  p.xp = (const unsigned short*)x_planes; p.x_plane = x_plane_stride; p.wih = (const uint4*)w_ih_packed; p.b_ih = b_ih;
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
   p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
   dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   hipStream_t st = (hipStream_t)stream;
-  if (H == 128) {
-    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 3>), grid, dim3(512), 0, st, p);
-    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 1>), grid, dim3(512), 0, st, p);
+  if (fused) {
+    if (K <= 32) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2, 1>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2, 2>), grid, dim3(512), 0, st, p);
+  } else if (H == 128) {
+    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 3, 0>), grid, dim3(512), 0, st, p);
+    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2, 0>), grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 1, 0>), grid, dim3(512), 0, st, p);
   } else {
-    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 3>), grid, dim3(256), 0, st, p);
-    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 1>), grid, dim3(256), 0, st, p);
+    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 3, 0>), grid, dim3(256), 0, st, p);
+    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 2, 0>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 1, 0>), grid, dim3(256), 0, st, p);
   }
   SLU_CHECK_LAUNCH("gru_bf_fwd_kernel");
   return SLU_OK;

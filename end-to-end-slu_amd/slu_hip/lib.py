@@ -68,7 +68,8 @@ SIGNATURES = {
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
                                    c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp]),
-    "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp]),
+    "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int,
+                                     vp]),
     "slu_comm_version": (c_int, []),
     "slu_comm_unique_id": (c_int, [vp]),
     "slu_comm_init": (c_int, [vp, vp, c_i64, c_i64]),

@@ -587,8 +587,13 @@ def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p
         T, B, I = x.shape
         planes = split_bf16(x.view(T * B, I), nsplit)
     packed = packed_ih if packed_ih is not None else gemm_bf16_pack(w_ih, nsplit)
-    gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
-    raw, _ = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, False)
+    if gru_fused_input_ok(I, H, D, nsplit):
+        # the first GRU layer (K = 60): the recurrence computes x W_ih^T + b_ih itself — no projection launch, no gx
+        raw, _ = gru_seq_fwd_bf16(None, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, False,
+                                  fused=(planes, I, packed, b_ih))
+    else:
+        gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
+        raw, _ = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, False)
     offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
     if out_planes and (D * H) % 32 == 0 and -(-T // factor) <= 65535:
         return dropout_pool_fwd_planes(raw, mask, p, seed, offset, method, factor, nsplit, offset_dev, sub_batch)
@@ -602,15 +607,35 @@ def split_path_supported(H, D):
     return H in (64, 128) and (D * 3 * H) % 64 == 0
 
 
-def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False):
-    """Recurrence on the split-precision MFMA kernels -> (out (T, B, D*H) fp32, reserve or None)."""
+def gru_fused_input_ok(I, H, D, nsplit):
+    """Layers whose input projection slu_gru_seq_fwd_bf16 computes itself (x_planes): at most 64 input channels, H = 128,
+    the f16x2 scheme — the first GRU layer of the reference architecture (K = 60).  SLU_FUSE_GRU_INPUT=0: off.
+    Measured on MI355X (tools/gru_fused_probe.py, T = 300, 1024 sequences, 128 CUs): projection GEMM 275 us + recurrence
+    385 us = 660 us against 511 us fused, bit-identical output, 1.9 GB less HBM traffic per super-batch (the fp32 gx of the
+    largest layer is never written); the pipelined loop: 343-346 k against 325-336 k utt/s (same box).  The fused step costs
+    1.70 instead of 1.27 us: its 18 extra MFMAs per wave run back to back at the end of the step (interleaving them with
+    the gate math by scheduling hints made the step 2.2 us)."""
+    return nsplit == 2 and H == 128 and 1 <= I <= 64 and os.environ.get("SLU_FUSE_GRU_INPUT", "1") != "0"
+
+
+def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False, fused=None):
+    """Recurrence on the split-precision MFMA kernels -> (out (T, B, D*H) fp32, reserve or None).
+    fused = (planes (nsplit, T*B, round_up(K, 32)), K, packed W_ih, b_ih) with gx None: the kernel computes the input
+    projection itself (gru_fused_input_ok shapes; bit-identical to gemm_bf16 + this call)."""
     L = _lib.load()
-    out = torch.empty(T, B, D * H, dtype=torch.float32, device=gx.device)
+    dev = w_hh_f.device
+    out = torch.empty(T, B, D * H, dtype=torch.float32, device=dev)
     reserve = None
     if want_reserve:
-        reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=gx.device)
-    _lib.check(L.slu_gru_seq_fwd_bf16(gx.data_ptr(), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r),
-                                      out.data_ptr(), _ptr(reserve), T, B, H, D, nsplit, _stream()),
+        reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=dev)
+    if fused is not None:
+        planes, K, packed, b_ih = fused
+        assert gx is None and planes.shape == (nsplit, T * B, round_up(K, 32)) and planes.stride(1) == planes.shape[2]
+        xa = (planes.data_ptr(), planes.stride(0), K, packed.data_ptr(), b_ih.data_ptr())
+    else:
+        xa = (None, 0, 0, None, None)
+    _lib.check(L.slu_gru_seq_fwd_bf16(_ptr(gx), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r),
+                                      out.data_ptr(), _ptr(reserve), *xa, T, B, H, D, nsplit, _stream()),
                "slu_gru_seq_fwd_bf16")
     return out, reserve
 

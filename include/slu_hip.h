@@ -213,10 +213,16 @@ int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t ta
 /* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
  * W_hh (3 gates x nsplit 16-bit planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
  * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)
- * back-propagates through a bf16 forward (BASELINE configs[4]: bf16 forward contractions, fp32 gradients).     */
+ * back-propagates through a bf16 forward (BASELINE configs[4]: bf16 forward contractions, fp32 gradients).
+ * Fused input projection (x_planes != NULL, then gx = NULL): for a layer with K <= 64 input channels (the first GRU
+ * layer: K = 60) the kernel computes x_t W_ih^T + b_ih itself — x as nsplit planes of (T*B) x round_up(K, 32) (the
+ * previous stage's plane output), W_ih (D*3H x K, both directions stacked) packed by slu_gemm_bf16_pack, b_ih (D*3H) —
+ * with the GEMM's accumulation order, i.e. the result equals slu_gemm_bf16 + this call bit for bit, without the
+ * projection launch and its fp32 gx round trip.  nsplit = 2, H = 128, reserve = NULL only.                          */
 int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
-                         const float* b_hh_rev, float* out, float* reserve, int64_t T, int64_t B, int64_t H,
-                         int64_t D, int nsplit, void* stream);
+                         const float* b_hh_rev, float* out, float* reserve, const void* x_planes,
+                         int64_t x_plane_stride, int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T,
+                         int64_t B, int64_t H, int64_t D, int nsplit, void* stream);
 
 /* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
  *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)

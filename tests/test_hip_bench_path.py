@@ -111,10 +111,11 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
 def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, monkeypatch, n_utt, math):
     """One look-ahead super-batch through the frozen encoder with the oracle's dropout masks, against the CPU oracle's
     encoder (models.py:349-361), features within 1e-4.  1024 = 16 x 64 utterances of 3 s is exactly what bench.py's
-    default launches: split-precision convolutions, the 96-row panel GEMM (M = 150 x 1024 = 153 600 rows >= 131 072,
-    K = 256), the tiled GEMM for the shorter layers, the row-panel GEMM for K = 60 and the 16-sequence split-precision
-    (f16x2) recurrence on 64 tiles x 2 directions; 1280 = the 20-batch super-batch of the 96 + 160 CU partition (rounds
-    1-2); 768 = a 12-batch super-batch (all launches below the panel threshold), on the bf16x3 scheme."""
+    default launches: split-precision convolutions, the first GRU layer's recurrence with the fused K = 60 input
+    projection, the 96-row panel GEMM (M = 150 x 1024 = 153 600 rows >= 131 072, K = 256), the tiled GEMM for the shorter
+    layers and the 16-sequence split-precision (f16x2) recurrence on 64 tiles x 2 directions; 1280 = the 20-batch
+    super-batch of the 96 + 160 CU partition (rounds 1-2); 768 = a 12-batch super-batch (all launches below the panel
+    threshold), on the bf16x3 scheme (whose first layer takes the row-panel GEMM for K = 60 + the plain recurrence)."""
     import models
     monkeypatch.setenv("SLU_FROZEN_MATH", math)
     cfg = _full_cfg(tmp_path)

@@ -146,6 +146,28 @@ def test_gru_bf16_vs_exact_fp32_kernel(ops, T, B, H, nsplit):
     assert err <= (5e-6 if nsplit >= 2 else 5e-2)
 
 
+@pytest.mark.parametrize("T,B,I", [(40, 64, 60), (23, 37, 60), (7, 16, 32), (300, 1024, 60)])
+def test_gru_fused_input_projection_equals_gemm_plus_recurrence(ops, T, B, I):
+    """slu_gru_seq_fwd_bf16(x_planes): the recurrence computes x W_ih^T + b_ih itself (first GRU layer, K <= 64, f16x2) with
+    the projection GEMM's accumulation order — bit-identical to slu_gemm_bf16 followed by the plain recurrence, for both
+    directions, ragged batches (B not a multiple of the 16-sequence tile) and the 1024-sequence super-batch."""
+    torch.manual_seed(T + B)
+    H, D, ns = 128, 2, 2
+    x = torch.randn(T * B, I, device="cuda")
+    w_ih = torch.randn(D * 3 * H, I, device="cuda") * 0.1
+    b_ih = torch.randn(D * 3 * H, device="cuda") * 0.1
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda") * 0.1, torch.randn(3 * H, device="cuda") * 0.1
+    planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
+    gx = ops.gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
+    ref, _ = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, ns)
+    out, _ = ops.gru_seq_fwd_bf16(None, wf, wr, bf, br, T, B, H, D, ns, False, fused=(planes, I, packed, b_ih))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    exact, _ = ops.gru_seq_fwd(ops.gemm(x, w_ih.t(), b_ih), wf, wr, bf, br, T, B, H, D, False)
+    assert (out - exact).abs().max().item() <= 5e-6
+
+
 def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):
     """BASELINE configs[4] arithmetic (SLU_DTYPE=bf16: the GRU layers' forward contractions on bf16 MFMA with
     fp32 accumulation and gate math, exact-fp32 backward on the saved gates).  The reference has no reduced

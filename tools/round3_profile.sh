@@ -18,38 +18,41 @@ rm -rf $O/trace_default
 python tools/inloop_json.py $O/default_kernel_stats_by_shape.txt > $O/inloop_kernel_us.json
 sed -i "s#$O/#profiles/${TAG}_#" $O/inloop_kernel_us.json
 cp $O/inloop_kernel_us.json profiles/inloop_kernel_us.json
-# HBM traffic of the dominant kernel (separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KiB, FETCH x 2 on gfx950)
+# HBM traffic of the dominant kernel (separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KiB, FETCH x 2 on gfx950): its two
+# launch kinds — T = 300 with the fused input projection (reads x planes), T = 150 plain (reads gx)
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/tools/run_one.py gru_bf 1024 2 > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/tools/run_one.py gru_bf_fused 1024 > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc2_$c -o p -- python $R/tools/run_one.py gru_bf 1024 2 > /dev/null 2>&1
 done
 cd $R
 python - <<PY > $O/pmc_gru_bf.txt 2>&1
-import csv, glob
-res = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("$O/pmc_%s/**/*counter_collection.csv" % c, recursive=True)
+import csv, glob, json
+def mean(dirname, c):
+    f = glob.glob("$O/%s_%s/**/*counter_collection.csv" % (dirname, c), recursive=True)
     v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f[0])) if "gru_bf_fwd" in r["Kernel_Name"] and r["Counter_Name"] == c]
-    res[c] = sum(v) / len(v)
-    print(c, "launches", len(v), "mean KiB", res[c])
-T, B, H, D = 300, 1024, 128, 2
-alg = 4.0 * (T * B * D * 3 * H + T * B * D * H + D * 3 * H * H)
-tot = 2 * res["FETCH_SIZE"] * 1024 + res["WRITE_SIZE"] * 1024
-print("gru_bf_fwd_kernel<128,2> T=300 B=1024: fetch x 2 = %d B, write = %d B, total %d B; algorithmic %d B; ratio %.3f"
-      % (2 * res["FETCH_SIZE"] * 1024, res["WRITE_SIZE"] * 1024, tot, alg, tot / alg))
-import json
+    return sum(v) / len(v), len(v)
+T, B, H, D, I = 300, 1024, 128, 2, 60
+shapes, tot_all, alg_all = {}, 0.0, 0.0
+for dirname, label, alg in (("pmc", "T=300 B=1024 H=128 D=2 K=60 fused input projection", 2.0 * 2 * T * B * 64 + 4.0 * (T * B * D * H + D * 3 * H * H) + 2.0 * 2 * D * 3 * H * 64),
+                            ("pmc2", "T=300 B=1024 H=128 D=2 (plain: gx in)", 4.0 * (T * B * D * 3 * H + T * B * D * H + D * 3 * H * H))):
+    fe, n = mean(dirname, "FETCH_SIZE"); wr, _ = mean(dirname, "WRITE_SIZE")
+    tot = 2 * fe * 1024 + wr * 1024
+    print("%s: %d launches, fetch x 2 = %d B, write = %d B, total %d B; algorithmic %d B; ratio %.3f" % (label, n, 2 * fe * 1024, wr * 1024, tot, alg, tot / alg))
+    shapes[label] = {"fetch_x2_bytes": round(2 * fe * 1024), "write_bytes": round(wr * 1024), "algorithmic_bytes": round(alg)}
+    tot_all += tot; alg_all += alg
 j = json.load(open("profiles/pmc_traffic.json"))
 j["gru_bf_fwd_kernel<128,2>"] = {
-    "bytes_per_launch_mean_of_measured_shapes": round(tot),
-    "shapes": {"T=300 B=1024 H=128 D=2": {"fetch_x2_bytes": round(2 * res["FETCH_SIZE"] * 1024), "write_bytes": round(res["WRITE_SIZE"] * 1024),
-                                          "algorithmic_bytes": round(alg)}},
-    "traffic_over_algorithmic": round(tot / alg, 3),
+    "bytes_per_launch_mean_of_measured_shapes": round(tot_all / 2), "shapes": shapes,
+    "traffic_over_algorithmic": round(tot_all / alg_all, 3),
     "source": "profiles/${TAG}_pmc_gru_bf.txt",
-    "note": "the T=300 launch of the default 16-batch (1024-sequence) super-batch only; roofline.algorithmic_bytes_per_launch in the "
-            "bench line averages the four launch shapes (T = 300, 150, 75, 38)"}
+    "note": "T = 300 launches of the default 16-batch (1024-sequence) super-batch: the first layer's (fused input projection: x planes in) and "
+            "the plain kernel at the same size (gx in; the default's plain launches are T = 150 / 75 / 38); roofline.algorithmic_bytes_per_launch "
+            "in the bench line averages the four launch shapes"}
 json.dump(j, open("profiles/pmc_traffic.json", "w"), indent=1)
 json.dump(j, open("$O/pmc_traffic.json", "w"), indent=1)
 PY
+rm -rf $O/pmc2_FETCH_SIZE $O/pmc2_WRITE_SIZE
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 cat $O/pmc_gru_bf.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?"

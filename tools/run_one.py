@@ -40,6 +40,15 @@ elif what == "gru_bf":
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
         ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS)
+elif what == "gru_bf_fused":
+    # the first frozen GRU layer of a super-batch (K = 60, T = 300): recurrence with the fused input projection
+    T, B, H, I = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128, 60
+    x = torch.randn(T * B, I, device="cuda"); w_ih = torch.randn(6 * H, I, device="cuda") * 0.1; b_ih = torch.randn(6 * H, device="cuda") * 0.1
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    planes, packed = ops.split_bf16(x, 2), ops.gemm_bf16_pack(w_ih, 2)
+    for _ in range(5):
+        ops.gru_seq_fwd_bf16(None, wf, wr, bf, br, T, B, H, 2, 2, False, fused=(planes, I, packed, b_ih))
 elif what == "tn":
     # the intent layer's three weight gradients in one batched launch (T = 19, B = 64)
     T, B, I, H, D = 19, 64, 256, 128, 2
