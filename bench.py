@@ -805,6 +805,7 @@ def main():
             # all bytes the frozen-prefix kernels move per super-batch against SURVEY 8(d)'s minimum (0.914 MB / utterance)
             prefix_bytes = sum(sh["algorithmic_MB"] * 1e6 for k in table for sh in k["shapes"] if "look-ahead" in sh["shape"])
             prefix_ms = sum(sh["us"] * 1e-3 for k in table for sh in k["shapes"] if "look-ahead" in sh["shape"])
+            prefix_gflop = sum(sh["gflop"] for k in table for sh in k["shapes"] if "look-ahead" in sh["shape"])
             n_utt = args.batch * width
             # HBM bytes per launch: the PMC passes measure the largest launch shape(s) of the kernel; their
             # measured / algorithmic ratio is applied to the per-launch mean `achieved` is quoted on
@@ -820,6 +821,11 @@ def main():
                 "prefix_traffic_over_8d": round(prefix_bytes / (0.914e6 * n_utt), 2) if width > 1 else None,
                 "prefix_bytes_per_super_batch": round(prefix_bytes) if width > 1 else None,
                 "prefix_ms_per_super_batch_isolated": round(prefix_ms, 3) if width > 1 else None,
+                # the frozen stages as a whole against the roofline of an exact-fp32 implementation: their algorithmic
+                # (fp32-equivalent) flops per super-batch / the sum of their isolated kernel times, of the whole chip's
+                # fp32 MFMA peak (they run on the look-ahead partition only; the split schemes are why this can pass 1)
+                "prefix_fp32_equiv_tflops_isolated": round(prefix_gflop / prefix_ms, 1) if width > 1 and prefix_ms else None,
+                "prefix_frac_of_fp32_mfma_peak": round(prefix_gflop / prefix_ms / PEAK_FP32_MFMA_TFLOPS, 3) if width > 1 and prefix_ms else None,
                 "traffic": round(alg_per_launch * ratio) if ratio else None,
                 "algorithmic_bytes_per_launch": alg_per_launch, "traffic_pmc": pmc,
                 "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
