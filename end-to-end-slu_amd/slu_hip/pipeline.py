@@ -264,11 +264,17 @@ class StepGraph:
                 self.loss.backward(self.one)
                 if self.world > 1:
                     bucket.pack()                   # one concatenation kernel per dtype; .grad -> slices
+                elif _one_graph():
+                    # single process: nothing sits between the backward pass and Adam, so they are ONE graph — a graph
+                    # launch costs the stream ~8 us of ramp (SLU_ONE_STEP_GRAPH=0: two graphs as under data parallelism)
+                    trainer.optimizer.step()
         finally:
             ops._Fork.capture_forks = False
-        self.g2 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
-            trainer.optimizer.step()
+        self.g2 = None
+        if self.world > 1 or not _one_graph():
+            self.g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
+                trainer.optimizer.step()
         bucket.observe()
         self.signature = bucket.signature
 
@@ -279,8 +285,13 @@ class StepGraph:
         self.g1.replay()
         if self.world > 1:                          # one collective per gradient dtype; the mean's 1/N is
             self.trainer.bucket.allreduce_flats()   # folded into the Adam kernel (HipAdam.grad_div)
-        self.g2.replay()
+        if self.g2 is not None:
+            self.g2.replay()
         return self.metrics
+
+
+def _one_graph():
+    return os.environ.get("SLU_ONE_STEP_GRAPH", "1") != "0"
 
 
 def graphs_enabled():

@@ -76,7 +76,8 @@ def g1_only(n):
 def g2_only(n):
     with torch.cuda.stream(main):
         for i in range(n):
-            sg.g2.replay()
+            if sg.g2 is not None:
+                sg.g2.replay()
 print("CPU enqueue cost: G1 replay %.1f us, G2 replay %.1f us" % (cpu_cost(g1_only, 12), cpu_cost(g2_only, 12)))
 
 # (f) is the real loop host-bound?  wall time until the step loop RETURNS (everything enqueued) vs until the GPU is done
