@@ -1,6 +1,8 @@
-mkdir -p gpurun_out/r03_w; cd /root/repo
-for f in 1 0 1 0; do
-  v=$(SLU_ONE_STEP_GRAPH=$f python bench.py --steps 20 --warmup 5 --no-kernel-table --no-cpu-baseline --no-large-batch --no-side-runs 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['pipeline_fill_ms'], (d.get('steady_state') or {}).get('utterances_per_s'), d['graphs_captured'])")
-  echo "one_step_graph=$f: $v" | tee -a gpurun_out/r03_w/onegraph.txt
+mkdir -p gpurun_out/r03_x; cd /root/repo
+for f in tests/test_hip_*.py; do
+  n=$(basename $f .py)
+  timeout 900 python -m pytest $f -q -m gpu -rP > gpurun_out/r03_x/$n.txt 2>&1
+  echo "$n: $(grep -E "passed|failed|error" gpurun_out/r03_x/$n.txt | tail -1)"
+  awk '/=+ FAILURES =+/{p=1} /=+ PASSES =+/{p=0} p && (/^_+ .* _+$/ || /^E    +(Assertion|assert)/)' gpurun_out/r03_x/$n.txt | cut -c1-220 | head -20
 done
-python -m pytest tests/test_hip_bench_path.py tests/test_hip_train_loop.py tests/test_hip_dp.py -q -m gpu 2>&1 | tail -2
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
