@@ -432,10 +432,13 @@ def gemm_a32(a, packed, bias, N, nsplit, out=None):
     return out
 
 
-def gemm_nt(a, w, bias=None, out=None, grad=False):
+def gemm_nt(a, w, bias=None, out=None, grad=False, bf16_ok=True):
     """a (M, K) @ w^T (w (N, K), any strides) + bias in the arithmetic of the trainable layers (train_nsplit; grad: a
-    is a gradient): the split-precision kernel where the shape allows it, else the exact fp32 GEMM."""
+    is a gradient): the split-precision kernel where the shape allows it, else the exact fp32 GEMM.
+    bf16_ok=False: this product stays fp32 in bf16 mode (the ASR heads: BASELINE configs[4] is the SLU model)."""
     ns = train_nsplit(grad)
+    if ns == 1 and not bf16_ok:
+        ns = 0
     N, K = w.shape
     if ns and a.is_cuda and gemm_a32_ok(a, N, K) and (out is None or (out.stride(1) == 1 and out.stride(0) % 4 == 0)):
         return gemm_a32(a, gemm_bf16_pack(w.detach(), ns), bias, N, ns, out)
@@ -868,7 +871,7 @@ class FrameHeadFn(torch.autograd.Function):
         if y_tm.dtype != torch.int64 or y_tm.numel() != T * B:
             raise TypeError("FrameHeadFn: y must be int64 of shape (B, T)")
         need = any(ctx.needs_input_grad[:3])
-        logits = gemm_nt(hn, weight, bias)                         # train_nsplit arithmetic
+        logits = gemm_nt(hn, weight, bias, bf16_ok=False)          # train_nsplit arithmetic (fp32 in bf16 mode)
         row_stats = torch.empty(2 * T * B, dtype=torch.float32, device=h.device)
         out3 = torch.empty(3, dtype=torch.float32, device=h.device)
         _lib.check(L.slu_frame_ce_fwd(logits.data_ptr(), y_tm.data_ptr(), T * B, V, -1, int(need),
@@ -890,9 +893,9 @@ class FrameHeadFn(torch.autograd.Function):
         g = d_loss.float()
         dh = dW = db = None
         if ctx.needs_input_grad[0]:
-            dh = gemm_nt(d_logits, weight.t(), grad=True).view(T, B, C)
+            dh = gemm_nt(d_logits, weight.t(), grad=True, bf16_ok=False).view(T, B, C)
         if ctx.needs_input_grad[1]:
-            dW = _wgrad(d_logits, hn, None)
+            dW = _wgrad(d_logits, hn, None, bf16_ok=False)
         if ctx.needs_input_grad[2]:
             db = colsum(d_logits)
         scale_multi([t for t in (dh, dW, db) if t is not None], g)      # d loss upstream (a device scalar), one launch
@@ -1009,10 +1012,12 @@ def gemm_tn_bf16(a, b, out=None, nsplit=1):
     return out
 
 
-def _wgrad(a, b, out):
+def _wgrad(a, b, out, bf16_ok=True):
     """out = a^T b (a (K, M) gradients, b (K, N) activations) in the arithmetic of the trainable layers (train_nsplit):
     the split-precision TN kernel where it takes the shape, else the exact fp32 GEMM on the transposed view."""
     ns = train_nsplit(True)
+    if ns == 1 and not bf16_ok:
+        ns = 0
     if ns and gemm_tn_bf16_ok(a, b) and (out is None or out.stride(1) == 1):
         return gemm_tn_bf16(a, b, out, ns)
     return gemm(a.t(), b, out=out)
