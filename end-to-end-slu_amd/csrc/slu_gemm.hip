@@ -14,6 +14,7 @@
 // transposed copy.  Small-output / long-K problems (weight gradients) are split along K into a
 // workspace and reduced in a fixed order (deterministic).
 #include "slu_common.h"
+#include <cstdlib>
 
 namespace slu {
 
@@ -467,6 +468,113 @@ gemm_tn_small_kernel(const TnArgs a) {
     }
 }
 
+// 64 x 64 output tiles (four columns of B per lane: one 16-byte load): a third fewer operand bytes per MAC than the
+// 64 x 32 kernel, twice the MFMAs per wave.  N % 4 == 0, ldb % 4 == 0, B 16-byte aligned.
+__global__ void __launch_bounds__(256)
+gemm_tn_small_wide_kernel(const TnArgs a) {
+  __shared__ float red[4][16][256];                    // [wave][tile][lane*4 + r]
+  if ((int)blockIdx.x < a.rs_blocks) {                 // the row-sum job
+    tn_rowsum(a, (int)blockIdx.x * 256 + threadIdx.x);
+    return;
+  }
+  const int bid = (int)blockIdx.x - a.rs_blocks;
+  int q = 0;
+  while (q + 1 < a.count && bid >= a.p[q].tile_end) ++q;
+  const TnProblem& P = a.p[q];
+  const int tile = bid - (q ? a.p[q - 1].tile_end : 0);
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  // this wave's k range: quarters of the FULL 4-row MFMA steps; a partial last step (K % 4 != 0) goes to wave 3.
+  // Rows / columns of the tile past M / N read column 0 instead: the accumulator rows / columns they feed are never
+  // stored, so no select sits between a load and its MFMA (a select there makes the compiler wait for each load
+  // where it is issued: measured 80 us instead of 50 for the intent layer's three matrices).
+  const int steps = P.K >> 2;
+  const int per = ((((steps + 3) >> 2) + 7) >> 3) << 3;   // a multiple of the batch size U = 8: no per-step tail loop
+  const int s0 = min(steps, w * per), s1 = min(steps, s0 + per);
+  // ONE 16-byte (A) and ONE 8-byte (B) load per k row feed all MFMA tiles of a 64 x 32 output tile: lane i holds
+  // columns 4i..4i+3 of A and 2i, 2i+1 of B, i.e. MFMA row-tile x covers the rows m0 + 4*(0..15) + x and column-tile
+  // y the columns n0 + 2*(0..15) + y (a permutation, undone at the store).  A workgroup moves (64 + 32) K floats
+  // for 64 x 32 x K MACs: the kernel is bound by what one CU can pull through its L1 (~60 GB/s), 32 x 32 tiles
+  // moved 1.5x as much per MAC.  (M % 4 == 0, N % 2 == 0: checked by the launcher.)
+  const float* __restrict__ pa = P.A + (m0 + 4 * i + 3 < P.M ? m0 + 4 * i : 0);
+  const float* __restrict__ pb = P.B + (n0 + 4 * i + 3 < P.N ? n0 + 4 * i : 0);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // batches of U = 8 MFMA steps (16 loads per lane), software-pipelined over two register sets: the next batch's
+  // loads are issued before the current batch's MFMAs (the batch index is clamped instead of branching around the
+  // loads, which would send the register arrays through scratch memory)
+  constexpr int U = 8;
+  const int nb = (s1 > s0) ? (s1 - s0) / U : 0;
+  float4 avA[U], avB[U];
+  float4 bvA[U], bvB[U];
+#define TN_LOAD(av, bv, batch)                                                        \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
+    const long long k = 4 * (s0 + (batch) * U + u) + kg;                               \
+    av[u] = *reinterpret_cast<const float4*>(pa + k * P.lda);                          \
+    bv[u] = *reinterpret_cast<const float4*>(pb + k * P.ldb);                          \
+  }                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+#define TN_ROW(x_, av_, b_)                                                            \
+  acc[x_][0] = mfma16(av_, b_.x, acc[x_][0]); acc[x_][1] = mfma16(av_, b_.y, acc[x_][1]); \
+  acc[x_][2] = mfma16(av_, b_.z, acc[x_][2]); acc[x_][3] = mfma16(av_, b_.w, acc[x_][3]);
+#define TN_STEP(a_, b_) TN_ROW(0, a_.x, b_) TN_ROW(1, a_.y, b_) TN_ROW(2, a_.z, b_) TN_ROW(3, a_.w, b_)
+#define TN_MFMA(av, bv)                                                                \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) { TN_STEP(av[u], bv[u]) }              \
+  __builtin_amdgcn_sched_barrier(0);
+  if (nb > 0) {
+    TN_LOAD(avA, bvA, 0)
+    for (int bt = 0; bt < nb; bt += 2) {
+      TN_LOAD(avB, bvB, min(bt + 1, nb - 1))
+      TN_MFMA(avA, bvA)
+      TN_LOAD(avA, bvA, min(bt + 2, nb - 1))
+      if (bt + 1 < nb) { TN_MFMA(avB, bvB) }
+    }
+  }
+  int sb = s0 + nb * U;
+  for (; sb < s1; ++sb) {                              // fewer than U full steps left
+    const long long k = 4 * sb + kg;
+    const float4 av = *reinterpret_cast<const float4*>(pa + k * P.lda);
+    const float4 bv = *reinterpret_cast<const float4*>(pb + k * P.ldb);
+    TN_STEP(av, bv)
+  }
+  if (w == 3 && (P.K & 3)) {                           // partial last step: zero the rows past K
+    const long long k = 4 * steps + kg;
+    const bool kok = k < P.K;
+    const long long kc = kok ? k : 0;
+    float4 av = *reinterpret_cast<const float4*>(pa + kc * P.lda);
+    const float4 bv = *reinterpret_cast<const float4*>(pb + kc * P.ldb);
+    av.x = kok ? av.x : 0.0f; av.y = kok ? av.y : 0.0f; av.z = kok ? av.z : 0.0f; av.w = kok ? av.w : 0.0f;
+    TN_STEP(av, bv)
+  }
+#undef TN_MFMA
+#undef TN_STEP
+#undef TN_ROW
+#undef TN_LOAD
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][4 * x + y][lane * 4 + r] = acc[x][y][r];
+  __syncthreads();
+  // wave w finishes the four tiles of row-tile x = w: element (lane, r) is row 4*kg + r, column i of a 16 x 16 tile
+#pragma unroll
+  for (int y = 0; y < 4; ++y)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane * 4 + r, t = 4 * w + y;
+      const float v = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+      const int m = m0 + 4 * (4 * kg + r) + w, n = n0 + 4 * i + y;
+      if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v;
+    }
+}
+
+
 // The same kernel with MT floats of A per lane and k row: 3 -> 48 x 32 output tiles, 12-byte loads, for matrices whose
 // M is not a multiple of 4 (or whose A is not 16-byte aligned).  A tile's k range is summed exactly as above.  Kept
 // apart from the 64-row kernel: writing that one as the MT = 4 instance of this template cost it 14 us (53 -> 67 us
@@ -827,6 +935,20 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
     if (!ok4 && !ok3)
       SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched: M must be a multiple of 3, or M and lda multiples of 4 with A 16-byte aligned");
     if (!ok4) mt = 3;
+    // 64 x 64 tiles (mt = 8: gemm_tn_small_wide_kernel) where B allows 16-byte loads and the tiles still make a few
+    // dozen workgroups: the kernel is bound by the operand bytes a CU pulls through its L1 per MAC — measured for the
+    // intent layer's three matrices on 128 CUs: 64 x 64 tiles 26.6 us, 64 x 32 tiles 34.6 us, 32 x 32 tiles 45.1 us
+    // (SLU_TN_WIDE=0: 64 x 32 tiles always)
+    static const int wide_env = [] { const char* e = getenv("SLU_TN_WIDE"); return e ? atoi(e) : 1; }();
+    if (ok4 && wide_env) {
+      bool okw = true;
+      int64_t wt = 0;
+      for (int q = 0; q < (int)count; ++q) {
+        okw = okw && ((N[q] | ldb[q]) & 3) == 0 && ((uintptr_t)B[q] & 15) == 0;
+        wt += cdiv(M[q], 64) * cdiv(N[q], 64);
+      }
+      if (okw && wt >= 32) mt = 8;
+    }
   }
   TnArgs a;
   int tiles = 0;
@@ -838,8 +960,9 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
     a.p[q].A = A[q]; a.p[q].B = B[q]; a.p[q].C = C[q];
     a.p[q].lda = lda[q]; a.p[q].ldb = ldb[q]; a.p[q].ldc = ldc[q];
     a.p[q].M = (int)M[q]; a.p[q].N = (int)N[q]; a.p[q].K = (int)K[q];
-    a.p[q].tiles_n = (int)cdiv(N[q], 32);
-    tiles += (int)(cdiv(M[q], 16 * mt) * cdiv(N[q], 32));
+    const int tile_n = mt == 8 ? 64 : 32, tile_m = mt == 8 ? 64 : 16 * mt;
+    a.p[q].tiles_n = (int)cdiv(N[q], tile_n);
+    tiles += (int)(cdiv(M[q], tile_m) * cdiv(N[q], tile_n));
     a.p[q].tile_end = tiles;
   }
   a.count = (int)count;
@@ -847,7 +970,9 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
   a.rs_src = rowsum_src; a.rs_dst = rowsum_dst; a.rs_rows = (int)rowsum_rows; a.rs_cols = (int)rowsum_cols;
   const int extra = rowsum_src ? (int)cdiv(rowsum_cols, 256) : 0;
   a.rs_blocks = extra;
-  if (mt == 4)
+  if (mt == 8)
+    hipLaunchKernelGGL(gemm_tn_small_wide_kernel, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
+  else if (mt == 4)
     hipLaunchKernelGGL(gemm_tn_small_kernel, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(gemm_tn_small_mt_kernel<3>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
