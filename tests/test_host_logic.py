@@ -84,3 +84,18 @@ def test_head_dropout_fusion_rule(monkeypatch):
     assert not ops.head_dropout_fusable(h[:, :, ::2], w, 0.5, None, "none", 1)
     monkeypatch.setenv("SLU_FUSE_HEAD_DROPOUT", "0")
     assert not ops.head_dropout_fusable(h, w, 0.5, None, "none", 1)
+
+
+def test_committed_profile_tables_cover_the_default_dominant_kernel():
+    """bench.py turns roofline.frac_isolated into frac_in_loop / traffic with profiles/inloop_kernel_us.json and
+    profiles/pmc_traffic.json: both must carry the dominant kernel of the default command under the name bench.py's
+    kernel table gives it (the split scheme is part of the name)."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "inloop_kernel_us.json")) as f:
+        inloop = json.load(f)
+    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    name = "gru_bf_fwd_kernel<128,2>"
+    assert inloop[name]["avg_us"] > 0 and os.path.exists(os.path.join(ROOT, inloop[name]["source"]))
+    assert 0.9 <= pmc[name]["traffic_over_algorithmic"] <= 1.5
+    assert os.path.exists(os.path.join(ROOT, pmc[name]["source"]))
