@@ -353,7 +353,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             pool = st.pool if st.pool in (1, 2) else 1
             tm = si == len(pm._cnn_stages) - 1
             conv_frozen = not any(q.requires_grad for q in conv.parameters())
-            ns = models.contraction_nsplit(True) if conv_frozen else (1 if ops.bf16_mode() else 0)
+            ns = models.guarded_frozen_nsplit(model) if conv_frozen else (1 if ops.bf16_mode() else 0)
             if ns and ops.wconv_bf16_supported(C, stride, pool, k, ns):
                 ms = _timed_graph(lambda: ops.wconv_fwd_bf16(x, w, bias, B, L, C, stride, st.do_abs, pool, st.slope, tm, ns), stream)
                 name, mult, peak = "wconv_bf_fwd_kernel<%d>" % ns, MFMA_PRODUCTS[ns], PEAK_BF16_MFMA_TFLOPS
@@ -371,7 +371,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             H, D, I = gru.hidden_size, 2 if gru.bidirectional else 1, gru.input_size
             T = L
             is_frozen = not any(q.requires_grad for q in gru.parameters())
-            ns = models.contraction_nsplit(is_frozen)
+            ns = models.guarded_frozen_nsplit(model) if is_frozen else models.contraction_nsplit(False)
             if not ops.split_path_supported(H, D):
                 ns = 0
             w_ih, b_ih = gru._stacked_ih()
@@ -484,11 +484,11 @@ def dtype_label():
     if models.contraction_nsplit(False) == 1:
         return ("bf16 (operands of every forward contraction - convolutions, input projections, recurrences - and of the "
                 "data-gradient contractions on bf16 MFMA; fp32 accumulation, gate math, weight gradients, master weights, Adam)")
-    if models.contraction_nsplit(True) == 2:
+    if models.guarded_frozen_nsplit() == 2:
         return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
                 "operands split into 2 fp16 terms (22-bit significand), 3 fp16 MFMA products, fp32 accumulation - "
                 "fp32-class: same deviation from float64 as an fp32 fmaf chain, parity <= 1e-4)")
-    if models.contraction_nsplit(True) == 3:
+    if models.guarded_frozen_nsplit() == 3:
         return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
                 "operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation - fp32-class, parity <= 1e-4)")
     return "f32"

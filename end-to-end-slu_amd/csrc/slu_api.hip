@@ -205,3 +205,42 @@ extern "C" int slu_scale_multi(float* const* ptrs, const int64_t* numel, int64_t
   SLU_CHECK_LAUNCH("scale_multi_kernel");
   return SLU_OK;
 }
+
+// ---- range words of up to MULTI_MAX fp32 tensors in ONE launch: words[k] = max(words[k], bit pattern of max |x| over
+// tensor k) — integer maximum of the sign-stripped IEEE patterns, so NaN / infinity report above every finite value.  The
+// host-side guard of the f16x2 split scheme checks a model's frozen weights with it once per weight version
+// (slu_hip/guard.py): a tensor whose largest entry leaves fp16's comfortable range sends the frozen stages to bf16x3. ----
+namespace slu {
+struct AbsmaxArgs { const float* ptr[MULTI_MAX]; long long numel[MULTI_MAX]; int n; unsigned* words; };
+
+__global__ void __launch_bounds__(256)
+absmax_multi_kernel(const AbsmaxArgs a) {
+  const int k = blockIdx.y;
+  if (k >= a.n) return;
+  const float* __restrict__ p = a.ptr[k];
+  unsigned mx = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.numel[k]; i += (long long)gridDim.x * 256)
+    mx = max(mx, __float_as_uint(p[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(a.words + k, mx);
+}
+}  // namespace slu
+
+extern "C" int slu_absmax_multi(const float* const* ptrs, const int64_t* numel, int64_t count, uint32_t* words, void* stream) {
+  SLU_REQUIRE(ptrs && numel && words && count >= 1 && count <= slu::MULTI_MAX, "slu_absmax_multi: 1..%d tensors", slu::MULTI_MAX);
+  slu::AbsmaxArgs a;
+  long long most = 0;
+  for (int k = 0; k < (int)count; ++k) {
+    SLU_REQUIRE(ptrs[k] && numel[k] > 0, "slu_absmax_multi: bad tensor %d", k);
+    a.ptr[k] = ptrs[k]; a.numel[k] = numel[k];
+    if (numel[k] > most) most = numel[k];
+  }
+  a.n = (int)count; a.words = words;
+  long long bx = (most + 4095) / 4096;
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(slu::absmax_multi_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("absmax_multi_kernel");
+  return SLU_OK;
+}

@@ -1,20 +1,27 @@
-// Split-precision persistent GRU recurrence (forward only, no saved gates) for FROZEN layers:
+// Split-precision persistent GRU recurrence (forward) for FROZEN layers and for the bf16 forward of trainable ones:
 // torch.nn.GRU semantics (models.py:232/:262: h0 = 0, gates [r; z; n], optional reverse direction), the
-// hidden x hidden contraction on v_mfma_f32_16x16x32_bf16 with W_hh and h_{t-1} each split into NS bf16
-// 16-bit terms (slu_bf16.h): NS = 3 (bf16x3) keeps six products (fp32-class result at 6/16 of the fp32-MFMA cycles),
-// NS = 2 (f16x2: two fp16 terms, v_mfma_f32_16x16x32_f16) three products (fp32-class at 3/16), NS = 1 is plain bf16
-// (BASELINE configs[4]).
+// hidden x hidden contraction on v_mfma_f32_16x16x32_{f16,bf16} with W_hh and h_{t-1} each split into NS 16-bit
+// terms (slu_bf16.h): NS = 3 (bf16x3) keeps six products (fp32-class result at 6/16 of the fp32-MFMA cycles),
+// NS = 2 (f16x2: two fp16 terms) three products (fp32-class at 3/16), NS = 1 is plain bf16 (BASELINE configs[4]).
 //
-// Geometry = gru_seq_fwd_kernel's: grid (16-sequence tile) x (direction), H/16 waves, wave w owns hidden
-// units [16w, 16w+16) of all three gates, so each lane ends up with r, z, n of the same (sequence, unit) and
-// the gate math is fused in registers.
-//   * the wave's W_hh slice — 3 gates x H/32 k-chunks x NS planes of 8 bf16 per lane — is split once at
-//     kernel start and stays RESIDENT in VGPRs (144 registers for H = 128, NS = 3) for all T steps;
-//   * h_{t-1} lives in LDS as NS bf16 planes (double buffered, 16-byte slots XOR-swizzled by the row: the
-//     ds_read_b128 fragments and the 2-byte stores are conflict-free), in fp32 in the owning lane for the blend;
-//   * per step and wave 3 x H/32 x (6 | 1) MFMAs of 16 cycles on six accumulator chains:
-//     72 x 16 = 1152 cycles per wave, 2304 per SIMD (two waves) for SIXTEEN sequences, against 1536 cycles for
-//     FOUR sequences on the fp32 4x4x1 kernel: 2.7x the sequences per CU-cycle.
+// Geometry: grid (16-sequence tile) x (direction), H/16 waves, wave w owns hidden units [16w, 16w+16) of all three
+// gates; its W_hh slice — 3 gates x H/32 k-chunks x NS planes of eight 16-bit terms per lane (96 VGPRs for H = 128 on
+// f16x2) — is split once at kernel start and stays RESIDENT for all T steps; h_{t-1} lives in LDS as NS planes
+// (double buffered, 16-byte slots XOR-swizzled by the row), in fp32 in the owning lane for the blend.
+//
+// gru_bf_fwd_kernel (round 4) computes the TRANSPOSED product per step — A = the wave's W_hh slice (rows = hidden
+// units), B = h_{t-1}^T (columns = sequences) — so that the MFMA's C layout hands a lane FOUR CONSECUTIVE hidden units of
+// ONE sequence (round 3: one unit of four sequences).  Same registers, same LDS reads, same products in the same order
+// (bit-identical results), but everything around the MFMAs shrinks: gx arrives as three 16-byte loads per lane and step
+// (were twelve 4-byte loads), the output leaves as one 16-byte store (were four), the split h goes to LDS as one 8-byte
+// store per plane (were four 2-byte stores), and the step's barrier waits for the LDS only (lds_barrier: the round-3
+// __syncthreads also drained the global stores of the step).  A lane's four units are exactly one Philox block of the
+// layer's dropout mask and the two frames of an average-pooling window arrive at the same lane on consecutive steps, so
+// the Dropout + Downsample(avg, 2) that follow the layer (models.py:246-251, 26-46) are applied HERE (EPI 1 / 2): the lane
+// keeps the masked h of a window's first frame and writes the pooled value — as the next frozen layer's 16-bit planes or
+// as fp32 — when the second one arrives.  The fp32 (T, B, D*H) output, its re-read and the dropout_pool launch are gone.
+// The keep bits come from slu_dropout_bits (one bit per element, drawn with the element -> counter map of
+// dropout_pool_fwd4_kernel: the fused and the two-launch paths produce identical bits).
 #include "slu_bf16.h"
 #include <stdlib.h>
 
@@ -27,16 +34,46 @@ __device__ __forceinline__ float bf_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-#ifdef SLU_GRU_PROBE
-#define SLU_BDBG(bit) (p.dbg & (bit))
-#else
-#define SLU_BDBG(bit) 0
-#endif
+// Workgroup barrier that orders LDS traffic only: the step's global loads (next step's gx, prefetched) and stores (this
+// step's output) stay in flight across it.  __syncthreads() = workgroup fence + s_barrier waits for vmcnt(0) as well,
+// i.e. for the write acknowledgement of the stores issued a few instructions earlier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+
+// MODE.FP_DENORM[7:6] (f16 / f64 denormals) = 0: v_cvt_pk_f16_f32 then returns ZERO for every result below fp16's smallest
+// normal — the "hi = 0, lo carries the value" rule of the f16x2 split (slu_bf16.h) without a compare + select per element.
+// f32 denormal handling (bits [5:4]) is untouched; the kernel has no other f16 / f64 arithmetic.
+__device__ __forceinline__ void f16_denorm_flush() { __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0); }
+// Four fp32 -> fp16 conversions with fp16 denormals PRESERVED, from inside a kernel that runs under f16_denorm_flush():
+// one asm block (mode switch, conversions, mode switch back), so that no scheduling pass can move a conversion across the
+// switch.  Used for the lo terms of the plane output, whose format (slu_bf16.h) is shared with kernels that run in the
+// default mode and keep a denormal lo.
+__device__ __forceinline__ void cvt4_f16_keep_denorm(const float (&x)[4], unsigned short (&h)[4]) {
+  unsigned r0, r1, r2, r3;
+  asm volatile(
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3\n\ts_nop 1\n\t"
+      "v_cvt_f16_f32 %0, %4\n\tv_cvt_f16_f32 %1, %5\n\tv_cvt_f16_f32 %2, %6\n\tv_cvt_f16_f32 %3, %7\n\t"
+      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0\n\ts_nop 1"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+  h[0] = (unsigned short)r0; h[1] = (unsigned short)r1; h[2] = (unsigned short)r2; h[3] = (unsigned short)r3;
+}
+
+// f16x2 terms of two values under f16_denorm_flush(): (hi0 | hi1 << 16), (lo0 | lo1 << 16).  hi = one packed conversion;
+// lo = fp16(2048 (x - hi)) with 2048 (x - hi) = fma(hi, -2048, 2048 x) exact (both products are exact, the difference of x and
+// its 11-bit rounding is representable): the compiler folds the widening of hi into v_fma_mix_f32.
+__device__ __forceinline__ void split_f16x2_pair_flush(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f16x2v h = __builtin_convertvector(f32x2{x0, x1}, f16x2v);
+  const float l0 = __builtin_fmaf((float)h[0], -F16X2_LO_SCALE, x0 * F16X2_LO_SCALE);
+  const float l1 = __builtin_fmaf((float)h[1], -F16X2_LO_SCALE, x1 * F16X2_LO_SCALE);
+  const f16x2v l = __builtin_convertvector(f32x2{l0, l1}, f16x2v);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
 
 struct GruBfParams {
-#ifdef SLU_GRU_PROBE
-  int dbg;                // ablation mask of the probe build (tools/gru_probe.py): never compiled into the product
-#endif
   const float* gx;        // (T, B, D*3H); unused by the fused-input kernels
   // fused input projection (KI > 0: K <= 32 KI input channels): x as NS planes of (T*B) x (32 KI) 16-bit terms
   // (plane stride x_plane elements), W_ih packed by gemm_bf_pack_kernel for N = D*3H columns, b_ih (D*3H)
@@ -44,23 +81,364 @@ struct GruBfParams {
   const uint4* wih; const float* b_ih;
   const float* w_hh[2];   // (3H, H) fp32
   const float* b_hh[2];   // (3H)
-  float* out;             // (T, B, D*H)
-  float* reserve;         // null, or the saved gates in gru_seq_bwd_kernel's layout [D][T][NBT][NW][5][64][4]
+  float* out;             // EPI 0: (T, B, D*H); EPI 2: the pooled (ceil(T/2), B, D*H)
+  float* reserve;         // gru_bf_fwd_rs_kernel only: the saved gates in gru_seq_bwd_kernel's layout [D][T][NBT][NW][5][64][4]
+  unsigned short* planes; long long plane;   // EPI 1: NS planes of (ceil(T/2) * B) x (D*H) 16-bit terms
+  const unsigned* keep;   // EPI > 0: keep bits (T, B, D*H/32), bit c % 32 of word c / 32 = element (t, b, c); null: no dropout
+  float keep_scale;       // 1 / (1 - p)
   int T, B, D;
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// EPI: 0 = fp32 output of every step; 1 = Dropout + avg-pool(2, ceil) -> NS planes; 2 = the same -> fp32.
 // KI > 0: the input projection x_t W_ih^T + b_ih is computed HERE instead of being read as gx — for layers whose input has
 // at most 32 KI channels (the first GRU layer: K = 60) the wave's W_ih slice fits beside W_hh (3 gates x KI chunks x NS
-// planes = 48 registers for KI = 2 on f16x2; the registers that prefetched gx are free), the A fragments of x_t are read
-// straight from the previous stage's planes (one 16-byte load per chunk and plane, a step ahead), and the extra MFMAs do
-// not depend on h_{t-1}.  Saves the projection GEMM and the fp32 gx round trip (T*B*D*3H*8 bytes) of that layer.
-template <int H, int NS, int KI>
+// planes = 48 registers for KI = 2 on f16x2), the fragments of x_t are read straight from the previous stage's planes (one
+// 16-byte load per chunk and plane, a step ahead), and the extra MFMAs do not depend on h_{t-1}.  Saves the projection
+// GEMM and the fp32 gx round trip (T*B*D*3H*8 bytes) of that layer.
+// VAR (scheduling experiments, bit-identical results): bit 0 = gate-outer MFMA order (all of r's products first, then z's,
+// then n's: the r / z gate math can issue under the remaining MFMAs; needs all h fragments in registers), bit 1 / bit 2 =
+// static s_setprio for the first / second half of the waves (the two waves of a SIMD are w and w + NW/2: a priority gap
+// skews them, so that one's gate math runs under the other's MFMAs).
+// bit 3 = "lean" gate arithmetic (fp32-class like the rest, but NOT the same roundings): the MFMA chains start from
+// b_hh (+ gx for r and z) instead of zero — the bias additions leave the dependent tail of the step —, the blend is
+// n + z (h - n), and the split of h uses split_f16x2_pair_flush (NS = 2).
+template <int H, int NS, int KI, int EPI, int VAR>
 __global__ void __launch_bounds__(H * 4)
 gru_bf_fwd_kernel(const GruBfParams p) {
   constexpr int NW = H / 16;          // waves
   constexpr int KC = H / 32;          // 32-wide k-chunks
   constexpr int ROWB = H * 2;         // bytes per LDS row (one sequence, one plane)
   constexpr int SLOTS = H / 8;        // 16-byte slots per row
+  constexpr bool GO = (VAR & 1) != 0;
+  constexpr bool LEAN = (VAR & 8) != 0;
+  constexpr bool BIAS_LDS = KI > 0;   // the fused kernel keeps its 24 bias values in LDS (register budget)
+  typedef Split<NS> SP;
+  __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][NS][16 * ROWB];
+  __shared__ __attribute__((aligned(16))) float bias_s[BIAS_LDS ? 2 : 1][BIAS_LDS ? 3 * H : 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kg = lane >> 4;      // i: sequence of the tile (MFMA column), kg: k slice / unit quad
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 16;
+  const int u0 = w * 16 + kg * 4;               // first of this lane's four hidden units
+  const int T = p.T, B = p.B, D = p.D;
+  const int seq = b0 + i;
+  const bool valid = seq < B;
+  const int seqc = valid ? seq : B - 1;         // rows past B repeat the last sequence and are never stored
+
+  if constexpr (LEAN && NS == 2) f16_denorm_flush();
+  if constexpr ((VAR & 2) != 0) { if (w < NW / 2) __builtin_amdgcn_s_setprio(2); }
+  if constexpr ((VAR & 4) != 0) { if (w >= NW / 2) __builtin_amdgcn_s_setprio(2); }
+
+  // resident W_hh fragments (MFMA A operand, row = unit 16w + i): wb[g][c][pl] = 8 terms of
+  // W_hh[g*H + 16w + i][c*32 + kg*8 .. +7], plane pl
+  uint4 wb[3][KC][NS];
+  {
+    const float* __restrict__ W = p.w_hh[dir];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float* src = W + (size_t)(g * H + w * 16 + i) * H + c * 32 + kg * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned short s[8][NS];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split_terms<NS>(v[e], s[e]);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+          uint4 o;
+          o.x = s[0][pl] | ((unsigned)s[1][pl] << 16); o.y = s[2][pl] | ((unsigned)s[3][pl] << 16);
+          o.z = s[4][pl] | ((unsigned)s[5][pl] << 16); o.w = s[6][pl] | ((unsigned)s[7][pl] << 16);
+          wb[g][c][pl] = o;
+        }
+      }
+  }
+  // biases of this lane's four units: registers, or (fused kernel) LDS rows re-read every step
+  float bh[3][4];
+  if constexpr (BIAS_LDS) {
+    for (int x = tid; x < 3 * H; x += H * 4) {
+      bias_s[0][x] = p.b_hh[dir][x];
+      bias_s[1][x] = p.b_ih[(size_t)dir * 3 * H + x];
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float4 v = *reinterpret_cast<const float4*>(p.b_hh[dir] + g * H + u0);
+      bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
+    }
+  }
+  // fused input projection: the wave's W_ih fragments (tile dir * 3H/16 + g * H/16 + w of the packed matrix)
+  constexpr int KIA = KI > 0 ? KI : 1;
+  uint4 wi[3][KIA][NS];
+  if constexpr (KI > 0) {
+    const int NTI = p.D * 3 * NW;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < KI; ++c)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          wi[g][c][pl] = p.wih[(size_t)pl * KI * NTI * 64 + ((size_t)c * NTI + dir * 3 * NW + g * NW + w) * 64 + lane];
+  }
+  // x_t W_ih^T + b_ih for this lane's (sequence, four units) from the fragments of x_t: the accumulation order
+  // of gemm_bf_panel_kernel (k-chunks outside, products inside), i.e. the gx the GEMM would write
+  auto xproj = [&](const uint4 (&xa)[KIA][NS], float (&o)[3][4]) {
+    f32x4 ax[SP::NACC][3];
+#pragma unroll
+    for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) ax[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KIA; ++c)
+#pragma unroll
+      for (int q = 0; q < SP::NPAIR; ++q)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+          ax[SP::ACC(q)][g] = mfma_split<NS>(wi[g][c][SP::PB(q)], xa[c][SP::PA(q)], ax[SP::ACC(q)][g]);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const f32x4 v = split_result<NS>(ax[0][g], ax[SP::NACC - 1][g]);
+      const float4 bi = *reinterpret_cast<const float4*>(&bias_s[BIAS_LDS ? 1 : 0][BIAS_LDS ? g * H + u0 : 0]);
+      o[g][0] = v[0] + bi.x; o[g][1] = v[1] + bi.y; o[g][2] = v[2] + bi.z; o[g][3] = v[3] + bi.w;
+    }
+  };
+  // fragment of x_t for this lane (MFMA B operand): column = sequence b0 + i (clamped), k slice kg of chunk c, plane pl
+  auto xload = [&](int t_, uint4 (&xa)[KIA][NS]) {
+    const unsigned short* base = p.xp + ((size_t)t_ * B + seqc) * (32 * KIA) + kg * 8;
+#pragma unroll
+    for (int c = 0; c < KIA; ++c)
+#pragma unroll
+      for (int pl = 0; pl < NS; ++pl)
+        xa[c][pl] = *reinterpret_cast<const uint4*>(base + (size_t)pl * p.x_plane + c * 32);
+  };
+
+  for (int x = tid; x < 2 * NS * 16 * ROWB / 4; x += H * 4) reinterpret_cast<unsigned*>(&hbuf[0][0][0])[x] = 0u;   // h0 = 0
+  float hprev[4] = {0.f, 0.f, 0.f, 0.f};
+  // 32-bit offsets inside one time step (B * D * 3H < 2^31 is checked by the launcher)
+  const int g_off = seqc * D * 3 * H + dir * 3 * H + u0;
+  const int o_off = seq * D * H + dir * H + u0;
+  const size_t gx_ts = (size_t)B * D * 3 * H, out_ts = (size_t)B * D * H;
+  // h fragment read (B operand): row i (sequence), slot (c*4 + kg) ^ i;  h store: row i, slot (u0/8) ^ i, 8 bytes at
+  // element u0 % 8 (2-way bank conflicts among a store's 16-lane groups: two of the step's ten LDS instructions)
+  int a_off[KC];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) a_off[c] = i * ROWB + (((c * 4 + kg) ^ i) & (SLOTS - 1)) * 16;
+  const int h_off = i * ROWB + ((((u0 >> 3) ^ i) & (SLOTS - 1)) * 16) + (u0 & 7) * 2;
+  // dropout keep bits of (t, sequence, this lane's four channels)
+  const int kw_off = seqc * ((D * H) >> 5) + ((dir * H + u0) >> 5);
+  const int kw_sh = (dir * H + u0) & 31;
+  const size_t kw_ts = (size_t)B * ((D * H) >> 5);
+  const bool drop = EPI > 0 && p.keep != nullptr;
+
+  float gcur[3][4];
+  unsigned kcur = 0xFu << kw_sh;
+  {
+    const int t0 = dir ? T - 1 : 0;
+    if constexpr (KI > 0) {
+      __syncthreads();                 // bias_s
+      uint4 xa0[KIA][NS];
+      xload(t0, xa0);
+      xproj(xa0, gcur);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(p.gx + (size_t)t0 * gx_ts + g_off + g * H);
+        gcur[g][0] = v.x; gcur[g][1] = v.y; gcur[g][2] = v.z; gcur[g][3] = v.w;
+      }
+    }
+    if (drop) kcur = p.keep[(size_t)t0 * kw_ts + kw_off];
+  }
+  float held[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    const int cur = s & 1;
+    const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
+    float gnext[3][4];
+    uint4 xan[KIA][NS];                                          // fused input: fragments of the NEXT step's x
+    if constexpr (KI > 0) {
+      xload(tn, xan);                                            // in flight during this step; multiplied at its end
+    } else {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(p.gx + (size_t)tn * gx_ts + g_off + g * H);
+        gnext[g][0] = v.x; gnext[g][1] = v.y; gnext[g][2] = v.z; gnext[g][3] = v.w;
+      }
+    }
+    unsigned knext = kcur;
+    if (drop) knext = p.keep[(size_t)tn * kw_ts + kw_off];
+
+    // one accumulator chain per gate (two for f16x2: the 2^11-scaled cross terms); h plane = PA(q), W plane = PB(q)
+    f32x4 accs[SP::NACC][3];
+#pragma unroll
+    for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) accs[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LEAN) {
+      if constexpr (BIAS_LDS) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const float4 v = *reinterpret_cast<const float4*>(&bias_s[0][g * H + u0]);
+          bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        accs[0][0][r] = gcur[0][r] + bh[0][r];
+        accs[0][1][r] = gcur[1][r] + bh[1][r];
+        accs[0][2][r] = bh[2][r];
+      }
+    }
+    if constexpr (GO) {
+      uint4 fa[KC][NS];
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) fa[c][pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+          for (int q = 0; q < SP::NPAIR; ++q)
+            accs[SP::ACC(q)][g] = mfma_split<NS>(wb[g][c][SP::PB(q)], fa[c][SP::PA(q)], accs[SP::ACC(q)][g]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        uint4 fa[NS];
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
+#pragma unroll
+        for (int q = 0; q < SP::NPAIR; ++q)
+#pragma unroll
+          for (int g = 0; g < 3; ++g)
+            accs[SP::ACC(q)][g] = mfma_split<NS>(wb[g][c][SP::PB(q)], fa[SP::PA(q)], accs[SP::ACC(q)][g]);
+      }
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = split_result<NS>(accs[0][g], accs[SP::NACC - 1][g]);
+    if constexpr (BIAS_LDS && !LEAN) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(&bias_s[0][g * H + u0]);
+        bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
+      }
+    }
+
+    float hn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (LEAN) {
+        const float rr = bf_sigmoid(acc[0][r]);
+        const float zz = bf_sigmoid(acc[1][r]);
+        const float nn = bf_tanh(gcur[2][r] + rr * acc[2][r]);
+        hn[r] = nn + zz * (hprev[r] - nn);
+      } else {
+        const float rr = bf_sigmoid(gcur[0][r] + (acc[0][r] + bh[0][r]));
+        const float zz = bf_sigmoid(gcur[1][r] + (acc[1][r] + bh[1][r]));
+        const float qq = acc[2][r] + bh[2][r];
+        const float nn = bf_tanh(gcur[2][r] + rr * qq);
+        hn[r] = (1.0f - zz) * nn + zz * hprev[r];
+      }
+    }
+    // h_t -> LDS as NS planes: four consecutive units = one 8-byte store per plane
+    {
+      unsigned char* __restrict__ hnext = &hbuf[cur ^ 1][0][0];
+      if constexpr (LEAN && NS == 2) {
+        unsigned hi01, lo01, hi23, lo23;
+        split_f16x2_pair_flush(hn[0], hn[1], hi01, lo01);
+        split_f16x2_pair_flush(hn[2], hn[3], hi23, lo23);
+        *reinterpret_cast<uint2*>(hnext + h_off) = make_uint2(hi01, hi23);
+        *reinterpret_cast<uint2*>(hnext + 16 * ROWB + h_off) = make_uint2(lo01, lo23);
+      } else {
+        unsigned short sp[4][NS];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split_terms<NS>(hn[r], sp[r]);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          *reinterpret_cast<uint2*>(hnext + pl * (16 * ROWB) + h_off) =
+              make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));
+      }
+    }
+    if constexpr (EPI == 0) {
+      if (valid) *reinterpret_cast<float4*>(p.out + (size_t)t * out_ts + o_off) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    } else {
+      // Dropout (keep bit ? h * scale : h * 0) and average pooling over frames (2 to, 2 to + 1), in the operation order of
+      // dropout_pool_fwd4_kernel: acc = 0 + v(2 to); acc += v(2 to + 1); acc / n  (n = 1 for the partial last window)
+      float m[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        m[r] = drop ? __fmul_rn(hn[r], ((kcur >> (kw_sh + r)) & 1u) ? p.keep_scale : 0.0f) : hn[r];
+      const bool even = (t & 1) == 0;
+      const bool single = even && t == T - 1;
+      const bool emit = dir ? even : (!even || single);
+      if (!emit) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) held[r] = dir ? m[r] : __fadd_rn(0.0f, m[r]);
+      } else {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float first = dir ? __fadd_rn(0.0f, m[r]) : held[r];      // 0 + v(2 to)
+          const float second = dir ? held[r] : m[r];                       // v(2 to + 1)
+          v[r] = single ? __fadd_rn(0.0f, m[r]) : __fmul_rn(__fadd_rn(first, second), 0.5f);
+        }
+        if (valid) {
+          const size_t o = (size_t)(t >> 1) * out_ts + o_off;
+          if constexpr (EPI == 2) {
+            *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            unsigned short sp[4][NS];
+            if constexpr (LEAN && NS == 2) {
+              // the plane format is shared with dropout_pool_fwd4_kernel, which keeps fp16 denormals in the lo term: hi by
+              // the mode-independent rule of split_f16x2, the four lo conversions outside this kernel's flush mode
+              float lo32[4];
+              unsigned short lo16[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float hi = __builtin_fabsf(v[r]) >= F16_MIN_NORMAL ? (float)(_Float16)v[r] : 0.0f;
+                sp[r][0] = __builtin_bit_cast(unsigned short, (_Float16)hi);
+                lo32[r] = (v[r] - hi) * F16X2_LO_SCALE;
+              }
+              cvt4_f16_keep_denorm(lo32, lo16);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sp[r][NS - 1] = lo16[r];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);
+            }
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+              *reinterpret_cast<uint2*>(p.planes + (size_t)pl * p.plane + o) =
+                  make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));
+          }
+        }
+      }
+    }
+    // the next step's x W_ih^T + b_ih: independent of h (round 3 measured this placement against two interleavings)
+    if constexpr (KI > 0) xproj(xan, gnext);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hprev[r] = hn[r];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gcur[g][r] = gnext[g][r];
+    kcur = knext;
+    lds_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round-3 geometry (A = h: a lane owns one hidden unit of four sequences), kept for the one caller that needs the saved
+// gates in the exact BPTT kernels' lane order: the bf16 forward of TRAINABLE layers (SLU_DTYPE=bf16; reserve != null).
+template <int H, int NS>
+__global__ void __launch_bounds__(H * 4)
+gru_bf_fwd_rs_kernel(const GruBfParams p) {
+  constexpr int NW = H / 16, KC = H / 32, ROWB = H * 2, SLOTS = H / 8;
   typedef Split<NS> SP;
   __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][NS][16 * ROWB];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +449,6 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   const int j = w * 16 + i;           // hidden unit of this lane's outputs
   const int T = p.T, B = p.B, D = p.D;
 
-  // resident W_hh fragments: wb[g][c][pl] = 8 bf16 of W_hh[g*H + j][c*32 + kg*8 .. +7], plane pl
   uint4 wb[3][KC][NS];
   {
     const float* __restrict__ W = p.w_hh[dir];
@@ -95,57 +472,8 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       }
   }
   const float bhr = p.b_hh[dir][j], bhz = p.b_hh[dir][H + j], bhn = p.b_hh[dir][2 * H + j];
-  // fused input projection: the wave's W_ih fragments (tile dir * 3H/16 + g * H/16 + w of the packed matrix) and biases
-  constexpr int KIA = KI > 0 ? KI : 1;
-  uint4 wi[3][KIA][NS];
-  float bir = 0.f, biz = 0.f, bin = 0.f;
-  if constexpr (KI > 0) {
-    const int NTI = p.D * 3 * NW;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int c = 0; c < KI; ++c)
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-          wi[g][c][pl] = p.wih[(size_t)pl * KI * NTI * 64 + ((size_t)c * NTI + dir * 3 * NW + g * NW + w) * 64 + lane];
-    const float* bi = p.b_ih + (size_t)dir * 3 * H + j;
-    bir = bi[0]; biz = bi[H]; bin = bi[2 * H];
-  }
-  // x_t W_ih^T + b_ih for this lane's four (sequence, unit) pairs from the A fragments of x_t: the accumulation order
-  // of gemm_bf_panel_kernel (k-chunks outside, products inside), i.e. bit-identical to the gx the GEMM would write
-  auto xproj = [&](const uint4 (&xa)[KIA][NS], float (&o_r)[4], float (&o_z)[4], float (&o_n)[4]) {
-    f32x4 ax[SP::NACC][3];
-#pragma unroll
-    for (int a = 0; a < SP::NACC; ++a)
-#pragma unroll
-      for (int g = 0; g < 3; ++g) ax[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KIA; ++c)
-#pragma unroll
-      for (int q = 0; q < SP::NPAIR; ++q)
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-          ax[SP::ACC(q)][g] = mfma_split<NS>(xa[c][SP::PA(q)], wi[g][c][SP::PB(q)], ax[SP::ACC(q)][g]);
-    const f32x4 vr = split_result<NS>(ax[0][0], ax[SP::NACC - 1][0]), vz = split_result<NS>(ax[0][1], ax[SP::NACC - 1][1]),
-                vn = split_result<NS>(ax[0][2], ax[SP::NACC - 1][2]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { o_r[r] = vr[r] + bir; o_z[r] = vz[r] + biz; o_n[r] = vn[r] + bin; }
-  };
-  // A fragment of x_t for this lane: row (sequence) b0 + i (clamped), k slice kg of chunk c, plane pl
-  const int xrow = min(b0 + i, p.B - 1);
-  auto xload = [&](int t_, uint4 (&xa)[KIA][NS]) {
-    const unsigned short* base = p.xp + ((size_t)t_ * p.B + xrow) * (32 * KIA) + kg * 8;
-#pragma unroll
-    for (int c = 0; c < KIA; ++c)
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl)
-        xa[c][pl] = *reinterpret_cast<const uint4*>(base + (size_t)pl * p.x_plane + c * 32);
-  };
-
   for (int x = tid; x < 2 * NS * 16 * ROWB / 4; x += H * 4) reinterpret_cast<unsigned*>(&hbuf[0][0][0])[x] = 0u;   // h0 = 0
   float hprev[4] = {0.f, 0.f, 0.f, 0.f};
-  // rows b0 + 4 kg + r of this lane: 32-bit offsets inside one time step (B * D * 3H < 2^31 is checked by the
-  // launcher); rows past B read row 0 and are never stored (oob row offset -1)
   int g_off[4], o_off[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -156,7 +484,6 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   const size_t gx_ts = (size_t)B * D * 3 * H, out_ts = (size_t)B * D * H;
   const float* __restrict__ gxd = p.gx + (size_t)dir * 3 * H + j;
   float* __restrict__ outd = p.out + (size_t)dir * H + j;
-  // A-fragment read: row i (sequence), slot (c*4 + kg) ^ i;  h store: row 4*kg + r, slot (j/8) ^ row, element j%8
   int a_off[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c) a_off[c] = i * ROWB + (((c * 4 + kg) ^ i) & (SLOTS - 1)) * 16;
@@ -166,20 +493,13 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     const int row = 4 * kg + r;
     h_off[r] = row * ROWB + ((((j >> 3) ^ row) & (SLOTS - 1)) * 16) + (j & 7) * 2;
   }
-
   float gr[4], gz[4], gn[4];
   {
     const int t0 = dir ? T - 1 : 0;
-    if constexpr (KI > 0) {
-      uint4 xa0[KIA][NS];
-      xload(t0, xa0);
-      xproj(xa0, gr, gz, gn);
-    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* g = gxd + (size_t)t0 * gx_ts + g_off[r];
-        gr[r] = g[0]; gz[r] = g[H]; gn[r] = g[2 * H];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float* g = gxd + (size_t)t0 * gx_ts + g_off[r];
+      gr[r] = g[0]; gz[r] = g[H]; gn[r] = g[2 * H];
     }
   }
   __syncthreads();
@@ -188,39 +508,27 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     float ngr[4], ngz[4], ngn[4];
-    uint4 xan[KIA][NS];                                          // fused input: A fragments of the NEXT step's x
-    const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
-    if constexpr (KI > 0) {
-      xload(tn, xan);                                            // in flight during this step; multiplied at its end
-    } else if (SLU_BDBG(1)) {
+    const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { ngr[r] = gr[r]; ngz[r] = gz[r]; ngn[r] = gn[r]; }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float* g = gxd + (size_t)tn * gx_ts + g_off[r];
-        ngr[r] = g[0]; ngz[r] = g[H]; ngn[r] = g[2 * H];
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float* g = gxd + (size_t)tn * gx_ts + g_off[r];
+      ngr[r] = g[0]; ngz[r] = g[H]; ngn[r] = g[2 * H];
     }
-    // one accumulator chain per gate (two for f16x2: the 2^11-scaled cross terms): three or six independent
-    // chains per wave, two waves per SIMD
     f32x4 accs[SP::NACC][3];
 #pragma unroll
     for (int a = 0; a < SP::NACC; ++a)
 #pragma unroll
       for (int g = 0; g < 3; ++g) accs[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!SLU_BDBG(16))
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-      uint4 fa[NS];                     // (W_hh takes 144 of the 256 registers: one fragment set at a time)
+      uint4 fa[NS];
 #pragma unroll
       for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
 #pragma unroll
-      for (int q = 0; q < SP::NPAIR; ++q) {
+      for (int q = 0; q < SP::NPAIR; ++q)
 #pragma unroll
         for (int g = 0; g < 3; ++g)
           accs[SP::ACC(q)][g] = mfma_split<NS>(fa[SP::PA(q)], wb[g][c][SP::PB(q)], accs[SP::ACC(q)][g]);
-      }
     }
     f32x4 acc[3];
 #pragma unroll
@@ -229,18 +537,13 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     float hn[4], rr[4], zz[4], nn[4], qq[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (SLU_BDBG(8)) {       // probe: gate math without the transcendentals
-        rr[r] = 0.5f + 0.01f * (gr[r] + (acc[0][r] + bhr)); zz[r] = 0.5f + 0.01f * (gz[r] + (acc[1][r] + bhz));
-        qq[r] = acc[2][r] + bhn; nn[r] = 0.01f * (gn[r] + rr[r] * qq[r]);
-      } else {
       rr[r] = bf_sigmoid(gr[r] + (acc[0][r] + bhr));
       zz[r] = bf_sigmoid(gz[r] + (acc[1][r] + bhz));
       qq[r] = acc[2][r] + bhn;
       nn[r] = bf_tanh(gn[r] + rr[r] * qq[r]);
-      }
       hn[r] = (1.0f - zz[r]) * nn[r] + zz[r] * hprev[r];
     }
-    if (p.reserve) {      // trainable layer (bf16 forward, fp32 BPTT): the gates the exact BPTT kernels read
+    {     // the gates the exact BPTT kernels read
       float4* __restrict__ rs = reinterpret_cast<float4*>(
           p.reserve + ((((size_t)dir * T + t) * gridDim.x + blockIdx.x) * NW + w) * (5 * 256)) + lane;
       rs[0 * 64] = make_float4(rr[0], rr[1], rr[2], rr[3]);
@@ -253,76 +556,148 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       unsigned short sp[NS];
-      if (SLU_BDBG(32)) {      // probe: one rounding instead of the NS-way split
-        sp[0] = f32_to_bf16_rne(hn[r]);
+      split_terms<NS>(hn[r], sp);
 #pragma unroll
-        for (int pl = 1; pl < NS; ++pl) sp[pl] = 0;
-      } else {
-        split_terms<NS>(hn[r], sp);
-      }
-#pragma unroll
-      for (int pl = 0; pl < NS; ++pl)
-        if (!SLU_BDBG(64)) *reinterpret_cast<unsigned short*>(hnext + pl * (16 * ROWB) + h_off[r]) = sp[pl];
-      if (o_off[r] >= 0 && !SLU_BDBG(2)) outd[(size_t)t * out_ts + o_off[r]] = hn[r];
+      for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<unsigned short*>(hnext + pl * (16 * ROWB) + h_off[r]) = sp[pl];
+      if (o_off[r] >= 0) outd[(size_t)t * out_ts + o_off[r]] = hn[r];
     }
-    // the next step's x W_ih^T + b_ih: independent of h.  (Measured alternatives, T = 300 x 1024 sequences, this
-    // placement 511 us: issued before the gate math and interleaved with it by sched_group_barrier hints, one MFMA per six
-    // VALU instructions — 662 us; THIS step's projection at the top of the step, under the h fragments' LDS latency, with
-    // the fragments carried across the barrier — 565 us, 256 VGPRs and 8 spilled.)
-    if constexpr (KI > 0) xproj(xan, ngr, ngz, ngn);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { hprev[r] = hn[r]; gr[r] = ngr[r]; gz[r] = ngz[r]; gn[r] = ngn[r]; }
     __syncthreads();
   }
 }
 
+// scheduling variant of the frozen-layer launches (SLU_GRU_VARIANT, read once): A/B switch for tools/gru_variants.py;
+// the default is what the measurements of DESIGN.md section 7 selected
+static int gru_variant() {
+  const char* e = getenv("SLU_GRU_VARIANT");      // read per launch (a captured graph keeps the variant it was captured with)
+  return e ? atoi(e) & 15 : 0;
+}
+
+template <int H, int NS, int KI, int EPI>
+static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
+  if constexpr (H == 128 && NS == 2) {
+    switch (gru_variant()) {
+      case 1: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 1>), grid, dim3(H * 4), 0, st, p); return;
+      case 2: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 2>), grid, dim3(H * 4), 0, st, p); return;
+      case 3: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 3>), grid, dim3(H * 4), 0, st, p); return;
+      case 4: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 4>), grid, dim3(H * 4), 0, st, p); return;
+      case 5: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 5>), grid, dim3(H * 4), 0, st, p); return;
+      case 8: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 8>), grid, dim3(H * 4), 0, st, p); return;
+      case 9: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 9>), grid, dim3(H * 4), 0, st, p); return;
+      case 10: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 10>), grid, dim3(H * 4), 0, st, p); return;
+      case 12: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 12>), grid, dim3(H * 4), 0, st, p); return;
+      default: break;
+    }
+  }
+  hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 0>), grid, dim3(H * 4), 0, st, p);
+}
+
+template <int H, int EPI>
+static int gru_bf_dispatch(int nsplit, int ki, dim3 grid, hipStream_t st, const GruBfParams& p) {
+  if (ki > 0) {        // fused input projection: f16x2, H = 128 (checked by the caller)
+    if constexpr (H == 128) {
+      if (ki == 1) gru_bf_launch<128, 2, 1, EPI>(grid, st, p); else gru_bf_launch<128, 2, 2, EPI>(grid, st, p);
+    }
+  } else if (nsplit == 3) {
+    gru_bf_launch<H, 3, 0, EPI>(grid, st, p);
+  } else if (nsplit == 2) {
+    gru_bf_launch<H, 2, 0, EPI>(grid, st, p);
+  } else {
+    gru_bf_launch<H, 1, 0, EPI>(grid, st, p);
+  }
+  SLU_CHECK_LAUNCH("gru_bf_fwd_kernel");
+  return SLU_OK;
+}
+
 }  // namespace slu
 
 using namespace slu;
+
+static int gru_bf_common(const char* who, GruBfParams& p, const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
+                         const float* b_hh_fwd, const float* b_hh_rev, const void* x_planes, int64_t x_plane_stride,
+                         int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D,
+                         int nsplit, bool has_reserve) {
+  SLU_REQUIRE((gx || x_planes) && w_hh_fwd && b_hh_fwd, "%s: null pointer", who);
+  const bool fused = x_planes != nullptr;
+  if (fused) {
+    SLU_REQUIRE(!gx && w_ih_packed && b_ih && !has_reserve, "%s: the fused input projection takes x_planes, "
+                "w_ih_packed and b_ih instead of gx, and no reserve (frozen layers only)", who);
+    if (!(nsplit == 2 && H == 128 && K >= 1 && K <= 64))
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: the fused input projection is instantiated for f16x2 (nsplit 2), "
+               "H = 128 and at most 64 input channels (got nsplit %d, H %lld, K %lld)", who, nsplit, (long long)H, (long long)K);
+    SLU_REQUIRE(x_plane_stride >= T * B * (cdiv(K, 32) * 32) && ((uintptr_t)x_planes & 15) == 0 && (x_plane_stride & 7) == 0,
+                "%s: x plane stride / alignment", who);
+  }
+  SLU_REQUIRE(D == 1 || (D == 2 && w_hh_rev && b_hh_rev), "%s: D must be 1 or 2 (with reverse weights)", who);
+  SLU_REQUIRE(T > 0 && B > 0, "%s: non-positive T or B", who);
+  SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "%s: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)", who);
+  if (H != 64 && H != 128)
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: hidden size %lld not instantiated (64, 128)", who, (long long)H);
+  SLU_REQUIRE(cdiv(B, 16) <= 65535 && B * D * 3 * H < (1LL << 31), "%s: B too large", who);
+  SLU_REQUIRE(!gx || ((uintptr_t)gx & 15) == 0, "%s: gx must be 16-byte aligned", who);
+  SLU_REQUIRE(((uintptr_t)b_hh_fwd & 15) == 0 && ((uintptr_t)b_hh_rev & 15) == 0, "%s: biases must be 16-byte aligned", who);
+  p.xp = (const unsigned short*)x_planes; p.x_plane = x_plane_stride; p.wih = (const uint4*)w_ih_packed; p.b_ih = b_ih;
+  p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
+  p.out = nullptr; p.reserve = nullptr; p.planes = nullptr; p.plane = 0; p.keep = nullptr; p.keep_scale = 1.0f;
+  p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  return SLU_OK;
+}
 
 extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
                                     const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
                                     const void* x_planes, int64_t x_plane_stride, int64_t K, const void* w_ih_packed,
                                     const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D, int nsplit,
                                     void* stream) {
-  SLU_REQUIRE((gx || x_planes) && w_hh_fwd && b_hh_fwd && out, "slu_gru_seq_fwd_bf16: null pointer");
-  const bool fused = x_planes != nullptr;
-  if (fused) {
-    SLU_REQUIRE(!gx && w_ih_packed && b_ih && !reserve, "slu_gru_seq_fwd_bf16: the fused input projection takes x_planes, "
-                "w_ih_packed and b_ih instead of gx, and no reserve (frozen layers only)");
-    if (!(nsplit == 2 && H == 128 && K >= 1 && K <= 64))
-      SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_bf16: the fused input projection is instantiated for f16x2 (nsplit 2), "
-               "H = 128 and at most 64 input channels (got nsplit %d, H %lld, K %lld)", nsplit, (long long)H, (long long)K);
-    SLU_REQUIRE(x_plane_stride >= T * B * (cdiv(K, 32) * 32) && ((uintptr_t)x_planes & 15) == 0 && (x_plane_stride & 7) == 0,
-                "slu_gru_seq_fwd_bf16: x plane stride / alignment");
-  }
-  SLU_REQUIRE(D == 1 || (D == 2 && w_hh_rev && b_hh_rev), "slu_gru_seq_fwd_bf16: D must be 1 or 2 (with reverse weights)");
-  SLU_REQUIRE(T > 0 && B > 0, "slu_gru_seq_fwd_bf16: non-positive T or B");
-  SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_gru_seq_fwd_bf16: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
-  if (H != 64 && H != 128)
-    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_bf16: hidden size %lld not instantiated (64, 128)", (long long)H);
-  SLU_REQUIRE(cdiv(B, 16) <= 65535 && B * D * 3 * H < (1LL << 31), "slu_gru_seq_fwd_bf16: B too large");
+  SLU_REQUIRE(out, "slu_gru_seq_fwd_bf16: null pointer");
   GruBfParams p;
-#ifdef SLU_GRU_PROBE
-  { const char* e = getenv("SLU_GRU_DBG"); p.dbg = e ? atoi(e) : 0; }
-#endif
-  p.xp = (const unsigned short*)x_planes; p.x_plane = x_plane_stride; p.wih = (const uint4*)w_ih_packed; p.b_ih = b_ih;
-  p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
-  p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
+  int rc = gru_bf_common("slu_gru_seq_fwd_bf16", p, gx, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, x_planes, x_plane_stride, K,
+                         w_ih_packed, b_ih, T, B, H, D, nsplit, reserve != nullptr);
+  if (rc) return rc;
+  p.out = out; p.reserve = reserve;
   dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
   hipStream_t st = (hipStream_t)stream;
-  if (fused) {
-    if (K <= 32) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2, 1>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2, 2>), grid, dim3(512), 0, st, p);
-  } else if (H == 128) {
-    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 3, 0>), grid, dim3(512), 0, st, p);
-    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 2, 0>), grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((gru_bf_fwd_kernel<128, 1, 0>), grid, dim3(512), 0, st, p);
-  } else {
-    if (nsplit == 3) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 3, 0>), grid, dim3(256), 0, st, p);
-    else if (nsplit == 2) hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 2, 0>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gru_bf_fwd_kernel<64, 1, 0>), grid, dim3(256), 0, st, p);
+  if (reserve) {       // bf16 forward of a trainable layer: the saved gates in the BPTT kernels' lane order
+#define SLU_RS(H_, NS_) hipLaunchKernelGGL((gru_bf_fwd_rs_kernel<H_, NS_>), grid, dim3(H_ * 4), 0, st, p)
+    if (H == 128) { if (nsplit == 3) SLU_RS(128, 3); else if (nsplit == 2) SLU_RS(128, 2); else SLU_RS(128, 1); }
+    else { if (nsplit == 3) SLU_RS(64, 3); else if (nsplit == 2) SLU_RS(64, 2); else SLU_RS(64, 1); }
+#undef SLU_RS
+    SLU_CHECK_LAUNCH("gru_bf_fwd_rs_kernel");
+    return SLU_OK;
   }
-  SLU_CHECK_LAUNCH("gru_bf_fwd_kernel");
-  return SLU_OK;
+  SLU_REQUIRE(((uintptr_t)out & 15) == 0, "slu_gru_seq_fwd_bf16: out must be 16-byte aligned");
+  const int ki = x_planes ? (K <= 32 ? 1 : 2) : 0;
+  return H == 128 ? gru_bf_dispatch<128, 0>(nsplit, ki, grid, st, p) : gru_bf_dispatch<64, 0>(nsplit, ki, grid, st, p);
+}
+
+extern "C" int slu_gru_seq_fwd_pool_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
+                                         const float* b_hh_fwd, const float* b_hh_rev, float* out_pooled,
+                                         void* out_planes, int64_t out_plane_stride, const uint32_t* keep_bits, float p_drop,
+                                         const void* x_planes, int64_t x_plane_stride, int64_t K, const void* w_ih_packed,
+                                         const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D, int nsplit,
+                                         void* stream) {
+  SLU_REQUIRE((out_pooled != nullptr) != (out_planes != nullptr),
+              "slu_gru_seq_fwd_pool_bf16: exactly one of out_pooled and out_planes");
+  SLU_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f && (keep_bits || p_drop == 0.0f),
+              "slu_gru_seq_fwd_pool_bf16: dropout p in [0, 1), with keep_bits when p > 0");
+  GruBfParams p;
+  int rc = gru_bf_common("slu_gru_seq_fwd_pool_bf16", p, gx, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, x_planes,
+                         x_plane_stride, K, w_ih_packed, b_ih, T, B, H, D, nsplit, false);
+  if (rc) return rc;
+  if ((D * H) % 32 != 0)
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_pool_bf16: D * H must be a multiple of 32 (got %lld)", (long long)(D * H));
+  const int64_t T_out = cdiv(T, 2);
+  if (out_planes)
+    SLU_REQUIRE(out_plane_stride >= T_out * B * D * H && ((uintptr_t)out_planes & 7) == 0 && (out_plane_stride & 3) == 0,
+                "slu_gru_seq_fwd_pool_bf16: plane stride / alignment");
+  else
+    SLU_REQUIRE(((uintptr_t)out_pooled & 15) == 0, "slu_gru_seq_fwd_pool_bf16: out_pooled must be 16-byte aligned");
+  p.out = out_pooled; p.planes = (unsigned short*)out_planes; p.plane = out_plane_stride;
+  p.keep = p_drop > 0.0f ? keep_bits : nullptr; p.keep_scale = 1.0f / (1.0f - p_drop);
+  dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
+  hipStream_t st = (hipStream_t)stream;
+  const int ki = x_planes ? (K <= 32 ? 1 : 2) : 0;
+  if (out_planes)
+    return H == 128 ? gru_bf_dispatch<128, 1>(nsplit, ki, grid, st, p) : gru_bf_dispatch<64, 1>(nsplit, ki, grid, st, p);
+  return H == 128 ? gru_bf_dispatch<128, 2>(nsplit, ki, grid, st, p) : gru_bf_dispatch<64, 2>(nsplit, ki, grid, st, p);
 }

@@ -116,7 +116,11 @@ __device__ __forceinline__ float4 keep_scale4(const PoolParams& q, uint64_t off_
   return philox_keep4(q.seed, off, idx, 1.0f - q.p, q.scale);
 }
 
-__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+// (explicitly rounded products and sums: no fma contraction, so that the recurrence epilogue of slu_gru_bf16.hip, which
+// applies the same mask and window to a value it holds in registers, reproduces these results bit for bit for any p)
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) {
+  return make_float4(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z), __fmul_rn(a.w, b.w));
+}
 
 // grid: x over B*C/4 quads, y over output frames.  NS = 0: fp32 output y; NS = 1 / 2 / 3: the output goes straight
 // into the split-precision activation format (NS 16-bit planes of (T_out*B) x C, plane stride `plane` elements)
@@ -142,7 +146,7 @@ dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, uns
     acc = (q.method == 1) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     for (int t = t0; t < t1; ++t) {
       const float4 v = mul4(*reinterpret_cast<const float4*>(x + t * row + col), keep_scale4(q, off, t, b, c));
-      if (q.method == 1) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      if (q.method == 1) { acc.x = __fadd_rn(acc.x, v.x); acc.y = __fadd_rn(acc.y, v.y); acc.z = __fadd_rn(acc.z, v.z); acc.w = __fadd_rn(acc.w, v.w); }
       else { acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w); }
     }
     if (q.method == 1) {
@@ -161,6 +165,39 @@ dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, uns
       *reinterpret_cast<uint2*>(planes + (size_t)pl * plane + to * row + col) =
           make_uint2(h[0][pl] | ((unsigned)h[1][pl] << 16), h[2][pl] | ((unsigned)h[3][pl] << 16));
   }
+}
+
+// Keep bits of a whole (T, B, C) dropout mask, one bit per element: word (t, b, c / 32), bit c % 32 — drawn with exactly
+// the element -> Philox counter map of keep_scale4 (one block per four channels), so that a consumer applying these bits
+// (the recurrence epilogue of slu_gru_bf16.hip) drops the elements dropout_pool_fwd4_kernel drops.  grid: x over B*C/32
+// words, y over frames; eight Philox blocks per thread.  T*B*C/8 bytes: 9.8 MB for the T = 300 layer of a 1024-sequence
+// super-batch, against the 630 MB the fp32 output + re-read of the two-launch path moved.
+__global__ void __launch_bounds__(256)
+dropout_bits_kernel(unsigned* __restrict__ bits, const PoolParams q) {
+  const int W = q.C >> 5;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= (unsigned)q.B * W) return;
+  const int b = e / W, wd = e - b * W;
+  const int t = blockIdx.y;
+  uint64_t off = q.offset + (q.offset_dev ? *q.offset_dev : 0ull);
+  uint64_t idx;
+  if (q.sub_batch > 0) {
+    const int k = b / q.sub_batch, bl = b - k * q.sub_batch;
+    idx = ((uint64_t)t * q.sub_batch + bl) * q.C + wd * 32;
+    off += (uint64_t)k * q.sub_stride;
+  } else {
+    idx = ((uint64_t)t * q.B + b) * q.C + wd * 32;
+  }
+  const float thr = 1.0f - q.p;
+  unsigned word = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t w4[4];
+    philox_block(q.seed, off, (idx >> 2) + k, w4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) word |= (philox_to_uniform(w4[j]) < thr ? 1u : 0u) << (4 * k + j);
+  }
+  bits[((size_t)t * q.B + b) * W + wd] = word;
 }
 
 // grid: x over B*C/4 quads, y over OUTPUT frames; a thread writes dx for every input frame of its window
@@ -315,6 +352,20 @@ extern "C" int slu_dropout_pool_fwd_planes(const float* x, const float* mask, in
   if (nsplit == 3) SLU_DPP(3); else if (nsplit == 2) SLU_DPP(2); else SLU_DPP(1);
 #undef SLU_DPP
   SLU_CHECK_LAUNCH("dropout_pool_fwd4_kernel(planes)");
+  return SLU_OK;
+}
+
+extern "C" int slu_dropout_bits(uint32_t* bits, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                int64_t sub_batch, uint64_t sub_stride, int64_t T, int64_t B, int64_t C, void* stream) {
+  SLU_REQUIRE(bits, "slu_dropout_bits: null pointer");
+  PoolParams q;
+  int rc = pool_fill(q, "slu_dropout_bits", nullptr, 0, 0, p, seed, offset, offset_dev, sub_batch, sub_stride, 1, 1, T, B, C);
+  if (rc) return rc;
+  if (C % 32 != 0 || T > 65535 || B * (C / 32) >= (1LL << 31))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_dropout_bits: needs C %% 32 == 0 (got %lld) and T <= 65535", (long long)C);
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)cdiv(B * (C / 32), 256), (unsigned)T), dim3(256), 0,
+                     (hipStream_t)stream, bits, q);
+  SLU_CHECK_LAUNCH("dropout_bits_kernel");
   return SLU_OK;
 }
 

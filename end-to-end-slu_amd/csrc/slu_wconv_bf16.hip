@@ -38,7 +38,21 @@ struct WconvBfParams {
   int do_abs, pool;
   float slope;
   int nrows;            // LDS rows staged per workgroup
+  unsigned* amax;       // null, or the f16x2 range word of this launch: atomicMax of the bit pattern of |v| over every value
+                        // the launch splits (input window, plane output) — what the host's guard reads (slu_hip.h)
 };
+
+// Range guard of the f16x2 scheme: the largest |v| a launch splits, as its IEEE bit pattern (integer maximum: NaN and
+// infinity compare above every finite value, so one word reports overflow and non-finite inputs alike).
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ void amax_publish(unsigned* word, unsigned mx) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, d, 64));
+  // the word only grows: a (possibly stale) read that already covers this wave's maximum makes the atomic unnecessary —
+  // after the first workgroups of a launch nearly every wave skips it
+  if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(word, mx);
+}
 
 // mode: filters W(c, q') for padded tap index q' = k * c_pad + ci (c_in > 1) or q' = tap (c_in == 1)
 template <int NS>
@@ -94,6 +108,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
     inb = p.in + (size_t)b * p.in_row;
   }
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
+  unsigned amx = 0;                               // f16x2 range guard (NS == 2 with p.amax only)
   const int row0 = SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT;   // this wave's first frame in the tile
   const int nb = SPLITN ? (wave & 1) * CT : 0;                        // ... and its first channel tile
 
@@ -126,6 +141,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
       for (int j = 0; j < U; ++j) {
         if (off[j] < 0) continue;
         unsigned short a[NS], c[NS];
+        if constexpr (NS == 2) amx = max(amx, max(abs_bits(v0[j]), abs_bits(v1[j])));
         split_terms<NS>(v0[j], a);
         split_terms<NS>(v1[j], c);
 #pragma unroll
@@ -213,6 +229,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
           t = p.do_abs ? fabsf(t) : t;
           t = real ? (t > 0.0f ? t : t * p.slope) : 0.0f;
           unsigned short sp[NS];
+          if constexpr (NS == 2) amx = max(amx, abs_bits(t));
           split_terms<NS>(t, sp);
 #pragma unroll
           for (int pl = 0; pl < NS; ++pl)
@@ -255,6 +272,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
       }
     }
   }
+  if constexpr (NS == 2) { if (p.amax) amax_publish(p.amax, amx); }
 }
 
 static inline int bf_nt_for(int64_t c) {
@@ -306,7 +324,8 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
                                   int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t,
                                   int do_abs, int pool, float slope, int64_t out_sb, int64_t out_sl,
                                   void* out_planes, int64_t out_plane_stride,
-                                  void* workspace, size_t workspace_bytes, int packed_valid, int nsplit, void* stream) {
+                                  void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,
+                                  uint32_t* absmax_word, void* stream) {
   SLU_REQUIRE((in || in_table) && weight && (out || out_planes), "slu_wconv_fwd_bf16: null pointer");
   SLU_REQUIRE(!in_table || (table_rows >= 1 && table_rows <= B), "slu_wconv_fwd_bf16: bad table_rows");
   SLU_REQUIRE(B > 0 && l_in > 0 && c_in > 0 && c_out > 0 && k_t > 0 && stride_t > 0, "slu_wconv_fwd_bf16: non-positive size");
@@ -354,6 +373,7 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   p.KC = (int)KC; p.pad = (int)(pad_t * c_in);
   p.l_conv = (int)l_conv; p.l_out = (int)cdiv(l_conv, pool); p.c_out = (int)c_out;
   p.do_abs = do_abs; p.pool = pool; p.slope = slope;
+  p.amax = nsplit == 2 ? absmax_word : nullptr;
   int MT = (B * cdiv(l_conv, 128) >= 256) ? 2 : 1;
   int F = 64 * MT;
   p.nrows = F + (int)cdiv(KC * 32, S) + 1;

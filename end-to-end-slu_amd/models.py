@@ -22,6 +22,7 @@ and `predict_intents` run the fused stage plan.  There is no CPU path: without a
 the forward methods raise.  The seq2seq head (models.py:381-651: Seq2SeqEncoder, Attention, DecoderRNN,
 Seq2SeqDecoder with beam search) is provided on the same kernels (ops.Seq2SeqDecoderFn).
 """
+import contextlib
 import os
 import sys
 
@@ -96,28 +97,78 @@ def _site(module, idx):
     return _SITE_BASE[module] + idx
 
 
+class _FrozenMath:
+    """State of the frozen stages' arithmetic in the default mode (SLU_FROZEN_MATH=auto; slu_hip/guard.py)."""
+    scope = None        # the RangeGuard watching the evaluation that is running now: only then auto = f16x2
+    no_guard = False    # a loop that cannot consult a guard (hipGraph-captured full steps): auto = bf16x3 throughout
+
+
+@contextlib.contextmanager
+def frozen_math_scope(guard):
+    """Run the enclosed frozen-stage evaluation under `guard` (a slu_hip.guard.RangeGuard; None = unguarded)."""
+    prev = _FrozenMath.scope
+    _FrozenMath.scope = guard
+    try:
+        yield guard
+    finally:
+        _FrozenMath.scope = prev
+
+
+@contextlib.contextmanager
+def unguarded_frozen_math():
+    """For loops whose steps are captured whole (frozen stages inside the step's hipGraph, nothing on the host between
+    them and the optimiser): no guard can act there, so the default arithmetic of frozen stages is bf16x3 for the whole
+    loop — eager warm-up steps and captured replays alike."""
+    prev = _FrozenMath.no_guard
+    _FrozenMath.no_guard = True
+    try:
+        yield
+    finally:
+        _FrozenMath.no_guard = prev
+
+
+def frozen_math_mode():
+    mode = os.environ.get("SLU_FROZEN_MATH", "auto")
+    if mode not in _FROZEN_MATH:
+        raise ValueError("SLU_FROZEN_MATH=%r: expected one of %s" % (mode, sorted(_FROZEN_MATH)))
+    return mode
+
+
 def contraction_nsplit(frozen):
-    """Arithmetic of the forward contractions of a GRU layer (input projection and recurrence):
+    """Arithmetic of the forward contractions of a stage (convolution, GRU input projection and recurrence):
       0  exact fp32 MFMA — trainable layers (default);
       2  "f16x2": fp32 values as two fp16 terms (22-bit significand), three fp16 MFMA products, two fp32
-         accumulators (fp32-class: the deviation from float64 equals an fp32 fmaf chain's, csrc/slu_bf16.h; values
-         up to 65504) — FROZEN layers (default);
-      3  "bf16x3": three bf16 terms, six bf16 MFMA products (fp32-class, no range limit) — FROZEN layers with
-         SLU_FROZEN_MATH=bf16x3; SLU_FROZEN_MATH=fp32 switches the split schemes off (0);
+         accumulators (fp32-class: the deviation from float64 equals an fp32 fmaf chain's, csrc/slu_bf16.h) — but fp16's
+         exponent range: operands below 65504.  FROZEN layers in the default mode (SLU_FROZEN_MATH=auto) use it ONLY
+         inside a guarded evaluation (frozen_math_scope: the range words of slu_hip/guard.py are checked before the
+         result is used, a violation re-runs the evaluation on bf16x3), or unguarded with SLU_FROZEN_MATH=f16x2;
+      3  "bf16x3": three bf16 terms, six bf16 MFMA products (fp32-class, fp32's range) — FROZEN layers in the default
+         mode wherever no guard is active, or always with SLU_FROZEN_MATH=bf16x3; SLU_FROZEN_MATH=fp32 switches the split
+         schemes off (0);
       1  plain bf16 operands, fp32 accumulation and gate math — every layer when SLU_DTYPE=bf16
          (BASELINE configs[4]: weights and activations enter every forward contraction and the data-gradient
          contractions as bf16 — ops.bf16_mode; weight gradients, master weights and Adam stay fp32)."""
     if os.environ.get("SLU_DTYPE", "f32") == "bf16":
         return 1
     if frozen:
-        mode = os.environ.get("SLU_FROZEN_MATH", "f16x2")
-        if mode not in _FROZEN_MATH:
-            raise ValueError("SLU_FROZEN_MATH=%r: expected one of %s" % (mode, sorted(_FROZEN_MATH)))
+        mode = frozen_math_mode()
+        if mode == "auto":
+            return 2 if _FrozenMath.scope is not None else 3
         return _FROZEN_MATH[mode]
     return 0
 
 
-_FROZEN_MATH = {"f16x2": 2, "bf16x3": 3, "fp32": 0}
+_FROZEN_MATH = {"auto": None, "f16x2": 2, "bf16x3": 3, "fp32": 0}
+
+
+def guarded_frozen_nsplit(model=None):
+    """The split scheme of frozen stages INSIDE a guarded evaluation (what the look-ahead pipeline and the eager entry
+    points run): the default mode gives f16x2 unless `model` (a PretrainedModel / Model) is pinned to bf16x3 or its
+    weights are out of range; explicit modes as set.  For reports (bench.py) and tests."""
+    if frozen_math_mode() != "auto" or os.environ.get("SLU_DTYPE", "f32") == "bf16":
+        return contraction_nsplit(True)
+    pm = getattr(model, "pretrained_model", model)
+    return 2 if (pm is None or pm.f16x2_allowed()) else 3
 
 
 def _require_device(t):
@@ -571,6 +622,7 @@ class _ConvStage:
 
     def __init__(self, conv, is_sinc, do_abs, pool, act, drop, idx=0):
         self.conv, self.is_sinc, self.do_abs, self.pool, self.drop = conv, is_sinc, do_abs, pool, drop
+        self.idx = idx
         self.drop_name, self.site = "dropout%d" % idx, (_site("cnn", idx) if drop > 0.0 else -1)
         self.slope = 0.2 if act == "leaky_relu" else 0.0
         self.time_major = False       # set on the last CNN stage: its output feeds the RNN stack
@@ -582,13 +634,15 @@ class _ConvStage:
         """What a FROZEN block recomputed per call in round 2: the Sinc filterbank and the filters packed in MFMA
         fragment order.  Kept per (weight version, arithmetic, HIP stream): a look-ahead slot's graph reads its own
         copy, built by that stream's first (eager) call, so no stream ever waits for another one's pack."""
-        key = (nsplit, torch.cuda.current_stream().cuda_stream) + tuple((q.data_ptr(), q._version) for q in self.parameters())
+        key = (nsplit, torch.cuda.current_stream().cuda_stream)
+        version = tuple((q.data_ptr(), q._version) for q in self.parameters())
         caches = self.__dict__.setdefault("_caches", {})
         c = caches.get(key)
-        if c is None:
-            if len(caches) >= 8:                   # weights were reloaded / streams retired: drop the stale entries
-                caches.clear()
-            c = caches[key] = {"filters": None, "pack": {}}
+        if c is None or c["version"] != version:
+            # one entry per (arithmetic, stream); new weights REPLACE that entry only.  (Round 3 cleared the whole table
+            # at eight entries, freeing packs that other streams' captured graphs still read.  A graph captured with the
+            # replaced entry belongs to the old weight version and is dropped by its owner: PrefixSlot.signature.)
+            c = caches[key] = {"version": version, "filters": None, "pack": {}}
         return c
 
     def run(self, h, training, out_planes=False):
@@ -626,8 +680,10 @@ class _ConvStage:
                     B, l_in = x3.shape[0], x3.shape[1]
                 planes = (out_planes and tm and not (self.drop > 0.0 and training)
                           and _ops.wconv_bf16_planes_ok(w.shape[0], pool))
+                scope = _FrozenMath.scope
                 h = _ops.wconv_fwd_bf16(x3, w, bias, B, l_in, c_in, self.conv.stride, do_abs, pool, slope,
-                                        tm, nsplit, planes, pack_cache=cache["pack"])
+                                        tm, nsplit, planes, pack_cache=cache["pack"],
+                                        absmax=scope.word(self.idx) if (scope is not None and nsplit == 2) else None)
                 if planes:
                     return h
             if self.drop > 0.0 and training:
@@ -749,7 +805,81 @@ class PretrainedModel(torch.nn.Module):
     def _stages(self):
         return self._cnn_stages + self._phone_stages + self._word_stages
 
+    # -- default arithmetic of frozen stages: guarded f16x2 (slu_hip/guard.py) -----------------------------------
+    def _frozen_split_tensors(self):
+        """The fp32 tensors the split-precision kernels of the FROZEN stages split: filters and GRU matrices."""
+        out = []
+        for st in self._stages():
+            if any(q.requires_grad for q in st.parameters()):
+                continue
+            if isinstance(st, _ConvStage):
+                out.append(st.conv.filters() if st.is_sinc else st.conv.weight)
+            else:
+                g = st.gru
+                out += [q for n, q in g.named_parameters() if n.startswith("weight")]
+        return out
+
+    def f16x2_allowed(self):
+        """May a guarded evaluation of this model's frozen stages use f16x2?  Default mode, not pinned to bf16x3 by an
+        earlier range violation, frozen weights inside fp16's comfortable range (checked once per weight version: one
+        launch + one read-back, never under capture)."""
+        if frozen_math_mode() != "auto" or _FrozenMath.no_guard or os.environ.get("SLU_DTYPE", "f32") == "bf16":
+            return False
+        if getattr(self, "_f16x2_pin", None) is not None:
+            return False
+        sig = tuple((q.data_ptr(), q._version, q.requires_grad) for q in self.parameters())
+        cached = getattr(self, "_f16x2_weights", None)
+        if cached is None or cached[0] != sig:
+            if torch.cuda.is_current_stream_capturing() or not next(self.parameters()).is_cuda:
+                return False
+            from slu_hip import guard as _guard
+            with torch.no_grad():
+                ok, worst = _guard.weights_in_range(self._frozen_split_tensors())
+            if not ok:
+                print("frozen stages on bf16x3: a frozen weight tensor's largest entry (%.3g) is outside the f16x2 "
+                      "scheme's range [%.3g, %.0f)" % (worst, _guard.WEIGHT_MIN, _guard.F16X2_LIMIT))
+            cached = self._f16x2_weights = (sig, ok)
+        return cached[1]
+
+    def pin_bf16x3(self, why):
+        """A range violation was observed: this model's frozen stages stay on bf16x3 from now on."""
+        if getattr(self, "_f16x2_pin", None) is None:
+            print("frozen stages pinned to bf16x3: %s" % why)
+        self._f16x2_pin = why
+
+    def range_guard(self):
+        from slu_hip import guard as _guard
+        dev = next(self.parameters()).device
+        g = getattr(self, "_range_guard", None)
+        if g is None or g.device != dev:
+            g = self._range_guard = _guard.RangeGuard(dev)
+        return g
+
     def run_stages(self, h, first, last):
+        """Run fused stages [first, last) of the encoder.  In the default arithmetic mode an evaluation that contains
+        FROZEN stages and that nobody else guards (the look-ahead pipeline guards its super-batches itself) runs them on
+        f16x2 under this model's range guard: the range words are read back before the result is returned (one stream
+        synchronisation — these are the eager paths: inference, evaluation, un-captured steps) and a violation repeats
+        the evaluation on bf16x3.  Under hipGraph capture no guard can act: frozen stages then run on bf16x3."""
+        stages = self._stages()
+        if (_FrozenMath.scope is None and not torch.cuda.is_current_stream_capturing()
+                and any(not any(q.requires_grad for q in st.parameters()) for st in stages[first:last])
+                and self.f16x2_allowed()):
+            g = self.range_guard()
+            g.arm()
+            with frozen_math_scope(g):
+                out = self._run_stages(h, first, last)
+            g.collect()
+            torch.cuda.current_stream().synchronize()
+            overflow, quiet, seen = g.verdict()
+            if overflow or quiet:
+                if overflow:
+                    self.pin_bf16x3("a split-precision stage saw |value| = %.3g (limit %.0f)" % (max(seen), 65504.0))
+                out = self._run_stages(h, first, last)          # no scope: bf16x3
+            return out
+        return self._run_stages(h, first, last)
+
+    def _run_stages(self, h, first, last):
         """Run fused stages [first, last) of the encoder (CNN blocks, then phoneme and word RNN
         layers).  Hand-off layouts: (B,T) waveform -> channels-last (B,L,C) between CNN blocks ->
         time-major (T,B,C) from the last CNN block on."""

@@ -30,6 +30,7 @@ SIGNATURES = {
     "slu_multi_max": (c_int, []),
     "slu_copy_multi": (c_int, [vp, vp, vp, c_i64, vp]),
     "slu_scale_multi": (c_int, [vp, vp, c_i64, vp, vp]),
+    "slu_absmax_multi": (c_int, [vp, vp, c_i64, vp, vp]),
     "slu_pool_act_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_i64, c_i64, vp]),
     "slu_pool_act_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_i64, c_i64, vp]),
     "slu_gru_cell_fwd": (c_int, [vp, vp, vp, c_i64, vp, c_i64, vp, vp, vp, c_f32, c_u64, c_u64, vp, c_u64, c_i64, c_i64, vp]),
@@ -67,9 +68,12 @@ SIGNATURES = {
     "slu_gemm_tn_bf16": (c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp, c_sz, vp]),
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
-                                   c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp]),
+                                   c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp, vp]),
     "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int,
                                      vp]),
+    "slu_gru_seq_fwd_pool_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_f32, vp, c_i64, c_i64, vp, vp, c_i64,
+                                          c_i64, c_i64, c_i64, c_int, vp]),
+    "slu_dropout_bits": (c_int, [vp, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_i64, c_i64, c_i64, vp]),
     "slu_comm_version": (c_int, []),
     "slu_comm_unique_id": (c_int, [vp]),
     "slu_comm_init": (c_int, [vp, vp, c_i64, c_i64]),
@@ -100,7 +104,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 5          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

@@ -500,11 +500,12 @@ def wconv_bf16_planes_ok(c_out, pool):
 
 
 def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, time_major, nsplit, out_planes=False,
-                   pack_cache=None, want_route=False):
+                   pack_cache=None, want_route=False, absmax=None):
     """wconv_fwd of a FROZEN block on the split-precision kernels (no route): x contiguous (B, l_in, c_in).
     out_planes: return a SplitAct (time-major rows, bf16 planes) for the next frozen GRU layer instead of fp32.
     pack_cache: a dict of the caller's (one per frozen block and weight version): the packed filters are built by
-    the first call and reused by the following ones (no pack launch per super-batch)."""
+    the first call and reused by the following ones (no pack launch per super-batch).
+    absmax: None, or the device address of this launch's f16x2 range word (slu_hip/guard.py)."""
     L = _lib.load()
     if isinstance(x, RowTable):
         x_ptr, tab, tab_rows = None, x.ptrs.data_ptr(), x.rows
@@ -522,7 +523,8 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
         ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
         _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, None, B, l_in, c_in, c_out,
                                         k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
-                                        planes.stride(0), ws.data_ptr(), wsb, valid, nsplit, _stream()), "slu_wconv_fwd_bf16")
+                                        planes.stride(0), ws.data_ptr(), wsb, valid, nsplit, absmax, _stream()),
+                   "slu_wconv_fwd_bf16")
         return SplitAct(planes, l_out, B, c_out)
     if time_major:
         out = torch.empty(l_out, B, c_out, dtype=torch.float32, device=x.device)
@@ -534,7 +536,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     route = torch.empty(B, l_out, c_out, dtype=torch.uint8, device=x.device) if want_route else None
     _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(route), B, l_in,
                                     c_in, c_out, k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
-                                    valid, nsplit, _stream()), "slu_wconv_fwd_bf16")
+                                    valid, nsplit, absmax, _stream()), "slu_wconv_fwd_bf16")
     return (out, route, l_conv) if want_route else out
 
 
@@ -576,6 +578,48 @@ def dropout_pool_fwd_planes(x, mask, p, seed, offset, method, factor, nsplit, of
     return SplitAct(planes, T_out, B, C)
 
 
+def dropout_bits(T, B, C, p, seed, offset, offset_dev=None, sub_batch=0, device=None):
+    """Keep bits of a (T, B, C) dropout mask, one bit per element (int32 (T, B, C // 32)): the mask dropout_pool_fwd draws
+    for the same (seed, offset, offset_dev, sub_batch) — slu_dropout_bits."""
+    L = _lib.load()
+    bits = torch.empty(T, B, C // 32, dtype=torch.int32, device=device)
+    _lib.check(L.slu_dropout_bits(bits.data_ptr(), float(p), int(seed), int(offset), _ptr(offset_dev), int(sub_batch), 16,
+                                  T, B, C, _stream()), "slu_dropout_bits")
+    return bits
+
+
+def gru_pool_fused_ok(H, D, T, p, mask, method, factor):
+    """Can the recurrence apply the layer's Dropout + Downsample in its epilogue (slu_gru_seq_fwd_pool_bf16)?  Average
+    pooling over two frames with an in-kernel Philox mask (or no dropout): every layer of the reference cfgs.  Injected
+    masks (parity tests) and other pooling modes take the two-launch path.  SLU_FUSE_GRU_POOL=0: off."""
+    return (method == "avg" and factor == 2 and mask is None and (D * H) % 32 == 0 and T <= 65535 and 0.0 <= p < 1.0
+            and os.environ.get("SLU_FUSE_GRU_POOL", "1") != "0")
+
+
+def gru_seq_fwd_pool_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, keep, p, out_planes, fused=None):
+    """Recurrence + Dropout(p; keep = dropout_bits or None) + avg-pool(2) in one launch -> SplitAct (out_planes) or fp32
+    (ceil(T/2), B, D*H).  fused as gru_seq_fwd_bf16."""
+    L = _lib.load()
+    dev = w_hh_f.device
+    T_out = -(-T // 2)
+    if out_planes:
+        planes = torch.empty(nsplit, T_out * B, D * H, dtype=plane_dtype(nsplit), device=dev)
+        oa = (None, planes.data_ptr(), planes.stride(0))
+    else:
+        out = torch.empty(T_out, B, D * H, dtype=torch.float32, device=dev)
+        oa = (out.data_ptr(), None, 0)
+    if fused is not None:
+        xp, K, packed, b_ih = fused
+        assert gx is None and xp.shape == (nsplit, T * B, round_up(K, 32)) and xp.stride(1) == xp.shape[2]
+        xa = (xp.data_ptr(), xp.stride(0), K, packed.data_ptr(), b_ih.data_ptr())
+    else:
+        xa = (None, 0, 0, None, None)
+    _lib.check(L.slu_gru_seq_fwd_pool_bf16(_ptr(gx), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r), *oa,
+                                           _ptr(keep), float(p), *xa, T, B, H, D, nsplit, _stream()),
+               "slu_gru_seq_fwd_pool_bf16")
+    return SplitAct(planes, T_out, B, D * H) if out_planes else out
+
+
 def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p, mask, seed, offset, method, factor,
                      nsplit, out_planes):
     """A FROZEN GRU layer + Dropout + Downsample on the split-precision kernels, outside autograd.
@@ -590,6 +634,17 @@ def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p
         T, B, I = x.shape
         planes = split_bf16(x.view(T * B, I), nsplit)
     packed = packed_ih if packed_ih is not None else gemm_bf16_pack(w_ih, nsplit)
+    if gru_pool_fused_ok(H, D, T, p, mask, method, factor):
+        # Dropout + Downsample(avg, 2) in the recurrence's epilogue: no fp32 (T, B, D*H) output, no pool launch; the mask
+        # is a 1-bit stream drawn by a small Philox launch with dropout_pool_fwd's element -> counter map
+        off, off_dev, sub = offset if isinstance(offset, tuple) else (offset, None, 0)
+        keep = dropout_bits(T, B, D * H, p, seed, off, off_dev, sub, w_hh_f.device) if p > 0.0 else None
+        to_planes = bool(out_planes) and -(-T // factor) <= 65535
+        if gru_fused_input_ok(I, H, D, nsplit):
+            return gru_seq_fwd_pool_bf16(None, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, keep, p, to_planes,
+                                         fused=(planes, I, packed, b_ih))
+        gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
+        return gru_seq_fwd_pool_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, keep, p, to_planes)
     if gru_fused_input_ok(I, H, D, nsplit):
         # the first GRU layer (K = 60): the recurrence computes x W_ih^T + b_ih itself — no projection launch, no gx
         raw, _ = gru_seq_fwd_bf16(None, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, False,

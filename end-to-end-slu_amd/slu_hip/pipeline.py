@@ -113,12 +113,27 @@ class PrefixSlot:
         else:
             self.copy_stream = torch.cuda.Stream(device)
         self.last_done = None      # event: this slot's previous super-batch has finished (its static input is free)
+        # range guard of the f16x2 scheme (slu_hip/guard.py): armed at the start and copied to pinned host memory at the
+        # end of every guarded super-batch (both inside the captured graph); the training loop reads it when it consumes
+        # the slot and re-runs the super-batch on bf16x3 after a violation
+        from . import guard as _guard
+        self.guard = _guard.RangeGuard(device)
 
     def invalidate(self):
         self.graphs = {}
         self.seen = {}
 
-    def run(self, model, xs, n_prefix, step0, use_graph, after=None):
+    def run(self, model, xs, n_prefix, step0, use_graph, after=None, guarded=True):
+        """-> (features, done event, guard or None).  guarded=False: the re-run of a super-batch whose range words
+        reported a violation — no guard scope, so the default arithmetic resolves to bf16x3."""
+        import models as _models
+        pm = getattr(model, "pretrained_model", model)
+        guard = self.guard if (guarded and hasattr(pm, "f16x2_allowed") and pm.f16x2_allowed()) else None
+        with _models.frozen_math_scope(guard):
+            feats, done = self._run(model, xs, n_prefix, step0, use_graph, after, guard)
+        return feats, done, guard
+
+    def _run(self, model, xs, n_prefix, step0, use_graph, after, guard):
         """Enqueue stages [0, n_prefix) for the batches `xs` (equal shapes; consecutive dropout steps
         step0, step0+1, ...) on this slot's stream, after the event `after` (the previous super-batch:
         two super-batches side by side would only delay the one the training step is waiting for).
@@ -136,14 +151,16 @@ class PrefixSlot:
                 self.stream.wait_event(after)
             feats = None
             if use_graph:
-                key = (len(xs), B, T, n_prefix, bool(model.training), self._table_ok(model, xs))
+                import models as _models
+                key = (len(xs), B, T, n_prefix, bool(model.training), _models.contraction_nsplit(True),
+                       self._table_ok(model, xs))
                 entry = self.graphs.get(key)
                 # capture a shape on its second appearance in this slot: a one-off shape (the ragged last
                 # group of an epoch, a short run) is cheaper launched eagerly than captured (~10 ms)
                 self.seen[key] = self.seen.get(key, 0) + 1
                 if (entry is None and key not in self.graphs and self.seen[key] >= 2
                         and len(self.graphs) < self.MAX_GRAPHS):
-                    entry = self._capture(model, xs, n_prefix, step0, key)
+                    entry = self._capture(model, xs, n_prefix, step0, key, guard)
                 if entry is not None:
                     graph, x_static, feats = entry
                     if isinstance(x_static, ops.RowTable):
@@ -157,7 +174,11 @@ class PrefixSlot:
             if feats is None:
                 x_cat = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
                 self._copy_in(x_cat, xs, host, after)
+                if guard is not None:
+                    guard.arm()
                 feats = model.prefix_features(x_cat, n_prefix, step0, sub_batch=B if len(xs) > 1 else 0)
+                if guard is not None:
+                    guard.collect()
             done = torch.cuda.Event()
             done.record(self.stream)
             self.last_done = done
@@ -199,7 +220,7 @@ class PrefixSlot:
                 and all(x.is_cuda and x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
                         and x.data_ptr() % 16 == 0 for x in xs))
 
-    def _capture(self, model, xs, n_prefix, step0, key):
+    def _capture(self, model, xs, n_prefix, step0, key, guard=None):
         B, T = xs[0].shape
         sub = B if len(xs) > 1 else 0
         if key[-1]:
@@ -216,7 +237,11 @@ class PrefixSlot:
             # thread-local capture mode: other threads (e.g. the RCCL watchdog) may keep calling the
             # runtime while this thread captures
             with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+                if guard is not None:
+                    guard.arm()                     # memset node
                 feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)
+                if guard is not None:
+                    guard.collect()                 # device -> pinned host copy node
         except RuntimeError as e:                   # stay eager for this shape
             print("hipGraph capture of the frozen prefix failed (%s); staying eager" % (e,))
             self.graphs[key] = None

@@ -312,8 +312,11 @@ class Trainer:
         # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it) and to
         # the frozen weights' contents (their packed bf16 planes are baked into the graph)
         trainable = _param_signature(self.model)
+        import models as _models
         try:
-            with torch.cuda.stream(main):
+            # frozen stages inside a captured step cannot be guarded (nothing runs on the host between them and the
+            # optimiser): this loop's default arithmetic for them is bf16x3 — warm-up steps and replays alike
+            with torch.cuda.stream(main), _models.unguarded_frozen_math():
                 pm.warm_weight_caches()
                 for batch in loader:
                     ins = [t.to(dev, non_blocking=True) for t in batch]
@@ -458,13 +461,13 @@ class Trainer:
             slot = self._slots[launched % len(self._slots)]
             launched += 1
             steps = [next_rng_step() for _ in group]                        # consecutive by construction
-            feats, done = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
-                                   after=last_done[0])
+            feats, done, guard = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
+                                          after=last_done[0])
             last_done[0] = done
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on
             # whatever the buffer holds by then (batches must stay unchanged until consumed)
-            pending.append((group, feats, done, steps, slot, versions))
+            pending.append((group, feats, done, steps, slot, versions, guard))
             return True
 
         # The consumer's per-step work (metric accumulation in _run) runs with `main` as the current
@@ -475,13 +478,25 @@ class Trainer:
                 for _ in self._slots:
                     launch_next()
                 while pending:
-                    group, feats_cat, done, steps, slot, versions = pending.popleft()
+                    group, feats_cat, done, steps, slot, versions, guard = pending.popleft()
                     for b, v in zip(group, versions):
                         if v is not None and b[0]._version != v:
                             raise RuntimeError(
                                 "a device-resident input batch was modified in place while its look-ahead super-batch was "
                                 "still reading it (the loader recycles device buffers): hand over fresh tensors per batch or "
                                 "host batches, or set SLU_LOOKAHEAD=0")
+                    if guard is not None:
+                        # f16x2 ran under the slot's range guard: read its words BEFORE the features are used (the
+                        # super-batch normally finished while the previous group's steps were running: the wait is short
+                        # and the training stream still has that group's tail to run)
+                        done.synchronize()
+                        overflow, quiet, seen = guard.verdict()
+                        if overflow or quiet:
+                            if overflow:
+                                pm.pin_bf16x3("a split-precision stage of a look-ahead super-batch saw |value| = %.3g "
+                                              "(limit 65504)" % max(seen))
+                            feats_cat, done, _ = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0],
+                                                          use_graph, after=None, guarded=False)
                     B = group[0][0].shape[0]
                     for k, batch in enumerate(group):
                         if k == 0:
@@ -562,10 +577,10 @@ class Trainer:
         means = self._epoch_means(self.epoch_sums[:len(names)].tolist() + [string_acc], num_examples, dev)
         if not all(math.isfinite(float(m)) for m in means[:len(names)]):
             import models
-            if models.contraction_nsplit(True) == 2:
-                warnings.warn("non-finite epoch metrics: the frozen stages run on the f16x2 split scheme, whose operands "
-                              "must stay below 65504 in magnitude (fp16 range) — if the waveforms are not scaled to "
-                              "[-1, 1] set SLU_FROZEN_MATH=bf16x3 (no range limit) or fp32")
+            if models.frozen_math_mode() == "f16x2":
+                warnings.warn("non-finite epoch metrics with SLU_FROZEN_MATH=f16x2 (the UNGUARDED form of the scheme: "
+                              "operands must stay below 65504 in magnitude) — the default mode guards the range and falls "
+                              "back to bf16x3 by itself")
         if seq2seq and not train:
             means[1] = means[1] + means[-1]          # intent_acc += string accuracy (the model's own acc is 0)
         return means[:len(names)]

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 4
+#define SLU_ABI_VERSION 5
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -68,6 +68,12 @@ int slu_stage_inputs(const void* const* src, void* const* dst, const int64_t* ro
 int slu_multi_max(void);
 int slu_copy_multi(const void* const* src, void* const* dst, const int64_t* nbytes, int64_t count, void* stream);
 int slu_scale_multi(float* const* ptrs, const int64_t* numel, int64_t count, const float* scale_dev, void* stream);
+/* Range words (ABI 5): words[k] = max(words[k], IEEE bit pattern of max |x| over tensor k) for up to slu_multi_max() fp32
+ * tensors in one launch — an unsigned integer maximum of the sign-stripped patterns, so NaN / infinity rank above every
+ * finite value.  The guard of the f16x2 split scheme (values must stay below 65504 = pattern 0x477FE000) checks a model's
+ * frozen weights with it once per weight version; the same word format is written by slu_wconv_fwd_bf16(absmax_word).  The
+ * reference needs no counterpart: its fp32 ATen kernels (models.py:108, :200, :232) have fp32's range.                   */
+int slu_absmax_multi(const float* const* ptrs, const int64_t* numel, int64_t count, uint32_t* words, void* stream);
 
 /* -------- Sinc filterbank: models.py:79-106 (SincLayer.forward up to the conv), :7-24 ------- */
 /* filters[n_filt][filt_dim] (float32) from the two float64 parameters, filt_dim odd.            */
@@ -202,14 +208,18 @@ int slu_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, f
  * route (NULL, or as slu_wconv_fwd's, with the fp32 `out`): the block is TRAINABLE and runs its forward on bf16
  * operands (nsplit = 1, BASELINE configs[4]); the backward is slu_wconv_bwd_act / _bwd_weight / _bwd_data as usual.
  * packed_valid != 0: `workspace` still holds the filter pack a previous call built from these very weights (a frozen
- * block: the caller keeps the workspace per weight version) — the pack launch is skipped.                           */
+ * block: the caller keeps the workspace per weight version) — the pack launch is skipped.
+ * absmax_word (ABI 5; NULL or a device uint32, used by nsplit = 2 only): the launch raises it (atomic maximum) to the IEEE
+ * bit pattern of the largest |v| among the values it splits into fp16 pairs — its input window and, with out_planes, its
+ * output.  f16x2 operands must stay below 65504; the caller zeroes the word, reads it back after the launch and re-runs
+ * the stage with nsplit = 3 (bf16x3: fp32's range) when the pattern is >= 0x477FE000 (65504.0f; NaN / inf rank higher).  */
 size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t, int nsplit);
 int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows, const float* weight,
                        const float* bias, float* out, uint8_t* route, int64_t B,
                        int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t, int do_abs,
                        int pool, float slope, int64_t out_sb, int64_t out_sl, void* out_planes,
                        int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,
-                       void* stream);
+                       uint32_t* absmax_word, void* stream);
 /* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
  * W_hh (3 gates x nsplit 16-bit planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
  * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)
@@ -223,6 +233,20 @@ int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_
                          const float* b_hh_rev, float* out, float* reserve, const void* x_planes,
                          int64_t x_plane_stride, int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T,
                          int64_t B, int64_t H, int64_t D, int nsplit, void* stream);
+/* The same recurrence of a FROZEN layer with the layer's Dropout(p) + Downsample("avg", 2) (models.py:246-251 / :276-281,
+ * :26-46) applied in its epilogue (ABI 5): the lane that owns four consecutive hidden units of a sequence keeps the masked
+ * h of a pooling window's first frame in registers and writes the average when the second frame arrives — the fp32
+ * (T, B, D*H) output, its re-read and the slu_dropout_pool_fwd launch disappear.  Exactly one output:
+ *   out_pooled  (ceil(T/2), B, D*H) fp32, or
+ *   out_planes  nsplit 16-bit planes of (ceil(T/2)*B) x (D*H) (plane stride out_plane_stride elements): what
+ *               slu_dropout_pool_fwd_planes writes, read by the next frozen layer's slu_gemm_bf16.
+ * keep_bits (NULL iff p_drop == 0): the mask from slu_dropout_bits, one bit per element.  The result equals
+ * slu_gru_seq_fwd_bf16 + slu_dropout_pool_fwd[_planes](method 1, factor 2) bit for bit.  D*H % 32 == 0.                  */
+int slu_gru_seq_fwd_pool_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
+                              const float* b_hh_rev, float* out_pooled, void* out_planes, int64_t out_plane_stride,
+                              const uint32_t* keep_bits, float p_drop, const void* x_planes, int64_t x_plane_stride,
+                              int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T, int64_t B, int64_t H,
+                              int64_t D, int nsplit, void* stream);
 
 /* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
  *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)
@@ -279,6 +303,12 @@ int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st,
                                 uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t sub_batch,
                                 uint64_t sub_stride, int method, int64_t factor, void* planes,
                                 int64_t plane_stride, int nsplit, int64_t T, int64_t B, int64_t C, void* stream);
+/* The keep bits of a whole (T,B,C) dropout mask (ABI 5): bits[(t*B + b) * C/32 + c/32] bit c%32 = element (t,b,c) is
+ * kept, drawn from the same Philox stream with the same element -> counter map as the two functions above (seed, offset,
+ * offset_dev, sub_batch, sub_stride as there), for consumers that apply the mask themselves (slu_gru_seq_fwd_pool_bf16).
+ * C % 32 == 0, T <= 65535.                                                                                             */
+int slu_dropout_bits(uint32_t* bits, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                     int64_t sub_batch, uint64_t sub_stride, int64_t T, int64_t B, int64_t C, void* stream);
 /* dx (T,B,C) from dy (T_out,B,C); x and y (forward input/output) are needed for method 2 only. */
 int slu_dropout_pool_bwd(const float* dy, const float* x, const float* y, const float* mask,
                          int64_t m_st, int64_t m_sb, float p, uint64_t seed, uint64_t offset,

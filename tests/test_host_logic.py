@@ -40,15 +40,29 @@ def test_lookahead_width_rules(monkeypatch):
 
 def test_arithmetic_mode_switches(monkeypatch):
     """SLU_FROZEN_MATH / SLU_TRAIN_MATH / SLU_DTYPE -> the split scheme of each class of contraction (csrc/slu_bf16.h):
-    frozen stages default to f16x2 (2), trainable GEMMs to exact fp32 (0); bf16 mode (BASELINE configs[4]) overrides both;
-    unknown values are rejected instead of silently running another arithmetic."""
+    frozen stages default to "auto" — f16x2 (2) ONLY inside a guarded evaluation (slu_hip/guard.py), bf16x3 (3: fp32's
+    range) wherever no guard is active —, trainable GEMMs to exact fp32 (0); bf16 mode (BASELINE configs[4]) overrides
+    both; unknown values are rejected instead of silently running another arithmetic."""
     import pytest
     import models
     from slu_hip import ops
     for k in ("SLU_FROZEN_MATH", "SLU_TRAIN_MATH", "SLU_DTYPE"):
         monkeypatch.delenv(k, raising=False)
-    assert models.contraction_nsplit(True) == 2 and models.contraction_nsplit(False) == 0
+    assert models.frozen_math_mode() == "auto"
+    assert models.contraction_nsplit(True) == 3 and models.contraction_nsplit(False) == 0      # no guard: fp32's range
+    with models.frozen_math_scope(object()):                                                   # a guard is watching
+        assert models.contraction_nsplit(True) == 2 and models.contraction_nsplit(False) == 0
+        with models.frozen_math_scope(None):                                                   # e.g. the bf16x3 re-run
+            assert models.contraction_nsplit(True) == 3
+        assert models.contraction_nsplit(True) == 2
+    assert models.contraction_nsplit(True) == 3
+    assert models.guarded_frozen_nsplit() == 2
+    with models.unguarded_frozen_math():
+        assert models._FrozenMath.no_guard
+    assert not models._FrozenMath.no_guard
     assert ops.train_nsplit() == 0 and ops.train_nsplit(True) == 0
+    monkeypatch.setenv("SLU_FROZEN_MATH", "f16x2")             # explicit: unguarded, the caller vouches for the range
+    assert models.contraction_nsplit(True) == 2 and models.guarded_frozen_nsplit() == 2
     monkeypatch.setenv("SLU_FROZEN_MATH", "bf16x3")
     assert models.contraction_nsplit(True) == 3 and models.contraction_nsplit(False) == 0
     monkeypatch.setenv("SLU_FROZEN_MATH", "fp32")
@@ -67,6 +81,37 @@ def test_arithmetic_mode_switches(monkeypatch):
     assert ops.bf16_mode() and ops.train_nsplit() == 1 and ops.train_nsplit(True) == 1
     assert models.contraction_nsplit(True) == 1 and models.contraction_nsplit(False) == 1
     assert ops.plane_dtype(2) == torch.float16 and ops.plane_dtype(3) == ops.plane_dtype(1) == torch.bfloat16
+
+
+def test_range_guard_verdict():
+    """slu_hip/guard.RangeGuard.verdict: the words are IEEE bit patterns of max |v| (integer maximum: NaN / inf rank above
+    every finite value); overflow = any word >= 65504.0f, quiet = a non-zero first-stage input maximum below 2^-8."""
+    import struct
+    from slu_hip import guard
+
+    def bits(x):
+        return struct.unpack("<i", struct.pack("<f", x))[0]
+
+    g = guard.RangeGuard.__new__(guard.RangeGuard)          # no device: fill the host words by hand
+    g.trips = 0
+    g.host = torch.zeros(guard.N_WORDS, dtype=torch.int32)
+    assert g.verdict()[:2] == (False, False)                # silence (all zero): exact in any scheme
+    g.host[0], g.host[1], g.host[2] = bits(0.5), bits(37.0), bits(65503.0)
+    assert g.verdict()[:2] == (False, False)
+    g.host[2] = bits(65504.0)
+    assert g.verdict()[:2] == (True, False)
+    g.host[2] = bits(float("inf"))
+    assert g.verdict()[0] is True
+    g.host[2] = struct.unpack("<i", struct.pack("<I", 0x7FC00000))[0]       # NaN pattern
+    ov, _, seen = g.verdict()
+    assert ov and seen[2] == float("inf")
+    g.host[2] = bits(1.0)
+    g.host[0] = bits(1e-3)
+    assert g.verdict()[:2] == (False, True)                 # very quiet audio: re-run on bf16x3, no pin
+    g.host[0] = bits(3.2e4)                                 # int16-scale audio: fits fp16, the NEXT stage's word decides
+    assert g.verdict()[:2] == (False, False)
+    assert g.trips == 4
+    assert guard.LIMIT_BITS == 0x477FE000
 
 
 def test_head_dropout_fusion_rule(monkeypatch):
