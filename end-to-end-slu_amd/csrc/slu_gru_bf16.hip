@@ -11,8 +11,8 @@
 //
 // gru_bf_fwd_kernel (round 4) computes the TRANSPOSED product per step — A = the wave's W_hh slice (rows = hidden
 // units), B = h_{t-1}^T (columns = sequences) — so that the MFMA's C layout hands a lane FOUR CONSECUTIVE hidden units of
-// ONE sequence (round 3: one unit of four sequences).  Same registers, same LDS reads, same products in the same order
-// (bit-identical results), but everything around the MFMAs shrinks: gx arrives as three 16-byte loads per lane and step
+// ONE sequence (round 3: one unit of four sequences).  Same registers, same LDS reads, same products in the same order,
+// but everything around the MFMAs shrinks: gx arrives as three 16-byte loads per lane and step
 // (were twelve 4-byte loads), the output leaves as one 16-byte store (were four), the split h goes to LDS as one 8-byte
 // store per plane (were four 2-byte stores), and the step's barrier waits for the LDS only (lds_barrier: the round-3
 // __syncthreads also drained the global stores of the step).  A lane's four units are exactly one Philox block of the
@@ -96,13 +96,20 @@ struct GruBfParams {
 // planes = 48 registers for KI = 2 on f16x2), the fragments of x_t are read straight from the previous stage's planes (one
 // 16-byte load per chunk and plane, a step ahead), and the extra MFMAs do not depend on h_{t-1}.  Saves the projection
 // GEMM and the fp32 gx round trip (T*B*D*3H*8 bytes) of that layer.
-// VAR (scheduling experiments, bit-identical results): bit 0 = gate-outer MFMA order (all of r's products first, then z's,
-// then n's: the r / z gate math can issue under the remaining MFMAs; needs all h fragments in registers), bit 1 / bit 2 =
-// static s_setprio for the first / second half of the waves (the two waves of a SIMD are w and w + NW/2: a priority gap
-// skews them, so that one's gate math runs under the other's MFMAs).
-// bit 3 = "lean" gate arithmetic (fp32-class like the rest, but NOT the same roundings): the MFMA chains start from
-// b_hh (+ gx for r and z) instead of zero — the bias additions leave the dependent tail of the step —, the blend is
-// n + z (h - n), and the split of h uses split_f16x2_pair_flush (NS = 2).
+//
+// Order of a step (measured, DESIGN.md section 7: the first version of this kernel issued the next step's loads at the
+// top and the output store after the gate math, and ran 1.66 us per step against round 3's 1.27):
+//   A. the MFMA chains are seeded with this step's gx + b_hh — the step's only use of prefetched VMEM data, placed FIRST:
+//      loads and stores share vmcnt and may complete out of order among themselves, so with both kinds outstanding the
+//      compiler can only wait for vmcnt(0); here everything outstanding was issued a whole step ago and the wait is free
+//      (after the gate math it also waited for the loads issued at the top of the same step);
+//   B. the next step's gx (or x fragments) and keep bits are requested, and the PREVIOUS step's output — kept in
+//      registers over the barrier — is stored;
+//   C. h fragments from LDS, 36 (f16x2) MFMAs, gate math, split h to LDS, barrier (LDS only).
+// Gate arithmetic (fp32-class, not the operation order of round 3): the bias additions ride in the accumulator seed,
+// the blend is n + z (h - n), the f16x2 split of h uses split_f16x2_pair_flush.
+// VAR (scheduling experiments, identical results): bit 0 = gate-outer MFMA order, bit 1 / bit 2 = static s_setprio for the
+// first / second half of the waves (the two waves of a SIMD are w and w + NW/2).
 template <int H, int NS, int KI, int EPI, int VAR>
 __global__ void __launch_bounds__(H * 4)
 gru_bf_fwd_kernel(const GruBfParams p) {
@@ -111,7 +118,6 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   constexpr int ROWB = H * 2;         // bytes per LDS row (one sequence, one plane)
   constexpr int SLOTS = H / 8;        // 16-byte slots per row
   constexpr bool GO = (VAR & 1) != 0;
-  constexpr bool LEAN = (VAR & 8) != 0;
   constexpr bool BIAS_LDS = KI > 0;   // the fused kernel keeps its 24 bias values in LDS (register budget)
   typedef Split<NS> SP;
   __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][NS][16 * ROWB];
@@ -127,7 +133,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   const bool valid = seq < B;
   const int seqc = valid ? seq : B - 1;         // rows past B repeat the last sequence and are never stored
 
-  if constexpr (LEAN && NS == 2) f16_denorm_flush();
+  if constexpr (NS == 2) f16_denorm_flush();
   if constexpr ((VAR & 2) != 0) { if (w < NW / 2) __builtin_amdgcn_s_setprio(2); }
   if constexpr ((VAR & 4) != 0) { if (w >= NW / 2) __builtin_amdgcn_s_setprio(2); }
 
@@ -221,7 +227,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   const int o_off = seq * D * H + dir * H + u0;
   const size_t gx_ts = (size_t)B * D * 3 * H, out_ts = (size_t)B * D * H;
   // h fragment read (B operand): row i (sequence), slot (c*4 + kg) ^ i;  h store: row i, slot (u0/8) ^ i, 8 bytes at
-  // element u0 % 8 (2-way bank conflicts among a store's 16-lane groups: two of the step's ten LDS instructions)
+  // element u0 % 8 (2-way bank conflicts among a store's 16-lane groups: one of the step's nine LDS instructions)
   int a_off[KC];
 #pragma unroll
   for (int c = 0; c < KC; ++c) a_off[c] = i * ROWB + (((c * 4 + kg) ^ i) & (SLOTS - 1)) * 16;
@@ -233,7 +239,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   const bool drop = EPI > 0 && p.keep != nullptr;
 
   float gcur[3][4];
-  unsigned kcur = 0xFu << kw_sh;
+  unsigned kcur = 0;
   {
     const int t0 = dir ? T - 1 : 0;
     if constexpr (KI > 0) {
@@ -251,12 +257,59 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     if (drop) kcur = p.keep[(size_t)t0 * kw_ts + kw_off];
   }
   float held[4] = {0.f, 0.f, 0.f, 0.f};
+  // the output of the previous step, stored at the top of the next one (phase B): EPI 0 re-uses hprev; EPI 2 four pooled
+  // values, EPI 1 their NS planes already packed (two 32-bit words per plane)
+  constexpr int NPEND = EPI == 1 ? 2 * NS : 4;
+  unsigned pend[NPEND];
+#pragma unroll
+  for (int x = 0; x < NPEND; ++x) pend[x] = 0;
+  int pend_t = -1;                     // frame (EPI 0) / pooled frame (EPI > 0) of the pending output, -1 = none
+  auto flush = [&]() {
+    if (pend_t >= 0 && valid) {
+      const size_t o = (size_t)pend_t * out_ts + o_off;
+      if constexpr (EPI == 0) {
+        *reinterpret_cast<float4*>(p.out + o) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
+      } else if constexpr (EPI == 2) {
+        *reinterpret_cast<uint4*>(p.out + o) = make_uint4(pend[0], pend[1], pend[2], pend[3]);
+      } else {
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl)
+          *reinterpret_cast<uint2*>(p.planes + (size_t)pl * p.plane + o) = make_uint2(pend[2 * pl], pend[2 * pl + 1]);
+      }
+    }
+  };
   __syncthreads();
 
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
+
+    // ---- A: seed the accumulator chains with gx + b_hh (r, z) and b_hh (n) ----
+    if constexpr (BIAS_LDS) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(&bias_s[0][g * H + u0]);
+        bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
+      }
+    }
+    f32x4 accs[SP::NACC][3];
+#pragma unroll
+    for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) accs[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      accs[0][0][r] = gcur[0][r] + bh[0][r];
+      accs[0][1][r] = gcur[1][r] + bh[1][r];
+      accs[0][2][r] = bh[2][r];
+      gn[r] = gcur[2][r];
+    }
+    const unsigned kbits = kcur >> kw_sh;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- B: the next step's operands; the previous step's output ----
     float gnext[3][4];
     uint4 xan[KIA][NS];                                          // fused input: fragments of the NEXT step's x
     if constexpr (KI > 0) {
@@ -268,30 +321,12 @@ gru_bf_fwd_kernel(const GruBfParams p) {
         gnext[g][0] = v.x; gnext[g][1] = v.y; gnext[g][2] = v.z; gnext[g][3] = v.w;
       }
     }
-    unsigned knext = kcur;
+    unsigned knext = 0;
     if (drop) knext = p.keep[(size_t)tn * kw_ts + kw_off];
+    flush();
+    __builtin_amdgcn_sched_barrier(0);
 
-    // one accumulator chain per gate (two for f16x2: the 2^11-scaled cross terms); h plane = PA(q), W plane = PB(q)
-    f32x4 accs[SP::NACC][3];
-#pragma unroll
-    for (int a = 0; a < SP::NACC; ++a)
-#pragma unroll
-      for (int g = 0; g < 3; ++g) accs[a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (LEAN) {
-      if constexpr (BIAS_LDS) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const float4 v = *reinterpret_cast<const float4*>(&bias_s[0][g * H + u0]);
-          bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        accs[0][0][r] = gcur[0][r] + bh[0][r];
-        accs[0][1][r] = gcur[1][r] + bh[1][r];
-        accs[0][2][r] = bh[2][r];
-      }
-    }
+    // ---- C: W_hh h_{t-1} (h plane = PA(q), W plane = PB(q)), gates, h_t ----
     if constexpr (GO) {
       uint4 fa[KC][NS];
 #pragma unroll
@@ -321,34 +356,19 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     f32x4 acc[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = split_result<NS>(accs[0][g], accs[SP::NACC - 1][g]);
-    if constexpr (BIAS_LDS && !LEAN) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(&bias_s[0][g * H + u0]);
-        bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
-      }
-    }
 
     float hn[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if constexpr (LEAN) {
-        const float rr = bf_sigmoid(acc[0][r]);
-        const float zz = bf_sigmoid(acc[1][r]);
-        const float nn = bf_tanh(gcur[2][r] + rr * acc[2][r]);
-        hn[r] = nn + zz * (hprev[r] - nn);
-      } else {
-        const float rr = bf_sigmoid(gcur[0][r] + (acc[0][r] + bh[0][r]));
-        const float zz = bf_sigmoid(gcur[1][r] + (acc[1][r] + bh[1][r]));
-        const float qq = acc[2][r] + bh[2][r];
-        const float nn = bf_tanh(gcur[2][r] + rr * qq);
-        hn[r] = (1.0f - zz) * nn + zz * hprev[r];
-      }
+      const float rr = bf_sigmoid(acc[0][r]);
+      const float zz = bf_sigmoid(acc[1][r]);
+      const float nn = bf_tanh(gn[r] + rr * acc[2][r]);
+      hn[r] = nn + zz * (hprev[r] - nn);
     }
     // h_t -> LDS as NS planes: four consecutive units = one 8-byte store per plane
     {
       unsigned char* __restrict__ hnext = &hbuf[cur ^ 1][0][0];
-      if constexpr (LEAN && NS == 2) {
+      if constexpr (NS == 2) {
         unsigned hi01, lo01, hi23, lo23;
         split_f16x2_pair_flush(hn[0], hn[1], hi01, lo01);
         split_f16x2_pair_flush(hn[2], hn[3], hi23, lo23);
@@ -365,17 +385,18 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       }
     }
     if constexpr (EPI == 0) {
-      if (valid) *reinterpret_cast<float4*>(p.out + (size_t)t * out_ts + o_off) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      pend_t = t;                      // hprev (= hn below) is this step's pending output
     } else {
       // Dropout (keep bit ? h * scale : h * 0) and average pooling over frames (2 to, 2 to + 1), in the operation order of
       // dropout_pool_fwd4_kernel: acc = 0 + v(2 to); acc += v(2 to + 1); acc / n  (n = 1 for the partial last window)
       float m[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        m[r] = drop ? __fmul_rn(hn[r], ((kcur >> (kw_sh + r)) & 1u) ? p.keep_scale : 0.0f) : hn[r];
+        m[r] = drop ? __fmul_rn(hn[r], ((kbits >> r) & 1u) ? p.keep_scale : 0.0f) : hn[r];
       const bool even = (t & 1) == 0;
       const bool single = even && t == T - 1;
       const bool emit = dir ? even : (!even || single);
+      pend_t = -1;
       if (!emit) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) held[r] = dir ? m[r] : __fadd_rn(0.0f, m[r]);
@@ -387,34 +408,34 @@ gru_bf_fwd_kernel(const GruBfParams p) {
           const float second = dir ? held[r] : m[r];                       // v(2 to + 1)
           v[r] = single ? __fadd_rn(0.0f, m[r]) : __fmul_rn(__fadd_rn(first, second), 0.5f);
         }
-        if (valid) {
-          const size_t o = (size_t)(t >> 1) * out_ts + o_off;
-          if constexpr (EPI == 2) {
-            *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            unsigned short sp[4][NS];
-            if constexpr (LEAN && NS == 2) {
-              // the plane format is shared with dropout_pool_fwd4_kernel, which keeps fp16 denormals in the lo term: hi by
-              // the mode-independent rule of split_f16x2, the four lo conversions outside this kernel's flush mode
-              float lo32[4];
-              unsigned short lo16[4];
+        pend_t = t >> 1;
+        if constexpr (EPI == 2) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float hi = __builtin_fabsf(v[r]) >= F16_MIN_NORMAL ? (float)(_Float16)v[r] : 0.0f;
-                sp[r][0] = __builtin_bit_cast(unsigned short, (_Float16)hi);
-                lo32[r] = (v[r] - hi) * F16X2_LO_SCALE;
-              }
-              cvt4_f16_keep_denorm(lo32, lo16);
+          for (int r = 0; r < 4; ++r) pend[r] = __float_as_uint(v[r]);
+        } else {
+          unsigned short sp[4][NS];
+          if constexpr (NS == 2) {
+            // the plane format is shared with dropout_pool_fwd4_kernel, which keeps fp16 denormals in the lo term: hi by
+            // the mode-independent rule of split_f16x2, the four lo conversions outside this kernel's flush mode
+            float lo32[4];
+            unsigned short lo16[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) sp[r][NS - 1] = lo16[r];
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);
+            for (int r = 0; r < 4; ++r) {
+              const float hi = __builtin_fabsf(v[r]) >= F16_MIN_NORMAL ? (float)(_Float16)v[r] : 0.0f;
+              sp[r][0] = __builtin_bit_cast(unsigned short, (_Float16)hi);
+              lo32[r] = (v[r] - hi) * F16X2_LO_SCALE;
             }
+            cvt4_f16_keep_denorm(lo32, lo16);
 #pragma unroll
-            for (int pl = 0; pl < NS; ++pl)
-              *reinterpret_cast<uint2*>(p.planes + (size_t)pl * p.plane + o) =
-                  make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));
+            for (int r = 0; r < 4; ++r) sp[r][NS - 1] = lo16[r];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);
+          }
+#pragma unroll
+          for (int pl = 0; pl < NS; ++pl) {
+            pend[2 * pl] = sp[0][pl] | ((unsigned)sp[1][pl] << 16);
+            pend[2 * pl + 1] = sp[2][pl] | ((unsigned)sp[3][pl] << 16);
           }
         }
       }
@@ -430,6 +451,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     kcur = knext;
     lds_barrier();
   }
+  flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -571,7 +593,7 @@ gru_bf_fwd_rs_kernel(const GruBfParams p) {
 // the default is what the measurements of DESIGN.md section 7 selected
 static int gru_variant() {
   const char* e = getenv("SLU_GRU_VARIANT");      // read per launch (a captured graph keeps the variant it was captured with)
-  return e ? atoi(e) & 15 : 0;
+  return e ? atoi(e) & 7 : 0;
 }
 
 template <int H, int NS, int KI, int EPI>
@@ -583,10 +605,6 @@ static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
       case 3: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 3>), grid, dim3(H * 4), 0, st, p); return;
       case 4: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 4>), grid, dim3(H * 4), 0, st, p); return;
       case 5: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 5>), grid, dim3(H * 4), 0, st, p); return;
-      case 8: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 8>), grid, dim3(H * 4), 0, st, p); return;
-      case 9: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 9>), grid, dim3(H * 4), 0, st, p); return;
-      case 10: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 10>), grid, dim3(H * 4), 0, st, p); return;
-      case 12: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 12>), grid, dim3(H * 4), 0, st, p); return;
       default: break;
     }
   }

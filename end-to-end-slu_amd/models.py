@@ -1130,7 +1130,7 @@ class Model(torch.nn.Module):
                     # the Dropout in front of the classifier is drawn inside the head kernels (same Philox stream, same
                     # bits as the stand-alone launch; two launches fewer per step) where ops.head_dropout_fusable allows
                     p, mask, seed, offset = _dropout_args(st.drop_name, st.site, st.p, self.training)
-                    if _ops.head_dropout_fusable(h, self.intent_layers[-2].weight, p, mask, st.method, st.factor):
+                    if _ops.head_dropout_fusable(self.intent_layers[-2].weight, p, mask, st.method, st.factor):
                         off, off_dev, sub = offset if isinstance(offset, tuple) else (offset, None, 0)
                         if sub == 0:
                             drop = (p, seed, off, off_dev)

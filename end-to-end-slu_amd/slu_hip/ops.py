@@ -849,11 +849,18 @@ def cls_maxpool_ce_fwd(h, weight, bias, y, values_per_slot, want_grad, epoch_sum
     return loss_acc, logits, pred, argmax_t, d_logits
 
 
-def head_dropout_fusable(h, weight, p, mask, method, factor):
+def head_dropout_fusable(weight, p, mask, method, factor, h=None):
     """The Dropout between the last intent GRU layer and the classifier can be drawn inside the head kernels: Philox
-    masks (no injected mask tensor), no Downsample, four-channel alignment."""
-    return (p > 0.0 and mask is None and factor == 1 and h.shape[-1] % 4 == 0 and h.is_contiguous()
-            and h.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and os.environ.get("SLU_FUSE_HEAD_DROPOUT", "1") != "0")
+    masks (no injected mask tensor), no Downsample, four-channel alignment OF WHAT THE HEAD READS — the classifier's
+    in_features (= the last GRU layer's D * H; the layer's output is a fresh contiguous tensor).  The decision is taken
+    before that layer runs, so it must not look at the layer's INPUT (round 3 did: an encoder width of 256 in front of a
+    unidirectional 50-unit intent layer passed the gate and the head kernel then refused the 50-channel rows).
+    h: optionally the head's actual input, checked as well."""
+    ok = (p > 0.0 and mask is None and factor == 1 and weight.dim() == 2 and weight.shape[1] % 4 == 0
+          and weight.data_ptr() % 16 == 0 and os.environ.get("SLU_FUSE_HEAD_DROPOUT", "1") != "0")
+    if ok and h is not None:
+        ok = h.shape[-1] == weight.shape[1] and h.is_contiguous() and h.data_ptr() % 16 == 0
+    return ok
 
 
 # ------------------------------------------------------------------------------------------------

@@ -34,11 +34,17 @@ def _full_cfg(tmp_path, **kw):
     return cfg
 
 
-def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps):
+def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps, math=None):
+    """math: SLU_FROZEN_MATH for this run (None = the default "auto": guarded f16x2 where a guard can act, bf16x3 where
+    none can)."""
     import models
     import training
     monkeypatch.setenv("SLU_LOOKAHEAD", lookahead)
     monkeypatch.setenv("SLU_GRAPHS", graphs)
+    if math is None:
+        monkeypatch.delenv("SLU_FROZEN_MATH", raising=False)
+    else:
+        monkeypatch.setenv("SLU_FROZEN_MATH", math)
     torch.manual_seed(2)
     model = models.Model(cfg)
     models.set_dropout_seed(1234)
@@ -81,12 +87,16 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     assert ref_tr.graph_stats() == {"step_graphs": 0, "prefix_graphs": 0, "capture_failures": 0}
     assert len(set(ref_losses)) == n_steps                      # dropout and the optimiser really moved
 
-    # sequential steps, each captured as a hipGraph (what --workload unfreeze_all / SLU_LOOKAHEAD=0 run)
+    # sequential steps, each captured as a hipGraph (what --workload unfreeze_all / SLU_LOOKAHEAD=0 run).  The frozen stages
+    # sit INSIDE the captured step there, where no range guard can act between them and the optimiser, so the default
+    # arithmetic of that loop is bf16x3 (slu_hip/guard.py): its reference is the eager loop on bf16x3
+    b3_tr, b3_losses, b3_sd = _run_training(cfg, loader, monkeypatch, "0", "0", n_steps, math="bf16x3")
     tr, losses, sd = _run_training(cfg, loader, monkeypatch, "0", "1", n_steps)
     assert tr.graph_stats() == {"step_graphs": 1, "prefix_graphs": 0, "capture_failures": 0}
-    assert losses == ref_losses
-    for k, v in ref_sd.items():
+    assert losses == b3_losses
+    for k, v in b3_sd.items():
         assert torch.equal(v, sd[k]), k
+    assert max(abs(a - b) for a, b in zip(b3_losses, ref_losses)) < 2e-5      # the two fp32-class schemes agree
 
     # the bench.py default: automatic look-ahead width (16 batches = 1024 sequences) + graphs
     tr, losses, sd = _run_training(cfg, loader, monkeypatch, "auto", "1", n_steps)
@@ -100,8 +110,11 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     assert all(max(slot.seen.values()) >= 3 for slot in tr._slots)
     from slu_hip import ops as _ops
     import models
-    if models.contraction_nsplit(True):      # the split-precision first stage reads the batches in place (row-pointer table)
+    if models.guarded_frozen_nsplit(tr.model):      # the split-precision first stage reads the batches in place (row-pointer table)
         assert all(isinstance(g[1], _ops.RowTable) for slot in tr._slots for g in slot.graphs.values() if g is not None)
+    # the default mode ran f16x2 under the slots' range guards, and nothing tripped them
+    assert models.guarded_frozen_nsplit(tr.model) == 2 and getattr(tr.model.pretrained_model, "_f16x2_pin", None) is None
+    assert all(slot.guard.trips == 0 for slot in tr._slots)
     assert losses == ref_losses
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k

@@ -423,8 +423,8 @@ def test_intent_head_with_fused_dropout_equals_separate_dropout_launches(ops, T,
         assert torch.equal(lb, la) and torch.equal(ab, aa) and torch.equal(lgb, lga) and torch.equal(pb, pa)
         assert torch.equal(hb.grad, dh_a)
         assert torch.equal(Wb.grad, Wa.grad) and torch.equal(bb.grad, ba.grad)
-    assert not ops.head_dropout_fusable(h[:, :, :C - 1], W, p, None, "none", 1)
-    assert not ops.head_dropout_fusable(h, W, p, torch.ones(1), "none", 1) and not ops.head_dropout_fusable(h, W, p, None, "avg", 2)
+    assert not ops.head_dropout_fusable(W[:, :C - 1], p, None, "none", 1) and not ops.head_dropout_fusable(W, p, None, "none", 1, h[:, :, :C - 1])
+    assert not ops.head_dropout_fusable(W, p, torch.ones(1), "none", 1) and not ops.head_dropout_fusable(W, p, None, "avg", 2)
 
 
 # ---------------------------------------------------------------------------------------------

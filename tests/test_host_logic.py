@@ -116,19 +116,23 @@ def test_range_guard_verdict():
 
 def test_head_dropout_fusion_rule(monkeypatch):
     """The Dropout in front of the classifier moves into the head kernels only for Philox masks (no injected mask
-    tensor), no Downsample, four-channel alignment; SLU_FUSE_HEAD_DROPOUT=0 switches it off."""
+    tensor), no Downsample, four-channel alignment of the CLASSIFIER's input width (the decision is taken before the last
+    GRU layer runs: it must not depend on that layer's input); SLU_FUSE_HEAD_DROPOUT=0 switches it off."""
     from slu_hip import ops
     monkeypatch.delenv("SLU_FUSE_HEAD_DROPOUT", raising=False)
     h, w = torch.zeros(19, 4, 256), torch.zeros(31, 256)
-    assert ops.head_dropout_fusable(h, w, 0.5, None, "none", 1)
-    assert ops.head_dropout_fusable(h, w, 0.5, None, "avg", 1)               # factor 1: the Downsample is the identity
-    assert not ops.head_dropout_fusable(h, w, 0.0, None, "none", 1)           # eval / p = 0: nothing to fuse
-    assert not ops.head_dropout_fusable(h, w, 0.5, torch.ones(1), "none", 1)  # the oracle's masks are injected
-    assert not ops.head_dropout_fusable(h, w, 0.5, None, "max", 2)
-    assert not ops.head_dropout_fusable(torch.zeros(19, 4, 30), torch.zeros(31, 30), 0.5, None, "none", 1)
-    assert not ops.head_dropout_fusable(h[:, :, ::2], w, 0.5, None, "none", 1)
+    assert ops.head_dropout_fusable(w, 0.5, None, "none", 1) and ops.head_dropout_fusable(w, 0.5, None, "none", 1, h)
+    assert ops.head_dropout_fusable(w, 0.5, None, "avg", 1)               # factor 1: the Downsample is the identity
+    assert not ops.head_dropout_fusable(w, 0.0, None, "none", 1)           # eval / p = 0: nothing to fuse
+    assert not ops.head_dropout_fusable(w, 0.5, torch.ones(1), "none", 1)  # the oracle's masks are injected
+    assert not ops.head_dropout_fusable(w, 0.5, None, "max", 2)
+    assert not ops.head_dropout_fusable(torch.zeros(31, 30), 0.5, None, "none", 1)
+    # round-3 advisor finding: a 256-wide encoder in front of a unidirectional 50-unit intent layer — the classifier reads
+    # 50-channel rows, whatever the width of the GRU's input
+    assert not ops.head_dropout_fusable(torch.zeros(24, 50), 0.5, None, "none", 1)
+    assert not ops.head_dropout_fusable(w, 0.5, None, "none", 1, h[:, :, ::2])
     monkeypatch.setenv("SLU_FUSE_HEAD_DROPOUT", "0")
-    assert not ops.head_dropout_fusable(h, w, 0.5, None, "none", 1)
+    assert not ops.head_dropout_fusable(w, 0.5, None, "none", 1)
 
 
 def test_committed_profile_tables_cover_the_default_dominant_kernel():

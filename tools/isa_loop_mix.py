@@ -16,7 +16,7 @@ def analyze(txt, sym):
             labels[mm.group(1)] = i
     best = None
     for i, l in enumerate(lines):
-        mm = re.match(r"^s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        mm = re.match(r"^s_c?branch\w* (\.LBB\d+_\d+)", l)
         if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
             span = (labels[mm.group(1)], i)
             if best is None or span[1] - span[0] > best[1] - best[0]:
@@ -47,7 +47,31 @@ def analyze(txt, sym):
     return len(loop), dict(sorted(cnt.items()))
 
 
+def loop_lines(txt, sym):
+    """The loop's instructions in order (for reading the schedule: --dump)."""
+    start = txt.index("\n" + sym + ":")
+    end = txt.index("s_endpgm", start)
+    lines = [l.strip() for l in txt[start:end].split("\n")]
+    labels = {re.match(r"^(\.LBB\d+_\d+):", l).group(1): i for i, l in enumerate(lines) if re.match(r"^(\.LBB\d+_\d+):", l)}
+    best = None
+    for i, l in enumerate(lines):
+        mm = re.match(r"^s_c?branch\w* (\.LBB\d+_\d+)", l)
+        if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+            span = (labels[mm.group(1)], i)
+            if best is None or span[1] - span[0] > best[1] - best[0]:
+                best = span
+    return [l for l in lines[best[0]:best[1] + 1] if l and not l.startswith((".", ";"))]
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--dump":
+        txt = open(sys.argv[2]).read()
+        syms = re.findall(r"^(_Z\w+):", txt, re.M)
+        for s_ in syms:
+            if sys.argv[3] in s_:
+                print("\n".join(loop_lines(txt, s_)))
+                break
+        sys.exit(0)
     txt = open(sys.argv[1]).read()
     syms = re.findall(r"^(_Z\w+):", txt, re.M)
     for pat in sys.argv[2:]:
