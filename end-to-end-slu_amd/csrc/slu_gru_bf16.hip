@@ -46,21 +46,6 @@ typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 // normal — the "hi = 0, lo carries the value" rule of the f16x2 split (slu_bf16.h) without a compare + select per element.
 // f32 denormal handling (bits [5:4]) is untouched; the kernel has no other f16 / f64 arithmetic.
 __device__ __forceinline__ void f16_denorm_flush() { __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0); }
-// Four fp32 -> fp16 conversions with fp16 denormals PRESERVED, from inside a kernel that runs under f16_denorm_flush():
-// one asm block (mode switch, conversions, mode switch back), so that no scheduling pass can move a conversion across the
-// switch.  Used for the lo terms of the plane output, whose format (slu_bf16.h) is shared with kernels that run in the
-// default mode and keep a denormal lo.
-__device__ __forceinline__ void cvt4_f16_keep_denorm(const float (&x)[4], unsigned short (&h)[4]) {
-  unsigned r0, r1, r2, r3;
-  asm volatile(
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3\n\ts_nop 1\n\t"
-      "v_cvt_f16_f32 %0, %4\n\tv_cvt_f16_f32 %1, %5\n\tv_cvt_f16_f32 %2, %6\n\tv_cvt_f16_f32 %3, %7\n\t"
-      "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 0\n\ts_nop 1"
-      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
-      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
-  h[0] = (unsigned short)r0; h[1] = (unsigned short)r1; h[2] = (unsigned short)r2; h[3] = (unsigned short)r3;
-}
-
 // f16x2 terms of two values under f16_denorm_flush(): (hi0 | hi1 << 16), (lo0 | lo1 << 16).  hi = one packed conversion;
 // lo = fp16(2048 (x - hi)) with 2048 (x - hi) = fma(hi, -2048, 2048 x) exact (both products are exact, the difference of x and
 // its 11-bit rounding is representable): the compiler folds the widening of hi into v_fma_mix_f32.
@@ -279,6 +264,12 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     }
   };
   __syncthreads();
+  // Nothing may be pending when the loop is entered: the compiler sinks the W_hh split below the barrier above, so
+  // without this wait the bias / first-step loads are still outstanding on the entry path, and the waits it then places
+  // INSIDE the loop for that path (vmcnt(5) / (4) / (3) with the step's own four operations on top) execute on every
+  // iteration — in steady state the last one stalls each step until the load issued at the top of the SAME step has
+  // returned from HBM (measured: 1.73 us per step with it).
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
@@ -413,29 +404,20 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) pend[r] = __float_as_uint(v[r]);
         } else {
-          unsigned short sp[4][NS];
           if constexpr (NS == 2) {
-            // the plane format is shared with dropout_pool_fwd4_kernel, which keeps fp16 denormals in the lo term: hi by
-            // the mode-independent rule of split_f16x2, the four lo conversions outside this kernel's flush mode
-            float lo32[4];
-            unsigned short lo16[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float hi = __builtin_fabsf(v[r]) >= F16_MIN_NORMAL ? (float)(_Float16)v[r] : 0.0f;
-              sp[r][0] = __builtin_bit_cast(unsigned short, (_Float16)hi);
-              lo32[r] = (v[r] - hi) * F16X2_LO_SCALE;
-            }
-            cvt4_f16_keep_denorm(lo32, lo16);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sp[r][NS - 1] = lo16[r];
+            // "round to fp16, flush denormals" (split_f16x2_flush of slu_bf16.h, the rule dropout_pool_fwd4_kernel<2> uses):
+            // in this kernel's flush mode that is two packed conversions per pair
+            split_f16x2_pair_flush(v[0], v[1], pend[0], pend[2]);
+            split_f16x2_pair_flush(v[2], v[3], pend[1], pend[3]);
           } else {
+            unsigned short sp[4][NS];
 #pragma unroll
             for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);
-          }
 #pragma unroll
-          for (int pl = 0; pl < NS; ++pl) {
-            pend[2 * pl] = sp[0][pl] | ((unsigned)sp[1][pl] << 16);
-            pend[2 * pl + 1] = sp[2][pl] | ((unsigned)sp[3][pl] << 16);
+            for (int pl = 0; pl < NS; ++pl) {
+              pend[2 * pl] = sp[0][pl] | ((unsigned)sp[1][pl] << 16);
+              pend[2 * pl + 1] = sp[2][pl] | ((unsigned)sp[3][pl] << 16);
+            }
           }
         }
       }

@@ -159,7 +159,11 @@ dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, uns
   } else {
     constexpr int NP = NS == 0 ? 1 : NS;
     unsigned short h[4][NP];
-    split_terms<NP>(acc.x, h[0]); split_terms<NP>(acc.y, h[1]); split_terms<NP>(acc.z, h[2]); split_terms<NP>(acc.w, h[3]);
+    if constexpr (NS == 2) {      // the flush rule shared with the recurrence's fused epilogue (slu_bf16.h)
+      split_f16x2_flush(acc.x, h[0]); split_f16x2_flush(acc.y, h[1]); split_f16x2_flush(acc.z, h[2]); split_f16x2_flush(acc.w, h[3]);
+    } else {
+      split_terms<NP>(acc.x, h[0]); split_terms<NP>(acc.y, h[1]); split_terms<NP>(acc.z, h[2]); split_terms<NP>(acc.w, h[3]);
+    }
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
       *reinterpret_cast<uint2*>(planes + (size_t)pl * plane + to * row + col) =

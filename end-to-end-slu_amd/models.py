@@ -100,7 +100,6 @@ def _site(module, idx):
 class _FrozenMath:
     """State of the frozen stages' arithmetic in the default mode (SLU_FROZEN_MATH=auto; slu_hip/guard.py)."""
     scope = None        # the RangeGuard watching the evaluation that is running now: only then auto = f16x2
-    no_guard = False    # a loop that cannot consult a guard (hipGraph-captured full steps): auto = bf16x3 throughout
 
 
 @contextlib.contextmanager
@@ -112,19 +111,6 @@ def frozen_math_scope(guard):
         yield guard
     finally:
         _FrozenMath.scope = prev
-
-
-@contextlib.contextmanager
-def unguarded_frozen_math():
-    """For loops whose steps are captured whole (frozen stages inside the step's hipGraph, nothing on the host between
-    them and the optimiser): no guard can act there, so the default arithmetic of frozen stages is bf16x3 for the whole
-    loop — eager warm-up steps and captured replays alike."""
-    prev = _FrozenMath.no_guard
-    _FrozenMath.no_guard = True
-    try:
-        yield
-    finally:
-        _FrozenMath.no_guard = prev
 
 
 def frozen_math_mode():
@@ -823,7 +809,7 @@ class PretrainedModel(torch.nn.Module):
         """May a guarded evaluation of this model's frozen stages use f16x2?  Default mode, not pinned to bf16x3 by an
         earlier range violation, frozen weights inside fp16's comfortable range (checked once per weight version: one
         launch + one read-back, never under capture)."""
-        if frozen_math_mode() != "auto" or _FrozenMath.no_guard or os.environ.get("SLU_DTYPE", "f32") == "bf16":
+        if frozen_math_mode() != "auto" or os.environ.get("SLU_DTYPE", "f32") == "bf16":
             return False
         if getattr(self, "_f16x2_pin", None) is not None:
             return False

@@ -252,6 +252,15 @@ class PrefixSlot:
         return entry
 
 
+class RangeTrip(RuntimeError):
+    """A captured step's range guard reported a violation (slu_hip/guard.py): the forward / backward graph has run on
+    f16x2 operands that left the scheme's range, the optimiser has NOT run — the caller repeats the step."""
+
+    def __init__(self, overflow, seen):
+        super().__init__("f16x2 range guard tripped")
+        self.overflow, self.seen = overflow, seen
+
+
 class StepGraph:
     """One optimisation step captured as two hipGraphs around the gradient all-reduce:
     G1 = forward, loss, backward (+ packing the gradients into the flat bucket under data
@@ -264,9 +273,15 @@ class StepGraph:
     forward(static_inputs, rng_dev) -> (metrics, loss): `metrics` a 1-D device tensor (what the epoch
     statistics accumulate), `loss` the 0-d tensor to back-propagate."""
 
-    def __init__(self, trainer, inputs, forward, stream, forks=False):
+    def __init__(self, trainer, inputs, forward, stream, forks=False, guard=None):
         """forks: keep the backward pass' independent branches (ops._Fork) as parallel graph branches —
-        for steps that have the device to themselves (no look-ahead streams beside them)."""
+        for steps that have the device to themselves (no look-ahead streams beside them).
+        guard: a RangeGuard when the step contains FROZEN stages that run on guarded f16x2 (a step without look-ahead:
+        SLU_LOOKAHEAD=0, or a CNN-block dropout inside the frozen prefix): the guard is armed and collected inside G1, the
+        optimiser always gets a graph of its own, and run() reads the guard between the two — a violation raises RangeTrip
+        before any parameter has moved."""
+        import models as _models
+        self.guard = guard
         dev = next(trainer.model.parameters()).device
         self.trainer = trainer
         self.inputs = [torch.empty(tuple(t.shape), dtype=t.dtype, device=dev) for t in inputs]
@@ -285,18 +300,23 @@ class StepGraph:
         ops._Fork.capture_forks = bool(forks)
         try:
             with torch.cuda.graph(self.g1, stream=stream, capture_error_mode="thread_local"):
-                self.metrics, self.loss = forward(self.inputs, self.rng)
+                if guard is not None:
+                    guard.arm()
+                with _models.frozen_math_scope(guard):
+                    self.metrics, self.loss = forward(self.inputs, self.rng)
                 self.loss.backward(self.one)
+                if guard is not None:
+                    guard.collect()
                 if self.world > 1:
                     bucket.pack()                   # one concatenation kernel per dtype; .grad -> slices
-                elif _one_graph():
+                elif _one_graph() and guard is None:
                     # single process: nothing sits between the backward pass and Adam, so they are ONE graph — a graph
                     # launch costs the stream ~8 us of ramp (SLU_ONE_STEP_GRAPH=0: two graphs as under data parallelism)
                     trainer.optimizer.step()
         finally:
             ops._Fork.capture_forks = False
         self.g2 = None
-        if self.world > 1 or not _one_graph():
+        if self.world > 1 or not _one_graph() or guard is not None:
             self.g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
                 trainer.optimizer.step()
@@ -308,6 +328,11 @@ class StepGraph:
         for dst, src in ops.stage_inputs(list(zip(self.inputs, inputs)), self.rng, step * 16):
             dst.copy_(src, non_blocking=True)
         self.g1.replay()
+        if self.guard is not None:
+            torch.cuda.current_stream().synchronize()
+            overflow, quiet, seen = self.guard.verdict()
+            if overflow or quiet:
+                raise RangeTrip(overflow, seen)
         if self.world > 1:                          # one collective per gradient dtype; the mean's 1/N is
             self.trainer.bucket.allreduce_flats()   # folded into the Adam kernel (HipAdam.grad_div)
         if self.g2 is not None:

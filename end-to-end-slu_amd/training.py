@@ -214,10 +214,14 @@ class Trainer:
                 "prefix_graphs": sum(1 for sl in slots for g in sl.graphs.values() if g is not None),
                 "capture_failures": self.capture_failures + sum(sl.capture_failures for sl in slots)}
 
-    def _graph_step(self, key, inputs, step, forward, stream, forks=False):
+    def _graph_step(self, key, inputs, step, forward, stream, forks=False, guard=None):
         """One optimisation step on `inputs` (device tensors): replay of the hipGraph captured for `key`
-        (captured after three eager steps of that key), else eagerly.  -> metrics (tensor or list)."""
+        (captured after three eager steps of that key), else eagerly.  -> metrics (tensor or list).
+        guard: the step evaluates FROZEN stages on guarded f16x2 (pipeline.StepGraph): a violation repeats the step
+        eagerly — where the model's own guard re-runs the frozen stages on bf16x3 — before the optimiser has run."""
         from slu_hip import pipeline
+        if guard is not None:
+            key = key + ("guarded",)
         sg = self._step_graphs.get(key)
         if sg is not None:
             self._step_graphs[key] = self._step_graphs.pop(key)          # most recently used last
@@ -227,7 +231,7 @@ class Trainer:
             if key not in self._step_graphs and len(self._step_graphs) >= _max_step_graphs():
                 self._step_graphs.pop(next(iter(self._step_graphs)))     # evict the LEAST RECENTLY USED capture
             try:
-                sg = pipeline.StepGraph(self, inputs, forward, stream, forks)
+                sg = pipeline.StepGraph(self, inputs, forward, stream, forks, guard)
                 self._step_graphs[key] = sg
             except RuntimeError as e:                   # keep training eagerly if capture fails
                 print("hipGraph capture of the training step failed (%s); staying eager" % (e,))
@@ -236,7 +240,19 @@ class Trainer:
                 self.capture_failures += 1
         if sg is not None:
             self._last_key = key
-            return sg.run(inputs, step)
+            try:
+                return sg.run(inputs, step)
+            except pipeline.RangeTrip as trip:
+                pm = getattr(self.model, "pretrained_model", self.model)
+                if trip.overflow:
+                    pm.pin_bf16x3("a split-precision stage of a captured step saw |value| = %.3g (limit 65504)"
+                                  % max(trip.seen))
+                self._step_graphs.pop(key, None)
+                self._eager_steps[key] = 0
+                self.bucket.release_grads()
+                metrics, loss = forward(inputs, step)          # eager: run_stages' own guard / pin decides the arithmetic
+                self._step(loss)
+                return metrics
         # only runs of equally-shaped steps are worth a capture (~50 ms, a private activation pool): with ragged
         # batches (real-data loaders without length bucketing) the count restarts at every shape change
         if getattr(self, "_last_key", None) != key and self._eager_steps.get(key, 0) >= 0:
@@ -307,24 +323,33 @@ class Trainer:
         fused = sums is not None and self._fused_sums()
         if hasattr(self.model, "pretrained_model"):
             pm, forward = self.model.pretrained_model, self._slu_forward(0, sums if fused else None)
+            forward_plain = self._slu_forward(0, None)
         else:
             pm, forward = self.model, self._asr_forward
+            forward_plain = forward
         # a captured step is specific to the set of trainable parameters (gradual unfreezing changes it) and to
         # the frozen weights' contents (their packed bf16 planes are baked into the graph)
         trainable = _param_signature(self.model)
-        import models as _models
+        # frozen stages inside a captured step run on guarded f16x2 like everywhere else (same arithmetic as the look-ahead
+        # loop, so the two stay bit-identical): the step is then two graphs with the range check between them, and the
+        # epoch statistics are accumulated after the check instead of inside the head's launch
+        def step_guard():
+            if pm is None or not any(not any(q.requires_grad for q in st.parameters()) for st in pm._stages()):
+                return None
+            return pm.range_guard() if pm.f16x2_allowed() else None
         try:
-            # frozen stages inside a captured step cannot be guarded (nothing runs on the host between them and the
-            # optimiser): this loop's default arithmetic for them is bf16x3 — warm-up steps and replays alike
-            with torch.cuda.stream(main), _models.unguarded_frozen_math():
+            with torch.cuda.stream(main):
                 pm.warm_weight_caches()
                 for batch in loader:
                     ins = [t.to(dev, non_blocking=True) for t in batch]
                     ins[0] = ins[0].float()
-                    key = ("full", asr, trainable, fused) + tuple(tuple(t.shape) for t in ins)
-                    vals = self._graph_step(key, ins, next_rng_step(), forward, main,
-                                            forks=os.environ.get("SLU_GRAPH_FORKS", "1") != "0")
-                    if sums is not None and not fused:
+                    guard = step_guard()
+                    fused_now = fused and guard is None
+                    fwd = forward if (fused_now or not fused) else forward_plain
+                    key = ("full", asr, trainable, fused_now) + tuple(tuple(t.shape) for t in ins)
+                    vals = self._graph_step(key, ins, next_rng_step(), fwd, main,
+                                            forks=os.environ.get("SLU_GRAPH_FORKS", "1") != "0", guard=guard)
+                    if sums is not None and not fused_now:
                         self._accumulate(sums, vals, len(batch[0]))
                     yield vals, len(batch[0])
         finally:

@@ -57,9 +57,6 @@ def test_arithmetic_mode_switches(monkeypatch):
         assert models.contraction_nsplit(True) == 2
     assert models.contraction_nsplit(True) == 3
     assert models.guarded_frozen_nsplit() == 2
-    with models.unguarded_frozen_math():
-        assert models._FrozenMath.no_guard
-    assert not models._FrozenMath.no_guard
     assert ops.train_nsplit() == 0 and ops.train_nsplit(True) == 0
     monkeypatch.setenv("SLU_FROZEN_MATH", "f16x2")             # explicit: unguarded, the caller vouches for the range
     assert models.contraction_nsplit(True) == 2 and models.guarded_frozen_nsplit() == 2
