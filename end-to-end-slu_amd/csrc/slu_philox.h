@@ -9,8 +9,10 @@ namespace slu {
 // Philox4x32-10 (Salmon et al.), counter = (element index / 4, offset), key = seed.
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-  const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-  const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+  // one 32 x 32 -> 64 product each (v_mad_u64_u32) instead of a mul_hi + mul_lo pair: the generator is multiply-bound
+  const uint64_t p0 = (uint64_t)M0 * c[0], p1 = (uint64_t)M1 * c[2];
+  const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+  const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
   const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
   k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
@@ -35,6 +37,17 @@ __device__ __forceinline__ void philox_block(uint64_t seed, uint64_t offset, uin
 }
 
 __device__ __forceinline__ float philox_to_uniform(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// philox_to_uniform(x) < thr as an integer comparison: (x >> 8) is exact in fp32 and so is the scaling by 2^-24, hence
+// u < thr  <=>  (x >> 8) < thr * 2^24  <=>  (x >> 8) < ceil(thr * 2^24) — the SAME keep decisions as philox_keep4, for
+// kernels that only need the bit (dropout_bits_kernel).  Returns n with: keep <=> (x >> 8) < n.
+__device__ __forceinline__ uint32_t philox_keep_threshold(float thr) {
+  const double t = (double)thr * 16777216.0;
+  if (t <= 0.0) return 0u;
+  if (t >= 16777216.0) return 16777216u;
+  const uint32_t f = (uint32_t)t;
+  return ((double)f < t) ? f + 1u : f;
+}
 
 // dropout keep factors (scale or 0) of elements idx .. idx + 3 (idx % 4 == 0) of the stream (seed, offset): element e
 // is kept iff its uniform draw is below thr = 1 - p.  The one formula every kernel that applies or re-derives a mask uses.

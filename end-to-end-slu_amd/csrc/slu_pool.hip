@@ -192,14 +192,14 @@ dropout_bits_kernel(unsigned* __restrict__ bits, const PoolParams q) {
   } else {
     idx = ((uint64_t)t * q.B + b) * q.C + wd * 32;
   }
-  const float thr = 1.0f - q.p;
+  const uint32_t thr = philox_keep_threshold(1.0f - q.p);
   unsigned word = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     uint32_t w4[4];
     philox_block(q.seed, off, (idx >> 2) + k, w4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) word |= (philox_to_uniform(w4[j]) < thr ? 1u : 0u) << (4 * k + j);
+    for (int j = 0; j < 4; ++j) word |= ((w4[j] >> 8) < thr ? 1u : 0u) << (4 * k + j);
   }
   bits[((size_t)t * q.B + b) * W + wd] = word;
 }

@@ -83,15 +83,26 @@ bf_wconv_pack_kernel(const float* __restrict__ w, uint4* __restrict__ wp, int c_
   }
 }
 
-// SPLITN: the four waves form a 2 x 2 grid (frames x channels) instead of 4 x 1: a wave then needs only half of the
-// filter fragments of a k-chunk.  With 4 x 1 every wave fetches ALL NT x NS fragments from L2 — 48 KB per workgroup
-// and chunk for 768 MFMA cycles = the whole 64 B/clk L2 port of the CU; 2 x 2 halves that (the A fragments, read
-// from LDS by two waves each, take the difference: 62 B/clk of the LDS' 128).  NT even only.
-template <int MT, int NT, int NS, bool SPLITN>
+// How the four waves share the (4 MT row tiles) x (NT column tiles) of a workgroup — MAP:
+//   0  4 x 1: a wave owns MT row tiles and ALL column tiles: it fetches all NT x NS filter fragments of a k-chunk from
+//      L2 — for the Sinc layer (NT = 5, f16x2) 40 KB per workgroup and chunk for 480 MFMA cycles = 85 B/clk against the
+//      CU's 64 B/clk L2 port: the round-3 Sinc launch ran at 0.26 of its partition's MFMA peak, L2-port bound;
+//   1  2 x 2 (NT even, MT = 2): frames x channels, a wave needs half of the filter fragments (the A fragments, read
+//      from LDS by two waves each, take the difference);
+//   2  column ownership (NT = 5, MT = 2; round 4): wave w owns column tile w over ALL eight row tiles, and the fifth
+//      column tile is shared by rows — wave w takes its row tiles 2w, 2w + 1.  Same 30 MFMAs per wave and chunk, but
+//      4 filter fragments per wave instead of 10 (16 KB per workgroup and chunk: 34 B/clk), paid with LDS reads
+//      (16 A fragments per wave and chunk instead of 4: 136 B/clk of the LDS' 256).  A wave numbers its row tiles from
+//      2w (local tile m' = global tile (m' + 2w) mod 8), so the two fragments the shared column needs are local 0 and 1.
+template <int MT, int NT, int NS, int MAP>
 __global__ void __launch_bounds__(WB_THREADS, 2)
 wconv_bf_fwd_kernel(const WconvBfParams p) {
-  constexpr int RT = SPLITN ? 2 * MT : MT;        // row (frame) tiles per wave
-  constexpr int CT = SPLITN ? NT / 2 : NT;        // column (channel) tiles per wave
+  constexpr bool SPLITN = MAP == 1;
+  constexpr bool COLS = MAP == 2;
+  static_assert(!COLS || (NT == 5 && MT == 2), "column ownership is written for NT = 5, MT = 2");
+  constexpr int RT = COLS ? 8 : (SPLITN ? 2 * MT : MT);        // row (frame) tiles per wave
+  constexpr int CT = COLS ? 1 : (SPLITN ? NT / 2 : NT);        // column (channel) tiles per wave (+ the shared one: COLS)
+  constexpr int XT = COLS ? 2 : 0;                             // row tiles of the shared column tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned short* lds = reinterpret_cast<unsigned short*>(smem);     // [NS][nrows][Sp]
   constexpr int F = 64 * MT;                      // frames per workgroup
@@ -109,8 +120,10 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   }
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
   unsigned amx = 0;                               // f16x2 range guard (NS == 2 with p.amax only)
-  const int row0 = SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT;   // this wave's first frame in the tile
-  const int nb = SPLITN ? (wave & 1) * CT : 0;                        // ... and its first channel tile
+  const int row0 = COLS ? 0 : (SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT);   // this wave's first frame in the tile
+  const int nb = COLS ? wave : (SPLITN ? (wave & 1) * CT : 0);                     // ... and its first channel tile
+  // global row tile of local row tile m (COLS: rotated by 2 * wave)
+  auto rtile = [&](int m) { return COLS ? ((m + 2 * wave) & 7) : m; };
 
   // ---- stage the window: LDS (row, col) <- global element u0 + row * S_real + col (col < S_real), zero elsewhere;
   //      two adjacent columns per thread and step (one 4-byte LDS store per plane), eight steps' loads in flight ----
@@ -159,27 +172,38 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
     for (int m = 0; m < RT; ++m)
 #pragma unroll
       for (int n = 0; n < CT; ++n) accs[a][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int XTA = XT > 0 ? XT : 1;
+  f32x4 accx[SP::NACC][XTA];                      // COLS: the shared column tile (NT - 1), local row tiles 0 .. XT-1
+#pragma unroll
+  for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+    for (int m = 0; m < XTA; ++m) accx[a][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int i = lane & 15, kg = lane >> 4;
   // tap chunk (kc, kg) starts at padded tap q = kc*32 + kg*8: LDS row offset q / S, column q % S (multiple of 8)
   int qd = (kg * 8) / p.S, qm = kg * 8 - qd * p.S;
   int abase[RT];
 #pragma unroll
-  for (int m = 0; m < RT; ++m) abase[m] = (row0 + m * 16 + i) * p.Sp;
+  for (int m = 0; m < RT; ++m) abase[m] = (row0 + rtile(m) * 16 + i) * p.Sp;
   const uint4* __restrict__ wp = p.wp + (size_t)nb * 64 + lane;
+  const uint4* __restrict__ wpx = p.wp + (size_t)(NT - 1) * 64 + lane;      // COLS: the shared column tile
   const size_t w_plane = (size_t)p.KC * NT * 64;
 
-  uint4 fb[NS][CT], fbn[NS][CT];
+  uint4 fb[NS][CT], fbn[NS][CT], fx[NS], fxn[NS];
 #pragma unroll
-  for (int pl = 0; pl < NS; ++pl)
+  for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
     for (int n = 0; n < CT; ++n) fb[pl][n] = wp[pl * w_plane + (size_t)n * 64];
+    if constexpr (COLS) fx[pl] = wpx[pl * w_plane];
+  }
   for (int kc = 0; kc < p.KC; ++kc) {
     const int kn = min(kc + 1, p.KC - 1);          // unconditional prefetch (the last chunk re-reads itself)
 #pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
+    for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
       for (int n = 0; n < CT; ++n) fbn[pl][n] = wp[pl * w_plane + ((size_t)kn * NT + n) * 64];
+      if constexpr (COLS) fxn[pl] = wpx[pl * w_plane + (size_t)kn * NT * 64];
+    }
     uint4 fa[NS][RT];
     const int aoff = qd * p.Sp + qm;
 #pragma unroll
@@ -194,28 +218,40 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
 #pragma unroll
         for (int n = 0; n < CT; ++n)
           accs[SP::ACC(q)][m][n] = mfma_split<NS>(fa[SP::PA(q)][m], fb[SP::PB(q)][n], accs[SP::ACC(q)][m][n]);
+      if constexpr (COLS) {
+#pragma unroll
+        for (int m = 0; m < XT; ++m)
+          accx[SP::ACC(q)][m] = mfma_split<NS>(fa[SP::PA(q)][m], fx[SP::PB(q)], accx[SP::ACC(q)][m]);
+      }
     }
     qm += 32;
     while (qm >= p.S) { qm -= p.S; ++qd; }
 #pragma unroll
-    for (int pl = 0; pl < NS; ++pl)
+    for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
       for (int n = 0; n < CT; ++n) fb[pl][n] = fbn[pl][n];
+      if constexpr (COLS) fx[pl] = fxn[pl];
+    }
   }
 
-  f32x4 acc[RT][CT];
+  // tiles of this wave: (local row tile m, column slot n < CT) and, COLS, (local row tile m < XT, the shared column)
+  constexpr int NTILE = RT * CT + XT;
+  f32x4 acc[NTILE];
 #pragma unroll
   for (int m = 0; m < RT; ++m)
 #pragma unroll
-    for (int n = 0; n < CT; ++n) acc[m][n] = split_result<NS>(accs[0][m][n], accs[SP::NACC - 1][m][n]);
+    for (int n = 0; n < CT; ++n) acc[m * CT + n] = split_result<NS>(accs[0][m][n], accs[SP::NACC - 1][m][n]);
+#pragma unroll
+  for (int m = 0; m < XT; ++m) acc[RT * CT + m] = split_result<NS>(accx[0][m], accx[SP::NACC - 1][m]);
 
   // ---- epilogue: bias, abs, max-pool over frame pairs, LeakyReLU, strided store (as wconv_fwd_kernel) ----
 #pragma unroll
-  for (int m = 0; m < RT; ++m) {
-    const int fbase = l0 + row0 + m * 16 + 4 * kg;   // multiple of 4
-#pragma unroll
-    for (int n = 0; n < CT; ++n) {
-      const int c = (nb + n) * 16 + i;
+  for (int tile = 0; tile < NTILE; ++tile) {
+    {
+      const bool shared = tile >= RT * CT;                              // COLS: a tile of the shared column
+      const int m = shared ? tile - RT * CT : tile / CT, n = shared ? 0 : tile % CT;
+      const int fbase = l0 + row0 + rtile(m) * 16 + 4 * kg;             // multiple of 4
+      const int c = (shared ? NT - 1 : nb + n) * 16 + i;
       if (p.planes) {
         // straight into the split format (pool == 1 only): columns [c_out, Kp_out) are the zero padding
         if (c >= p.Kp_out) continue;
@@ -225,7 +261,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
         for (int r = 0; r < 4; ++r) {
           const int f = fbase + r;
           if (f >= p.l_conv) continue;
-          float t = acc[m][n][r] + bias;
+          float t = acc[tile][r] + bias;
           t = p.do_abs ? fabsf(t) : t;
           t = real ? (t > 0.0f ? t : t * p.slope) : 0.0f;
           unsigned short sp[NS];
@@ -243,7 +279,7 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
       bool neg[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t = acc[m][n][r] + bias;
+        const float t = acc[tile][r] + bias;
         neg[r] = t < 0.0f;
         v[r] = p.do_abs ? fabsf(t) : t;
       }
@@ -287,7 +323,8 @@ static inline int bf_nt_for(int64_t c) {
 
 template <int MT, int NT, int NS>
 static int bf_launch(dim3 grid, size_t lds, hipStream_t st, const WconvBfParams& p) {
-  constexpr bool SPLITN = (NT % 2 == 0) && MT == 2;      // 2 x 2 waves where the channel tiles divide
+  // 2 x 2 waves where the channel tiles divide; column ownership for the five-tile (Sinc, 80 filters) launch
+  constexpr int SPLITN = ((NT % 2 == 0) && MT == 2) ? 1 : ((NT == 5 && MT == 2) ? 2 : 0);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)wconv_bf_fwd_kernel<MT, NT, NS, SPLITN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -14,5 +14,11 @@ for o in "$LIB"/*.o; do
   b=$(basename "$o")
   if [ "$b" = "$UNIT.o" ]; then OBJS+=("$ALT/$UNIT.o"); else OBJS+=("$o"); fi
 done
+# EXTRA_UNITS="path/to/a.hip ...": further translation units linked into the alt library only (A/B baselines)
+for x in ${EXTRA_UNITS:-}; do
+  b=$(basename "$x" .hip)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I"$SRC" -c "$x" -o "$ALT/$b.o"
+  OBJS+=("$ALT/$b.o")
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -ldl -o "$ALT/libslu_hip.so"
 echo "[build_alt] $ALT/libslu_hip.so ($UNIT with $*)"

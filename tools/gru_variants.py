@@ -14,7 +14,27 @@ dev = torch.device("cuda", 0)
 n = pipeline.cu_split()
 st = pipeline.cu_range_stream(dev, n, pipeline.n_compute_units(dev) - n)
 H, D, ns = 128, 2, 2
-VARIANTS = [0, 1, 2, 4, 3, 5]
+VARIANTS = [int(v) for v in os.environ.get("PROBE_VARIANTS", "0,1,2,4").split(",")]
+
+
+def r3_kernel(gx, wf, wr, bf, br, T, B, planes=None, I=0, packed=None, b_ih=None):
+    """The round-3 kernel (tools/probes/slu_gru_bf16_r3.hip), when the loaded library carries it (tools/build_alt.sh with
+    EXTRA_UNITS): same-box baseline."""
+    import ctypes
+    from slu_hip import lib as _lib
+    L = _lib.load()
+    if not hasattr(L, "slu_gru_seq_fwd_bf16_r3"):
+        return None
+    fn = L.slu_gru_seq_fwd_bf16_r3
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [vp] * 8 + [i64, i64, vp, vp, i64, i64, i64, i64, ctypes.c_int, vp]
+    out = torch.empty(T, B, D * H, device=dev)
+    xa = (planes.data_ptr(), planes.stride(0), I, packed.data_ptr(), b_ih.data_ptr()) if planes is not None else (None, 0, 0, None, None)
+    rc = fn(None if planes is not None else gx.data_ptr(), wf.data_ptr(), wr.data_ptr(), bf.data_ptr(), br.data_ptr(), out.data_ptr(),
+            None, *xa, T, B, H, D, ns, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    return out
 
 
 def weights(I, seed):
@@ -73,6 +93,13 @@ def timing(T, B, I):
     print("T=%d B=%d on %d CUs: dropout_bits %.1f us; dropout_pool_fwd_planes (two-launch path) %.1f us" %
           (T, B, pipeline.n_compute_units(dev) - n, t_bits, t_pool), flush=True)
     fus = (planes, I, packed, b_ih) if ops.gru_fused_input_ok(I, H, D, ns) else None
+    if r3_kernel(gx, wf, wr, bf, br, T, B) is not None:
+        t0 = 1e3 * _timed_graph(lambda: r3_kernel(gx, wf, wr, bf, br, T, B), st)
+        line = "  ROUND-3 kernel, this box: plain %.1f us (%.3f us/step)" % (t0, t0 / T)
+        if fus is not None:
+            t2 = 1e3 * _timed_graph(lambda: r3_kernel(None, wf, wr, bf, br, T, B, planes, I, packed, b_ih), st)
+            line += " | fused input %.1f us (%.3f us/step)" % (t2, t2 / T)
+        print(line, flush=True)
     for v in VARIANTS:
         os.environ["SLU_GRU_VARIANT"] = str(v)
         t0 = 1e3 * _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, ns), st)

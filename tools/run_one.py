@@ -40,6 +40,23 @@ elif what == "gru_bf":
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
         ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS)
+elif what == "gru_bf_r3":
+    # the round-3 kernel from the alt library (tools/build_alt.sh EXTRA_UNITS=tools/probes/slu_gru_bf16_r3.hip; SLU_HIP_LIB)
+    import ctypes
+    from slu_hip import lib as _lib
+    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128
+    gx = torch.randn(T, B, 6 * H, device="cuda")
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    out = torch.empty(T, B, 2 * H, device="cuda")
+    fn = _lib.load().slu_gru_seq_fwd_bf16_r3
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [vp] * 8 + [i64, i64, vp, vp, i64, i64, i64, i64, ctypes.c_int, vp]
+    for _ in range(5):
+        assert fn(gx.data_ptr(), wf.data_ptr(), wr.data_ptr(), bf.data_ptr(), br.data_ptr(), out.data_ptr(), None, None, 0, 0,
+                  None, None, T, B, H, 2, 2, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
 elif what == "gru_bf_fused":
     # the first frozen GRU layer of a super-batch (K = 60, T = 300): recurrence with the fused input projection
     T, B, H, I = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128, 60
