@@ -82,45 +82,65 @@ struct GruBfParams {
 // 16-byte load per chunk and plane, a step ahead), and the extra MFMAs do not depend on h_{t-1}.  Saves the projection
 // GEMM and the fp32 gx round trip (T*B*D*3H*8 bytes) of that layer.
 //
-// Order of a step (measured, DESIGN.md section 7: the first version of this kernel issued the next step's loads at the
-// top and the output store after the gate math, and ran 1.66 us per step against round 3's 1.27):
-//   A. the MFMA chains are seeded with this step's gx + b_hh — the step's only use of prefetched VMEM data, placed FIRST:
-//      loads and stores share vmcnt and may complete out of order among themselves, so with both kinds outstanding the
-//      compiler can only wait for vmcnt(0); here everything outstanding was issued a whole step ago and the wait is free
-//      (after the gate math it also waited for the loads issued at the top of the same step);
-//   B. the next step's gx (or x fragments) and keep bits are requested, and the PREVIOUS step's output — kept in
-//      registers over the barrier — is stored;
-//   C. h fragments from LDS, 36 (f16x2) MFMAs, gate math, split h to LDS, barrier (LDS only).
-// Gate arithmetic (fp32-class, not the operation order of round 3): the bias additions ride in the accumulator seed,
-// the blend is n + z (h - n), the f16x2 split of h uses split_f16x2_pair_flush.
-// VAR (scheduling experiments, identical results): bit 0 = gate-outer MFMA order, bit 1 / bit 2 = static s_setprio for the
-// first / second half of the waves (the two waves of a SIMD are w and w + NW/2).
+// Global memory goes through LDS (measured).  In the compute layout a lane owns 16 bytes of ONE
+// sequence's row and its neighbours own other sequences (rows 1 - 3 KB apart): a global_load_dwordx4 / store in that
+// layout is 64 separate 16-byte requests touching 16 lines four times each.  Timing probes on the first version of this
+// kernel (1024 sequences, T = 300, 128 CUs): 1.41 us per step; 1.02 without the gx loads; 1.13 without the output store —
+// the compute core was already below round 3's 1.29 us and the scattered accesses gave it all back.  So a wave moves
+// WHOLE ROWS: rows 16/NW w .. of the tile, consecutive lanes = consecutive 16 bytes (a half-wave = one 512-byte output row,
+// 1.5 waves = one 1536-byte gx row), and the transposition between the two layouts happens in padded, conflict-free LDS
+// staging tiles: gx of step s+1 is requested at the top of step s, written to LDS at its end (a full step later: the wait
+// is free) and read in the compute layout at the top of step s+1; the output of step s is written to LDS in the compute
+// layout, read back row-wise after the barrier and stored at the top of step s+1.
+//
+// Order of a step:
+//   A. gx (from LDS) + b_hh seed the MFMA chains (r, z) — the bias additions leave the dependent tail of the step;
+//   B. next step's gx rows / x fragments / keep bits are requested; the previous step's output rows are stored;
+//   C. h fragments from LDS, 36 (f16x2) MFMAs, gate math, split h to LDS, output to its staging tile;
+//   D. the gx rows requested in B go to their staging tile; barrier (LDS only).
+// Gate arithmetic (fp32-class, not the operation order of round 3): the blend is n + z (h - n), the f16x2 split of h uses
+// split_f16x2_pair_flush.
+// VAR: bit 0 = gate-outer MFMA order (scheduling experiment, identical results).
+template <int H, int NS, int KI, int EPI>
+struct GruLds {
+  static constexpr int ROWB = H * 2;                       // bytes per h row (one sequence, one plane)
+  static constexpr int GXROW = 3 * H + 8;                  // floats per staged gx row (+ 32 B: conflict-free b128 reads)
+  static constexpr int OROW = H + 4;                       // floats per staged fp32 output row
+  static constexpr int PROWB = H * 2 + 16;                 // bytes per staged plane row
+  static constexpr int HBUF = 2 * NS * 16 * ROWB;
+  static constexpr int BIAS = KI > 0 ? 2 * 3 * H * 4 : 0;
+  static constexpr int GXS = KI > 0 ? 0 : 2 * 16 * GXROW * 4;
+  static constexpr int OST = EPI == 1 ? 2 * NS * 16 * PROWB : 2 * 16 * OROW * 4;
+  static constexpr int BYTES = HBUF + BIAS + GXS + OST;
+};
+
 template <int H, int NS, int KI, int EPI, int VAR>
 __global__ void __launch_bounds__(H * 4)
 gru_bf_fwd_kernel(const GruBfParams p) {
   constexpr int NW = H / 16;          // waves
   constexpr int KC = H / 32;          // 32-wide k-chunks
-  constexpr int ROWB = H * 2;         // bytes per LDS row (one sequence, one plane)
-  constexpr int SLOTS = H / 8;        // 16-byte slots per row
+  constexpr int SLOTS = H / 8;        // 16-byte slots per h row
   constexpr bool GO = (VAR & 1) != 0;
   constexpr bool BIAS_LDS = KI > 0;   // the fused kernel keeps its 24 bias values in LDS (register budget)
   typedef Split<NS> SP;
-  __shared__ __attribute__((aligned(16))) unsigned char hbuf[2][NS][16 * ROWB];
-  __shared__ __attribute__((aligned(16))) float bias_s[BIAS_LDS ? 2 : 1][BIAS_LDS ? 3 * H : 4];
+  typedef GruLds<H, NS, KI, EPI> LD;
+  constexpr int ROWB = LD::ROWB, GXROW = LD::GXROW, OROW = LD::OROW, PROWB = LD::PROWB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const hbuf = smem;                                                   // [2][NS][16 * ROWB]
+  float* const bias_s = reinterpret_cast<float*>(smem + LD::HBUF);                    // [2][3H] (KI > 0)
+  float* const gxs = reinterpret_cast<float*>(smem + LD::HBUF + LD::BIAS);            // [2][16][GXROW] (KI == 0)
+  unsigned char* const ost = smem + LD::HBUF + LD::BIAS + LD::GXS;                    // output staging, see LD::OST
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 15, kg = lane >> 4;      // i: sequence of the tile (MFMA column), kg: k slice / unit quad
+  const int i = lane & 15, kg = lane >> 4;      // compute layout: i = sequence of the tile (MFMA column), kg = unit quad
   const int dir = blockIdx.y;
   const int b0 = blockIdx.x * 16;
   const int u0 = w * 16 + kg * 4;               // first of this lane's four hidden units
   const int T = p.T, B = p.B, D = p.D;
   const int seq = b0 + i;
-  const bool valid = seq < B;
-  const int seqc = valid ? seq : B - 1;         // rows past B repeat the last sequence and are never stored
+  const int seqc = seq < B ? seq : B - 1;       // rows past B repeat the last sequence and are never stored
 
   if constexpr (NS == 2) f16_denorm_flush();
-  if constexpr ((VAR & 2) != 0) { if (w < NW / 2) __builtin_amdgcn_s_setprio(2); }
-  if constexpr ((VAR & 4) != 0) { if (w >= NW / 2) __builtin_amdgcn_s_setprio(2); }
 
   // resident W_hh fragments (MFMA A operand, row = unit 16w + i): wb[g][c][pl] = 8 terms of
   // W_hh[g*H + 16w + i][c*32 + kg*8 .. +7], plane pl
@@ -150,8 +170,8 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   float bh[3][4];
   if constexpr (BIAS_LDS) {
     for (int x = tid; x < 3 * H; x += H * 4) {
-      bias_s[0][x] = p.b_hh[dir][x];
-      bias_s[1][x] = p.b_ih[(size_t)dir * 3 * H + x];
+      bias_s[x] = p.b_hh[dir][x];
+      bias_s[3 * H + x] = p.b_ih[(size_t)dir * 3 * H + x];
     }
   } else {
 #pragma unroll
@@ -191,7 +211,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       const f32x4 v = split_result<NS>(ax[0][g], ax[SP::NACC - 1][g]);
-      const float4 bi = *reinterpret_cast<const float4*>(&bias_s[BIAS_LDS ? 1 : 0][BIAS_LDS ? g * H + u0 : 0]);
+      const float4 bi = *reinterpret_cast<const float4*>(&bias_s[BIAS_LDS ? 3 * H + g * H + u0 : 0]);
       o[g][0] = v[0] + bi.x; o[g][1] = v[1] + bi.y; o[g][2] = v[2] + bi.z; o[g][3] = v[3] + bi.w;
     }
   };
@@ -205,24 +225,52 @@ gru_bf_fwd_kernel(const GruBfParams p) {
         xa[c][pl] = *reinterpret_cast<const uint4*>(base + (size_t)pl * p.x_plane + c * 32);
   };
 
-  for (int x = tid; x < 2 * NS * 16 * ROWB / 4; x += H * 4) reinterpret_cast<unsigned*>(&hbuf[0][0][0])[x] = 0u;   // h0 = 0
-  float hprev[4] = {0.f, 0.f, 0.f, 0.f};
-  // 32-bit offsets inside one time step (B * D * 3H < 2^31 is checked by the launcher)
-  const int g_off = seqc * D * 3 * H + dir * 3 * H + u0;
-  const int o_off = seq * D * H + dir * H + u0;
+  // ---- row-wise (coalesced) side of the staging tiles: a wave moves rows RW w .. RW w + RW - 1 of the 16 ----
+  constexpr int RW = 16 / NW;                   // rows (sequences) per wave
+  // gx: 3H floats = 3H/4 lanes per row, RW rows = 192 lanes = three 16-byte loads per lane (any H)
+  constexpr int GLR = 3 * H / 4;                // lanes per gx row
+  // (plain scalars, not arrays handed to lambdas: those were demoted to scratch memory)
+  auto gx_g = [&](int j) { const int f = j * 64 + lane; return min(b0 + RW * w + f / GLR, B - 1) * D * 3 * H + dir * 3 * H + (f % GLR) * 4; };
+  auto gx_s = [&](int j) { const int f = j * 64 + lane; return (RW * w + f / GLR) * GXROW + (f % GLR) * 4; };
+  const int gx_g0 = gx_g(0), gx_g1 = gx_g(1), gx_g2 = gx_g(2);   // global element offsets inside a time step
+  const int gx_s0 = gx_s(0), gx_s1 = gx_s(1), gx_s2 = gx_s(2);   // float offsets inside a staging tile
   const size_t gx_ts = (size_t)B * D * 3 * H, out_ts = (size_t)B * D * H;
-  // h fragment read (B operand): row i (sequence), slot (c*4 + kg) ^ i;  h store: row i, slot (u0/8) ^ i, 8 bytes at
-  // element u0 % 8 (2-way bank conflicts among a store's 16-lane groups: one of the step's nine LDS instructions)
-  int a_off[KC];
+#define SLU_GX_REQUEST(t_, a, b, c)                                                         \
+  do {                                                                                      \
+    const float* gp__ = p.gx + (size_t)(t_) * gx_ts;                                        \
+    a = *reinterpret_cast<const float4*>(gp__ + gx_g0);                                     \
+    b = *reinterpret_cast<const float4*>(gp__ + gx_g1);                                     \
+    c = *reinterpret_cast<const float4*>(gp__ + gx_g2);                                     \
+  } while (0)
+#define SLU_GX_STAGE(buf, a, b, c)                                                          \
+  do {                                                                                      \
+    float* gs__ = gxs + (buf) * (16 * GXROW);                                               \
+    *reinterpret_cast<float4*>(gs__ + gx_s0) = a;                                           \
+    *reinterpret_cast<float4*>(gs__ + gx_s1) = b;                                           \
+    *reinterpret_cast<float4*>(gs__ + gx_s2) = c;                                           \
+  } while (0)
+  // output rows: fp32 (EPI 0 / 2): H/4 lanes per row, RW rows = 64 lanes = one 16-byte store per lane;
+  // planes (EPI 1): H/8 lanes per row and plane, NS planes x 16 rows = NS * 2H lanes: wave-instructions c = w, w + NW, ...
+  const int orow = RW * w + lane / (H / 4), oc16 = lane % (H / 4);
+  const bool orow_ok = b0 + orow < B;
+  const int o_goff = (b0 + orow) * D * H + dir * H + oc16 * 4;
+
+  // compute-layout side
+  int a_off[KC];                                // h fragment (B operand): row i, slot (c*4 + kg) ^ i
 #pragma unroll
   for (int c = 0; c < KC; ++c) a_off[c] = i * ROWB + (((c * 4 + kg) ^ i) & (SLOTS - 1)) * 16;
-  const int h_off = i * ROWB + ((((u0 >> 3) ^ i) & (SLOTS - 1)) * 16) + (u0 & 7) * 2;
+  const int h_off = i * ROWB + ((((u0 >> 3) ^ i) & (SLOTS - 1)) * 16) + (u0 & 7) * 2;     // h store: 8 bytes at unit u0
+  const int gs_off = i * GXROW + u0;            // gx seed read: + g * H
+  const int os_off = i * OROW + u0;             // fp32 output write
+  const int ps_off = i * PROWB + u0 * 2;        // plane output write (bytes)
   // dropout keep bits of (t, sequence, this lane's four channels)
   const int kw_off = seqc * ((D * H) >> 5) + ((dir * H + u0) >> 5);
   const int kw_sh = (dir * H + u0) & 31;
   const size_t kw_ts = (size_t)B * ((D * H) >> 5);
   const bool drop = EPI > 0 && p.keep != nullptr;
 
+  for (int x = tid; x < 2 * NS * 16 * ROWB / 4; x += H * 4) reinterpret_cast<unsigned*>(hbuf)[x] = 0u;   // h0 = 0
+  float hprev[4] = {0.f, 0.f, 0.f, 0.f};
   float gcur[3][4];
   unsigned kcur = 0;
   {
@@ -233,42 +281,38 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       xload(t0, xa0);
       xproj(xa0, gcur);
     } else {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(p.gx + (size_t)t0 * gx_ts + g_off + g * H);
-        gcur[g][0] = v.x; gcur[g][1] = v.y; gcur[g][2] = v.z; gcur[g][3] = v.w;
-      }
+      float4 ga, gb, gc;
+      SLU_GX_REQUEST(t0, ga, gb, gc);
+      SLU_GX_STAGE(0, ga, gb, gc);
     }
     if (drop) kcur = p.keep[(size_t)t0 * kw_ts + kw_off];
   }
   float held[4] = {0.f, 0.f, 0.f, 0.f};
-  // the output of the previous step, stored at the top of the next one (phase B): EPI 0 re-uses hprev; EPI 2 four pooled
-  // values, EPI 1 their NS planes already packed (two 32-bit words per plane)
-  constexpr int NPEND = EPI == 1 ? 2 * NS : 4;
-  unsigned pend[NPEND];
-#pragma unroll
-  for (int x = 0; x < NPEND; ++x) pend[x] = 0;
-  int pend_t = -1;                     // frame (EPI 0) / pooled frame (EPI > 0) of the pending output, -1 = none
+  int pend_t = -1;                     // frame (EPI 0) / pooled frame (EPI > 0) whose rows wait in ost[pend_buf], -1 = none
+  int pend_buf = 0;
+  // the previous step's output: staging tile -> global memory, whole rows
   auto flush = [&]() {
-    if (pend_t >= 0 && valid) {
-      const size_t o = (size_t)pend_t * out_ts + o_off;
-      if constexpr (EPI == 0) {
-        *reinterpret_cast<float4*>(p.out + o) = make_float4(hprev[0], hprev[1], hprev[2], hprev[3]);
-      } else if constexpr (EPI == 2) {
-        *reinterpret_cast<uint4*>(p.out + o) = make_uint4(pend[0], pend[1], pend[2], pend[3]);
-      } else {
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-          *reinterpret_cast<uint2*>(p.planes + (size_t)pl * p.plane + o) = make_uint2(pend[2 * pl], pend[2 * pl + 1]);
+    if (pend_t < 0) return;
+    if constexpr (EPI == 1) {
+      constexpr int LPR = H / 8;                               // lanes per plane row
+      constexpr int NCH = NS * 16 * LPR / 64;                  // wave-instructions for the whole tile
+      for (int c = w; c < NCH; c += NW) {
+        const int f = c * 64 + lane, pl = f / (16 * LPR), r = (f / LPR) % 16, c16 = f % LPR;
+        if (b0 + r < B) {
+          const uint4 v = *reinterpret_cast<const uint4*>(ost + ((pend_buf * NS + pl) * 16 + r) * PROWB + c16 * 16);
+          *reinterpret_cast<uint4*>(p.planes + (size_t)pl * p.plane + (size_t)pend_t * out_ts + (b0 + r) * D * H + dir * H + c16 * 8) = v;
+        }
+      }
+    } else {
+      if (orow_ok) {
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ost) + (pend_buf * 16 + orow) * OROW + oc16 * 4);
+        *reinterpret_cast<float4*>(p.out + (size_t)pend_t * out_ts + o_goff) = v;
       }
     }
   };
   __syncthreads();
-  // Nothing may be pending when the loop is entered: the compiler sinks the W_hh split below the barrier above, so
-  // without this wait the bias / first-step loads are still outstanding on the entry path, and the waits it then places
-  // INSIDE the loop for that path (vmcnt(5) / (4) / (3) with the step's own four operations on top) execute on every
-  // iteration — in steady state the last one stalls each step until the load issued at the top of the SAME step has
-  // returned from HBM (measured: 1.73 us per step with it).
+  // Nothing may be pending when the loop is entered: the compiler sinks the W_hh split below the barrier above, and waits
+  // it would otherwise place INSIDE the loop for the entry path would execute on every iteration.
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
   for (int s = 0; s < T; ++s) {
@@ -280,8 +324,15 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     if constexpr (BIAS_LDS) {
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(&bias_s[0][g * H + u0]);
+        const float4 v = *reinterpret_cast<const float4*>(&bias_s[g * H + u0]);
         bh[g][0] = v.x; bh[g][1] = v.y; bh[g][2] = v.z; bh[g][3] = v.w;
+      }
+    }
+    if constexpr (KI == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(gxs + cur * (16 * GXROW) + gs_off + g * H);
+        gcur[g][0] = v.x; gcur[g][1] = v.y; gcur[g][2] = v.z; gcur[g][3] = v.w;
       }
     }
     f32x4 accs[SP::NACC][3];
@@ -298,32 +349,25 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       gn[r] = gcur[2][r];
     }
     const unsigned kbits = kcur >> kw_sh;
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- B: the next step's operands; the previous step's output ----
     float gnext[3][4];
+    float4 gl0 = make_float4(0.f, 0.f, 0.f, 0.f), gl1 = gl0, gl2 = gl0;   // gx rows of the next step (row-wise layout)
     uint4 xan[KIA][NS];                                          // fused input: fragments of the NEXT step's x
-    if constexpr (KI > 0) {
-      xload(tn, xan);                                            // in flight during this step; multiplied at its end
-    } else {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(p.gx + (size_t)tn * gx_ts + g_off + g * H);
-        gnext[g][0] = v.x; gnext[g][1] = v.y; gnext[g][2] = v.z; gnext[g][3] = v.w;
-      }
-    }
+    if constexpr (KI > 0) xload(tn, xan);                        // in flight during this step; multiplied at its end
+    else SLU_GX_REQUEST(tn, gl0, gl1, gl2);
     unsigned knext = 0;
     if (drop) knext = p.keep[(size_t)tn * kw_ts + kw_off];
     flush();
-    __builtin_amdgcn_sched_barrier(0);
 
     // ---- C: W_hh h_{t-1} (h plane = PA(q), W plane = PB(q)), gates, h_t ----
+    const unsigned char* hc = hbuf + cur * (NS * 16 * ROWB);
     if constexpr (GO) {
       uint4 fa[KC][NS];
 #pragma unroll
       for (int c = 0; c < KC; ++c)
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl) fa[c][pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
+        for (int pl = 0; pl < NS; ++pl) fa[c][pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -336,7 +380,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       for (int c = 0; c < KC; ++c) {
         uint4 fa[NS];
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(&hbuf[cur][pl][a_off[c]]);
+        for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
 #pragma unroll
         for (int q = 0; q < SP::NPAIR; ++q)
 #pragma unroll
@@ -358,7 +402,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     }
     // h_t -> LDS as NS planes: four consecutive units = one 8-byte store per plane
     {
-      unsigned char* __restrict__ hnext = &hbuf[cur ^ 1][0][0];
+      unsigned char* __restrict__ hnext = hbuf + (cur ^ 1) * (NS * 16 * ROWB);
       if constexpr (NS == 2) {
         unsigned hi01, lo01, hi23, lo23;
         split_f16x2_pair_flush(hn[0], hn[1], hi01, lo01);
@@ -375,8 +419,10 @@ gru_bf_fwd_kernel(const GruBfParams p) {
               make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));
       }
     }
+    // this step's output -> its staging tile (compute layout); stored row-wise at the top of the next step
     if constexpr (EPI == 0) {
-      pend_t = t;                      // hprev (= hn below) is this step's pending output
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(ost) + cur * (16 * OROW) + os_off) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      pend_t = t; pend_buf = cur;
     } else {
       // Dropout (keep bit ? h * scale : h * 0) and average pooling over frames (2 to, 2 to + 1), in the operation order of
       // dropout_pool_fwd4_kernel: acc = 0 + v(2 to); acc += v(2 to + 1); acc / n  (n = 1 for the partial last window)
@@ -399,41 +445,47 @@ gru_bf_fwd_kernel(const GruBfParams p) {
           const float second = dir ? held[r] : m[r];                       // v(2 to + 1)
           v[r] = single ? __fadd_rn(0.0f, m[r]) : __fmul_rn(__fadd_rn(first, second), 0.5f);
         }
-        pend_t = t >> 1;
+        pend_t = t >> 1; pend_buf = cur;
         if constexpr (EPI == 2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) pend[r] = __float_as_uint(v[r]);
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(ost) + cur * (16 * OROW) + os_off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (NS == 2) {
+          // "round to fp16, flush denormals" (split_f16x2_flush of slu_bf16.h, the rule dropout_pool_fwd4_kernel<2> uses):
+          // in this kernel's flush mode that is two packed conversions per pair
+          unsigned hi01, lo01, hi23, lo23;
+          split_f16x2_pair_flush(v[0], v[1], hi01, lo01);
+          split_f16x2_pair_flush(v[2], v[3], hi23, lo23);
+          *reinterpret_cast<uint2*>(ost + ((cur * NS + 0) * 16) * PROWB + ps_off) = make_uint2(hi01, hi23);
+          *reinterpret_cast<uint2*>(ost + ((cur * NS + 1) * 16) * PROWB + ps_off) = make_uint2(lo01, lo23);
         } else {
-          if constexpr (NS == 2) {
-            // "round to fp16, flush denormals" (split_f16x2_flush of slu_bf16.h, the rule dropout_pool_fwd4_kernel<2> uses):
-            // in this kernel's flush mode that is two packed conversions per pair
-            split_f16x2_pair_flush(v[0], v[1], pend[0], pend[2]);
-            split_f16x2_pair_flush(v[2], v[3], pend[1], pend[3]);
-          } else {
-            unsigned short sp[4][NS];
+          unsigned short sp[4][NS];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);
+          for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);
 #pragma unroll
-            for (int pl = 0; pl < NS; ++pl) {
-              pend[2 * pl] = sp[0][pl] | ((unsigned)sp[1][pl] << 16);
-              pend[2 * pl + 1] = sp[2][pl] | ((unsigned)sp[3][pl] << 16);
-            }
-          }
+          for (int pl = 0; pl < NS; ++pl)
+            *reinterpret_cast<uint2*>(ost + ((cur * NS + pl) * 16) * PROWB + ps_off) =
+                make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));
         }
       }
     }
     // the next step's x W_ih^T + b_ih: independent of h (round 3 measured this placement against two interleavings)
-    if constexpr (KI > 0) xproj(xan, gnext);
+    if constexpr (KI > 0) {
+      xproj(xan, gnext);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gcur[g][r] = gnext[g][r];
+    } else {
+      // ---- D: the gx rows requested in B (a step ago in wall time: the wait is free) -> the other staging tile ----
+      SLU_GX_STAGE(cur ^ 1, gl0, gl1, gl2);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) hprev[r] = hn[r];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) gcur[g][r] = gnext[g][r];
     kcur = knext;
     lds_barrier();
   }
   flush();
+#undef SLU_GX_REQUEST
+#undef SLU_GX_STAGE
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -575,22 +627,26 @@ gru_bf_fwd_rs_kernel(const GruBfParams p) {
 // the default is what the measurements of DESIGN.md section 7 selected
 static int gru_variant() {
   const char* e = getenv("SLU_GRU_VARIANT");      // read per launch (a captured graph keeps the variant it was captured with)
-  return e ? atoi(e) & 7 : 0;
+  return e ? atoi(e) & 1 : 0;
+}
+
+template <int H, int NS, int KI, int EPI, int VAR>
+static void gru_bf_launch_var(dim3 grid, hipStream_t st, const GruBfParams& p) {
+  constexpr int lds = GruLds<H, NS, KI, EPI>::BYTES;
+  static bool raised = false;      // > 64 KiB of dynamic LDS needs the function attribute (once per instantiation)
+  if (lds > 64 * 1024 && !raised) {
+    (void)hipFuncSetAttribute((const void*)gru_bf_fwd_kernel<H, NS, KI, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    raised = true;
+  }
+  hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, VAR>), grid, dim3(H * 4), lds, st, p);
 }
 
 template <int H, int NS, int KI, int EPI>
 static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
   if constexpr (H == 128 && NS == 2) {
-    switch (gru_variant()) {
-      case 1: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 1>), grid, dim3(H * 4), 0, st, p); return;
-      case 2: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 2>), grid, dim3(H * 4), 0, st, p); return;
-      case 3: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 3>), grid, dim3(H * 4), 0, st, p); return;
-      case 4: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 4>), grid, dim3(H * 4), 0, st, p); return;
-      case 5: hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 5>), grid, dim3(H * 4), 0, st, p); return;
-      default: break;
-    }
+    if (gru_variant() == 1) { gru_bf_launch_var<H, NS, KI, EPI, 1>(grid, st, p); return; }
   }
-  hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, 0>), grid, dim3(H * 4), 0, st, p);
+  gru_bf_launch_var<H, NS, KI, EPI, 0>(grid, st, p);
 }
 
 template <int H, int EPI>

@@ -1037,16 +1037,25 @@ class ConvBlockFn(torch.autograd.Function):
                 wconv_bwd_weight(d_conv, x, B, l_in, c_in, c_out, k_t, stride, ctx.has_bias, out=(dW, db))
         if ctx.needs_input_grad[0]:
             if stride != 1:
-                raise NotImplementedError("data gradient of a strided Conv1d layer is not implemented "
-                                          "(only the first CNN layer of the reference is strided)")
-            ns = train_nsplit(True)
-            if ns and wconv_bf16_supported(c_out, 1, 1, k_t, ns) and c_in <= 128:
-                # data gradient = the same windowed contraction with the filters transposed and reversed in time, on
-                # split-precision operands (the flip / transpose is a 72 KB copy)
-                w_t = weight.detach().transpose(0, 1).flip(2).contiguous()
-                dx = wconv_fwd_bf16(d_conv, w_t, None, B, l_conv, c_out, 1, False, 1, 1.0, False, ns)
+                # a strided layer that is not the first one (the reference accepts any cnn_stride, models.py:200): its data
+                # gradient is the stride-1 data gradient of d_conv with stride - 1 zeros inserted between frames — the zeros
+                # add nothing, so the result is exact; the kernel does `stride` times the necessary work, which is fine for
+                # a geometry no shipped cfg uses.  (zeros + strided copy: data movement only)
+                l_conv1 = l_in + 2 * (k_t // 2) - k_t + 1
+                d_up = torch.zeros(B, l_conv1, c_out, dtype=torch.float32, device=dev)
+                d_up[:, :(l_conv - 1) * stride + 1:stride] = d_conv
+                d_conv_dx, l_dx = d_up, l_conv1
             else:
-                dx = wconv_bwd_data(d_conv, weight, B, l_in)
+                d_conv_dx, l_dx = d_conv, l_conv
+            ns = train_nsplit(True)
+            if ns and k_t % 2 == 1 and wconv_bf16_supported(c_out, 1, 1, k_t, ns) and c_in <= 128:
+                # data gradient = the same windowed contraction with the filters transposed and reversed in time, on
+                # split-precision operands (the flip / transpose is a 72 KB copy).  Odd kernel sizes only: for an even k_t
+                # the "same"-padded forward convolution is one frame longer than its input and is not this transpose
+                w_t = weight.detach().transpose(0, 1).flip(2).contiguous()
+                dx = wconv_fwd_bf16(d_conv_dx, w_t, None, B, l_dx, c_out, 1, False, 1, 1.0, False, ns)
+            else:
+                dx = wconv_bwd_data(d_conv_dx, weight, B, l_in)
         _Fork.join(dev)
         return dx, dW, db, None, None, None, None, None
 

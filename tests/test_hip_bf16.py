@@ -168,6 +168,38 @@ def test_gru_fused_input_projection_equals_gemm_plus_recurrence(ops, T, B, I):
     assert (out - exact).abs().max().item() <= 5e-6
 
 
+@pytest.mark.parametrize("T,B,H,D,sub", [(75, 128, 128, 2, 64), (38, 37, 128, 2, 0), (300, 1024, 128, 2, 64), (9, 16, 64, 2, 0),
+                                          (20, 48, 128, 1, 16)])
+@pytest.mark.parametrize("nsplit", [2, 3])
+def test_gru_dropout_pool_epilogue_equals_the_two_launch_path(ops, T, B, H, D, sub, nsplit):
+    """slu_gru_seq_fwd_pool_bf16: Dropout(p) + Downsample("avg", 2) of a frozen layer (models.py:246-251, 26-46) applied in the
+    recurrence's epilogue from the 1-bit mask of slu_dropout_bits — bit-identical to recurrence + slu_dropout_pool_fwd /
+    _fwd_planes with the same (seed, offset, sub-batch) Philox stream: odd T (partial last window), ragged tiles, both
+    directions and a unidirectional layer, eval mode (p = 0), the 1024-sequence super-batch, fp32 and plane outputs."""
+    torch.manual_seed(T * 7 + B)
+    gx = torch.randn(T, B, D * 3 * H, device="cuda")
+    wf, bf = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, device="cuda") * 0.1
+    wr, br = (torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, device="cuda") * 0.1) if D == 2 else (None, None)
+    raw, _ = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit)
+    off_dev = torch.tensor([5 * 16], dtype=torch.int64, device="cuda")
+    for p, offset, odev in ((0.5, 7 * 16 + 3, None), (0.25, 3, off_dev), (0.0, 0, None)):
+        two_f = ops.dropout_pool_fwd(raw, None, p, 1234, offset, "avg", 2, odev, sub)
+        two_p = ops.dropout_pool_fwd_planes(raw, None, p, 1234, offset, "avg", 2, nsplit, odev, sub).planes
+        keep = ops.dropout_bits(T, B, D * H, p, 1234, offset, odev, sub, gx.device) if p > 0 else None
+        one_f = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, False)
+        one_p = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, True).planes
+        torch.cuda.synchronize()
+        assert torch.equal(one_f, two_f), "fp32 output, p = %g" % p
+        assert torch.equal(one_p.view(torch.int16), two_p.view(torch.int16)), "plane output, p = %g" % p
+        if p > 0:
+            # the bit stream is the mask itself: element (t, b, c) is dropped in the two-launch output iff its bit is clear
+            bits = keep.view(T, B, D * H // 32, 1).bitwise_right_shift(torch.arange(32, device="cuda")).bitwise_and(1)
+            kept = bits.view(T, B, D * H).bool()
+            full = ops.dropout_pool_fwd(raw, None, p, 1234, offset, "none", 1, odev, sub)
+            assert torch.equal(full != 0, kept & (raw != 0))
+            assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+
+
 def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):
     """BASELINE configs[4] arithmetic (SLU_DTYPE=bf16: the GRU layers' forward contractions on bf16 MFMA with
     fp32 accumulation and gate math, exact-fp32 backward on the saved gates).  The reference has no reduced

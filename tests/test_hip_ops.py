@@ -107,9 +107,18 @@ def test_wconv_fwd(ops, case, time_major):
     (2, 33, 6, 6, 3, 1, False, 1, 0.0),
     (3, 4040, 1, 80, 401, 80, True, 2, 0.2),
     (2, 700, 1, 8, 41, 10, True, 2, 0.2),
+    # strided layers that are NOT the first one need a data gradient too (the reference takes any cnn_stride,
+    # models.py:200): zero-upsampled d_conv through the stride-1 kernel
+    (2, 64, 8, 12, 5, 2, False, 1, 0.2),
+    (2, 61, 8, 12, 3, 3, False, 2, 0.2),
+    (2, 64, 8, 12, 4, 1, False, 1, 0.2),          # even kernel size (l_conv = l_in + 1)
 ])
-def test_wconv_bwd(ops, case):
+@pytest.mark.parametrize("train_math", ["fp32", "split"])
+def test_wconv_bwd(ops, case, train_math, monkeypatch):
     B, L, Cin, Cout, K, stride, do_abs, pool, slope = case
+    # "split": the data gradient of odd kernel sizes runs as a transposed-filter convolution on the split-precision kernel;
+    # even kernel sizes must stay on the exact data-gradient kernel (round-3 advisor finding)
+    monkeypatch.setenv("SLU_TRAIN_MATH", train_math)
     g = torch.Generator().manual_seed(7 + L)
     x = torch.randn(B, L, Cin, generator=g).requires_grad_()
     w = (torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5).requires_grad_()
@@ -117,7 +126,8 @@ def test_wconv_bwd(ops, case):
     ref = _conv_ref(x, w, bias, stride, do_abs, pool, slope)
     gy = torch.randn(ref.shape, generator=g)
     (ref * gy).sum().backward()
-    xg, wg = cu(x.detach()).requires_grad_(stride == 1), cu(w.detach()).requires_grad_()
+    want_dx = stride == 1 or Cin > 1
+    xg, wg = cu(x.detach()).requires_grad_(want_dx), cu(w.detach()).requires_grad_()
     bg = None if bias is None else cu(bias.detach()).requires_grad_()
     out = ops.ConvBlockFn.apply(xg, wg, bg, stride, do_abs, pool, slope, False)
     assert_close(out, ref, 2e-5, "fwd")
@@ -125,7 +135,7 @@ def test_wconv_bwd(ops, case):
     assert_grad_close(wg.grad, w.grad, 1e-4, "dW %s" % (case,))
     if bias is not None:
         assert_grad_close(bg.grad, bias.grad, 1e-4, "dbias")
-    if stride == 1:
+    if want_dx:
         assert_grad_close(xg.grad, x.grad, 1e-4, "dx %s" % (case,))
 
 
