@@ -82,20 +82,22 @@ __device__ __forceinline__ void split_f16x2(float x, unsigned short (&h)[2]) {
   h[1] = __builtin_bit_cast(unsigned short, (_Float16)((x - hi) * F16X2_LO_SCALE));     // x - hi is exact
 }
 
-// The same pair under the rule "round to fp16, then flush fp16 denormals to (signed) zero" — what v_cvt_pk_f16_f32 returns
-// when MODE.FP_DENORM[7:6] = 0, written with integer operations for kernels that run in the default (denormal-keeping)
-// mode.  hi differs from split_f16x2's only for |x| in [2^-14 (1 - 2^-12), 2^-14), which rounds UP to the smallest normal
-// here and is zeroed there; lo loses the values below 2^-25 (absolute error <= 3e-8).  Both are valid f16x2 pairs for every
-// consumer; the rule exists so that the recurrence's dropout + pool epilogue (slu_gru_bf16.hip, which runs in flush mode
-// and splits with two packed conversions) and dropout_pool_fwd4_kernel write IDENTICAL planes.
-__device__ __forceinline__ unsigned short f16_flush_denorm(unsigned short h) {
-  return (h & 0x7C00u) ? h : (unsigned short)(h & 0x8000u);
+// The same pair under the rule v_cvt_pk_f16_f32 follows when MODE.FP_DENORM[7:6] = 0 (fp16 denormal results flushed): a
+// value whose magnitude is below 2^-14 BEFORE rounding becomes a signed zero — also one that would round up to the smallest
+// normal (measured: post-rounding emulation differed from the hardware in 2 of 39 M elements) —, everything else is the
+// round-to-nearest-even conversion.  Written with a compare + select for kernels that run in the default (denormal-keeping)
+// mode.  hi equals split_f16x2's up to the sign of a flushed zero; lo loses the values below 2^-25 (absolute error
+// <= 3e-8).  Both are valid f16x2 pairs for every consumer; the rule exists so that the recurrence's dropout + pool
+// epilogue (slu_gru_bf16.hip, which runs in flush mode and splits with two packed conversions) and
+// dropout_pool_fwd4_kernel write IDENTICAL planes.
+__device__ __forceinline__ unsigned short f16_cvt_flush(float x) {
+  const unsigned short h = __builtin_bit_cast(unsigned short, (_Float16)x);
+  return __builtin_fabsf(x) >= F16_MIN_NORMAL ? h : (unsigned short)(h & 0x8000u);
 }
 __device__ __forceinline__ void split_f16x2_flush(float x, unsigned short (&h)[2]) {
-  const _Float16 hi = (_Float16)x;
-  h[0] = f16_flush_denorm(__builtin_bit_cast(unsigned short, hi));
+  h[0] = f16_cvt_flush(x);
   const float hf = (float)__builtin_bit_cast(_Float16, h[0]);
-  h[1] = f16_flush_denorm(__builtin_bit_cast(unsigned short, (_Float16)((x - hf) * F16X2_LO_SCALE)));
+  h[1] = f16_cvt_flush((x - hf) * F16X2_LO_SCALE);
 }
 
 // the NS terms of scheme NS

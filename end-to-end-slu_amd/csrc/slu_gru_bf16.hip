@@ -362,6 +362,50 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 
     // ---- C: W_hh h_{t-1} (h plane = PA(q), W plane = PB(q)), gates, h_t ----
     const unsigned char* hc = hbuf + cur * (NS * 16 * ROWB);
+    float hn[4];
+    if constexpr (GO && NS == 2) {
+      // Interleaved schedule (VAR bit 0).  Gate-outer product order: r's twelve MFMAs, then z's, then n's — r's
+      // accumulators are complete after the first third, z's after the second.  The two waves of a SIMD share its matrix
+      // pipe, so a wave's own MFMAs leave every ~32 cycles: each of z's MFMAs is followed by a slice of r's gate
+      // arithmetic (fold, scale, exp2, +1, rcp over the lane's four elements), each of n's by a slice of z's, pinned in
+      // this order by sched_barrier — the arithmetic that used to run after the last product runs in the matrix pipe's
+      // shadow; only n's tanh, the blend and the split of h remain behind it.
+      constexpr int PG = KC * SP::NPAIR;          // MFMAs per gate (12)
+      static_assert(PG == 12, "the slices below are written for 12 MFMAs per gate");
+      uint4 fa[KC][NS];
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) fa[c][pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
+#pragma unroll
+      for (int k = 0; k < PG; ++k)
+        accs[SP::ACC(k % SP::NPAIR)][0] = mfma_split<NS>(wb[0][k / SP::NPAIR][SP::PB(k % SP::NPAIR)],
+                                                         fa[k / SP::NPAIR][SP::PA(k % SP::NPAIR)], accs[SP::ACC(k % SP::NPAIR)][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      float sg[2][4];                             // sigmoid chains of r (0) and z (1): x -> exp2(-x log2e) -> 1 + . -> rcp
+      auto slice = [&](int gate, int k) {         // slice k (0..11) of a gate's four sigmoid chains
+        const int e = k & 3;
+        if (k < 4) sg[gate][e] = -1.4426950408889634f * __builtin_fmaf(accs[1][gate][e], F16X2_LO_INV, accs[0][gate][e]);
+        else if (k < 8) sg[gate][e] = 1.0f + __builtin_amdgcn_exp2f(sg[gate][e]);
+        else sg[gate][e] = __builtin_amdgcn_rcpf(sg[gate][e]);
+      };
+#pragma unroll
+      for (int g = 1; g < 3; ++g) {
+#pragma unroll
+        for (int k = 0; k < PG; ++k) {
+          accs[SP::ACC(k % SP::NPAIR)][g] = mfma_split<NS>(wb[g][k / SP::NPAIR][SP::PB(k % SP::NPAIR)],
+                                                           fa[k / SP::NPAIR][SP::PA(k % SP::NPAIR)], accs[SP::ACC(k % SP::NPAIR)][g]);
+          slice(g - 1, k);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float q = __builtin_fmaf(accs[1][2][r], F16X2_LO_INV, accs[0][2][r]);
+        const float nn = bf_tanh(gn[r] + sg[0][r] * q);
+        hn[r] = nn + sg[1][r] * (hprev[r] - nn);
+      }
+    } else {
     if constexpr (GO) {
       uint4 fa[KC][NS];
 #pragma unroll
@@ -392,13 +436,13 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) acc[g] = split_result<NS>(accs[0][g], accs[SP::NACC - 1][g]);
 
-    float hn[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float rr = bf_sigmoid(acc[0][r]);
       const float zz = bf_sigmoid(acc[1][r]);
       const float nn = bf_tanh(gn[r] + rr * acc[2][r]);
       hn[r] = nn + zz * (hprev[r] - nn);
+    }
     }
     // h_t -> LDS as NS planes: four consecutive units = one 8-byte store per plane
     {

@@ -475,6 +475,39 @@ class DecoderRNN(torch.nn.Module):
     def cells(self):
         return [l for l in self.layers if isinstance(l, torch.nn.GRUCell)]
 
+    def forward(self, input, previous_state):
+        """input (B, input_size), previous_state (B, num_layers, hidden) -> the new state (B, num_layers, hidden)
+        (reference models.py:459-484: each GRUCell takes the previous cell's output through the Dropout between them; the
+        Dropout behind the last cell does not reach the returned state).  On the HIP cell kernels (ops.decoder_step's:
+        slu_gemm_small_batched + slu_gru_cell_fwd).  A stand-alone call is a forward evaluation: NO gradient flows through
+        it — the decoder is trained through Seq2SeqDecoder.forward, whose autograd Function owns the backward kernels —
+        so tensors that require a gradient are refused instead of being silently detached."""
+        _require_device(input)
+        if torch.is_grad_enabled() and (input.requires_grad or previous_state.requires_grad):
+            raise NotImplementedError("DecoderRNN.forward is a forward evaluation on the HIP kernels: call it under "
+                                      "torch.no_grad() or with detached tensors (Seq2SeqDecoder.forward trains the decoder)")
+        cells = self.cells()
+        Lc, Dd = len(cells), cells[0].hidden_size
+        with torch.no_grad():
+            x_in = input.detach().float().contiguous()
+            prev = previous_state.detach().float().contiguous()
+            B = x_in.shape[0]
+            dev = x_in.device
+            state = torch.empty(B, Lc, Dd, dtype=torch.float32, device=dev)
+            seed = _DropoutState.seed if _DropoutState.seed is not None else torch.initial_seed()
+            offset = _DropoutState.current * 16 + _DECODER_SITE
+            for l, cell in enumerate(cells):
+                gi = torch.empty(B, 3 * Dd, dtype=torch.float32, device=dev)
+                gh = torch.empty(B, 3 * Dd, dtype=torch.float32, device=dev)
+                _ops.gemm_small_batched([(x_in, cell.weight_ih.detach(), cell.bias_ih.detach(), gi, 0, 0),
+                                         (prev[:, l], cell.weight_hh.detach(), cell.bias_hh.detach(), gh, 0, 0)])
+                p = self.dropout if (self.training and l < Lc - 1) else 0.0
+                drop = torch.empty(B, Dd, dtype=torch.float32, device=dev) if p > 0.0 else None
+                _ops.gru_cell_fwd(gi, gh, prev[:, l], state[:, l], None, drop, None, p, seed & 0xFFFFFFFFFFFFFFFF, offset,
+                                  None, l * B * Dd)
+                x_in = drop if drop is not None else state[:, l]
+        return state
+
 
 def sort_beam(beam_extensions, beam_extension_scores, beam_pointers):
     """Order the candidate extensions of every utterance by score, descending (reference models.py:487-502).

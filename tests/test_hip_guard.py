@@ -106,7 +106,9 @@ def test_default_arithmetic_over_the_input_dynamic_range_vs_oracle(tmp_path, mon
 
 def _assert_as_close_as_exact_fp32(monkeypatch, pm, x, ref, got, slack=0.002):
     """For ill-conditioned inputs (saturated gates): the default arithmetic must deviate from the oracle on no more elements
-    than the package's exact fp32 kernels (SLU_FROZEN_MATH=fp32) do, and equal the explicit bf16x3 mode bit for bit."""
+    than the package's exact fp32 kernels (SLU_FROZEN_MATH=fp32) do, and — when the guard switched the model to bf16x3 —
+    equal the explicit bf16x3 mode bit for bit."""
+    switched = getattr(pm, "_f16x2_pin", None) is not None or not pm.f16x2_allowed()
     monkeypatch.setenv("SLU_FROZEN_MATH", "fp32")
     with torch.no_grad():
         exact = pm.compute_features(x).float().cpu()
@@ -116,7 +118,7 @@ def _assert_as_close_as_exact_fp32(monkeypatch, pm, x, ref, got, slack=0.002):
     monkeypatch.delenv("SLU_FROZEN_MATH")
     frac = lambda a: ((a - ref).abs() > TOL).float().mean().item()
     print("   fraction of features further than 1e-4 from the oracle: default %.4f, exact fp32 kernels %.4f" % (frac(got), frac(exact)))
-    assert torch.equal(b3, got)
+    assert not switched or torch.equal(b3, got)
     assert frac(got) <= 2.0 * frac(exact) + slack
 
 

@@ -302,6 +302,33 @@ def _train_seq2seq(cfg, loader, monkeypatch, lookahead, graphs, n_steps, seed=3)
     return trainer, losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
 
+def test_decoder_rnn_forward_vs_torch_cells(models_mod):
+    """DecoderRNN.forward(input, previous_state) (reference models.py:459-484: the GRUCell stack, Dropout between the
+    cells) on the HIP cell kernels against the same torch.nn.GRUCell parameters evaluated by ATen on the CPU, eval mode;
+    train mode drops ~p of the inter-cell activations (the last cell's state is what the reference returns: untouched by
+    the Dropout behind it); tensors that require a gradient are refused (training goes through Seq2SeqDecoder)."""
+    torch.manual_seed(3)
+    dec = models_mod.DecoderRNN(3, 64, 40, 0.5).cuda().eval()
+    x, prev = torch.randn(5, 40), torch.randn(5, 3, 64)
+    got = dec(x.cuda(), prev.cuda()).cpu()
+    cpu = [c.cpu() for c in dec.cells()]
+    want, h = [], x
+    with torch.no_grad():
+        for l, cell in enumerate(cpu):
+            h = torch.nn.GRUCell(cell.input_size, cell.hidden_size)
+            h.load_state_dict(cell.state_dict())
+            out = h(x if l == 0 else want[-1], prev[:, l])
+            want.append(out)
+    want = torch.stack(want, dim=1)
+    assert got.shape == (5, 3, 64) and (got - want).abs().max().item() <= 2e-6
+    dec.train()
+    models_mod.set_dropout_seed(11)
+    tr = dec(x.cuda(), prev.cuda()).cpu()
+    assert torch.equal(tr[:, 0], got[:, 0]) and not torch.equal(tr[:, 1], got[:, 1])        # layer 1 sees dropped inputs
+    with pytest.raises(NotImplementedError):
+        dec(x.cuda().requires_grad_(), prev.cuda())
+
+
 def test_seq2seq_training_loops(models_mod, tmp_path, monkeypatch):
     """Trainer on the seq2seq model: the hipGraph-captured step and the look-ahead pipeline (frozen pre-trained
     encoder, seq2seq encoder + decoder trained) give the eager sequential loop's losses and parameters bit for bit;

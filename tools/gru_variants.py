@@ -72,6 +72,12 @@ def check(T, B, I, sub):
             one_f = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, ns, keep, p, False)
             one_p = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, ns, keep, p, True).planes
             line += " | pool p=%.1f fp32 %s planes %s" % (p, torch.equal(one_f, two_f), torch.equal(one_p.view(torch.int16), two_p.view(torch.int16)))
+            if not torch.equal(one_p.view(torch.int16), two_p.view(torch.int16)):
+                bad = (one_p.view(torch.int16) != two_p.view(torch.int16))
+                idx = bad.nonzero()[:4]
+                line += " (planes: %d of %d differ, e.g. %s -> fused %s vs two-launch %s)" % (
+                    int(bad.sum()), bad.numel(), idx.tolist(), [hex(int(one_p.view(torch.int16)[tuple(i)]) & 0xffff) for i in idx],
+                    [hex(int(two_p.view(torch.int16)[tuple(i)]) & 0xffff) for i in idx])
             if not torch.equal(one_f, two_f):
                 d = (one_f - two_f).abs()
                 line += " (max %.2e, %d of %d differ)" % (d.max().item(), int((d > 0).sum()), d.numel())
