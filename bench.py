@@ -382,18 +382,38 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
             br = gru.bias_hh_l0_reverse.detach() if D == 2 else None
             gx = torch.randn(T, B, N, device=dev)
             fused_in = bool(ns) and is_frozen and ops.gru_fused_input_ok(I, H, D, ns)
+            # Dropout + Downsample(avg, 2) in the recurrence's epilogue (round 4): the layer's launch writes the pooled output
+            # (the next frozen layer's 16-bit planes, or fp32 for the trainable part) from a 1-bit mask drawn by a small launch
+            nxt = stages[si + 1] if si + 1 < len(stages) else None
+            nxt_frozen = (nxt is not None and hasattr(nxt, "gru") and si + 1 < n_prefix
+                          and not any(q.requires_grad for q in nxt.gru.parameters()))
+            pool_fused = bool(ns) and is_frozen and ops.gru_pool_fused_ok(H, D, T, st.p, None, st.method, st.factor)
+            T_out = -(-T // st.factor)
+            if pool_fused:
+                keep = ops.dropout_bits(T, B, D * H, st.p, 1234, 16 + st.site, None, batch if B > batch else 0, dev) if st.p > 0 else None
+                if keep is not None:
+                    ms = _timed_graph(lambda: ops.dropout_bits(T, B, D * H, st.p, 1234, 16 + st.site, None, batch if B > batch else 0, dev), stream)
+                    rows.setdefault("dropout_bits_kernel", []).append(
+                        {"shape": "T=%d B=%d C=%d keep bits (%s)" % (T, B, D * H, where), "flops": 0.0, "ms": ms,
+                         "mfma_mult": 1.0, "peak": PEAK_FP32_MFMA_TFLOPS, "bytes": T * B * D * H / 8.0})
+                out_bytes = (2.0 * ns if nxt_frozen else 4.0) * T_out * B * D * H + (T * B * D * H / 8.0 if keep is not None else 0.0)
             if fused_in:
                 # the first frozen GRU layer (K = 60): the recurrence computes x W_ih^T + b_ih itself (no projection
                 # launch, no gx round trip): flops of both contractions, bytes = the input planes + the output
                 planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
                 mult = MFMA_PRODUCTS[ns]
-                ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(None, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
-                                                               T, B, H, D, ns, False, fused=(planes, I, packed, b_ih)), stream)
+                if pool_fused:
+                    ms = _timed_graph(lambda: ops.gru_seq_fwd_pool_bf16(None, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                                        T, B, H, D, ns, keep, st.p, nxt_frozen,
+                                                                        fused=(planes, I, packed, b_ih)), stream)
+                else:
+                    ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(None, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                                   T, B, H, D, ns, False, fused=(planes, I, packed, b_ih)), stream)
                 rows.setdefault("gru_bf_fwd_kernel<%d,%d>" % (H, ns), []).append(
-                    {"shape": "T=%d B=%d H=%d D=%d K=%d fused input projection (%s)" % (T, B, H, D, I, where),
+                    {"shape": "T=%d B=%d H=%d D=%d K=%d fused input projection%s (%s)" % (T, B, H, D, I, " + dropout/pool epilogue" if pool_fused else "", where),
                      "flops": 2.0 * B * H * 3 * H * D * T + 2.0 * T * B * N * I, "ms": ms,
                      "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
-                     "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + 4.0 * (T * B * D * H + D * 3 * H * H) + 2.0 * ns * N * ops.round_up(I, 32)})
+                     "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + (out_bytes if pool_fused else 4.0 * T * B * D * H) + 4.0 * D * 3 * H * H + 2.0 * ns * N * ops.round_up(I, 32)})
             elif ns:
                 planes, packed = ops.split_bf16(x, ns), ops.gemm_bf16_pack(w_ih, ns)
                 mult = MFMA_PRODUCTS[ns]
@@ -410,11 +430,17 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                     {"shape": "M=%d N=%d K=%d input projection, %d 16-bit plane(s) (%s)" % (T * B, N, I, ns, where),
                      "flops": 2.0 * T * B * N * I, "ms": ms, "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
                      "bytes": 2.0 * ns * T * B * ops.round_up(I, 32) + 2.0 * ns * N * ops.round_up(I, 32) + 4.0 * T * B * N})
-                ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
-                                                               T, B, H, D, ns, not is_frozen), stream)
+                if pool_fused:
+                    ms = _timed_graph(lambda: ops.gru_seq_fwd_pool_bf16(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                                        T, B, H, D, ns, keep, st.p, nxt_frozen), stream)
+                else:
+                    ms = _timed_graph(lambda: ops.gru_seq_fwd_bf16(gx, gru.weight_hh_l0.detach(), wr, gru.bias_hh_l0.detach(), br,
+                                                                   T, B, H, D, ns, not is_frozen), stream)
                 rows.setdefault("gru_bf_fwd_kernel<%d,%d>" % (H, ns), []).append(
-                    {"shape": "T=%d B=%d H=%d D=%d (%s)" % (T, B, H, D, where), "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
-                     "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS, "bytes": 4.0 * (T * B * N + T * B * D * H + D * 3 * H * H)})
+                    {"shape": "T=%d B=%d H=%d D=%d%s (%s)" % (T, B, H, D, " + dropout/pool epilogue" if pool_fused else "", where),
+                     "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
+                     "mfma_mult": mult, "peak": PEAK_BF16_MFMA_TFLOPS,
+                     "bytes": 4.0 * T * B * N + (out_bytes if pool_fused else 4.0 * T * B * D * H) + 4.0 * D * 3 * H * H})
             else:
                 ms = _timed_graph(lambda: ops.gemm(x, w_ih.t(), b_ih), stream)
                 rows.setdefault("gemm_f32_kernel<true,true,2>", []).append(
@@ -425,8 +451,9 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                 rows.setdefault("gru_seq_fwd4_kernel<%d>" % H, []).append(
                     {"shape": "T=%d B=%d H=%d D=%d (%s)" % (T, B, H, D, where), "flops": 2.0 * B * H * 3 * H * D * T, "ms": ms,
                      "mfma_mult": 1.0, "peak": PEAK_FP32_MFMA_TFLOPS, "bytes": 4.0 * (T * B * N + T * B * D * H + D * 3 * H * H)})
-            # Dropout + Downsample after the layer (frozen -> frozen hand-off writes bf16 planes)
-            if st.p > 0.0 or st.factor > 1:
+            # Dropout + Downsample after the layer as launches of their own (trainable layers; pooling modes the epilogue
+            # does not cover): frozen -> frozen hand-off writes bf16 planes
+            if (st.p > 0.0 or st.factor > 1) and not (bool(ns) and is_frozen and ops.gru_pool_fused_ok(H, D, T, st.p, None, st.method, st.factor)):
                 nxt = stages[si + 1] if si + 1 < len(stages) else None
                 nxt_frozen = (nxt is not None and hasattr(nxt, "gru") and si + 1 < n_prefix
                               and not any(q.requires_grad for q in nxt.gru.parameters()))
@@ -562,6 +589,116 @@ def host_inputs_point(model, trainer, batches, steps, asr):
     return {"utterances_per_s": round(len(host[0][0]) * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
             "h2d_bytes_per_step": nbytes, "h2d_gb_per_s": round(nbytes * steps / dt / 1e9, 2),
             "note": "pinned host batches, H2D inside the timed region; `value` is quoted with inputs resident in HBM"}
+
+
+def feature_parity(model, config, batch, samples, n_batches=16):
+    """Encoder features of ONE look-ahead super-batch (n_batches x batch utterances: 1024 x 3 s by default) in eval mode
+    against the CPU oracle, for each arithmetic of the frozen stages — the number that tells the three modes apart (the
+    16 x 1 s golden logits agree to one ulp in all of them).  The oracle runs once (a few seconds of host time)."""
+    import models
+    from oracle import slu_oracle as O
+    pm = model.pretrained_model
+    g = torch.Generator().manual_seed(4321)
+    x = 0.1 * torch.randn(n_batches * batch, samples, generator=g)
+    sd = {k: v.detach().cpu() for k, v in pm.state_dict().items()}
+    was_training = model.training
+    model.eval()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = O.encoder_stages(sd, x, config, None, explicit_gru=False)["features"]
+    cpu_s = time.perf_counter() - t0
+    out = {"utterances": n_batches * batch, "samples": samples, "oracle_cpu_s": round(cpu_s, 1), "max_abs_dev": {}}
+    old = os.environ.get("SLU_FROZEN_MATH")
+    xd = x.cuda()
+    try:
+        for mode in ("auto", "bf16x3", "fp32"):
+            os.environ["SLU_FROZEN_MATH"] = mode
+            with torch.no_grad():
+                got = pm.compute_features(xd).float().cpu()
+            label = mode if mode != "auto" else "default (f16x2 under the range guard)"
+            out["max_abs_dev"][label] = float((got - ref).abs().max())
+        out["guard_trips"] = pm.range_guard().trips
+        out["frozen_arithmetic_after"] = {2: "f16x2", 3: "bf16x3"}.get(models.guarded_frozen_nsplit(model))
+    finally:
+        if old is None:
+            os.environ.pop("SLU_FROZEN_MATH", None)
+        else:
+            os.environ["SLU_FROZEN_MATH"] = old
+        model.train(was_training)
+    del xd
+    return out
+
+
+def frontend_fwd_point(model, config, batch, samples):
+    """BASELINE.json configs[1]: the SincNet + Conv1d front end of the phoneme module alone (reference models.py:77-110,
+    180-220: sinc -> abs -> pool -> LeakyReLU -> conv -> LeakyReLU -> conv -> LeakyReLU), B = 64 x 3 s, forward only, on
+    the whole device: time per batch, utterances/s, algorithmic HBM GB/s (waveform in + conv2 output out = SURVEY 8(d)'s
+    minimum for these stages) and MFMA rate, in the default arithmetic of frozen stages and on the exact fp32 kernels,
+    with the CPU oracle's front end timed beside it."""
+    import copy
+    import models
+    from oracle import slu_oracle as O
+    pm = model.pretrained_model
+    n_cnn = len(pm._cnn_stages)
+    g = torch.Generator().manual_seed(99)
+    x = 0.1 * torch.randn(batch, samples, generator=g)
+    xd = x.cuda()
+    stream = torch.cuda.Stream()
+    l_out = samples
+    flops = 0.0
+    c_prev = 1
+    for k, st in enumerate(pm._cnn_stages):
+        conv = st.conv
+        c_out = conv.N_filt if st.is_sinc else conv.out_channels
+        k_t = conv.Filt_dim if st.is_sinc else conv.kernel_size
+        l_conv = (l_out + 2 * (k_t // 2) - k_t) // conv.stride + 1
+        flops += 2.0 * batch * l_conv * c_out * k_t * c_prev
+        l_out, c_prev = -(-l_conv // st.pool), c_out
+    nbytes = 4.0 * batch * samples + 4.0 * batch * l_out * c_prev
+    was_training = model.training
+    model.eval()
+    res = {"workload": "SincNet + Conv1d front end of the phoneme module, forward only, B=%d x %.0f s (BASELINE configs[1])" % (batch, samples / 16000.0),
+           "algorithmic_gflop": round(flops / 1e9, 3), "algorithmic_MB": round(nbytes / 1e6, 2)}
+    old = os.environ.get("SLU_FROZEN_MATH")
+    try:
+        for mode, label in (("auto", "default"), ("fp32", "exact_fp32")):
+            os.environ["SLU_FROZEN_MATH"] = mode
+            with torch.no_grad():
+                if mode == "auto":
+                    scope = models.frozen_math_scope(pm.range_guard() if pm.f16x2_allowed() else None)
+                else:
+                    scope = models.frozen_math_scope(None)
+                with scope:
+                    ms = _timed_graph(lambda: pm._run_stages(xd, 0, n_cnn), stream)
+            res[label] = {"ms": round(ms, 4), "utterances_per_s": round(batch / (ms * 1e-3), 1),
+                          "algorithmic_hbm_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                          "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                          "frac_of_fp16_mfma_peak" if mode == "auto" else "frac_of_fp32_mfma_peak":
+                              round(flops * (MFMA_PRODUCTS[2] if mode == "auto" else 1.0) / (ms * 1e-3) / 1e12
+                                    / (PEAK_BF16_MFMA_TFLOPS if mode == "auto" else PEAK_FP32_MFMA_TFLOPS), 4)}
+    finally:
+        if old is None:
+            os.environ.pop("SLU_FROZEN_MATH", None)
+        else:
+            os.environ["SLU_FROZEN_MATH"] = old
+        model.train(was_training)
+    # the oracle's front end on the host cores: the same three blocks (an encoder config without RNN layers)
+    cfg = copy.copy(config)
+    cfg.phone_rnn_num_hidden, cfg.word_rnn_num_hidden = [], []
+    sd = {k: v.detach().cpu() for k, v in pm.state_dict().items()}
+    n_thr = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(n_thr)
+    with torch.no_grad():
+        O.encoder_stages(sd, x, cfg, None, upto="phoneme_features")
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            O.encoder_stages(sd, x, cfg, None, upto="phoneme_features")
+        cpu_ms = 1e3 * (time.perf_counter() - t0) / reps
+    res["cpu"] = {"ms": round(cpu_ms, 2), "utterances_per_s": round(batch / (cpu_ms * 1e-3), 1), "threads": n_thr,
+                  "algorithmic_hbm_gbs": round(nbytes / (cpu_ms * 1e-3) / 1e9, 2),
+                  "kind": "oracle (torch CPU, one conv per Sinc forward)"}
+    return res
 
 
 def large_batch_point(rank, samples, batch=2048, steps=3):
@@ -848,6 +985,16 @@ def main():
         if default_line:
             note("host-input point")
             out["host_inputs"] = host_inputs_point(model, trainer, batches, max(args.steps, 256), asr)
+            note("feature parity of a super-batch, per arithmetic")
+            try:
+                out["parity"]["features_vs_oracle"] = feature_parity(model, config, args.batch, samples)
+            except Exception as e:                           # a side measurement never takes the headline down
+                out["parity"]["features_vs_oracle"] = {"error": str(e)[:200]}
+            note("front end forward (configs[1])")
+            try:
+                out.setdefault("other_workloads", {})["frontend_fwd"] = frontend_fwd_point(model, config, args.batch, samples)
+            except Exception as e:
+                out.setdefault("other_workloads", {})["frontend_fwd"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline and not asr:
             note("cpu baseline")
             out["cpu_baseline"] = (cpu_baseline_seq2seq(config, args.batch, samples) if args.workload == "seq2seq"
@@ -862,7 +1009,7 @@ def main():
             note("side run: frozen stages on bf16x3")
             out["frozen_bf16x3"] = side_run(common, {"SLU_FROZEN_MATH": "bf16x3"})
             short = ["--steps", "40", "--warmup", "10", "--batch", str(args.batch), "--seconds", str(args.seconds)]
-            out["other_workloads"] = {w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain", "seq2seq")}
+            out.setdefault("other_workloads", {}).update({w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain", "seq2seq")})
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -82,17 +82,18 @@ __device__ __forceinline__ void split_f16x2(float x, unsigned short (&h)[2]) {
   h[1] = __builtin_bit_cast(unsigned short, (_Float16)((x - hi) * F16X2_LO_SCALE));     // x - hi is exact
 }
 
-// The same pair under the rule v_cvt_pk_f16_f32 follows when MODE.FP_DENORM[7:6] = 0 (fp16 denormal results flushed): a
-// value whose magnitude is below 2^-14 BEFORE rounding becomes a signed zero — also one that would round up to the smallest
-// normal (measured: post-rounding emulation differed from the hardware in 2 of 39 M elements) —, everything else is the
-// round-to-nearest-even conversion.  Written with a compare + select for kernels that run in the default (denormal-keeping)
-// mode.  hi equals split_f16x2's up to the sign of a flushed zero; lo loses the values below 2^-25 (absolute error
-// <= 3e-8).  Both are valid f16x2 pairs for every consumer; the rule exists so that the recurrence's dropout + pool
-// epilogue (slu_gru_bf16.hip, which runs in flush mode and splits with two packed conversions) and
-// dropout_pool_fwd4_kernel write IDENTICAL planes.
+// The same pair under the rule v_cvt_pk_f16_f32 follows when MODE.FP_DENORM[7:6] = 0 (fp16 denormal results flushed).
+// Measured exhaustively over all 2^32 inputs (tools/probes/f16_flush_probe.cpp): tininess is detected AFTER rounding to 11
+// bits with an unbounded exponent — |x| >= 2^-14 - 2^-26 (bit pattern 0x387FF000) rounds up to the smallest normal and is
+// kept, anything smaller becomes a signed zero (flushing the denormal of the default-mode conversion would keep 4096 more
+// patterns per sign, flushing every |x| < 2^-14 4096 fewer).  Written with a compare + select for kernels that run in the
+// default (denormal-keeping) mode.  hi differs from split_f16x2's only on those 4096 patterns and in the sign of a flushed
+// zero; lo loses the values below 2^-25 (absolute error <= 3e-8).  Both are valid f16x2 pairs for every consumer; the rule
+// exists so that the recurrence's dropout + pool epilogue (slu_gru_bf16.hip, which runs in flush mode and splits with two
+// packed conversions) and dropout_pool_fwd4_kernel write IDENTICAL planes.
 __device__ __forceinline__ unsigned short f16_cvt_flush(float x) {
   const unsigned short h = __builtin_bit_cast(unsigned short, (_Float16)x);
-  return __builtin_fabsf(x) >= F16_MIN_NORMAL ? h : (unsigned short)(h & 0x8000u);
+  return (__float_as_uint(x) & 0x7fffffffu) >= 0x387FF000u ? h : (unsigned short)(h & 0x8000u);
 }
 __device__ __forceinline__ void split_f16x2_flush(float x, unsigned short (&h)[2]) {
   h[0] = f16_cvt_flush(x);

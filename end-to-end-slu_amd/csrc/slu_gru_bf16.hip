@@ -23,7 +23,6 @@
 // The keep bits come from slu_dropout_bits (one bit per element, drawn with the element -> counter map of
 // dropout_pool_fwd4_kernel: the fused and the two-launch paths produce identical bits).
 #include "slu_bf16.h"
-#include <stdlib.h>
 
 namespace slu {
 
@@ -99,8 +98,8 @@ struct GruBfParams {
 //   C. h fragments from LDS, 36 (f16x2) MFMAs, gate math, split h to LDS, output to its staging tile;
 //   D. the gx rows requested in B go to their staging tile; barrier (LDS only).
 // Gate arithmetic (fp32-class, not the operation order of round 3): the blend is n + z (h - n), the f16x2 split of h uses
-// split_f16x2_pair_flush.
-// VAR: bit 0 = gate-outer MFMA order (scheduling experiment, identical results).
+// split_f16x2_pair_flush.  (Measured and not kept, DESIGN.md section 7: gate-outer MFMA order with the r / z gate arithmetic
+// interleaved between the remaining MFMAs; static wave priorities.)
 template <int H, int NS, int KI, int EPI>
 struct GruLds {
   static constexpr int ROWB = H * 2;                       // bytes per h row (one sequence, one plane)
@@ -114,13 +113,12 @@ struct GruLds {
   static constexpr int BYTES = HBUF + BIAS + GXS + OST;
 };
 
-template <int H, int NS, int KI, int EPI, int VAR>
+template <int H, int NS, int KI, int EPI>
 __global__ void __launch_bounds__(H * 4)
 gru_bf_fwd_kernel(const GruBfParams p) {
   constexpr int NW = H / 16;          // waves
   constexpr int KC = H / 32;          // 32-wide k-chunks
   constexpr int SLOTS = H / 8;        // 16-byte slots per h row
-  constexpr bool GO = (VAR & 1) != 0;
   constexpr bool BIAS_LDS = KI > 0;   // the fused kernel keeps its 24 bias values in LDS (register budget)
   typedef Split<NS> SP;
   typedef GruLds<H, NS, KI, EPI> LD;
@@ -363,74 +361,16 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     // ---- C: W_hh h_{t-1} (h plane = PA(q), W plane = PB(q)), gates, h_t ----
     const unsigned char* hc = hbuf + cur * (NS * 16 * ROWB);
     float hn[4];
-    if constexpr (GO && NS == 2) {
-      // Interleaved schedule (VAR bit 0).  Gate-outer product order: r's twelve MFMAs, then z's, then n's — r's
-      // accumulators are complete after the first third, z's after the second.  The two waves of a SIMD share its matrix
-      // pipe, so a wave's own MFMAs leave every ~32 cycles: each of z's MFMAs is followed by a slice of r's gate
-      // arithmetic (fold, scale, exp2, +1, rcp over the lane's four elements), each of n's by a slice of z's, pinned in
-      // this order by sched_barrier — the arithmetic that used to run after the last product runs in the matrix pipe's
-      // shadow; only n's tanh, the blend and the split of h remain behind it.
-      constexpr int PG = KC * SP::NPAIR;          // MFMAs per gate (12)
-      static_assert(PG == 12, "the slices below are written for 12 MFMAs per gate");
-      uint4 fa[KC][NS];
 #pragma unroll
-      for (int c = 0; c < KC; ++c)
+    for (int c = 0; c < KC; ++c) {
+      uint4 fa[NS];
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl) fa[c][pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
+      for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
 #pragma unroll
-      for (int k = 0; k < PG; ++k)
-        accs[SP::ACC(k % SP::NPAIR)][0] = mfma_split<NS>(wb[0][k / SP::NPAIR][SP::PB(k % SP::NPAIR)],
-                                                         fa[k / SP::NPAIR][SP::PA(k % SP::NPAIR)], accs[SP::ACC(k % SP::NPAIR)][0]);
-      __builtin_amdgcn_sched_barrier(0);
-      float sg[2][4];                             // sigmoid chains of r (0) and z (1): x -> exp2(-x log2e) -> 1 + . -> rcp
-      auto slice = [&](int gate, int k) {         // slice k (0..11) of a gate's four sigmoid chains
-        const int e = k & 3;
-        if (k < 4) sg[gate][e] = -1.4426950408889634f * __builtin_fmaf(accs[1][gate][e], F16X2_LO_INV, accs[0][gate][e]);
-        else if (k < 8) sg[gate][e] = 1.0f + __builtin_amdgcn_exp2f(sg[gate][e]);
-        else sg[gate][e] = __builtin_amdgcn_rcpf(sg[gate][e]);
-      };
+      for (int q = 0; q < SP::NPAIR; ++q)
 #pragma unroll
-      for (int g = 1; g < 3; ++g) {
-#pragma unroll
-        for (int k = 0; k < PG; ++k) {
-          accs[SP::ACC(k % SP::NPAIR)][g] = mfma_split<NS>(wb[g][k / SP::NPAIR][SP::PB(k % SP::NPAIR)],
-                                                           fa[k / SP::NPAIR][SP::PA(k % SP::NPAIR)], accs[SP::ACC(k % SP::NPAIR)][g]);
-          slice(g - 1, k);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float q = __builtin_fmaf(accs[1][2][r], F16X2_LO_INV, accs[0][2][r]);
-        const float nn = bf_tanh(gn[r] + sg[0][r] * q);
-        hn[r] = nn + sg[1][r] * (hprev[r] - nn);
-      }
-    } else {
-    if constexpr (GO) {
-      uint4 fa[KC][NS];
-#pragma unroll
-      for (int c = 0; c < KC; ++c)
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl) fa[c][pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int c = 0; c < KC; ++c)
-#pragma unroll
-          for (int q = 0; q < SP::NPAIR; ++q)
-            accs[SP::ACC(q)][g] = mfma_split<NS>(wb[g][c][SP::PB(q)], fa[c][SP::PA(q)], accs[SP::ACC(q)][g]);
-    } else {
-#pragma unroll
-      for (int c = 0; c < KC; ++c) {
-        uint4 fa[NS];
-#pragma unroll
-        for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(hc + pl * (16 * ROWB) + a_off[c]);
-#pragma unroll
-        for (int q = 0; q < SP::NPAIR; ++q)
-#pragma unroll
-          for (int g = 0; g < 3; ++g)
-            accs[SP::ACC(q)][g] = mfma_split<NS>(wb[g][c][SP::PB(q)], fa[SP::PA(q)], accs[SP::ACC(q)][g]);
-      }
+        for (int g = 0; g < 3; ++g)
+          accs[SP::ACC(q)][g] = mfma_split<NS>(wb[g][c][SP::PB(q)], fa[SP::PA(q)], accs[SP::ACC(q)][g]);
     }
     f32x4 acc[3];
 #pragma unroll
@@ -442,7 +382,6 @@ gru_bf_fwd_kernel(const GruBfParams p) {
       const float zz = bf_sigmoid(acc[1][r]);
       const float nn = bf_tanh(gn[r] + rr * acc[2][r]);
       hn[r] = nn + zz * (hprev[r] - nn);
-    }
     }
     // h_t -> LDS as NS planes: four consecutive units = one 8-byte store per plane
     {
@@ -667,30 +606,15 @@ gru_bf_fwd_rs_kernel(const GruBfParams p) {
   }
 }
 
-// scheduling variant of the frozen-layer launches (SLU_GRU_VARIANT, read once): A/B switch for tools/gru_variants.py;
-// the default is what the measurements of DESIGN.md section 7 selected
-static int gru_variant() {
-  const char* e = getenv("SLU_GRU_VARIANT");      // read per launch (a captured graph keeps the variant it was captured with)
-  return e ? atoi(e) & 1 : 0;
-}
-
-template <int H, int NS, int KI, int EPI, int VAR>
-static void gru_bf_launch_var(dim3 grid, hipStream_t st, const GruBfParams& p) {
+template <int H, int NS, int KI, int EPI>
+static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
   constexpr int lds = GruLds<H, NS, KI, EPI>::BYTES;
   static bool raised = false;      // > 64 KiB of dynamic LDS needs the function attribute (once per instantiation)
   if (lds > 64 * 1024 && !raised) {
-    (void)hipFuncSetAttribute((const void*)gru_bf_fwd_kernel<H, NS, KI, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gru_bf_fwd_kernel<H, NS, KI, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     raised = true;
   }
-  hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI, VAR>), grid, dim3(H * 4), lds, st, p);
-}
-
-template <int H, int NS, int KI, int EPI>
-static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
-  if constexpr (H == 128 && NS == 2) {
-    if (gru_variant() == 1) { gru_bf_launch_var<H, NS, KI, EPI, 1>(grid, st, p); return; }
-  }
-  gru_bf_launch_var<H, NS, KI, EPI, 0>(grid, st, p);
+  hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI>), grid, dim3(H * 4), lds, st, p);
 }
 
 template <int H, int EPI>

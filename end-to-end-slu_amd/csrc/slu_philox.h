@@ -38,17 +38,6 @@ __device__ __forceinline__ void philox_block(uint64_t seed, uint64_t offset, uin
 
 __device__ __forceinline__ float philox_to_uniform(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
-// philox_to_uniform(x) < thr as an integer comparison: (x >> 8) is exact in fp32 and so is the scaling by 2^-24, hence
-// u < thr  <=>  (x >> 8) < thr * 2^24  <=>  (x >> 8) < ceil(thr * 2^24) — the SAME keep decisions as philox_keep4, for
-// kernels that only need the bit (dropout_bits_kernel).  Returns n with: keep <=> (x >> 8) < n.
-__device__ __forceinline__ uint32_t philox_keep_threshold(float thr) {
-  const double t = (double)thr * 16777216.0;
-  if (t <= 0.0) return 0u;
-  if (t >= 16777216.0) return 16777216u;
-  const uint32_t f = (uint32_t)t;
-  return ((double)f < t) ? f + 1u : f;
-}
-
 // dropout keep factors (scale or 0) of elements idx .. idx + 3 (idx % 4 == 0) of the stream (seed, offset): element e
 // is kept iff its uniform draw is below thr = 1 - p.  The one formula every kernel that applies or re-derives a mask uses.
 __device__ __forceinline__ float4 philox_keep4(uint64_t seed, uint64_t offset, uint64_t idx, float thr, float scale) {

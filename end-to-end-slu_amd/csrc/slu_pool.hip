@@ -13,6 +13,7 @@ namespace slu {
 
 struct PoolParams {
   const float* mask; long long m_st, m_sb;
+  const unsigned* keep_bits;              // optional 1-bit mask (slu_dropout_bits): word (t*B + b) * C/32 + c/32, bit c % 32
   float p, scale;
   unsigned long long seed, offset;
   const unsigned long long* offset_dev;   // optional run-time addend (hipGraph replays)
@@ -26,6 +27,7 @@ struct PoolParams {
 __device__ __forceinline__ float keep_scale(const PoolParams& q, int t, int b, int c) {
   if (q.p <= 0.0f) return 1.0f;
   if (q.mask) return q.mask[(long long)t * q.m_st + (long long)b * q.m_sb + c] * q.scale;
+  if (q.keep_bits) return ((q.keep_bits[((size_t)t * q.B + b) * (q.C >> 5) + (c >> 5)] >> (c & 31)) & 1u) ? q.scale : 0.0f;
   uint64_t off = q.offset + (q.offset_dev ? *q.offset_dev : 0ull);
   uint64_t idx;
   if (q.sub_batch > 0) {
@@ -103,6 +105,10 @@ __device__ __forceinline__ float4 keep_scale4(const PoolParams& q, uint64_t off_
     const float* m = q.mask + (long long)t * q.m_st + (long long)b * q.m_sb + c;
     return make_float4(m[0] * q.scale, m[1] * q.scale, m[2] * q.scale, m[3] * q.scale);
   }
+  if (q.keep_bits) {          // c % 4 == 0: the four bits sit in one word
+    const unsigned m = q.keep_bits[((size_t)t * q.B + b) * (q.C >> 5) + (c >> 5)] >> (c & 31);
+    return make_float4((m & 1u) ? q.scale : 0.0f, (m & 2u) ? q.scale : 0.0f, (m & 4u) ? q.scale : 0.0f, (m & 8u) ? q.scale : 0.0f);
+  }
   uint64_t off = off_base;
   uint64_t idx;
   if (q.sub_batch > 0) {
@@ -171,37 +177,53 @@ dropout_pool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, uns
   }
 }
 
-// Keep bits of a whole (T, B, C) dropout mask, one bit per element: word (t, b, c / 32), bit c % 32 — drawn with exactly
-// the element -> Philox counter map of keep_scale4 (one block per four channels), so that a consumer applying these bits
-// (the recurrence epilogue of slu_gru_bf16.hip) drops the elements dropout_pool_fwd4_kernel drops.  grid: x over B*C/32
-// words, y over frames; eight Philox blocks per thread.  T*B*C/8 bytes: 9.8 MB for the T = 300 layer of a 1024-sequence
-// super-batch, against the 630 MB the fp32 output + re-read of the two-launch path moved.
+// The dropout mask of a FROZEN layer as a bit stream (one bit per element: word (t, b, c / 32), bit c % 32), consumed by the
+// recurrence's fused epilogue (slu_gru_bf16.hip) and, for pooling modes that epilogue does not cover, by the kernels above
+// (keep_bits) — one definition of a frozen layer's mask whichever path applies it.  Random bits are used economically:
+//   p == 0.5 and C % 128 == 0 (every layer of the reference cfgs): element (t, b, c) is kept iff bit c % 32 of word
+//     (c / 32) % 4 of the Philox block with counter (row * C/128 + c / 128, offset) is set — 128 elements per block, where the
+//     one-uniform-per-element rule of the trainable layers' kernels spends a block on four (the T = 300 mask of a
+//     1024-sequence super-batch: 111 us -> a few us on the look-ahead partition);
+//   otherwise: a 16-bit draw per element — element e = row * C + c is kept iff halfword e % 2 of word (e / 2) % 4 of block
+//     e / 8 is below round((1 - p) 2^16).
+// row = t * B + b, or t * sub_batch + (b % sub_batch) with the offset advanced by sub_stride per sub-batch (several steps'
+// frozen stages in one launch, each with its own step's stream).  grid: x over the (b, group) pairs, y over frames.
 __global__ void __launch_bounds__(256)
-dropout_bits_kernel(unsigned* __restrict__ bits, const PoolParams q) {
-  const int W = q.C >> 5;
+dropout_bits_kernel(unsigned* __restrict__ bits, const PoolParams q, const int half_mode, const unsigned thr16) {
+  const int G = half_mode ? (q.C >> 7) : (q.C >> 5);          // groups per row: 128 channels (one block) / 32 channels (one word)
   const unsigned e = blockIdx.x * 256u + threadIdx.x;
-  if (e >= (unsigned)q.B * W) return;
-  const int b = e / W, wd = e - b * W;
+  if (e >= (unsigned)q.B * G) return;
+  const int b = e / G, gi = e - b * G;
   const int t = blockIdx.y;
   uint64_t off = q.offset + (q.offset_dev ? *q.offset_dev : 0ull);
-  uint64_t idx;
+  uint64_t row;
   if (q.sub_batch > 0) {
     const int k = b / q.sub_batch, bl = b - k * q.sub_batch;
-    idx = ((uint64_t)t * q.sub_batch + bl) * q.C + wd * 32;
+    row = (uint64_t)t * q.sub_batch + bl;
     off += (uint64_t)k * q.sub_stride;
   } else {
-    idx = ((uint64_t)t * q.B + b) * q.C + wd * 32;
+    row = (uint64_t)t * q.B + b;
   }
-  const uint32_t thr = philox_keep_threshold(1.0f - q.p);
-  unsigned word = 0;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  unsigned* dst = bits + ((size_t)t * q.B + b) * (q.C >> 5);
+  if (half_mode) {
     uint32_t w4[4];
-    philox_block(q.seed, off, (idx >> 2) + k, w4);
+    philox_block(q.seed, off, row * G + gi, w4);
+    *reinterpret_cast<uint4*>(dst + gi * 4) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+  } else {
+    const uint64_t blk0 = (row * q.C + (uint64_t)gi * 32) >> 3;
+    unsigned word = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) word |= ((w4[j] >> 8) < thr ? 1u : 0u) << (4 * k + j);
+    for (int k = 0; k < 4; ++k) {
+      uint32_t w4[4];
+      philox_block(q.seed, off, blk0 + k, w4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        word |= ((w4[j] & 0xffffu) < thr16 ? 1u : 0u) << (8 * k + 2 * j);
+        word |= ((w4[j] >> 16) < thr16 ? 1u : 0u) << (8 * k + 2 * j + 1);
+      }
+    }
+    dst[gi] = word;
   }
-  bits[((size_t)t * q.B + b) * W + wd] = word;
 }
 
 // grid: x over B*C/4 quads, y over OUTPUT frames; a thread writes dx for every input frame of its window
@@ -288,7 +310,7 @@ pool_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, c
   for (int l = l0; l < l1; ++l) dx[((size_t)b * L + l) * C + c] = (l - l0 == arg) ? g : 0.0f;
 }
 
-static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t m_st, int64_t m_sb,
+static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t m_st, int64_t m_sb, const uint32_t* keep_bits,
                      float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                      int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, int64_t T,
                      int64_t B, int64_t C) {
@@ -297,7 +319,8 @@ static int pool_fill(PoolParams& q, const char* who, const float* mask, int64_t 
   SLU_REQUIRE(T > 0 && B > 0 && C > 0 && factor > 0, "%s: non-positive size", who);
   SLU_REQUIRE(method >= 0 && method <= 2, "%s: downsampling method must be 0 (none), 1 (avg) or 2 (max)", who);
   SLU_REQUIRE(p >= 0.0f && p < 1.0f, "%s: dropout p must be in [0,1)", who);
-  q.mask = mask; q.m_st = m_st; q.m_sb = m_sb; q.p = p; q.scale = 1.0f / (1.0f - p);
+  SLU_REQUIRE(!keep_bits || (!mask && C % 32 == 0), "%s: keep_bits excludes a float mask and needs C %% 32 == 0", who);
+  q.mask = mask; q.m_st = m_st; q.m_sb = m_sb; q.keep_bits = keep_bits; q.p = p; q.scale = 1.0f / (1.0f - p);
   q.seed = seed; q.offset = offset; q.offset_dev = (const unsigned long long*)offset_dev; q.method = method; q.factor = (int)factor;
   q.T = (int)T; q.B = (int)B; q.C = (int)C; q.T_out = (int)cdiv(T, factor);
   return SLU_OK;
@@ -315,14 +338,14 @@ static bool pool_vec_ok(const PoolParams& q, const float* a, const float* b, con
 
 using namespace slu;
 
-extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb,
+extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb, const uint32_t* keep_bits,
                                     float p, uint64_t seed, uint64_t offset,
                                     const uint64_t* offset_dev, int64_t sub_batch,
                                     uint64_t sub_stride, int method, int64_t factor, float* y,
                                     int64_t T, int64_t B, int64_t C, void* stream) {
   SLU_REQUIRE(x && y, "slu_dropout_pool_fwd: null pointer");
   PoolParams q;
-  int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
+  int rc = pool_fill(q, "slu_dropout_pool_fwd", mask, m_st, m_sb, keep_bits, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
   if (pool_vec_ok(q, x, y, mask)) {
     hipLaunchKernelGGL(dropout_pool_fwd4_kernel<0>, dim3((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out),
@@ -338,14 +361,14 @@ extern "C" int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m
 }
 
 extern "C" int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st, int64_t m_sb,
-                                           float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                           const uint32_t* keep_bits, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                            int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor,
                                            void* planes, int64_t plane_stride, int nsplit, int64_t T, int64_t B,
                                            int64_t C, void* stream) {
   SLU_REQUIRE(x && planes, "slu_dropout_pool_fwd_planes: null pointer");
   SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_dropout_pool_fwd_planes: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   PoolParams q;
-  int rc = pool_fill(q, "slu_dropout_pool_fwd_planes", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
+  int rc = pool_fill(q, "slu_dropout_pool_fwd_planes", mask, m_st, m_sb, keep_bits, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
   if (C % 32 != 0 || !pool_vec_ok(q, x, x, mask) || (reinterpret_cast<uintptr_t>(planes) & 15) || (plane_stride & 7))
     SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_dropout_pool_fwd_planes: needs C %% 32 == 0 (got %lld), aligned buffers, T_out <= 65535", (long long)C);
@@ -363,12 +386,15 @@ extern "C" int slu_dropout_bits(uint32_t* bits, float p, uint64_t seed, uint64_t
                                 int64_t sub_batch, uint64_t sub_stride, int64_t T, int64_t B, int64_t C, void* stream) {
   SLU_REQUIRE(bits, "slu_dropout_bits: null pointer");
   PoolParams q;
-  int rc = pool_fill(q, "slu_dropout_bits", nullptr, 0, 0, p, seed, offset, offset_dev, sub_batch, sub_stride, 1, 1, T, B, C);
+  int rc = pool_fill(q, "slu_dropout_bits", nullptr, 0, 0, nullptr, p, seed, offset, offset_dev, sub_batch, sub_stride, 1, 1, T, B, C);
   if (rc) return rc;
-  if (C % 32 != 0 || T > 65535 || B * (C / 32) >= (1LL << 31))
-    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_dropout_bits: needs C %% 32 == 0 (got %lld) and T <= 65535", (long long)C);
-  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)cdiv(B * (C / 32), 256), (unsigned)T), dim3(256), 0,
-                     (hipStream_t)stream, bits, q);
+  if (C % 32 != 0 || T > 65535 || B * (C / 32) >= (1LL << 31) || ((uintptr_t)bits & 15))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_dropout_bits: needs C %% 32 == 0 (got %lld), T <= 65535 and a 16-byte aligned buffer", (long long)C);
+  const int half_mode = (p == 0.5f && C % 128 == 0) ? 1 : 0;
+  const double t16 = (1.0 - (double)p) * 65536.0 + 0.5;
+  const unsigned thr16 = t16 >= 65536.0 ? 65536u : (unsigned)t16;
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)cdiv(B * (half_mode ? C / 128 : C / 32), 256), (unsigned)T), dim3(256), 0,
+                     (hipStream_t)stream, bits, q, half_mode, thr16);
   SLU_CHECK_LAUNCH("dropout_bits_kernel");
   return SLU_OK;
 }
@@ -383,7 +409,7 @@ extern "C" int slu_dropout_pool_bwd(const float* dy, const float* x, const float
   SLU_REQUIRE(method != 2 || x, "slu_dropout_pool_bwd: x is required for max pooling");
   (void)y;
   PoolParams q;
-  int rc = pool_fill(q, "slu_dropout_pool_bwd", mask, m_st, m_sb, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
+  int rc = pool_fill(q, "slu_dropout_pool_bwd", mask, m_st, m_sb, nullptr, p, seed, offset, offset_dev, sub_batch, sub_stride, method, factor, T, B, C);
   if (rc) return rc;
   if (pool_vec_ok(q, dy, dx, mask) && (method != 2 || (reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
     hipLaunchKernelGGL(dropout_pool_bwd4_kernel, dim3((unsigned)cdiv(B * (C / 4), 256), (unsigned)q.T_out),

@@ -91,9 +91,9 @@ SIGNATURES = {
     "slu_adam_advance_step": (c_int, [vp, c_u64, vp]),
     "slu_gru_seq_fwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
     "slu_gru_seq_bwd": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, vp]),
-    "slu_dropout_pool_fwd": (c_int, [vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_int,
+    "slu_dropout_pool_fwd": (c_int, [vp, vp, c_i64, c_i64, vp, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_int,
                                      c_i64, vp, c_i64, c_i64, c_i64, vp]),
-    "slu_dropout_pool_fwd_planes": (c_int, [vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_int,
+    "slu_dropout_pool_fwd_planes": (c_int, [vp, vp, c_i64, c_i64, vp, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_int,
                                             c_i64, vp, c_i64, c_int, c_i64, c_i64, c_i64, vp]),
     "slu_dropout_pool_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_f32, c_u64, c_u64, vp, c_i64, c_u64,
                                      c_int, c_i64, vp, c_i64, c_i64, c_i64, vp]),

@@ -564,14 +564,15 @@ class SplitAct:
         self.planes, self.T, self.B, self.C = planes, T, B, C
 
 
-def dropout_pool_fwd_planes(x, mask, p, seed, offset, method, factor, nsplit, offset_dev=None, sub_batch=0):
-    """dropout_pool_fwd whose result is written as split-precision planes (C % 32 == 0) -> SplitAct."""
+def dropout_pool_fwd_planes(x, mask, p, seed, offset, method, factor, nsplit, offset_dev=None, sub_batch=0, keep_bits=None):
+    """dropout_pool_fwd whose result is written as split-precision planes (C % 32 == 0) -> SplitAct.
+    keep_bits: the 1-bit mask of dropout_bits instead of in-kernel Philox draws (frozen layers)."""
     L = _lib.load()
     T, B, C = x.shape
     T_out = -(-T // factor)
     planes = torch.empty(nsplit, T_out * B, C, dtype=plane_dtype(nsplit), device=x.device)
     mp, mst, msb = _mask_args(mask, T, B, C)
-    _lib.check(L.slu_dropout_pool_fwd_planes(x.data_ptr(), mp, mst, msb, float(p), int(seed), int(offset),
+    _lib.check(L.slu_dropout_pool_fwd_planes(x.data_ptr(), mp, mst, msb, _ptr(keep_bits), float(p), int(seed), int(offset),
                                              _ptr(offset_dev), int(sub_batch), 16, METHODS[method], factor,
                                              planes.data_ptr(), planes.stride(0), nsplit, T, B, C, _stream()),
                "slu_dropout_pool_fwd_planes")
@@ -579,8 +580,8 @@ def dropout_pool_fwd_planes(x, mask, p, seed, offset, method, factor, nsplit, of
 
 
 def dropout_bits(T, B, C, p, seed, offset, offset_dev=None, sub_batch=0, device=None):
-    """Keep bits of a (T, B, C) dropout mask, one bit per element (int32 (T, B, C // 32)): the mask dropout_pool_fwd draws
-    for the same (seed, offset, offset_dev, sub_batch) — slu_dropout_bits."""
+    """The dropout mask of a FROZEN layer as a bit stream (int32 (T, B, C // 32), bit c % 32 of word c // 32 = keep):
+    slu_dropout_bits.  Consumed by gru_seq_fwd_pool_bf16 and by dropout_pool_fwd[_planes](keep_bits=...)."""
     L = _lib.load()
     bits = torch.empty(T, B, C // 32, dtype=torch.int32, device=device)
     _lib.check(L.slu_dropout_bits(bits.data_ptr(), float(p), int(seed), int(offset), _ptr(offset_dev), int(sub_batch), 16,
@@ -634,11 +635,14 @@ def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p
         T, B, I = x.shape
         planes = split_bf16(x.view(T * B, I), nsplit)
     packed = packed_ih if packed_ih is not None else gemm_bf16_pack(w_ih, nsplit)
+    # the mask of a frozen layer is a bit stream (dropout_bits) whichever kernel applies it; injected float masks (parity
+    # tests) and channel counts without whole 32-bit words keep the in-kernel Philox / float-mask forms
+    off, off_dev, sub = offset if isinstance(offset, tuple) else (offset, None, 0)
+    keep = None
+    if p > 0.0 and mask is None and (D * H) % 32 == 0 and T <= 65535:
+        keep = dropout_bits(T, B, D * H, p, seed, off, off_dev, sub, w_hh_f.device)
     if gru_pool_fused_ok(H, D, T, p, mask, method, factor):
-        # Dropout + Downsample(avg, 2) in the recurrence's epilogue: no fp32 (T, B, D*H) output, no pool launch; the mask
-        # is a 1-bit stream drawn by a small Philox launch with dropout_pool_fwd's element -> counter map
-        off, off_dev, sub = offset if isinstance(offset, tuple) else (offset, None, 0)
-        keep = dropout_bits(T, B, D * H, p, seed, off, off_dev, sub, w_hh_f.device) if p > 0.0 else None
+        # Dropout + Downsample(avg, 2) in the recurrence's epilogue: no fp32 (T, B, D*H) output, no pool launch
         to_planes = bool(out_planes) and -(-T // factor) <= 65535
         if gru_fused_input_ok(I, H, D, nsplit):
             return gru_seq_fwd_pool_bf16(None, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, keep, p, to_planes,
@@ -652,12 +656,11 @@ def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p
     else:
         gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
         raw, _ = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, False)
-    offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
     if out_planes and (D * H) % 32 == 0 and -(-T // factor) <= 65535:
-        return dropout_pool_fwd_planes(raw, mask, p, seed, offset, method, factor, nsplit, offset_dev, sub_batch)
+        return dropout_pool_fwd_planes(raw, mask, p, seed, off, method, factor, nsplit, off_dev, sub, keep_bits=keep)
     if p == 0.0 and factor == 1:
         return raw
-    return dropout_pool_fwd(raw, mask, p, seed, offset, method, factor, offset_dev, sub_batch)
+    return dropout_pool_fwd(raw, mask, p, seed, off, method, factor, off_dev, sub, keep_bits=keep)
 
 
 def split_path_supported(H, D):
@@ -772,15 +775,16 @@ def _mask_args(mask, T, B, C):
     return mask.data_ptr(), mask.stride(0), mask.stride(1)
 
 
-def dropout_pool_fwd(x, mask, p, seed, offset, method, factor, offset_dev=None, sub_batch=0):
+def dropout_pool_fwd(x, mask, p, seed, offset, method, factor, offset_dev=None, sub_batch=0, keep_bits=None):
     """offset_dev: optional 1-element int64 CUDA tensor added to `offset` on the device;
-    sub_batch > 0: B is sub-batches of that size, sub-batch k uses offset + 16 k (consecutive steps)."""
+    sub_batch > 0: B is sub-batches of that size, sub-batch k uses offset + 16 k (consecutive steps);
+    keep_bits: the 1-bit mask of dropout_bits instead of in-kernel Philox draws (frozen layers)."""
     L = _lib.load()
     T, B, C = x.shape
     T_out = -(-T // factor)
     y = torch.empty(T_out, B, C, dtype=torch.float32, device=x.device)
     mp, mst, msb = _mask_args(mask, T, B, C)
-    _lib.check(L.slu_dropout_pool_fwd(x.data_ptr(), mp, mst, msb, float(p), int(seed), int(offset),
+    _lib.check(L.slu_dropout_pool_fwd(x.data_ptr(), mp, mst, msb, _ptr(keep_bits), float(p), int(seed), int(offset),
                                       _ptr(offset_dev), int(sub_batch), 16, METHODS[method], factor, y.data_ptr(),
                                       T, B, C, _stream()),
                "slu_dropout_pool_fwd")

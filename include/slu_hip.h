@@ -292,21 +292,27 @@ int slu_gru_seq_bwd(const float* d_out, const float* reserve, const float* w_hh_
  *                              sub-batch k draws from offset + k*sub_stride (several training
  *                              steps' frozen stages evaluated in one launch, each with the masks
  *                              its own step would have drawn)
- *     p == 0 : no dropout (eval mode)                                                            */
-int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb, float p,
+ *     keep_bits != NULL (ABI 5, forward only; mask must be NULL, C % 32 == 0): the 1-bit mask of slu_dropout_bits —
+                              word (t*B + b) * C/32 + c/32, bit c % 32 = element (t,b,c) is kept: the mask of a FROZEN layer
+     p == 0 : no dropout (eval mode)                                                            */
+int slu_dropout_pool_fwd(const float* x, const float* mask, int64_t m_st, int64_t m_sb, const uint32_t* keep_bits, float p,
                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                          int64_t sub_batch, uint64_t sub_stride, int method, int64_t factor, float* y,
                          int64_t T, int64_t B, int64_t C, void* stream);
 /* The same, writing the result straight into the split-precision activation format (nsplit 16-bit planes of
  * (T_out*B) x C, see slu_split_bf16) read by the next frozen layer's slu_gemm_bf16.  C % 32 == 0.             */
-int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st, int64_t m_sb, float p,
-                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t sub_batch,
+int slu_dropout_pool_fwd_planes(const float* x, const float* mask, int64_t m_st, int64_t m_sb, const uint32_t* keep_bits,
+                                float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int64_t sub_batch,
                                 uint64_t sub_stride, int method, int64_t factor, void* planes,
                                 int64_t plane_stride, int nsplit, int64_t T, int64_t B, int64_t C, void* stream);
-/* The keep bits of a whole (T,B,C) dropout mask (ABI 5): bits[(t*B + b) * C/32 + c/32] bit c%32 = element (t,b,c) is
- * kept, drawn from the same Philox stream with the same element -> counter map as the two functions above (seed, offset,
- * offset_dev, sub_batch, sub_stride as there), for consumers that apply the mask themselves (slu_gru_seq_fwd_pool_bf16).
- * C % 32 == 0, T <= 65535.                                                                                             */
+/* The dropout mask of a FROZEN layer as a bit stream (ABI 5): bits[(t*B + b) * C/32 + c/32] bit c%32 = element (t,b,c)
+ * is kept — consumed by slu_gru_seq_fwd_pool_bf16 and by slu_dropout_pool_fwd[_planes](keep_bits), so that a frozen layer
+ * has one mask whichever kernel applies it.  Philox4x32-10 keyed by (seed, offset [+ *offset_dev]); sub_batch / sub_stride
+ * as above (row = t*B + b, or t*sub_batch + b % sub_batch on the stream of sub-batch b / sub_batch).  Random bits are used
+ * economically: for p == 0.5 and C % 128 == 0 (every layer of the reference cfgs) the four words of block
+ * (row * C/128 + c/128) ARE the 128 keep bits of channels [128 (c/128), +128); otherwise element e = row*C + c is kept iff
+ * the 16-bit draw e%2 of word (e/2)%4 of block e/8 is below round((1-p) 2^16).  (The trainable layers' kernels above draw one
+ * 24-bit uniform per element; the two streams are unrelated.)  C % 32 == 0, T <= 65535, bits 16-byte aligned.           */
 int slu_dropout_bits(uint32_t* bits, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                      int64_t sub_batch, uint64_t sub_stride, int64_t T, int64_t B, int64_t C, void* stream);
 /* dx (T,B,C) from dy (T_out,B,C); x and y (forward input/output) are needed for method 2 only. */

@@ -183,9 +183,9 @@ def test_gru_dropout_pool_epilogue_equals_the_two_launch_path(ops, T, B, H, D, s
     raw, _ = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit)
     off_dev = torch.tensor([5 * 16], dtype=torch.int64, device="cuda")
     for p, offset, odev in ((0.5, 7 * 16 + 3, None), (0.25, 3, off_dev), (0.0, 0, None)):
-        two_f = ops.dropout_pool_fwd(raw, None, p, 1234, offset, "avg", 2, odev, sub)
-        two_p = ops.dropout_pool_fwd_planes(raw, None, p, 1234, offset, "avg", 2, nsplit, odev, sub).planes
         keep = ops.dropout_bits(T, B, D * H, p, 1234, offset, odev, sub, gx.device) if p > 0 else None
+        two_f = ops.dropout_pool_fwd(raw, None, p, 1234, offset, "avg", 2, odev, sub, keep_bits=keep)
+        two_p = ops.dropout_pool_fwd_planes(raw, None, p, 1234, offset, "avg", 2, nsplit, odev, sub, keep_bits=keep).planes
         one_f = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, False)
         one_p = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, True).planes
         torch.cuda.synchronize()
@@ -195,9 +195,14 @@ def test_gru_dropout_pool_epilogue_equals_the_two_launch_path(ops, T, B, H, D, s
             # the bit stream is the mask itself: element (t, b, c) is dropped in the two-launch output iff its bit is clear
             bits = keep.view(T, B, D * H // 32, 1).bitwise_right_shift(torch.arange(32, device="cuda")).bitwise_and(1)
             kept = bits.view(T, B, D * H).bool()
-            full = ops.dropout_pool_fwd(raw, None, p, 1234, offset, "none", 1, odev, sub)
+            full = ops.dropout_pool_fwd(raw, None, p, 1234, offset, "none", 1, odev, sub, keep_bits=keep)
             assert torch.equal(full != 0, kept & (raw != 0))
             assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+            if sub:      # every sub-batch (training step) draws its own mask, and so does every frame
+                assert not torch.equal(kept[:, :sub], kept[:, sub:2 * sub]) and not torch.equal(kept[0], kept[1])
+                # the mask of sub-batch k is the mask a stand-alone batch would draw on stream offset + 16 k
+                alone = ops.dropout_bits(T, sub, D * H, p, 1234, offset + 16, odev, 0, gx.device)
+                assert torch.equal(alone, keep[:, sub:2 * sub])
 
 
 def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):

@@ -311,14 +311,12 @@ def test_decoder_rnn_forward_vs_torch_cells(models_mod):
     dec = models_mod.DecoderRNN(3, 64, 40, 0.5).cuda().eval()
     x, prev = torch.randn(5, 40), torch.randn(5, 3, 64)
     got = dec(x.cuda(), prev.cuda()).cpu()
-    cpu = [c.cpu() for c in dec.cells()]
-    want, h = [], x
+    want = []
     with torch.no_grad():
-        for l, cell in enumerate(cpu):
-            h = torch.nn.GRUCell(cell.input_size, cell.hidden_size)
-            h.load_state_dict(cell.state_dict())
-            out = h(x if l == 0 else want[-1], prev[:, l])
-            want.append(out)
+        for l, cell in enumerate(dec.cells()):
+            ref = torch.nn.GRUCell(cell.input_size, cell.hidden_size)          # a CPU copy (Module.cpu() would move `cell`)
+            ref.load_state_dict({k: v.detach().cpu() for k, v in cell.state_dict().items()})
+            want.append(ref(x if l == 0 else want[-1], prev[:, l]))
     want = torch.stack(want, dim=1)
     assert got.shape == (5, 3, 64) and (got - want).abs().max().item() <= 2e-6
     dec.train()

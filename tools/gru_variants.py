@@ -66,9 +66,9 @@ def check(T, B, I, sub):
             line += " | fused input == GEMM + recurrence: %s (%.1e)" % (torch.equal(fo, out), (fo - out).abs().max().item())
         # Dropout(0.5) + avg-pool(2): fused epilogue against recurrence + dropout_pool launch
         for p in (0.5, 0.0):
-            two_f = ops.dropout_pool_fwd(out, None, p, 1234, 7 * 16 + 3, "avg", 2, None, sub)
-            two_p = ops.dropout_pool_fwd_planes(out, None, p, 1234, 7 * 16 + 3, "avg", 2, ns, None, sub).planes
             keep = ops.dropout_bits(T, B, D * H, p, 1234, 7 * 16 + 3, None, sub, dev) if p > 0 else None
+            two_f = ops.dropout_pool_fwd(out, None, p, 1234, 7 * 16 + 3, "avg", 2, None, sub, keep_bits=keep)
+            two_p = ops.dropout_pool_fwd_planes(out, None, p, 1234, 7 * 16 + 3, "avg", 2, ns, None, sub, keep_bits=keep).planes
             one_f = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, ns, keep, p, False)
             one_p = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, ns, keep, p, True).planes
             line += " | pool p=%.1f fp32 %s planes %s" % (p, torch.equal(one_f, two_f), torch.equal(one_p.view(torch.int16), two_p.view(torch.int16)))
