@@ -618,13 +618,13 @@ def feature_parity(model, config, batch, samples, n_batches=16):
             label = mode if mode != "auto" else "default (f16x2 under the range guard)"
             out["max_abs_dev"][label] = float((got - ref).abs().max())
         out["guard_trips"] = pm.range_guard().trips
-        out["frozen_arithmetic_after"] = {2: "f16x2", 3: "bf16x3"}.get(models.guarded_frozen_nsplit(model))
     finally:
         if old is None:
             os.environ.pop("SLU_FROZEN_MATH", None)
         else:
             os.environ["SLU_FROZEN_MATH"] = old
         model.train(was_training)
+    out["frozen_arithmetic_after"] = {2: "f16x2", 3: "bf16x3", 0: "fp32"}.get(models.guarded_frozen_nsplit(model))
     del xd
     return out
 

@@ -83,18 +83,24 @@ def _dropout_args(name, site, p, training, cnn=False):
     return p, None, seed & 0xFFFFFFFFFFFFFFFF, _DropoutState.current * 16 + site
 
 
-# 16 dropout sites per step (Philox offset).  The seq2seq head replaces the intent stack, so its encoder layers take
-# the intent sites (at most 3 layers) and the decoder's per-step dropouts share site 11 (element index = step, layer, b, j)
+# 16 dropout sites per step (Philox offset = step * 16 + site).  The seq2seq head replaces the intent stack, so its encoder
+# layers take the intent sites and the decoder's per-step dropouts share site 11 (element index = step, layer, b, j) — which
+# is also the site a fourth encoder layer would take, so deeper stacks continue in a disjoint region of the 64-bit offset
+# (below).
 _SITE_BASE = {"phone": 0, "word": 4, "intent": 8, "cnn": 12, "intent_encoder": 8}
 _DECODER_SITE = 11
+_SITE_OVERFLOW_SHIFT = 40       # layers past a module's own sites: offset += (extra block) << 40 (steps stay below 2^36)
 
 
 def _site(module, idx):
-    """Dropout-site number of layer `idx` of a module: the Philox offset of a step is step*16 + site."""
-    if not 0 <= idx < 4:
-        raise NotImplementedError("at most 4 layers per module (%s layer %d): a step owns 16 dropout-stream "
-                                  "offsets, 4 per module" % (module, idx))
-    return _SITE_BASE[module] + idx
+    """Dropout-site number of layer `idx` of a module: the Philox offset of a step is step*16 + site.  A module owns four
+    consecutive sites (the seq2seq encoder three: site 11 is its decoder's); the reference builds as many layers as
+    its cfg lists name (models.py:227-286, 683-705), so deeper layers get offsets of their own in a region no step count
+    reaches: site = base + idx % n + ((idx // n) << 40).  Every layer of the shipped cfgs keeps the offset it always had."""
+    if idx < 0:
+        raise ValueError("negative layer index")
+    n = 3 if module == "intent_encoder" else 4
+    return _SITE_BASE[module] + idx % n + ((idx // n) << _SITE_OVERFLOW_SHIFT)
 
 
 class _FrozenMath:
@@ -403,8 +409,6 @@ class Seq2SeqEncoder(torch.nn.Module):
 
     def __init__(self, input_dim, num_layers, encoder_dim):
         super().__init__()
-        if num_layers > 3:
-            raise NotImplementedError("Seq2SeqEncoder: at most 3 layers (dropout-stream sites 8-10 of a step)")
         layers, self._stages = [], []
         out_dim = input_dim
         for idx in range(num_layers):

@@ -80,6 +80,28 @@ def test_arithmetic_mode_switches(monkeypatch):
     assert ops.plane_dtype(2) == torch.float16 and ops.plane_dtype(3) == ops.plane_dtype(1) == torch.bfloat16
 
 
+def test_dropout_sites_for_any_layer_count():
+    """A step owns 16 Philox offsets (step * 16 + site); the reference builds as many layers as its cfg lists name
+    (models.py:227-286, 683-705).  Layers of the shipped geometry keep the sites they always had; deeper stacks get offsets
+    in a region of the 64-bit counter that no step count reaches, distinct for every (module, layer)."""
+    import models
+    assert [models._site("phone", i) for i in range(4)] == [0, 1, 2, 3]
+    assert [models._site("word", i) for i in range(4)] == [4, 5, 6, 7]
+    assert [models._site("intent", i) for i in range(4)] == [8, 9, 10, 11]
+    assert [models._site("cnn", i) for i in range(4)] == [12, 13, 14, 15]
+    assert [models._site("intent_encoder", i) for i in range(3)] == [8, 9, 10] and models._DECODER_SITE == 11
+    seen = set()
+    for mod in ("phone", "word", "intent", "cnn"):
+        for i in range(12):
+            s = models._site(mod, i)
+            assert s not in seen and (i < 4 or s >= 1 << 40) and s % 16 == models._site(mod, i % 4)
+            seen.add(s)
+    enc = [models._site("intent_encoder", i) for i in range(7)]
+    assert len(set(enc)) == 7 and models._DECODER_SITE not in [e % 16 for e in enc]
+    # a step's own offsets never reach the deeper layers' region: (step * 16 + site) < 2^40 for every step below 2^36
+    assert ((1 << 36) - 1) * 16 + 15 < (1 << 40)
+
+
 def test_range_guard_verdict():
     """slu_hip/guard.RangeGuard.verdict: the words are IEEE bit patterns of max |v| (integer maximum: NaN / inf rank above
     every finite value); overflow = any word >= 65504.0f, quiet = a non-zero first-stage input maximum below 2^-8."""

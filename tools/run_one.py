@@ -57,6 +57,15 @@ elif what == "gru_bf_r3":
         assert fn(gx.data_ptr(), wf.data_ptr(), wr.data_ptr(), bf.data_ptr(), br.data_ptr(), out.data_ptr(), None, None, 0, 0,
                   None, None, T, B, H, 2, 2, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
+elif what in ("wconv_sinc", "wconv_conv1"):
+    # frozen CNN blocks of a 1024-sequence super-batch on the split-precision kernel (f16x2)
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    L, C, Co, k, stride, do_abs, pool = (48000, 1, 80, 401, 80, True, 2) if what == "wconv_sinc" else (300, 80, 60, 5, 1, False, 1)
+    x = torch.randn(B, L, C, device="cuda") * 0.1
+    w = torch.randn(Co, C, k, device="cuda") / (C * k) ** 0.5
+    for _ in range(5):
+        ops.wconv_fwd_bf16(x, w, None, B, L, C, stride, do_abs, pool, 0.2, False, 2)
+    torch.cuda.synchronize()
 elif what == "gru_bf_fused":
     # the first frozen GRU layer of a super-batch (K = 60, T = 300): recurrence with the fused input projection
     T, B, H, I = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128, 60
