@@ -586,9 +586,25 @@ def host_inputs_point(model, trainer, batches, steps, asr):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nbytes = sum(t.numel() * t.element_size() for t in host[0])
-    return {"utterances_per_s": round(len(host[0][0]) * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
-            "h2d_bytes_per_step": nbytes, "h2d_gb_per_s": round(nbytes * steps / dt / 1e9, 2),
-            "note": "pinned host batches, H2D inside the timed region; `value` is quoted with inputs resident in HBM"}
+    out = {"utterances_per_s": round(len(host[0][0]) * steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps,
+           "h2d_bytes_per_step": nbytes, "h2d_gb_per_s": round(nbytes * steps / dt / 1e9, 2),
+           "note": "pinned host batches, H2D inside the timed region; `value` is quoted with inputs resident in HBM"}
+    if not asr:
+        # the same waveforms as PCM16 (what SLU_PCM16_BATCHES=1 loaders hand over for 16-bit wavs): int16 across PCIe, scaled by
+        # 1 / 32768 inside the first stage — half the bytes
+        host16 = [((b[0] * 32768.0).round().clamp(-32768, 32767).to(torch.int16).pin_memory(),) + tuple(b[1:]) for b in host]
+        run_steps(model, trainer, host16, steps, asr)
+        run_steps(model, trainer, host16, steps, asr)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(model, trainer, host16, steps, asr)
+        torch.cuda.synchronize()
+        dt16 = time.perf_counter() - t0
+        nb16 = sum(t.numel() * t.element_size() for t in host16[0])
+        out["pcm16"] = {"utterances_per_s": round(len(host16[0][0]) * steps / dt16, 2), "ms_per_step": round(1e3 * dt16 / steps, 4),
+                        "h2d_bytes_per_step": nb16, "h2d_gb_per_s": round(nb16 * steps / dt16 / 1e9, 2),
+                        "note": "int16 PCM batches (SLU_PCM16_BATCHES=1), scaled on the device by the first stage"}
+    return out
 
 
 def feature_parity(model, config, batch, samples, n_batches=16):

@@ -244,3 +244,22 @@ extern "C" int slu_absmax_multi(const float* const* ptrs, const int64_t* numel, 
   SLU_CHECK_LAUNCH("absmax_multi_kernel");
   return SLU_OK;
 }
+
+// ---- PCM16 samples -> fp32 (sample * scale; scale = 1 / 32768 is the sox / soundfile convention the reference's loaders
+// hand the model, data.py:273-293): for first blocks that run on the exact fp32 kernels — the split-precision first block
+// reads the int16 samples itself (slu_wconv_fwd_bf16 in_pcm16) ----
+namespace slu {
+__global__ void __launch_bounds__(256)
+pcm16_to_f32_kernel(const short* __restrict__ in, float* __restrict__ out, long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = (float)in[i] * scale;
+}
+}  // namespace slu
+
+extern "C" int slu_pcm16_to_f32(const int16_t* in, float* out, int64_t n, float scale, void* stream) {
+  SLU_REQUIRE(in && out && n > 0, "slu_pcm16_to_f32: null pointer / empty");
+  long long bx = (n + 255) / 256;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(slu::pcm16_to_f32_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, in, out, (long long)n, scale);
+  SLU_CHECK_LAUNCH("pcm16_to_f32_kernel");
+  return SLU_OK;
+}

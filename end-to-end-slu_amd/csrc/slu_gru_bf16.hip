@@ -38,25 +38,6 @@ __device__ __forceinline__ float bf_tanh(float x) {
 // i.e. for the write acknowledgement of the stores issued a few instructions earlier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-
-// MODE.FP_DENORM[7:6] (f16 / f64 denormals) = 0: v_cvt_pk_f16_f32 then returns ZERO for every result below fp16's smallest
-// normal — the "hi = 0, lo carries the value" rule of the f16x2 split (slu_bf16.h) without a compare + select per element.
-// f32 denormal handling (bits [5:4]) is untouched; the kernel has no other f16 / f64 arithmetic.
-__device__ __forceinline__ void f16_denorm_flush() { __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0); }
-// f16x2 terms of two values under f16_denorm_flush(): (hi0 | hi1 << 16), (lo0 | lo1 << 16).  hi = one packed conversion;
-// lo = fp16(2048 (x - hi)) with 2048 (x - hi) = fma(hi, -2048, 2048 x) exact (both products are exact, the difference of x and
-// its 11-bit rounding is representable): the compiler folds the widening of hi into v_fma_mix_f32.
-__device__ __forceinline__ void split_f16x2_pair_flush(float x0, float x1, unsigned& hi, unsigned& lo) {
-  const f16x2v h = __builtin_convertvector(f32x2{x0, x1}, f16x2v);
-  const float l0 = __builtin_fmaf((float)h[0], -F16X2_LO_SCALE, x0 * F16X2_LO_SCALE);
-  const float l1 = __builtin_fmaf((float)h[1], -F16X2_LO_SCALE, x1 * F16X2_LO_SCALE);
-  const f16x2v l = __builtin_convertvector(f32x2{l0, l1}, f16x2v);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
-}
-
 struct GruBfParams {
   const float* gx;        // (T, B, D*3H); unused by the fused-input kernels
   // fused input projection (KI > 0: K <= 32 KI input channels): x as NS planes of (T*B) x (32 KI) 16-bit terms

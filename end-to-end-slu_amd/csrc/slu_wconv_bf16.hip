@@ -22,6 +22,8 @@ struct WconvBfParams {
   const float* in;      // (B, in_row) flat fp32 rows
   const float* const* in_tab;   // null, or a device table of base pointers: row b = in_tab[b / tab_rows] + (b % tab_rows) * in_row
   int tab_rows;                 // (a look-ahead super-batch reads its batches where they lie: no concatenation copy)
+  int pcm16;                    // != 0: `in` / the table's pointers address int16 samples; value = sample * in_scale (PCM16 wavs
+  float in_scale;               // cross PCIe as int16, half the bytes, and become sample / 32768 here: exact in fp32)
   const uint4* wp;      // packed filters [plane][KC][NT][64]
   const float* bias;    // (c_out) or null
   float* out;
@@ -112,11 +114,12 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   const int b = blockIdx.y;
   const int l0 = blockIdx.x * F;
   const float* __restrict__ inb;
-  if (p.in_tab) {
-    const int e = b / p.tab_rows;
-    inb = p.in_tab[e] + (size_t)(b - e * p.tab_rows) * p.in_row;
-  } else {
-    inb = p.in + (size_t)b * p.in_row;
+  const short* __restrict__ inb16;
+  {
+    const size_t roff = (size_t)(p.in_tab ? b % p.tab_rows : b) * p.in_row;
+    const float* base = p.in_tab ? p.in_tab[b / p.tab_rows] : p.in;
+    inb = base + roff;
+    inb16 = reinterpret_cast<const short*>(base) + roff;
   }
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
   unsigned amx = 0;                               // f16x2 range guard (NS == 2 with p.amax only)
@@ -125,44 +128,54 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   // global row tile of local row tile m (COLS: rotated by 2 * wave)
   auto rtile = [&](int m) { return COLS ? ((m + 2 * wave) & 7) : m; };
 
-  // ---- stage the window: LDS (row, col) <- global element u0 + row * S_real + col (col < S_real), zero elsewhere;
-  //      two adjacent columns per thread and step (one 4-byte LDS store per plane), eight steps' loads in flight ----
+  // ---- stage the window: LDS (row, col) <- global element u0 + row * S_real + col (col < S_real), zero elsewhere; two
+  //      adjacent columns per thread and step (one 4-byte LDS store per plane).  The round-3 loop spent ~80 VALU
+  //      instructions per pair (index arithmetic through a float reciprocal, 64-bit addresses and bounds, select-based
+  //      splits) and made the kernel VALU-bound: SQ counters of the Sinc launch showed 2 700 VALU instructions per wave beside
+  //      390 MFMAs, VALU-active 12.7 k cycles against 6.2 k of MFMA.  Now: (row, pair) advance incrementally in 32-bit
+  //      integers, one unsigned compare covers both bounds of an index, and the f16x2 split is the packed flush-mode form
+  //      (two conversions + two fused multiply-adds per pair). ----
+  if constexpr (NS == 2) f16_denorm_flush();
   {
-    const long long u0 = (long long)l0 * p.S_real - p.pad;
-    const int half = p.S >> 1;                     // column pairs per row
+    const int u0 = l0 * p.S_real - p.pad;            // (the launcher checks in_row < 2^31)
+    const int half = p.S >> 1;                       // column pairs per row
     const int total = p.nrows * half;
-    const float inv = 1.0f / (float)half;
-    constexpr int U = 8;
-    for (int base = 0; base < total; base += WB_THREADS * U) {
-      float v0[U], v1[U];
-      int off[U];
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        const int idx = base + j * WB_THREADS + tid;
-        int row = (int)((float)idx * inv);
-        int cp = idx - row * half;
-        if (cp < 0) { cp += half; --row; }
-        if (cp >= half) { cp -= half; ++row; }
-        const int col = 2 * cp;
-        const long long u = u0 + (long long)row * p.S_real + col;
-        const bool ok = idx < total;
-        off[j] = ok ? row * p.Sp + col : -1;
-        v0[j] = (ok && col < p.S_real && u >= 0 && u < p.in_row) ? inb[u] : 0.0f;
-        v1[j] = (ok && col + 1 < p.S_real && u + 1 >= 0 && u + 1 < p.in_row) ? inb[u + 1] : 0.0f;
+    const unsigned in_row = (unsigned)p.in_row;
+    int row = tid / half, cp = tid - row * half;     // this thread's first pair; per step: + WB_THREADS pairs
+    const int drow = WB_THREADS / half, dcp = WB_THREADS - drow * half;
+#pragma unroll 4
+    for (int e = tid; e < total; e += WB_THREADS) {
+      const int col = 2 * cp;
+      const int u = u0 + row * p.S_real + col;
+      const bool ok0 = col < p.S_real && (unsigned)u < in_row;
+      const bool ok1 = col + 1 < p.S_real && (unsigned)(u + 1) < in_row;
+      float v0, v1;
+      if (p.pcm16) {
+        v0 = ok0 ? (float)inb16[u] * p.in_scale : 0.0f;
+        v1 = ok1 ? (float)inb16[u + 1] * p.in_scale : 0.0f;
+      } else {
+        v0 = ok0 ? inb[u] : 0.0f;
+        v1 = ok1 ? inb[u + 1] : 0.0f;
       }
-#pragma unroll
-      for (int j = 0; j < U; ++j) {
-        if (off[j] < 0) continue;
+      unsigned short* dst = lds + row * p.Sp + col;
+      if constexpr (NS == 2) {
+        amx = max(amx, max(abs_bits(v0), abs_bits(v1)));
+        unsigned hi, lo;
+        split_f16x2_pair_flush(v0, v1, hi, lo);
+        *reinterpret_cast<unsigned*>(dst) = hi;
+        *reinterpret_cast<unsigned*>(dst + plane) = lo;
+      } else {
         unsigned short a[NS], c[NS];
-        if constexpr (NS == 2) amx = max(amx, max(abs_bits(v0[j]), abs_bits(v1[j])));
-        split_terms<NS>(v0[j], a);
-        split_terms<NS>(v1[j], c);
+        split_terms<NS>(v0, a);
+        split_terms<NS>(v1, c);
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl)
-          *reinterpret_cast<unsigned*>(lds + pl * plane + off[j]) = a[pl] | ((unsigned)c[pl] << 16);
+        for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<unsigned*>(dst + pl * plane) = a[pl] | ((unsigned)c[pl] << 16);
       }
+      cp += dcp; row += drow;
+      if (cp >= half) { cp -= half; ++row; }
     }
   }
+  if constexpr (NS == 2) f16_denorm_keep();          // the epilogue's plane output follows the default-mode rule (slu_bf16.h)
   __syncthreads();
 
   f32x4 accs[SP::NACC][RT][CT];
@@ -244,7 +257,11 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
 #pragma unroll
   for (int m = 0; m < XT; ++m) acc[RT * CT + m] = split_result<NS>(accx[0][m], accx[SP::NACC - 1][m]);
 
-  // ---- epilogue: bias, abs, max-pool over frame pairs, LeakyReLU, strided store (as wconv_fwd_kernel) ----
+  // ---- epilogue: bias, abs, max-pool over frame pairs, LeakyReLU, strided store (as wconv_fwd_kernel); row bases in 64
+  //      bits once, 32-bit offsets inside (the launcher checks l_out * out_sl + c_out < 2^31) ----
+  float* __restrict__ outb = p.out ? p.out + (size_t)b * p.out_sb : nullptr;
+  unsigned char* __restrict__ routeb = p.route ? p.route + (size_t)b * p.l_out * p.c_out : nullptr;
+  const int osl = (int)p.out_sl;
 #pragma unroll
   for (int tile = 0; tile < NTILE; ++tile) {
     {
@@ -291,10 +308,10 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
           const bool has1 = (f0 + 1) < p.l_conv;                // ceil_mode: last window may be partial
           const bool pick1 = has1 && v[2 * h + 1] > v[2 * h];
           const float pooled = pick1 ? v[2 * h + 1] : v[2 * h];
-          p.out[(size_t)b * p.out_sb + (long long)(f0 >> 1) * p.out_sl + c] = pooled > 0.0f ? pooled : pooled * p.slope;
-          if (p.route) {
+          outb[(f0 >> 1) * osl + c] = pooled > 0.0f ? pooled : pooled * p.slope;
+          if (routeb) {
             const bool sgn = pick1 ? neg[2 * h + 1] : neg[2 * h];
-            p.route[((size_t)b * p.l_out + (f0 >> 1)) * p.c_out + c] = (unsigned char)((pick1 ? 1 : 0) | (sgn ? 2 : 0));
+            routeb[(f0 >> 1) * p.c_out + c] = (unsigned char)((pick1 ? 1 : 0) | (sgn ? 2 : 0));
           }
         }
       } else {
@@ -302,8 +319,8 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
         for (int r = 0; r < 4; ++r) {
           const int f = fbase + r;
           if (f >= p.l_conv) continue;
-          p.out[(size_t)b * p.out_sb + (long long)f * p.out_sl + c] = v[r] > 0.0f ? v[r] : v[r] * p.slope;
-          if (p.route) p.route[((size_t)b * p.l_out + f) * p.c_out + c] = (unsigned char)(neg[r] ? 2 : 0);
+          outb[f * osl + c] = v[r] > 0.0f ? v[r] : v[r] * p.slope;
+          if (routeb) routeb[f * p.c_out + c] = (unsigned char)(neg[r] ? 2 : 0);
         }
       }
     }
@@ -362,13 +379,14 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
                                   int do_abs, int pool, float slope, int64_t out_sb, int64_t out_sl,
                                   void* out_planes, int64_t out_plane_stride,
                                   void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,
-                                  uint32_t* absmax_word, void* stream) {
+                                  uint32_t* absmax_word, int in_pcm16, float in_scale, void* stream) {
   SLU_REQUIRE((in || in_table) && weight && (out || out_planes), "slu_wconv_fwd_bf16: null pointer");
   SLU_REQUIRE(!in_table || (table_rows >= 1 && table_rows <= B), "slu_wconv_fwd_bf16: bad table_rows");
   SLU_REQUIRE(B > 0 && l_in > 0 && c_in > 0 && c_out > 0 && k_t > 0 && stride_t > 0, "slu_wconv_fwd_bf16: non-positive size");
   SLU_REQUIRE(pool == 1 || pool == 2, "slu_wconv_fwd_bf16: pool must be 1 or 2 (got %d)", pool);
   SLU_REQUIRE(nsplit >= 1 && nsplit <= 3, "slu_wconv_fwd_bf16: nsplit must be 1 (bf16), 2 (f16x2) or 3 (bf16x3)");
   SLU_REQUIRE(B <= 65535, "slu_wconv_fwd_bf16: B must be <= 65535");
+  SLU_REQUIRE(l_in * c_in < (1LL << 31) - 2, "slu_wconv_fwd_bf16: a row of l_in * c_in elements must fit 32-bit indexing");
   const int64_t c_pad = bf_c_pad(c_in);
   const int64_t S = stride_t * c_pad, S_real = stride_t * c_in;
   if (S % 8 != 0 || (c_in > 1 && stride_t != 1))
@@ -397,6 +415,8 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   p.in = in; p.wp = wp; p.bias = bias; p.out = out; p.route = route;
   SLU_REQUIRE(!route || (out && !out_planes), "slu_wconv_fwd_bf16: route goes with the fp32 output");
   p.in_tab = in_table; p.tab_rows = (int)(in_table ? table_rows : 1);
+  SLU_REQUIRE(!in_pcm16 || (c_in == 1 && !route), "slu_wconv_fwd_bf16: PCM16 input is the waveform of a frozen first block (c_in == 1)");
+  p.pcm16 = in_pcm16 ? 1 : 0; p.in_scale = in_pcm16 ? in_scale : 1.0f;
   p.planes = (unsigned short*)out_planes; p.plane = out_plane_stride; p.Kp_out = (int)(cdiv(c_out, 32) * 32); p.Bn = (int)B;
   if (out_planes) {
     if (pool != 1 || NT * 16 < p.Kp_out)
@@ -406,6 +426,7 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
                 "slu_wconv_fwd_bf16: plane stride too small");
   }
   p.in_row = l_in * c_in; p.out_sb = out_sb; p.out_sl = out_sl;
+  SLU_REQUIRE(out_planes || (cdiv(l_conv, pool) + 1) * out_sl + c_out < (1LL << 31), "slu_wconv_fwd_bf16: output row offsets must fit 32 bits");
   p.S = (int)S; p.S_real = (int)S_real; p.Sp = (int)S + 8;
   p.KC = (int)KC; p.pad = (int)(pad_t * c_in);
   p.l_conv = (int)l_conv; p.l_out = (int)cdiv(l_conv, pool); p.c_out = (int)c_out;

@@ -175,15 +175,25 @@ class _SyntheticLoader:
         return len(self.batches)
 
 
-def read_wav(path):
+def pcm16_batches():
+    """SLU_PCM16_BATCHES=1: loaders hand PCM16 audio over as int16 batches (B, T) — half the bytes on PCIe; the model's
+    first stage computes on sample / 32768 (slu_hip.ops.PCM16_SCALE), which is exactly the float32 value the default
+    loaders (and the reference's, data.py:273-293) produce, so losses and parameters are bit-identical.  Off by default:
+    code that consumes `dataset.loader` directly keeps seeing the reference's float32 waveforms."""
+    return os.environ.get("SLU_PCM16_BATCHES", "0") == "1"
+
+
+def read_wav(path, keep_pcm16=False):
     """First channel of a wav file as float32 in [-1, 1) and its sample rate — the array
     `SoxEffectsChain.sox_build_flow_effects()` hands the reference (data.py:273-293; augmentation is
     hard-wired off there, so the chain is a plain decode): PCM16 / 32768, PCM32 / 2^31, unsigned 8-bit
-    (v - 128) / 128, float wavs as stored."""
+    (v - 128) / 128, float wavs as stored.  keep_pcm16: PCM16 files come back as the int16 samples themselves."""
     from scipy.io import wavfile
     fs, a = wavfile.read(path)
     if a.ndim > 1:
         a = a[:, 0]
+    if a.dtype == np.int16 and keep_pcm16:
+        return np.ascontiguousarray(a), fs
     if a.dtype == np.int16:
         x = a.astype(np.float32) / 32768.0
     elif a.dtype == np.int32:
@@ -193,6 +203,21 @@ def read_wav(path):
     else:
         x = a.astype(np.float32)
     return x, fs
+
+
+def _pad_waveforms(waves, T):
+    """list of 1-D waveforms -> (B, T) zero-padded at the end: int16 when every item is PCM16 samples (pcm16_batches),
+    else float32 (int16 items are converted as read_wav would have)."""
+    as_np = [np.asarray(w) for w in waves]
+    if all(a.dtype == np.int16 for a in as_np):
+        x = torch.zeros(len(as_np), T, dtype=torch.int16)
+        for i, a in enumerate(as_np):
+            x[i, :len(a)] = torch.from_numpy(a)
+        return x
+    x = torch.zeros(len(as_np), T, dtype=torch.float32)
+    for i, a in enumerate(as_np):
+        x[i, :len(a)] = torch.from_numpy(a.astype(np.float32) / 32768.0) if a.dtype == np.int16 else torch.as_tensor(a, dtype=torch.float32)
+    return x
 
 
 def one_hot(letters, S):
@@ -226,9 +251,7 @@ class CollateWavsSLU:
         T = max(len(x) for x, _ in batch)
         if self.pad_multiple > 1:
             T = -(-T // self.pad_multiple) * self.pad_multiple
-        x = torch.zeros(len(batch), T, dtype=torch.float32)
-        for i, (xi, _) in enumerate(batch):
-            x[i, :len(xi)] = torch.as_tensor(np.asarray(xi), dtype=torch.float32)
+        x = _pad_waveforms([xi for xi, _ in batch], T)
         if self.seq2seq:
             U = max(len(yi) for _, yi in batch)
             idx = torch.full((len(batch), U), self.EOS, dtype=torch.int64)
@@ -364,7 +387,7 @@ class SLUDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         idx = idx % len(self._paths)
-        x, _fs = read_wav(self._paths[idx])
+        x, _fs = read_wav(self._paths[idx], keep_pcm16=pcm16_batches())
         if self.seq2seq:                         # <sos> + the characters of the semantics string + <eos> (data.py:322-326)
             y_intent = [self._index["<sos>"]] + [self._index[c] for c in self._values[idx]] + [self._index["<eos>"]]
             return x, y_intent
@@ -489,11 +512,10 @@ class CollateWavsASR:
         T = max(len(b[0]) for b in batch)
         Up = max(len(b[1]) for b in batch)
         Uw = max(len(b[2]) for b in batch)
-        x = torch.zeros(n, T, dtype=torch.float32)
+        x = _pad_waveforms([b[0] for b in batch], T)
         yp = torch.full((n, Up), -1, dtype=torch.int64)
         yw = torch.full((n, Uw), -1, dtype=torch.int64)
         for i, (xi, pi, wi) in enumerate(batch):
-            x[i, :len(xi)] = torch.as_tensor(np.asarray(xi)).float()
             yp[i, :len(pi)] = torch.as_tensor(np.asarray(pi, dtype=np.int64))
             yw[i, :len(wi)] = torch.as_tensor(np.asarray(wi, dtype=np.int64))
         return x, yp, yw

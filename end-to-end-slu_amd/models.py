@@ -699,7 +699,7 @@ class _ConvStage:
                 if isinstance(h, _ops.RowTable):       # a look-ahead super-batch read where its batches lie
                     x3, (B, l_in) = h, h.shape
                 else:
-                    x3 = (h if h.dim() == 3 else h.unsqueeze(2)).contiguous()
+                    x3 = (h if h.dim() == 3 else h.unsqueeze(2)).contiguous()      # (int16 PCM samples stay int16)
                     B, l_in = x3.shape[0], x3.shape[1]
                 planes = (out_planes and tm and not (self.drop > 0.0 and training)
                           and _ops.wconv_bf16_planes_ok(w.shape[0], pool))
@@ -715,6 +715,10 @@ class _ConvStage:
             if time_major and not tm:
                 h = h.transpose(0, 1).contiguous()
             return h
+        if isinstance(h, _ops.RowTable):
+            raise _lib.SluHipError("a row-pointer table can only be read by the split-precision first block")
+        if h.dtype == torch.int16:             # PCM16 batch, first block on the exact fp32 kernels: sample / 32768
+            h = _ops.pcm16_to_f32(h)
         if self.is_sinc:
             h = _ops.SincBlockFn.apply(h, self.conv.filt_b1, self.conv.filt_band, self.conv.Filt_dim,
                                        self.conv.fs, self.conv.stride, pool, slope, tm,
@@ -907,7 +911,7 @@ class PretrainedModel(torch.nn.Module):
         layers).  Hand-off layouts: (B,T) waveform -> channels-last (B,L,C) between CNN blocks ->
         time-major (T,B,C) from the last CNN block on."""
         self._cnn_stages[-1].time_major = True
-        if first == 0:
+        if first == 0 and h.dtype != torch.int16:       # PCM16 batches stay int16: the first block scales them (ops.PCM16_SCALE)
             h = h.float()
         stages = self._stages()
         for k in range(first, last):

@@ -31,6 +31,7 @@ SIGNATURES = {
     "slu_copy_multi": (c_int, [vp, vp, vp, c_i64, vp]),
     "slu_scale_multi": (c_int, [vp, vp, c_i64, vp, vp]),
     "slu_absmax_multi": (c_int, [vp, vp, c_i64, vp, vp]),
+    "slu_pcm16_to_f32": (c_int, [vp, vp, c_i64, c_f32, vp]),
     "slu_pool_act_fwd": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_i64, c_i64, vp]),
     "slu_pool_act_bwd": (c_int, [vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_i64, c_i64, vp]),
     "slu_gru_cell_fwd": (c_int, [vp, vp, vp, c_i64, vp, c_i64, vp, vp, vp, c_f32, c_u64, c_u64, vp, c_u64, c_i64, c_i64, vp]),
@@ -68,7 +69,7 @@ SIGNATURES = {
     "slu_gemm_tn_bf16": (c_int, [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_i64, c_i64, c_int, vp, c_sz, vp]),
     "slu_wconv_bf16_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_int]),
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
-                                   c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp, vp]),
+                                   c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp, c_int, c_f32, vp]),
     "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int,
                                      vp]),
     "slu_gru_seq_fwd_pool_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_f32, vp, c_i64, c_i64, vp, vp, c_i64,

@@ -466,10 +466,11 @@ class RowTable:
     slu_wconv_fwd_bf16 (in_table) can read.  The address table is refreshed with store_u64 before each replay."""
     requires_grad = False
 
-    def __init__(self, ptrs, rows, T):
+    def __init__(self, ptrs, rows, T, dtype=torch.float32):
         self.ptrs, self.rows = ptrs, rows
         self.shape = (ptrs.numel() * rows, T)
         self.device = ptrs.device
+        self.dtype = dtype            # float32, or int16: PCM16 samples the first block scales by PCM16_SCALE itself
 
     def dim(self):
         return 2
@@ -479,6 +480,18 @@ class RowTable:
 
     def to(self, *args, **kwargs):
         return self
+
+
+PCM16_SCALE = 1.0 / 32768.0        # int16 sample -> [-1, 1): the sox / soundfile convention of the reference's loaders
+
+
+def pcm16_to_f32(x):
+    """int16 PCM samples -> fp32 sample / 32768 (slu_pcm16_to_f32): for a first block on the exact fp32 kernels."""
+    L = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _lib.check(L.slu_pcm16_to_f32(x.data_ptr(), out.data_ptr(), x.numel(), PCM16_SCALE, _stream()), "slu_pcm16_to_f32")
+    return out
 
 
 def store_u64(dst, values):
@@ -507,12 +520,18 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     the first call and reused by the following ones (no pack launch per super-batch).
     absmax: None, or the device address of this launch's f16x2 range word (slu_hip/guard.py)."""
     L = _lib.load()
+    pcm16 = x.dtype == torch.int16          # PCM16 waveform: scaled by 1 / 32768 inside the kernel (frozen first block)
     if isinstance(x, RowTable):
         x_ptr, tab, tab_rows = None, x.ptrs.data_ptr(), x.rows
         assert c_in == 1 and x.shape == (B, l_in)
+    elif pcm16:
+        assert c_in == 1 and x.is_cuda and not want_route
+        x = x.contiguous()
+        x_ptr, tab, tab_rows = x.data_ptr(), None, 0
     else:
         x = _f32c(x, "x")
         x_ptr, tab, tab_rows = x.data_ptr(), None, 0
+    pcm = (1, PCM16_SCALE) if pcm16 else (0, 1.0)
     weight = _f32c(weight, "weight")
     c_out, _, k_t = weight.shape
     l_conv = conv_out_len(l_in, k_t, stride)
@@ -523,7 +542,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
         ws, wsb, valid = _wconv_pack_ws(L, pack_cache, c_out, c_in, k_t, nsplit, x.device)
         _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), None, None, B, l_in, c_in, c_out,
                                         k_t, stride, int(do_abs), pool, float(slope), 0, 0, planes.data_ptr(),
-                                        planes.stride(0), ws.data_ptr(), wsb, valid, nsplit, absmax, _stream()),
+                                        planes.stride(0), ws.data_ptr(), wsb, valid, nsplit, absmax, *pcm, _stream()),
                    "slu_wconv_fwd_bf16")
         return SplitAct(planes, l_out, B, c_out)
     if time_major:
@@ -536,7 +555,7 @@ def wconv_fwd_bf16(x, weight, bias, B, l_in, c_in, stride, do_abs, pool, slope, 
     route = torch.empty(B, l_out, c_out, dtype=torch.uint8, device=x.device) if want_route else None
     _lib.check(L.slu_wconv_fwd_bf16(x_ptr, tab, tab_rows, weight.data_ptr(), _ptr(bias), out.data_ptr(), _ptr(route), B, l_in,
                                     c_in, c_out, k_t, stride, int(do_abs), pool, float(slope), sb, sl, None, 0, ws.data_ptr(), wsb,
-                                    valid, nsplit, absmax, _stream()), "slu_wconv_fwd_bf16")
+                                    valid, nsplit, absmax, *pcm, _stream()), "slu_wconv_fwd_bf16")
     return (out, route, l_conv) if want_route else out
 
 

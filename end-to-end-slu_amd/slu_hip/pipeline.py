@@ -153,7 +153,7 @@ class PrefixSlot:
             if use_graph:
                 import models as _models
                 key = (len(xs), B, T, n_prefix, bool(model.training), _models.contraction_nsplit(True),
-                       self._table_ok(model, xs))
+                       self._table_ok(model, xs), xs[0].dtype)
                 entry = self.graphs.get(key)
                 # capture a shape on its second appearance in this slot: a one-off shape (the ragged last
                 # group of an epoch, a short run) is cheaper launched eagerly than captured (~10 ms)
@@ -172,7 +172,7 @@ class PrefixSlot:
                         self.rng.fill_(step0 * 16)
                     graph.replay()
             if feats is None:
-                x_cat = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
+                x_cat = torch.empty(len(xs) * B, T, dtype=xs[0].dtype, device=self.device)
                 self._copy_in(x_cat, xs, host, after)
                 if guard is not None:
                     guard.arm()
@@ -217,17 +217,18 @@ class PrefixSlot:
         pm = getattr(model, "pretrained_model", model)
         return (os.environ.get("SLU_ROW_TABLE", "1") != "0" and 1 < len(xs) <= self.MAX_TABLE
                 and hasattr(pm, "accepts_row_table") and pm.accepts_row_table()
-                and all(x.is_cuda and x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
+                and xs[0].dtype in (torch.float32, torch.int16)
+                and all(x.is_cuda and x.device == self.device and x.dtype == xs[0].dtype and x.is_contiguous()
                         and x.data_ptr() % 16 == 0 for x in xs))
 
     def _capture(self, model, xs, n_prefix, step0, key, guard=None):
         B, T = xs[0].shape
         sub = B if len(xs) > 1 else 0
-        if key[-1]:
-            x_static = ops.RowTable(self.words[:len(xs)], B, T)
+        if key[-2]:
+            x_static = ops.RowTable(self.words[:len(xs)], B, T, xs[0].dtype)
             ops.store_u64(self.words, [x.data_ptr() for x in xs] + [0] * (self.MAX_TABLE - len(xs)) + [step0 * 16])
         else:
-            x_static = torch.empty(len(xs) * B, T, dtype=torch.float32, device=self.device)
+            x_static = torch.empty(len(xs) * B, T, dtype=xs[0].dtype, device=self.device)
             self._fill(x_static, xs)
             self.rng.fill_(step0 * 16)
         model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)      # warm-up (lazy initialisation)

@@ -342,7 +342,8 @@ class Trainer:
                 pm.warm_weight_caches()
                 for batch in loader:
                     ins = [t.to(dev, non_blocking=True) for t in batch]
-                    ins[0] = ins[0].float()
+                    if ins[0].dtype != torch.int16:           # PCM16 batches stay int16 (the model's first block scales them)
+                        ins[0] = ins[0].float()
                     guard = step_guard()
                     fused_now = fused and guard is None
                     fwd = forward if (fused_now or not fused) else forward_plain

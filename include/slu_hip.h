@@ -74,6 +74,9 @@ int slu_scale_multi(float* const* ptrs, const int64_t* numel, int64_t count, con
  * frozen weights with it once per weight version; the same word format is written by slu_wconv_fwd_bf16(absmax_word).  The
  * reference needs no counterpart: its fp32 ATen kernels (models.py:108, :200, :232) have fp32's range.                   */
 int slu_absmax_multi(const float* const* ptrs, const int64_t* numel, int64_t count, uint32_t* words, void* stream);
+/* out[i] = in[i] * scale (ABI 5): PCM16 samples to fp32 for a first block on the exact fp32 kernels (a trainable Sinc
+ * layer); the split-precision first block reads the samples itself (slu_wconv_fwd_bf16 in_pcm16).                      */
+int slu_pcm16_to_f32(const int16_t* in, float* out, int64_t n, float scale, void* stream);
 
 /* -------- Sinc filterbank: models.py:79-106 (SincLayer.forward up to the conv), :7-24 ------- */
 /* filters[n_filt][filt_dim] (float32) from the two float64 parameters, filt_dim odd.            */
@@ -212,14 +215,17 @@ int slu_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, f
  * absmax_word (ABI 5; NULL or a device uint32, used by nsplit = 2 only): the launch raises it (atomic maximum) to the IEEE
  * bit pattern of the largest |v| among the values it splits into fp16 pairs — its input window and, with out_planes, its
  * output.  f16x2 operands must stay below 65504; the caller zeroes the word, reads it back after the launch and re-runs
- * the stage with nsplit = 3 (bf16x3: fp32's range) when the pattern is >= 0x477FE000 (65504.0f; NaN / inf rank higher).  */
+ * the stage with nsplit = 3 (bf16x3: fp32's range) when the pattern is >= 0x477FE000 (65504.0f; NaN / inf rank higher).
+ * in_pcm16 != 0 (ABI 5; c_in == 1, no route): `in` / the table's pointers address int16 samples and the block computes on
+ * sample * in_scale (1 / 32768: what the reference's loaders hand the model, data.py:273-293 — exact in fp32, so the result
+ * equals the call on the converted fp32 waveform bit for bit): PCM16 audio crosses PCIe at half the bytes.               */
 size_t slu_wconv_bf16_workspace_bytes(int64_t c_out, int64_t c_in, int64_t k_t, int nsplit);
 int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t table_rows, const float* weight,
                        const float* bias, float* out, uint8_t* route, int64_t B,
                        int64_t l_in, int64_t c_in, int64_t c_out, int64_t k_t, int64_t stride_t, int do_abs,
                        int pool, float slope, int64_t out_sb, int64_t out_sl, void* out_planes,
                        int64_t out_plane_stride, void* workspace, size_t workspace_bytes, int packed_valid, int nsplit,
-                       uint32_t* absmax_word, void* stream);
+                       uint32_t* absmax_word, int in_pcm16, float in_scale, void* stream);
 /* Persistent GRU recurrence on the split-precision MFMA path; arguments as slu_gru_seq_fwd, 16-sequence tiles,
  * W_hh (3 gates x nsplit 16-bit planes) resident in VGPRs, H = 64 / 128.  `reserve` (NULL for frozen layers) takes
  * the saved gates in the 16-sequence layout of slu_gru_reserve_bytes, so that slu_gru_seq_bwd (exact fp32 BPTT)

@@ -130,6 +130,34 @@ def test_loader_batches_and_wav_formats(tmp_path, monkeypatch):
         te[0]
 
 
+def test_pcm16_batches_are_the_float_batches_times_32768(tmp_path, monkeypatch):
+    """SLU_PCM16_BATCHES=1: PCM16 wavs travel as int16 batches (half the bytes on PCIe); sample / 32768 — what the model's
+    first stage computes — is exactly the float32 batch of the default loader (and of the reference: data.py:273-293), padding
+    included.  A batch with a non-PCM16 item falls back to float32."""
+    from scipy.io import wavfile
+    monkeypatch.setenv("SLU_DATA_WORKERS", "0")
+    root = str(tmp_path)
+    fx.make_fsc_tree(root, seed=3)
+    cfg = _config(root, {})
+    monkeypatch.delenv("SLU_PCM16_BATCHES", raising=False)
+    assert not data.pcm16_batches()
+    _, va, _ = data.get_SLU_datasets(cfg)
+    ref = [(x.clone(), y.clone()) for x, y in va.loader]
+    monkeypatch.setenv("SLU_PCM16_BATCHES", "1")
+    _, va16, _ = data.get_SLU_datasets(cfg)
+    got = list(va16.loader)
+    assert len(got) == len(ref) > 0
+    for (x16, y16), (xf, yf) in zip(got, ref):
+        assert x16.dtype == torch.int16 and x16.shape == xf.shape and torch.equal(y16, yf)
+        assert torch.equal(x16.float() / 32768.0, xf)
+    p = os.path.join(root, "f.wav")
+    wavfile.write(p, 16000, np.array([0.25, -0.75], dtype=np.float32))
+    a, _ = data.read_wav(p, keep_pcm16=True)
+    assert a.dtype == np.float32                              # not PCM16: stays float
+    mixed = data._pad_waveforms([np.array([16384, -32768], dtype=np.int16), a], 3)
+    assert mixed.dtype == torch.float32 and mixed.tolist() == [[0.5, -1.0, 0.0], [0.25, -0.75, 0.0]]
+
+
 def test_trainer_consumes_real_loader_shapes(tmp_path, monkeypatch):
     """The batch tuples of the real loader are what Trainer._forward_losses expects (x (B,T), y (B,3))."""
     monkeypatch.setenv("SLU_DATA_WORKERS", "2")          # worker processes + collate in the workers
