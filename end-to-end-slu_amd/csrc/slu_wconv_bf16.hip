@@ -13,6 +13,7 @@
 //   * filters are split and packed once per launch in B-fragment order (bf_wconv_pack_kernel) and read from L2 one
 //     chunk ahead; bias, abs, max-pool, LeakyReLU and the output layout are the fp32 kernel's epilogue.
 #include "slu_bf16.h"
+#include <type_traits>
 
 namespace slu {
 
@@ -141,39 +142,55 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
     const int half = p.S >> 1;                       // column pairs per row
     const int total = p.nrows * half;
     const unsigned in_row = (unsigned)p.in_row;
-    int row = tid / half, cp = tid - row * half;     // this thread's first pair; per step: + WB_THREADS pairs
     const int drow = WB_THREADS / half, dcp = WB_THREADS - drow * half;
-#pragma unroll 4
-    for (int e = tid; e < total; e += WB_THREADS) {
-      const int col = 2 * cp;
-      const int u = u0 + row * p.S_real + col;
-      const bool ok0 = col < p.S_real && (unsigned)u < in_row;
-      const bool ok1 = col + 1 < p.S_real && (unsigned)(u + 1) < in_row;
-      float v0, v1;
-      if (p.pcm16) {
-        v0 = ok0 ? (float)inb16[u] * p.in_scale : 0.0f;
-        v1 = ok1 ? (float)inb16[u + 1] * p.in_scale : 0.0f;
-      } else {
-        v0 = ok0 ? inb[u] : 0.0f;
-        v1 = ok1 ? inb[u + 1] : 0.0f;
-      }
-      unsigned short* dst = lds + row * p.Sp + col;
-      if constexpr (NS == 2) {
-        amx = max(amx, max(abs_bits(v0), abs_bits(v1)));
-        unsigned hi, lo;
-        split_f16x2_pair_flush(v0, v1, hi, lo);
-        *reinterpret_cast<unsigned*>(dst) = hi;
-        *reinterpret_cast<unsigned*>(dst + plane) = lo;
-      } else {
-        unsigned short a[NS], c[NS];
-        split_terms<NS>(v0, a);
-        split_terms<NS>(v1, c);
+    constexpr int U = 8;                             // pairs per thread and batch: 16 loads in flight before the first split
+    // PCM: the rows hold int16 samples (decided once, outside the loop: a branch inside it would split the batch of loads)
+    auto stage = [&](auto PCM) {
+      int row = tid / half, cp = tid - row * half;   // this thread's next pair; + WB_THREADS pairs per step
+      for (int base = tid; base < total; base += WB_THREADS * U) {
+        float v0[U], v1[U];
+        int off[U];
 #pragma unroll
-        for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<unsigned*>(dst + pl * plane) = a[pl] | ((unsigned)c[pl] << 16);
+        for (int j = 0; j < U; ++j) {
+          const bool ok = base + j * WB_THREADS < total;
+          const int col = 2 * cp;
+          const int u = u0 + row * p.S_real + col;
+          const bool ok0 = ok && col < p.S_real && (unsigned)u < in_row;
+          const bool ok1 = ok && col + 1 < p.S_real && (unsigned)(u + 1) < in_row;
+          off[j] = ok ? row * p.Sp + col : -1;
+          if constexpr (decltype(PCM)::value) {
+            v0[j] = ok0 ? (float)inb16[u] : 0.0f;
+            v1[j] = ok1 ? (float)inb16[u + 1] : 0.0f;
+          } else {
+            v0[j] = ok0 ? inb[u] : 0.0f;
+            v1[j] = ok1 ? inb[u + 1] : 0.0f;
+          }
+          cp += dcp; row += drow;
+          if (cp >= half) { cp -= half; ++row; }
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+          if (off[j] < 0) continue;
+          float a0 = v0[j], a1 = v1[j];
+          if constexpr (decltype(PCM)::value) { a0 *= p.in_scale; a1 *= p.in_scale; }
+          unsigned short* dst = lds + off[j];
+          if constexpr (NS == 2) {
+            amx = max(amx, max(abs_bits(a0), abs_bits(a1)));
+            unsigned hi, lo;
+            split_f16x2_pair_flush(a0, a1, hi, lo);
+            *reinterpret_cast<unsigned*>(dst) = hi;
+            *reinterpret_cast<unsigned*>(dst + plane) = lo;
+          } else {
+            unsigned short a[NS], c[NS];
+            split_terms<NS>(a0, a);
+            split_terms<NS>(a1, c);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl) *reinterpret_cast<unsigned*>(dst + pl * plane) = a[pl] | ((unsigned)c[pl] << 16);
+          }
+        }
       }
-      cp += dcp; row += drow;
-      if (cp >= half) { cp -= half; ++row; }
-    }
+    };
+    if (p.pcm16) stage(std::true_type{}); else stage(std::false_type{});
   }
   if constexpr (NS == 2) f16_denorm_keep();          // the epilogue's plane output follows the default-mode rule (slu_bf16.h)
   __syncthreads();

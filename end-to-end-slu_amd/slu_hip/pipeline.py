@@ -25,9 +25,10 @@ def cu_split(device=None):
     """CUs [0, n) of the device are reserved for the trainable part of the step, the look-ahead
     super-batches get the rest.  Without the partition the big frozen-prefix kernels keep every CU
     busy and each of the ~25 small, latency-bound kernels of the trainable part waits for workgroup
-    slots (measured: the two streams then take almost the SUM of their times).  Default: half of the device
-    (128 of 256 CUs = 16 per XCD; the mask bits interleave over the 8 XCDs, odd counts per XCD split CU pairs between the
-    partitions and are markedly slower) with 16-batch super-batches (one recurrence workgroup per look-ahead CU).
+    slots (measured: the two streams then take almost the SUM of their times).  Default: three eighths of the device
+    (96 of 256 CUs = 12 per XCD; the mask bits interleave over the 8 XCDs, odd counts per XCD split CU pairs between the
+    partitions and are markedly slower) with 20-batch super-batches (one recurrence workgroup per look-ahead CU).
+    Round 3 ran 128 + 128 with 16-batch super-batches:
     Round 3, with the frozen stages on the f16x2 scheme (their share of a step fell from 0.20 to 0.145 ms, the trainable
     part's ten launches became the longer side; tools/cu_split_sweep.sh, 512 steps, same box, CUs + batches -> k utt/s):
     96 + 20: 296-299, 112 + 16: 311, 128 + 16: 316-321, 128 + 12: 303, 144 + 14: 226, 160 + 12: 257, 80 + 22: 272,
@@ -39,9 +40,14 @@ def cu_split(device=None):
     if not torch.cuda.is_available():
         return 0
     n = n_compute_units(torch.cuda.current_device() if device is None else device)
-    # one half, rounded to whole CU PAIRS per XCD (a multiple of 16: the mask bits interleave over 8 XCDs and an
-    # odd count per XCD splits a pair between the partitions); 256 CUs -> 128, other parts their nearest even share
-    return max(16, (n // 2) // 16 * 16) if n >= 32 else 0
+    # three eighths, rounded to whole CU PAIRS per XCD (a multiple of 16: the mask bits interleave over 8 XCDs and an
+    # odd count per XCD splits a pair between the partitions); 256 CUs -> 96 (+ 160 for the look-ahead super-batches of
+    # 20 batches).  Round 4 (tools/cu_split_sweep.sh, same box; suffix CUs + batches -> steady-state k utt/s | the driver's
+    # 20-step command): 128 + 16: 386 | 227; 112 + 16: 385 | 228; 96 + 20: 381-384 | 234-236; 96 + 18: 385 | 232;
+    # 96 + 22: 354 | 233; 112 + 18 / 20: 310 / 316 | 230 / 223; 128 + 18: 307 | 228; 144 + 14 / 16: 247 / 262 | 212; 80 + 22:
+    # 315 | 205 — with the faster frozen stages the steady state is flat from 96 to 128 and short runs prefer the wider
+    # look-ahead partition (their first super-batch is pure pipeline fill).
+    return max(16, (n * 3 // 8) // 16 * 16) if n >= 32 else 0
 
 
 _CU_MASK_BROKEN = [False]

@@ -142,14 +142,21 @@ def test_pcm16_batches_are_the_float_batches_times_32768(tmp_path, monkeypatch):
     monkeypatch.delenv("SLU_PCM16_BATCHES", raising=False)
     assert not data.pcm16_batches()
     _, va, _ = data.get_SLU_datasets(cfg)
-    ref = [(x.clone(), y.clone()) for x, y in va.loader]
+    items_f = [va[i] for i in range(len(va))]
     monkeypatch.setenv("SLU_PCM16_BATCHES", "1")
     _, va16, _ = data.get_SLU_datasets(cfg)
-    got = list(va16.loader)
-    assert len(got) == len(ref) > 0
-    for (x16, y16), (xf, yf) in zip(got, ref):
-        assert x16.dtype == torch.int16 and x16.shape == xf.shape and torch.equal(y16, yf)
-        assert torch.equal(x16.float() / 32768.0, xf)
+    items_i = [va16[i] for i in range(len(va16))]
+    assert len(items_i) == len(items_f) > 4
+    for (xi, yi), (xf, yf) in zip(items_i, items_f):
+        assert np.asarray(xi).dtype == np.int16 and list(yi) == list(yf)
+        assert np.array_equal(np.asarray(xi).astype(np.float32) / 32768.0, np.asarray(xf))
+    collate = data.CollateWavsSLU(va.Sy_intent, False)
+    x16, y16 = collate(items_i[:5])
+    xf, yf = collate(items_f[:5])
+    assert x16.dtype == torch.int16 and x16.shape == xf.shape and torch.equal(y16, yf)
+    assert torch.equal(x16.float() / 32768.0, xf)                # padding included
+    for x, _ in va16.loader:
+        assert x.dtype == torch.int16
     p = os.path.join(root, "f.wav")
     wavfile.write(p, 16000, np.array([0.25, -0.75], dtype=np.float32))
     a, _ = data.read_wav(p, keep_pcm16=True)

@@ -1,5 +1,5 @@
 """GPU parity of the EXACT path bench.py times (BASELINE.json configs[3] at full size: no_unfreezing
-architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 16 batches (1024 sequences, split-precision
+architecture, H = 128, B = 64, 3 s): look-ahead super-batches of 20 batches (1280 sequences on the 160-CU partition, split-precision
 (f16x2) MFMA input projections and 16-sequence recurrence kernels for the frozen layers, sub-batch Philox streams) replayed from captured hipGraphs + the captured training
 step, against (1) the plain sequential eager loop, bit for bit, and (2) the CPU oracle (<= 1e-4).
 
@@ -70,8 +70,8 @@ def _run_training(cfg, loader, monkeypatch, lookahead, graphs, n_steps, math=Non
 
 
 def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, monkeypatch):
-    """120 steps of B = 64 x 3 s: seven 16-batch super-batches (+ one of 8), four per look-ahead slot: each slot captures its shape
-    on the second appearance and REPLAYS it afterwards; the training step is captured after three eager steps.
+    """120 steps of B = 64 x 3 s: six 20-batch super-batches, three per look-ahead slot: each slot captures its shape
+    on the second appearance and REPLAYS it on the third; the training step is captured after three eager steps.
     Per-step losses and final parameters must be bit-equal to the eager sequential loop."""
     import data
     cfg = _full_cfg(tmp_path)
@@ -97,15 +97,15 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k
 
-    # the bench.py default: automatic look-ahead width (16 batches = 1024 sequences) + graphs
+    # the bench.py default: automatic look-ahead width (20 batches = 1280 sequences on 160 CUs) + graphs
     tr, losses, sd = _run_training(cfg, loader, monkeypatch, "auto", "1", n_steps)
     import training
-    assert training._lookahead_width(-1, 64) == 16
+    assert training._lookahead_width(-1, 64) == 20
     stats = tr.graph_stats()
     assert stats["step_graphs"] == 1 and stats["capture_failures"] == 0
     assert all(len([g for g in slot.graphs.values() if g is not None]) >= 1 for slot in tr._slots)
     assert stats["prefix_graphs"] == 2
-    # every slot replayed its captured graph at least once (seen >= 3 for the 16-batch key)
+    # every slot replayed its captured graph at least once (seen >= 3 for the 20-batch key)
     assert all(max(slot.seen.values()) >= 3 for slot in tr._slots)
     from slu_hip import ops as _ops
     import models
