@@ -143,7 +143,11 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
     const int total = p.nrows * half;
     const unsigned in_row = (unsigned)p.in_row;
     const int drow = WB_THREADS / half, dcp = WB_THREADS - drow * half;
-    constexpr int U = 8;                             // pairs per thread and batch: 16 loads in flight before the first split
+    // pairs per thread and batch: ALL of a 128-frame window (135 rows x 40 pairs / 256 threads = 21.1) in one round — 44 loads
+    // in flight per thread before the first split (the accumulators are not live yet: the registers are free).  With 8 per
+    // round a workgroup paid three dependent HBM round trips before its first MFMA (same box, Sinc launch of a 1024-sequence
+    // super-batch on 128 CUs: DESIGN.md section 7)
+    constexpr int U = 22;
     // PCM: the rows hold int16 samples (decided once, outside the loop: a branch inside it would split the batch of loads)
     auto stage = [&](auto PCM) {
       int row = tid / half, cp = tid - row * half;   // this thread's next pair; + WB_THREADS pairs per step
