@@ -29,8 +29,10 @@ spec = {  # bench.py table name -> (name prefix in the trace, launch shapes per 
 }
 for ns in (2, 3):           # the split scheme of the frozen stages: f16x2 (default) / bf16x3
     spec.update({
-        # the four T share one grid; the first layer's launch is the fused-input instantiation (<128, NS, 2>)
-        "gru_bf_fwd_kernel<128,%d>" % ns: ("void slu::gru_bf_fwd_kernel<128, %d," % ns, 2),
+        # round 4: <H, NS, KI, EPI> — the first layer's launch (fused input projection, plane output), the K = 256 layers
+        # with plane output (two launches per cycle, one grid) and the last frozen layer (fp32 output): three instantiations
+        "gru_bf_fwd_kernel<128,%d>" % ns: ("void slu::gru_bf_fwd_kernel<128, %d," % ns, 3),
+        "dropout_bits_kernel": ("slu::dropout_bits_kernel", 1),
         "gemm_bf_panel96_kernel<%d,8>" % ns: ("void slu::gemm_bf_panel96_kernel<%d, 8>" % ns, 1),
         "gemm_bf_kernel<%d>" % ns: ("void slu::gemm_bf_kernel<%d>" % ns, 2),
         "gemm_bf_panel_kernel<%d,2>" % ns: ("void slu::gemm_bf_panel_kernel<%d, 2>" % ns, 1),

@@ -40,6 +40,24 @@ elif what == "gru_bf":
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
         ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS)
+elif what in ("gru_bf_pool_fused", "gru_bf_pool"):
+    # the product form of a frozen GRU layer (round 4): recurrence + Dropout(0.5) + avg-pool(2) in one launch, plane output;
+    # _fused: the first layer (K = 60, input projection inside the kernel, T = 300); else a K = 256 layer reading gx (T = 150)
+    fused = what == "gru_bf_pool_fused"
+    T, B, H, I = (300 if fused else 150), (int(sys.argv[2]) if len(sys.argv) > 2 else 1280), 128, 60
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    keep = ops.dropout_bits(T, B, 2 * H, 0.5, 1234, 19, None, 64, "cuda")
+    if fused:
+        x = torch.randn(T * B, I, device="cuda"); w_ih = torch.randn(6 * H, I, device="cuda") * 0.1; b_ih = torch.randn(6 * H, device="cuda") * 0.1
+        planes, packed = ops.split_bf16(x, 2), ops.gemm_bf16_pack(w_ih, 2)
+        for _ in range(5):
+            ops.gru_seq_fwd_pool_bf16(None, wf, wr, bf, br, T, B, H, 2, 2, keep, 0.5, True, fused=(planes, I, packed, b_ih))
+    else:
+        gx = torch.randn(T, B, 6 * H, device="cuda")
+        for _ in range(5):
+            ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, 2, keep, 0.5, True)
+    torch.cuda.synchronize()
 elif what == "gru_bf_r3":
     # the round-3 kernel from the alt library (tools/build_alt.sh EXTRA_UNITS=tools/probes/slu_gru_bf16_r3.hip; SLU_HIP_LIB)
     import ctypes
