@@ -515,10 +515,13 @@ class DecoderRNN(torch.nn.Module):
 
 def sort_beam(beam_extensions, beam_extension_scores, beam_pointers):
     """Order the candidate extensions of every utterance by score, descending (reference models.py:487-502).
-    Lists of W tensors (B, V) / (B) / (B) -> stacked (W, B, V), (W, B), (W, B)."""
+    Lists of W tensors (B, V) / (B) / (B) -> stacked (W, B, V), (W, B), (W, B).
+    Ties: the reference calls torch.sort without `stable`, i.e. leaves the order of EQUAL scores to the sort implementation;
+    here the sort is stable — equal scores keep their candidate order (source hypothesis major, then extension rank: the order
+    in which the reference appends them, models.py:622-632) — so the result is deterministic on every device."""
     ext, sc, ptr = torch.stack(beam_extensions), torch.stack(beam_extension_scores), torch.stack(beam_pointers)
     sc = sc.view(len(beam_pointers), -1)
-    order = sc.sort(dim=0, descending=True)[1]
+    order = sc.sort(dim=0, descending=True, stable=True)[1]
     cols = torch.arange(sc.shape[1], device=sc.device)
     return ext[order, cols], sc[order, cols], ptr[order, cols]
 
@@ -581,7 +584,14 @@ class Seq2SeqDecoder(torch.nn.Module):
         -> (beam_scores (B, batch), beam (B, batch, U, |Sy|) one-hot), U = 200 or max(y_lengths).
         All B hypotheses of all utterances advance in ONE batched decoder step on the HIP kernels (rows w * batch +
         b); the first input is the all-zero vector and only hypothesis 0 is expanded at the first step, as in the
-        reference.  Candidate selection is host-side torch (top-k per hypothesis, then the B best of the B * B)."""
+        reference.  Candidate selection is host-side torch (top-k per hypothesis, then the B best of the B * B, by a STABLE
+        descending sort over the reference's candidate order — source hypothesis major — so exact ties resolve as
+        sort_beam's).  Against the reference's own run the BEST hypothesis of every utterance is identical; hypotheses
+        further down the beam can differ where two candidates' scores are closer than the fp32 round-off between the two
+        evaluations (1e-6 on log-probabilities of ~-10: the search continues for U = 200 steps past <eos>, where many
+        continuations are nearly equally (im)probable) — that is a property of comparing two fp32 implementations, not of
+        the tie rule (tests/test_hip_seq2seq.py::test_tiny_seq2seq_beam_search_vs_reference: best hypothesis identical,
+        >= 95 % of all hypothesis labels, scores to 1e-4 relative)."""
         _require_device(encoder_outputs)
         dev = encoder_outputs.device
         W, bsz, V = B, encoder_outputs.shape[0], len(Sy)
@@ -620,7 +630,7 @@ class Seq2SeqDecoder(torch.nn.Module):
                 if u == 0:
                     cand[1:] = float("-inf")
                 flat = cand.permute(1, 0, 2).reshape(bsz, W * W)                        # candidate order: src major
-                best, pick = flat.sort(dim=1, descending=True)
+                best, pick = flat.sort(dim=1, descending=True, stable=True)
                 best, pick = best[:, :W].t().contiguous(), pick[:, :W].t()              # (W, bsz)
                 src, ext = pick // W, pick % W
                 label = top_i.view(W, bsz, W)[src, cols.unsqueeze(0), ext]              # (W, bsz)

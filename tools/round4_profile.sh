@@ -56,7 +56,7 @@ for w, label, T, in_bytes in (("gru_bf_pool_fused", "T=300 B=1280 H=128 D=2 K=60
     waves = (B // 16) * D * 8
     print("   SQ counters (mean of %d launches, %.1f us each, %d waves, whole chip unmasked): %s" % (n, sum(us) / len(us), waves, {k: round(v) for k, v in sq.items()}))
     print("   per wave and step: wave cycles %.0f, active %.0f, VALU-active %.0f, waiting (s_waitcnt / barrier) %.0f, issue stalls %.0f; MFMA pipe busy %.0f cycles per wave-step"
-          % tuple(4 * sq[k] / waves / T for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")) + (sq["SQ_VALU_MFMA_BUSY_CYCLES"] / waves / T,))
+          % (tuple(4 * sq[k] / waves / T for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")) + (sq["SQ_VALU_MFMA_BUSY_CYCLES"] / waves / T,)))
     print("   instructions per wave and step:", {k: round(v / waves / T, 1) for k, v in sq2.items()})
 j = json.load(open("profiles/pmc_traffic.json"))
 j["gru_bf_fwd_kernel<128,2>"] = {
