@@ -746,6 +746,28 @@ def note(msg):
 
 
 _T0 = time.perf_counter()
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Library code prints there too — the reference-style config messages
+    (`read_config`), RCCL's version banner (C stdio, flushed at exit, i.e. AFTER the line) — and under torchrun all ranks
+    share the pipe.  So: keep the real stdout aside for the JSON line and point file descriptor 1 at stderr for
+    everything else, Python and C alike."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_json(out):
+    sys.stdout.flush()
+    line = (json.dumps(out) + "\n").encode()
+    if _JSON_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_JSON_FD, line)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -794,8 +816,46 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def dp_point(model, trainer, batches, steps, asr, fence):
+    """Data parallel runs, EVERY rank (collectives inside): (1) the step's gradient all-reduce alone — the flat bucket(s),
+    50 back-to-back calls on the training stream between two HIP events; (2) the timed loop once more with the collective
+    stubbed out (each rank applies its local gradients: the replicas diverge, nothing is measured after this) — the
+    difference to the headline's ms_per_step is what the collective costs INSIDE the loop."""
+    b = trainer.bucket
+    stream = getattr(trainer, "_train_stream", None) or getattr(trainer, "_full_stream", None) or torch.cuda.current_stream()
+    for f in b.flats.values():
+        f.zero_()                                    # repeated in-place sums of real gradients would overflow
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            b.allreduce_flats()
+        e0.record(stream)
+        for _ in range(50):
+            b.allreduce_flats()
+        e1.record(stream)
+    e1.synchronize()
+    out = {"allreduce_us_alone": round(1e3 * e0.elapsed_time(e1) / 50, 2), "allreduce_bytes": b.nbytes(),
+           "collectives_per_step": len(b.flats)}
+    b.stub = True
+    trainer._step_graphs.clear()
+    try:
+        run_steps(model, trainer, batches, steps, asr)           # re-captures the step without its collective
+        fence()
+        t0 = time.perf_counter()
+        run_steps(model, trainer, batches, steps, asr)
+        fence()
+        dt = time.perf_counter() - t0
+    finally:
+        b.stub = False
+        trainer._step_graphs.clear()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=next(model.parameters()).device)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    out["ms_per_step_without_collective"] = round(1e3 * tmax.item() / steps, 4)
+    return out
+
+
 def rccl_info(world):
-    if world == 1:
+    if not torch.distributed.is_initialized():
         return None
     import torch.distributed as dist
     backend = dist.get_backend()
@@ -838,6 +898,7 @@ def main():
         self_launch(args)
         return
 
+    claim_stdout()
     from slu_hip import dp, lib
     rank, world, local = dp.init_from_env()
     if world != args.gpus:
@@ -895,6 +956,13 @@ def main():
     elapsed = tmax.item()
     loss_mean = (sums[0] / (args.steps * args.batch)).item()
     graphs = trainer.graph_stats()
+    dp_costs = None
+    if trainer.data_parallel:
+        note("data parallel: the collective alone, the loop without it")
+        try:
+            dp_costs = dp_point(model, trainer, batches, args.steps, asr, fence)
+        except Exception as e:                                   # a side measurement never takes the headline down
+            dp_costs = {"error": str(e)[:200]}
 
     # steady state of the same loop (long run), reported beside `value` when K is short: the first
     # super-batch of a run has to be computed before its first step can start (pipeline fill)
@@ -934,8 +1002,12 @@ def main():
         }
         if steady:
             out["steady_state"] = steady
-        if world > 1:
+        if trainer.data_parallel:
             out["rccl"] = rccl_info(world)
+            if dp_costs:
+                # per step: where the all-reduce sits, what it costs alone and what the loop costs without it
+                out["rccl"].update(dp_costs)
+                out["rccl"]["collective"] = graphs.get("collective")
             if os.environ.get("SLU_DIST_BACKEND") == "gloo":
                 out["config"]["parallelism"] += " (ranks share the visible GPU(s) over gloo: functional check only)"
         if world == 1 and not args.no_kernel_table:
@@ -1026,8 +1098,8 @@ def main():
             out["frozen_bf16x3"] = side_run(common, {"SLU_FROZEN_MATH": "bf16x3"})
             short = ["--steps", "40", "--warmup", "10", "--batch", str(args.batch), "--seconds", str(args.seconds)]
             out.setdefault("other_workloads", {}).update({w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain", "seq2seq")})
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit_json(out)
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     shutil.rmtree(work, ignore_errors=True)

@@ -20,6 +20,20 @@ def world():
     return 0, 1
 
 
+def _single_rank_dp():
+    """Test aid: SLU_DP_SINGLE=1 treats an initialised ONE-rank process group as data parallel (bucket packing, the
+    collective, 1/N in Adam with N = 1), which exercises the whole data-parallel step — including an RCCL all-reduce
+    captured inside the step's hipGraph — on a single-GPU box."""
+    return os.environ.get("SLU_DP_SINGLE", "0") == "1"
+
+
+def data_parallel():
+    """Does a training step of this process contain a gradient collective?"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or _single_rank_dp()
+
+
 def init_from_env(backend=None):
     """Initialises torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world_size, local_rank).  No-op for 1 process."""
@@ -29,7 +43,7 @@ def init_from_env(backend=None):
     # Test aid: SLU_DIST_BACKEND=gloo SLU_LOCAL_DEVICE=0 runs several ranks on ONE GPU (RCCL refuses
     # duplicate devices), which exercises the whole multi-process step path on a single-GPU box.
     local = int(os.environ.get("SLU_LOCAL_DEVICE", local))
-    if ws > 1 and not (dist.is_available() and dist.is_initialized()):
+    if (ws > 1 or _single_rank_dp()) and not (dist.is_available() and dist.is_initialized()):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -98,6 +112,8 @@ class GradBucket:
         self.signature = None
         self.divide = True        # False: the optimiser divides by the world size itself (HipAdam.grad_div)
         self.comm = None          # DirectComm: all-reduce through slu_comm_* on the current stream (SLU_COMM=rccl)
+        self.stub = False         # measurement aid (bench.py): skip the collective — "the step without its all-reduce"
+        self._in_graph = None     # collective_in_graph()'s verdict, agreed between the ranks once per trainer
 
     def reset(self):
         """Forget the bucket (call after the trainable set changed, e.g. unfreeze_one_layer)."""
@@ -151,6 +167,8 @@ class GradBucket:
         """ONE collective per gradient dtype over the packed flat buffers: the sum over ranks, and the
         division by the world size unless the optimiser folds it into its update (`divide` False)."""
         ws = world()[1]
+        if self.stub:
+            return
         for flat in self.flats.values():
             if self.comm is not None:
                 self.comm.allreduce(flat)
@@ -161,12 +179,64 @@ class GradBucket:
 
     def allreduce_mean(self):
         """Average the gradients of all ranks (call after backward).  One process: bookkeeping only."""
-        rank, ws = world()
-        if ws == 1:
+        if not data_parallel():
             self.observe()
             return
         self.pack()
         self.allreduce_flats()
+
+    def collective_in_graph(self, device):
+        """Can the step's all-reduce be a node of the step's hipGraph?  (pipeline.StepGraph: ONE graph per step under data
+        parallelism — forward, backward, bucket packing, all-reduce, Adam — instead of graph / eager collective / graph;
+        the collective is then ordered by the graph on the CU-masked training stream and costs no host call per step.)
+        SLU_DP_GRAPH: "0" never, "1" without the self-test, "auto" (default): backend nccl (RCCL collectives are
+        capturable; gloo stages through the host) AND a self-test passes on every rank — a tiny all-reduce captured on a
+        side stream and replayed twice must give the known sum.  The ranks agree on the verdict with an eager MIN
+        all-reduce BEFORE any replay (a rank whose capture failed must not leave the others waiting inside a captured
+        collective), so they all build the same kind of step."""
+        if self._in_graph is not None:
+            return self._in_graph
+        mode = os.environ.get("SLU_DP_GRAPH", "auto")
+        ok = data_parallel() and mode != "0" and device.type == "cuda" and (self.comm is not None or dist.get_backend() == "nccl")
+        if ok and mode != "1":
+            ok = self._capture_selftest(device)
+        self._in_graph = bool(ok)
+        return self._in_graph
+
+    def _capture_selftest(self, device):
+        rank, ws = world()
+        src = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=device)
+        t = torch.zeros_like(src)
+        side = torch.cuda.Stream(device)
+        graph, captured = torch.cuda.CUDAGraph(), 1.0
+        torch.cuda.synchronize(device)
+        try:
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                t.copy_(src)
+                if self.comm is not None:
+                    self.comm.allreduce(t)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        except Exception as e:                          # noqa: BLE001 - any capture failure means "stay eager"
+            print("data parallel: the all-reduce cannot be captured in a hipGraph here (%s); it stays an eager call "
+                  "between two graphs" % (str(e)[:200],))
+            captured = 0.0
+        torch.cuda.synchronize(device)
+        flag = torch.tensor([captured], dtype=torch.float32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # eager: every rank reaches this whatever its capture did
+        if flag.item() < 1.0:
+            return False
+        want = ws * (ws + 1) / 2.0
+        good = 1.0
+        for _ in range(2):
+            with torch.cuda.stream(side):
+                graph.replay()
+            side.synchronize()
+            if not bool((t == want).all()):
+                good = 0.0
+        flag = torch.tensor([good], dtype=torch.float32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return flag.item() >= 1.0
 
 
 def allreduce_sums(values, device, comm=None):

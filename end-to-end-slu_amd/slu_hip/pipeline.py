@@ -269,9 +269,12 @@ class RangeTrip(RuntimeError):
 
 
 class StepGraph:
-    """One optimisation step captured as two hipGraphs around the gradient all-reduce:
-    G1 = forward, loss, backward (+ packing the gradients into the flat bucket under data
-    parallelism);  [RCCL all-reduce, eager];  G2 = Adam.  Used for the trainable remainder of an SLU
+    """One optimisation step captured as hipGraph(s).  Single process: ONE graph (forward, loss, backward, Adam).
+    Data parallel: ONE graph as well when the collective can be a graph node (backend nccl = RCCL; dp.GradBucket.
+    collective_in_graph) — forward, loss, backward, packing the gradients into the flat bucket, the RCCL all-reduce
+    and Adam, all ordered by the graph on the CU-masked training stream, no host call between them; otherwise (gloo,
+    SLU_DP_GRAPH=0, a failed self-test) two graphs around an eager collective:
+    G1 = forward, loss, backward, packing;  [all-reduce, eager];  G2 = Adam.  Used for the trainable remainder of an SLU
     step (inputs = prefix features + labels), for a fully trainable SLU step (waveforms + labels) and
     for an ASR pre-training step (waveforms + phoneme / word labels): a B = 64 step is ~100 short
     kernels, i.e. host-bound when launched one by one.  Inputs and the dropout step are static device
@@ -298,7 +301,9 @@ class StepGraph:
         from . import dp
         bucket = trainer.bucket
         assert bucket is not None and bucket.active
-        self.world = dp.world()[1]
+        self.dp = dp.data_parallel()
+        # the all-reduce as a graph node (decided once per trainer, the same on every rank)
+        self.collective_in_graph = self.dp and bucket.collective_in_graph(dev)
         torch.cuda.synchronize()
         bucket.release_grads()
         self.one = torch.ones((), dtype=torch.float32, device=dev)      # root gradient (no per-step fill)
@@ -314,8 +319,11 @@ class StepGraph:
                 self.loss.backward(self.one)
                 if guard is not None:
                     guard.collect()
-                if self.world > 1:
+                if self.dp:
                     bucket.pack()                   # one concatenation kernel per dtype; .grad -> slices
+                    if self.collective_in_graph and guard is None:
+                        bucket.allreduce_flats()    # one collective per gradient dtype, captured; the mean's 1 / N is
+                        trainer.optimizer.step()    # folded into the Adam kernel (HipAdam.grad_div)
                 elif _one_graph() and guard is None:
                     # single process: nothing sits between the backward pass and Adam, so they are ONE graph — a graph
                     # launch costs the stream ~8 us of ramp (SLU_ONE_STEP_GRAPH=0: two graphs as under data parallelism)
@@ -323,9 +331,12 @@ class StepGraph:
         finally:
             ops._Fork.capture_forks = False
         self.g2 = None
-        if self.world > 1 or not _one_graph() or guard is not None:
+        one = (self.collective_in_graph if self.dp else _one_graph()) and guard is None
+        if not one:
             self.g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
+                if self.collective_in_graph:        # guarded step: the range check sits between backward and the collective
+                    bucket.allreduce_flats()
                 trainer.optimizer.step()
         bucket.observe()
         self.signature = bucket.signature
@@ -340,8 +351,8 @@ class StepGraph:
             overflow, quiet, seen = self.guard.verdict()
             if overflow or quiet:
                 raise RangeTrip(overflow, seen)
-        if self.world > 1:                          # one collective per gradient dtype; the mean's 1/N is
-            self.trainer.bucket.allreduce_flats()   # folded into the Adam kernel (HipAdam.grad_div)
+        if self.dp and not self.collective_in_graph:
+            self.trainer.bucket.allreduce_flats()   # eager, between the two graphs
         if self.g2 is not None:
             self.g2.replay()
         return self.metrics

@@ -13,6 +13,7 @@ back once per print interval / epoch instead of four `.cpu()` round trips per st
 moves the model to the CPU for its seq2seq beam search, training.py:150,166, and crashes on a
 CPU-only host); under torch.distributed only rank 0 prints, logs and writes checkpoints.
 """
+import collections
 import contextlib
 import math
 import os
@@ -87,11 +88,12 @@ class Trainer:
         self.rank, self.world_size = dp.world()
         # flat gradient bucket: the unit of the per-step all-reduce under data parallelism, and (on a
         # GPU) what gives the gradients fixed addresses for hipGraph-captured steps
-        self.bucket = dp.GradBucket(model.parameters()) if (self.world_size > 1 or on_gpu) else None
+        self.data_parallel = dp.data_parallel()      # world size > 1 (or the one-rank test mode SLU_DP_SINGLE=1)
+        self.bucket = dp.GradBucket(model.parameters()) if (self.data_parallel or on_gpu) else None
         self._step_graphs, self._eager_steps = {}, {}
         self.capture_failures = 0
         self._hip_adam = on_gpu
-        if on_gpu and self.world_size > 1:
+        if on_gpu and self.data_parallel:
             # data-parallel mean: the all-reduce delivers the SUM, Adam divides by the world size in-kernel
             self.optimizer.grad_div = float(self.world_size)
             self.bucket.divide = False
@@ -210,9 +212,16 @@ class Trainer:
         """{"step_graphs": captured optimisation steps, "prefix_graphs": captured look-ahead super-batch
         shapes, "capture_failures": shapes that fell back to eager launches} — reported by bench.py."""
         slots = getattr(self, "_slots", None) or []
-        return {"step_graphs": len(self._step_graphs),
-                "prefix_graphs": sum(1 for sl in slots for g in sl.graphs.values() if g is not None),
-                "capture_failures": self.capture_failures + sum(sl.capture_failures for sl in slots)}
+        out = {"step_graphs": len(self._step_graphs),
+               "prefix_graphs": sum(1 for sl in slots for g in sl.graphs.values() if g is not None),
+               "capture_failures": self.capture_failures + sum(sl.capture_failures for sl in slots)}
+        if self.data_parallel:
+            # where the gradient all-reduce of a captured step sits (slu_hip/pipeline.StepGraph)
+            sgs = list(self._step_graphs.values())
+            out["collective"] = ("none captured yet" if not sgs else
+                                 "a node of the step's hipGraph" if all(g.collective_in_graph for g in sgs) else
+                                 "eager call between two hipGraphs")
+        return out
 
     def _graph_step(self, key, inputs, step, forward, stream, forks=False, guard=None):
         """One optimisation step on `inputs` (device tensors): replay of the hipGraph captured for `key`
@@ -570,12 +579,13 @@ class Trainer:
         # the batch_size-weighted sums of the metrics (reference training.py:100-104) stay on the device:
         # self.epoch_sums, filled by the step loop itself (inside the captured step's kernels where it can)
         seq2seq = not asr and getattr(self.model, "seq2seq", False)
-        batches_seen = []
+        batches_read = collections.deque()
         if seq2seq:                      # the decoded strings need the batch the step consumed
+            # the step loop reads AHEAD of the step it yields (look-ahead super-batches, grouped evaluation) but
+            # yields exactly once per batch, in reading order: the batch of the idx-th yield is the idx-th one read
             def tee(loader):
                 for b in loader:
-                    batches_seen.append(b)
-                    del batches_seen[:-64]
+                    batches_read.append(b)
                     yield b
             src = it
             it = tee(src)
@@ -583,16 +593,17 @@ class Trainer:
         with contextlib.closing(self._iterate(it, train, asr, accumulate=True)) as steps:
             for idx, (vals, batch_size) in enumerate(steps):
                 num_examples += batch_size
+                current = batches_read.popleft() if seq2seq else None
                 if train and idx % print_interval == 0 and self.rank == 0:
                     step_vals = vals if torch.is_tensor(vals) else [v.detach().reshape(()) for v in vals]
                     for n, v in zip(names, [float(v) for v in step_vals]):   # one host sync per print interval
                         print(n + ": " + str(v))
                     if seq2seq:          # reference training.py:103-112: show one decoded utterance
-                        self._say_seq2seq_sample(batches_seen, batch_size)
+                        self._say_seq2seq_sample(current)
                 if seq2seq and not train and self.epoch > 1:
                     # reference training.py:158-164: from the third epoch on the test accuracy is the fraction of
                     # utterances whose beam-search string equals the label string
-                    x, y = next(b for b in reversed(batches_seen) if len(b[0]) == batch_size)
+                    x, y = current
                     guess = self.model.decode_intents(x)
                     truth = [self.model.one_hot_to_string(y[i], self.model.Sy_intent) for i in range(batch_size)]
                     hit = sum(g == t for g, t in zip(guess, truth)) / batch_size
@@ -611,8 +622,9 @@ class Trainer:
             means[1] = means[1] + means[-1]          # intent_acc += string accuracy (the model's own acc is 0)
         return means[:len(names)]
 
-    def _say_seq2seq_sample(self, batches_seen, batch_size):
-        x, y = next(b for b in reversed(batches_seen) if len(b[0]) == batch_size)
+    def _say_seq2seq_sample(self, batch):
+        """Reference training.py:103-112: decode the first utterance of the batch the step just consumed."""
+        x, y = batch
         import models
         was_training = self.model.training
         step = models._DropoutState.step          # the sample must not shift the training run's dropout streams

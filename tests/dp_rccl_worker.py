@@ -43,7 +43,7 @@ ds = data.SyntheticSLUDataset(4, GLOBAL, 6000, cfg.values_per_slot, seed=5)     
 n = GLOBAL // ws
 ds.batches = [(x[rank * n:(rank + 1) * n].contiguous(), y[rank * n:(rank + 1) * n].contiguous()) for x, y in ds.batches]
 ds.loader = data._SyntheticLoader(ds.batches)
-epochs, payloads, live = [], [], []
+epochs, payloads, live, collective = [], [], [], []
 _reset = trainer.bucket.reset
 
 
@@ -57,13 +57,14 @@ for _ in range(3):
     acc, loss = trainer.train(ds, print_interval=1000)
     epochs.append((acc, loss))
     live.append(sum(1 for p in model.parameters() if p.requires_grad))
+    collective.append(trainer.graph_stats().get("collective"))     # where the captured steps' all-reduce sits
 assert len(payloads) == 3
 torch.cuda.synchronize()
-torch.save({"epochs": epochs, "payloads": payloads, "live": live,
+torch.save({"epochs": epochs, "payloads": payloads, "live": live, "collective": collective,
             "sd": {k: v.detach().cpu() for k, v in model.state_dict().items()},
             "comm": type(trainer.bucket.comm).__name__ if trainer.bucket.comm is not None else "torch.distributed",
-            "backend": torch.distributed.get_backend() if ws > 1 else "none"}, out)
+            "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"}, out)
 trainer.close()
-if ws > 1:
+if torch.distributed.is_initialized():
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

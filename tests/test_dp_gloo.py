@@ -137,6 +137,15 @@ def _bucket_worker(rank, world, port, out):
     ok = ok and sums == [3.0, 4.0]
     bucket.reset()
     ok = ok and a.grad is None and not bucket.active
+    # a step of this process contains a collective; over gloo (host-staged) it is never a node of the step's hipGraph
+    ok = ok and dp.data_parallel() and not bucket.collective_in_graph(torch.device("cpu"))
+    # bench.py's measurement aid: with the collective stubbed out the gradients stay the local ones
+    a.grad = torch.full((4,), float(rank + 1))
+    b.grad = None
+    bucket.stub = True
+    bucket.allreduce_mean()
+    ok = ok and torch.equal(a.grad, torch.full((4,), float(rank + 1)))
+    bucket.stub = False
     open(os.path.join(out, "ok%d" % rank), "w").write(str(ok))
     torch.distributed.destroy_process_group()
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, world, comm, shared_gpu=False):
+def _run(tmp_path, world, comm, shared_gpu=False, extra_env=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -27,8 +27,10 @@ def _run(tmp_path, world, comm, shared_gpu=False):
                    MASTER_PORT=str(port), SLU_COMM=comm, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         env.pop("SLU_DIST_BACKEND", None)
         env.pop("SLU_LOCAL_DEVICE", None)
+        env.pop("SLU_DP_SINGLE", None)
         if shared_gpu:                       # all ranks on GPU 0 over gloo (RCCL refuses duplicate devices)
             env.update(SLU_DIST_BACKEND="gloo", SLU_LOCAL_DEVICE="0")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_rccl_worker.py"), out, str(world)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         outs.append(out)
@@ -80,7 +82,33 @@ def test_two_ranks_on_one_gpu_over_gloo(tmp_path, single):
     Adam, reduced epoch metrics, bucket rebuild across unfreeze_one_layer(), look-ahead pipeline per rank)."""
     ranks = _run(tmp_path, 2, "torch", shared_gpu=True)
     assert ranks[0]["backend"] == "gloo"
+    assert ranks[0]["collective"] == ["eager call between two hipGraphs"] * 3        # gloo stages through the host
     _check(ranks, single, 2, "gloo on one GPU")
+
+
+@pytest.mark.parametrize("comm", ["torch", "rccl"])
+def test_one_rank_rccl_collective_inside_the_step_graph(tmp_path, single, comm):
+    """What a ONE-GPU box can run of the real thing: a one-rank RCCL group treated as data parallel (SLU_DP_SINGLE=1) —
+    bucket packing, the RCCL all-reduce as a NODE OF THE STEP'S hipGraph (torch.distributed's collective captured, and
+    slu_comm_* on the training stream), 1 / N in Adam.  A one-rank sum is the identity and N = 1 divides exactly, so the
+    run must equal the plain single-process run bit for bit — captured == eager, and nothing of the step was lost
+    around the collective."""
+    (a,) = _run(tmp_path, 1, comm, extra_env={"SLU_DP_SINGLE": "1"})
+    assert a["backend"] == "nccl"
+    assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
+    assert a["collective"] == ["a node of the step's hipGraph"] * 3, a["collective"]
+    for k, v in single["sd"].items():
+        assert torch.equal(v, a["sd"][k]), k
+    assert a["epochs"] == single["epochs"] and a["payloads"] == single["payloads"]
+
+
+def test_one_rank_rccl_collective_eager_between_graphs(tmp_path, single):
+    """SLU_DP_GRAPH=0: the round-3 shape of the step (graph, eager all-reduce, graph) stays available and gives the same
+    parameters."""
+    (a,) = _run(tmp_path, 1, "torch", extra_env={"SLU_DP_SINGLE": "1", "SLU_DP_GRAPH": "0"})
+    assert a["collective"] == ["eager call between two hipGraphs"] * 3, a["collective"]
+    for k, v in single["sd"].items():
+        assert torch.equal(v, a["sd"][k]), k
 
 
 @pytest.mark.parametrize("comm", ["torch", "rccl"])
@@ -92,4 +120,5 @@ def test_rccl_data_parallel_training(tmp_path, single, world, comm):
     a = ranks[0]
     assert a["backend"] == "nccl"
     assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
+    assert a["collective"] == ["a node of the step's hipGraph"] * 3, a["collective"]
     _check(ranks, single, world, comm)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The default bench loop fed from pinned HOST batches (H2D inside the clock) for several placements of the copies:
 SLU_COPY_CUS = 0 (on the slot's stream, serialised with its kernels), 16 / 32 / 160 (a copy stream confined to that many
-CUs of the look-ahead partition), 999 (an unmasked copy stream)."""
+CUs of the look-ahead partition), 999 (an unmasked copy stream); "default" leaves the variable alone.  An argument
+"<cus>:<slots>" also sets SLU_LOOKAHEAD_SLOTS (super-batches in flight: 2 = the copy of group g + 2 starts when group g's
+steps end, 3 = one group earlier, beside group g + 1's encoder)."""
 import json
 import os
 import subprocess
@@ -9,10 +11,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "SLU_PROBE_CHILD" not in os.environ:
-    for cus in sys.argv[1:] or ["0", "16", "32", "160", "999"]:
-        env = dict(os.environ, SLU_PROBE_CHILD="1", SLU_COPY_CUS=cus)
+    for arg in sys.argv[1:] or ["0", "16", "32", "160", "999"]:
+        cus, _, slots = arg.partition(":")
+        env = dict(os.environ, SLU_PROBE_CHILD="1")
+        if cus != "default":
+            env["SLU_COPY_CUS"] = cus
+        if slots:
+            env["SLU_LOOKAHEAD_SLOTS"] = slots
         out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
-        print("SLU_COPY_CUS=%s: %s" % (cus, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:]))
+        print("SLU_COPY_CUS=%s SLU_LOOKAHEAD_SLOTS=%s: %s" % (cus, slots or "default", out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-400:]), flush=True)
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
