@@ -41,6 +41,16 @@ struct WconvBfParams {
   int do_abs, pool;
   float slope;
   int nrows;            // LDS rows staged per workgroup
+  int vec4;             // != 0: the window is staged four elements at a time through a buffer descriptor of the sequence's
+                        // row (S_real, pad and in_row multiples of 4): 16-byte (8-byte for PCM16) loads, and the convolution's
+                        // zero padding — reads before the start / past the end of the row — is the descriptor's bounds check
+  int stagger;          // > 0: workgroups of the FIRST dispatch round that hold an odd slot of their CU start `stagger` x 8128
+                        // clocks late — two workgroups share a CU and, all being alike, would run in lock-step (both staging,
+                        // then both on the MFMA pipe, then both storing); half a tile of offset lets one's memory phases
+                        // run under the other's MFMAs, and the offset persists because slots are refilled as they free up
+  int first_round;      // linear workgroup ids below this belong to the first round
+  int stage_out;        // != 0: the epilogue goes through LDS — the workgroup's output tile (fp32 rows or plane rows) is
+                        // assembled in the window's LDS and leaves in whole rows of 16-byte stores (launcher: alignment, size)
   unsigned* amax;       // null, or the f16x2 range word of this launch: atomicMax of the bit pattern of |v| over every value
                         // the launch splits (input window, plane output) — what the host's guard reads (slu_hip.h)
 };
@@ -123,6 +133,12 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
     inb16 = reinterpret_cast<const short*>(base) + roff;
   }
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
+  if (p.stagger > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < p.first_round) {
+    // HW_REG_HW_ID (4), bits 16..19: the workgroup's slot on its CU (uniform over the workgroup)
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+    if (tg & 1u)
+      for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+  }
   unsigned amx = 0;                               // f16x2 range guard (NS == 2 with p.amax only)
   const int row0 = COLS ? 0 : (SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT);   // this wave's first frame in the tile
   const int nb = COLS ? wave : (SPLITN ? (wave & 1) * CT : 0);                     // ... and its first channel tile
@@ -194,7 +210,74 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
         }
       }
     };
-    if (p.pcm16) stage(std::true_type{}); else stage(std::false_type{});
+    // Four elements per step (S_real, pad, in_row multiples of 4).  The pair loop above costs ~40 VALU instructions per
+    // pair (two bounds per element, 64-bit addresses, conditional loads compiled to branches): SQ counters of the Sinc
+    // launch showed 2 360 VALU instructions per wave beside 390 MFMAs, and on this chip the VALU and MFMA issue of the
+    // two waves of a SIMD add up rather than overlap — the kernel was bound by VALU + MFMA issue.
+    // Here the row is read through a buffer descriptor whose bounds check returns 0 outside [0, in_row): no bounds
+    // arithmetic, one 16-byte (PCM16: 8-byte) load, two packed splits and one 8-byte LDS store per plane and quad.
+    auto stage4 = [&](auto PCM) {
+      constexpr bool pcm = decltype(PCM)::value;
+      constexpr int ESZ = pcm ? 2 : 4;
+      const unsigned long long gbase = pcm ? (unsigned long long)inb16 : (unsigned long long)inb;
+      const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)gbase), bhi = __builtin_amdgcn_readfirstlane((unsigned)(gbase >> 32));
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo), 0, (int)(in_row * ESZ), 0x00020000);
+      const int quads = p.S >> 2;
+      const int totq = p.nrows * quads;
+      const int drq = WB_THREADS / quads, dcq = WB_THREADS - drq * quads;
+      int row = tid / quads, cq = tid - row * quads;
+      constexpr int UQ = 11;                           // 135 rows x 20 quads / 256 threads = 10.5: one round for the Sinc window
+      for (int base = tid; base < totq; base += WB_THREADS * UQ) {
+        float v[UQ][4];
+        int off[UQ];
+#pragma unroll
+        for (int j = 0; j < UQ; ++j) {
+          const bool ok = base + j * WB_THREADS < totq;
+          const int col = 4 * cq;
+          const int u = u0 + row * p.S_real + col;
+          // columns [S_real, S) are the channel padding, rows past the window nothing: an offset the descriptor rejects
+          const int voff = (ok && col < p.S_real) ? u * ESZ : (int)0x80000000;
+          off[j] = ok ? row * p.Sp + col : -1;
+          if constexpr (pcm) {
+            const auto w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, 0, 0);
+            v[j][0] = (float)(short)(w[0] & 0xffffu); v[j][1] = (float)(short)(w[0] >> 16);
+            v[j][2] = (float)(short)(w[1] & 0xffffu); v[j][3] = (float)(short)(w[1] >> 16);
+          } else {
+            const auto w = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+            v[j][0] = __uint_as_float(w[0]); v[j][1] = __uint_as_float(w[1]);
+            v[j][2] = __uint_as_float(w[2]); v[j][3] = __uint_as_float(w[3]);
+          }
+          cq += dcq; row += drq;
+          if (cq >= quads) { cq -= quads; ++row; }
+        }
+#pragma unroll
+        for (int j = 0; j < UQ; ++j) {
+          if (off[j] < 0) continue;
+          float a[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] = pcm ? v[j][e] * p.in_scale : v[j][e];
+          unsigned short* dst = lds + off[j];
+          if constexpr (NS == 2) {
+            amx = max(amx, max(max(abs_bits(a[0]), abs_bits(a[1])), max(abs_bits(a[2]), abs_bits(a[3]))));
+            uint2 hi, lo;
+            split_f16x2_pair_flush(a[0], a[1], hi.x, lo.x);
+            split_f16x2_pair_flush(a[2], a[3], hi.y, lo.y);
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + plane) = lo;
+          } else {
+            unsigned short t[4][NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_terms<NS>(a[e], t[e]);
+#pragma unroll
+            for (int pl = 0; pl < NS; ++pl)
+              *reinterpret_cast<uint2*>(dst + pl * plane) = make_uint2(t[0][pl] | ((unsigned)t[1][pl] << 16), t[2][pl] | ((unsigned)t[3][pl] << 16));
+          }
+        }
+      }
+    };
+    if (p.vec4) { if (p.pcm16) stage4(std::true_type{}); else stage4(std::false_type{}); }
+    else if (p.pcm16) stage(std::true_type{}); else stage(std::false_type{});
   }
   if constexpr (NS == 2) f16_denorm_keep();          // the epilogue's plane output follows the default-mode rule (slu_bf16.h)
   __syncthreads();
@@ -283,6 +366,100 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
   float* __restrict__ outb = p.out ? p.out + (size_t)b * p.out_sb : nullptr;
   unsigned char* __restrict__ routeb = p.route ? p.route + (size_t)b * p.l_out * p.c_out : nullptr;
   const int osl = (int)p.out_sl;
+  if (p.stage_out) {
+    // ---- LDS-staged epilogue.  Written straight from the accumulator layout, a store instruction covers 4 rows x 16
+    //      channels: 64-byte (fp32) or 32-byte (plane) segments, 20-40 store instructions per lane — probe builds put the
+    //      Sinc launch's stores at 50 of its 270 us (tools/build_wconv_probe.sh, profiles/r04_r_wconv_probe_bits.txt).  Here
+    //      the tile is assembled in the window's LDS (every wave is done with it after the tap loop) and leaves as whole
+    //      rows, 16 bytes per lane. ----
+    __syncthreads();
+    if (p.planes) {
+      const int LDP = p.Kp_out + 8;                                      // plane row stride in LDS (elements; 16-byte rows)
+#pragma unroll
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool shared = tile >= RT * CT;
+        const int m = shared ? tile - RT * CT : tile / CT, n = shared ? 0 : tile % CT;
+        const int lr0 = row0 + rtile(m) * 16 + 4 * kg;                   // local frame of acc[tile][0]
+        const int c = (shared ? NT - 1 : nb + n) * 16 + i;
+        if (c >= p.Kp_out) continue;
+        const bool real = c < p.c_out;
+        const float bias = (real && p.bias) ? p.bias[c] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = acc[tile][r] + bias;
+          t = p.do_abs ? fabsf(t) : t;
+          t = real ? (t > 0.0f ? t : t * p.slope) : 0.0f;
+          if (l0 + lr0 + r >= p.l_conv) t = 0.0f;                       // rows past the end: never stored, keep them out of the guard
+          unsigned short sp[NS];
+          if constexpr (NS == 2) amx = max(amx, abs_bits(t));
+          split_terms<NS>(t, sp);
+#pragma unroll
+          for (int pl = 0; pl < NS; ++pl) lds[(pl * F + lr0 + r) * LDP + c] = sp[pl];
+        }
+      }
+      __syncthreads();
+      const int cpr = p.Kp_out >> 3;                                     // 16-byte chunks per row
+      const int per_plane = F * cpr;
+      for (int q = tid; q < NS * per_plane; q += WB_THREADS) {
+        const int pl = q / per_plane, rem = q - pl * per_plane;
+        const int lr = rem / cpr, ch = rem - lr * cpr;
+        const int f = l0 + lr;
+        if (f >= p.l_conv) continue;
+        *reinterpret_cast<uint4*>(p.planes + (size_t)pl * p.plane + ((size_t)f * p.Bn + b) * p.Kp_out + 8 * ch) =
+            *reinterpret_cast<const uint4*>(lds + (pl * F + lr) * LDP + 8 * ch);
+      }
+    } else {
+      float* so = reinterpret_cast<float*>(smem);                        // [F / pool][c_out + 4]
+      const int LDO = p.c_out + 4;
+      const bool full = l0 + F <= p.l_conv;                              // uniform: no partial pooling window in this tile
+      // |x| >= 0: LeakyReLU is the identity after Abs (0 * slope = 0, NaN stays NaN) — skipped, bit for bit the same
+      const bool leaky = !p.do_abs;
+      // this lane's element of a 16 x 16 tile: rows 4 kg + r, column i (pooled: rows 2 kg + h)
+      const int lane_off = (p.pool == 2 ? 2 * kg : 4 * kg) * LDO + i;
+#pragma unroll
+      for (int tile = 0; tile < NTILE; ++tile) {
+        const bool shared = tile >= RT * CT;
+        const int m = shared ? tile - RT * CT : tile / CT, n = shared ? 0 : tile % CT;
+        const int ut = row0 + rtile(m) * 16;                             // wave-uniform: first local frame of the tile
+        const int ct = (shared ? NT - 1 : nb + n) * 16;                  // wave-uniform: first channel of the tile
+        if (ct + i >= p.c_out) continue;
+        const float bias = p.bias ? p.bias[ct + i] : 0.0f;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = acc[tile][r] + bias;
+          v[r] = p.do_abs ? fabsf(t) : t;
+        }
+        if (p.pool == 2) {
+          float* dst = so + (ut >> 1) * LDO + ct + lane_off;
+          float o[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            // ceil_mode: the last window of a sequence may hold one frame (a tile past l_conv stores nothing: read-out skips it)
+            const bool has1 = full || (l0 + ut + 4 * kg + 2 * h + 1) < p.l_conv;
+            const float pooled = (has1 && v[2 * h + 1] > v[2 * h]) ? v[2 * h + 1] : v[2 * h];
+            o[h] = leaky ? (pooled > 0.0f ? pooled : pooled * p.slope) : pooled;
+          }
+          dst[0] = o[0];
+          dst[LDO] = o[1];
+        } else {
+          float* dst = so + ut * LDO + ct + lane_off;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[r * LDO] = leaky ? (v[r] > 0.0f ? v[r] : v[r] * p.slope) : v[r];
+        }
+      }
+      __syncthreads();
+      const int cpr = p.c_out >> 2;                                      // float4 chunks per row
+      const int rows = F / p.pool, o0 = l0 / p.pool;                     // l0 is a multiple of 64
+      for (int q = tid; q < rows * cpr; q += WB_THREADS) {
+        const int lr = q / cpr, ch = q - lr * cpr;
+        if (o0 + lr >= p.l_out) continue;
+        *reinterpret_cast<float4*>(outb + (size_t)(o0 + lr) * osl + 4 * ch) = *reinterpret_cast<const float4*>(so + lr * LDO + 4 * ch);
+      }
+    }
+    if constexpr (NS == 2) { if (p.amax) amax_publish(p.amax, amx); }
+    return;
+  }
 #pragma unroll
   for (int tile = 0; tile < NTILE; ++tile) {
     {
@@ -453,6 +630,13 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   p.l_conv = (int)l_conv; p.l_out = (int)cdiv(l_conv, pool); p.c_out = (int)c_out;
   p.do_abs = do_abs; p.pool = pool; p.slope = slope;
   p.amax = nsplit == 2 ? absmax_word : nullptr;
+  // plane offset (nrows * Sp elements) and row starts (Sp elements) must keep the 8-byte LDS stores aligned: Sp = S + 8, S % 8 == 0
+  p.vec4 = (S_real % 4 == 0 && (pad_t * c_in) % 4 == 0 && (l_in * c_in) % 4 == 0 && l_in * c_in * 4 < (1LL << 31)
+            && (in_table || (uintptr_t)in % (in_pcm16 ? 8 : 16) == 0)) ? 1 : 0;
+  {
+    static const int stagger = [] { const char* e = getenv("SLU_WCONV_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = stagger; p.first_round = 512;
+  }
   int MT = (B * cdiv(l_conv, 128) >= 256) ? 2 : 1;
   int F = 64 * MT;
   p.nrows = F + (int)cdiv(KC * 32, S) + 1;
@@ -463,6 +647,20 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
     lds = (size_t)nsplit * p.nrows * p.Sp * sizeof(unsigned short);
   }
   if (lds > 160 * 1024) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_wconv_fwd_bf16: window of %zu bytes exceeds the 160 KiB LDS", lds);
+  // LDS-staged epilogue (whole-row 16-byte stores) where the output allows it: no route bytes, 16-byte aligned rows
+  {
+    size_t tile = 0;
+    bool ok = false;
+    if (out_planes) {
+      ok = (out_plane_stride % 8 == 0) && ((uintptr_t)out_planes % 16 == 0);
+      tile = (size_t)nsplit * F * (p.Kp_out + 8) * sizeof(unsigned short);
+    } else {
+      ok = !route && c_out % 4 == 0 && out_sl % 4 == 0 && out_sb % 4 == 0 && ((uintptr_t)out % 16 == 0);
+      tile = (size_t)(F / pool) * (c_out + 4) * sizeof(float);
+    }
+    p.stage_out = (ok && tile <= 64 * 1024) ? 1 : 0;
+    if (p.stage_out && tile > lds) lds = tile;
+  }
   dim3 grid((unsigned)cdiv(l_conv, F), (unsigned)B);
   return nsplit == 3 ? bf_launch_nt<3>(MT, NT, grid, lds, st, p)
        : nsplit == 2 ? bf_launch_nt<2>(MT, NT, grid, lds, st, p) : bf_launch_nt<1>(MT, NT, grid, lds, st, p);
