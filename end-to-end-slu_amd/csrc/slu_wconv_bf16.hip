@@ -44,11 +44,6 @@ struct WconvBfParams {
   int vec4;             // != 0: the window is staged four elements at a time through a buffer descriptor of the sequence's
                         // row (S_real, pad and in_row multiples of 4): 16-byte (8-byte for PCM16) loads, and the convolution's
                         // zero padding — reads before the start / past the end of the row — is the descriptor's bounds check
-  int stagger;          // > 0: workgroups of the FIRST dispatch round that hold an odd slot of their CU start `stagger` x 8128
-                        // clocks late — two workgroups share a CU and, all being alike, would run in lock-step (both staging,
-                        // then both on the MFMA pipe, then both storing); half a tile of offset lets one's memory phases
-                        // run under the other's MFMAs, and the offset persists because slots are refilled as they free up
-  int first_round;      // linear workgroup ids below this belong to the first round
   int stage_out;        // != 0: the epilogue goes through LDS — the workgroup's output tile (fp32 rows or plane rows) is
                         // assembled in the window's LDS and leaves in whole rows of 16-byte stores (launcher: alignment, size)
   unsigned* amax;       // null, or the f16x2 range word of this launch: atomicMax of the bit pattern of |v| over every value
@@ -133,12 +128,6 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
     inb16 = reinterpret_cast<const short*>(base) + roff;
   }
   const int plane = p.nrows * p.Sp;               // bf16 elements per LDS plane
-  if (p.stagger > 0 && (int)(blockIdx.y * gridDim.x + blockIdx.x) < p.first_round) {
-    // HW_REG_HW_ID (4), bits 16..19: the workgroup's slot on its CU (uniform over the workgroup)
-    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
-    if (tg & 1u)
-      for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
-  }
   unsigned amx = 0;                               // f16x2 range guard (NS == 2 with p.amax only)
   const int row0 = COLS ? 0 : (SPLITN ? (wave >> 1) * 16 * RT : wave * 16 * MT);   // this wave's first frame in the tile
   const int nb = COLS ? wave : (SPLITN ? (wave & 1) * CT : 0);                     // ... and its first channel tile
@@ -647,10 +636,6 @@ extern "C" int slu_wconv_fwd_bf16(const float* in, const float* const* in_table,
   // plane offset (nrows * Sp elements) and row starts (Sp elements) keep the 8-byte LDS stores aligned: Sp % 16 == 0
   p.vec4 = (S_real % 4 == 0 && (pad_t * c_in) % 4 == 0 && (l_in * c_in) % 4 == 0 && l_in * c_in * 4 < (1LL << 31)
             && (in_table || (uintptr_t)in % (in_pcm16 ? 8 : 16) == 0)) ? 1 : 0;
-  {
-    static const int stagger = [] { const char* e = getenv("SLU_WCONV_STAGGER"); return e ? atoi(e) : 0; }();
-    p.stagger = stagger; p.first_round = 512;
-  }
   int MT = (B * cdiv(l_conv, 128) >= 256) ? 2 : 1;
   int F = 64 * MT;
   p.nrows = F + (int)cdiv(KC * 32, S) + 1;

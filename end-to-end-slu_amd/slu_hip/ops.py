@@ -116,6 +116,15 @@ class _Fork:
         for i in sorted(_Fork._used.pop(key, ())):
             cur.wait_stream(_AUX[key][i])
 
+    # Why the join sits at the end of each layer's backward function and not at the end of the whole backward pass
+    # (round 4, tried: one join queued with autograd's queue_callback, branch operands kept alive until then, so that a
+    # layer's weight-gradient GEMMs run beside the LOWER layer's BPTT, which fills 32 of 256 CUs for hundreds of
+    # microseconds): (1) it is slower — fully trainable step 2.79 -> 3.04 ms, ASR pre-training 3.23 -> 3.52 ms
+    # (profiles/r04_aa_fork_join.txt): full-chip GEMMs beside the latency-bound recurrence lengthen its dependent steps
+    # by more than the GEMMs' own time (the likely cause; the measurement is the fact); (2) it is not safe under autograd as is: AccumulateGrad CLONES a gradient it
+    # cannot steal (a view of a stacked buffer, or a tensor someone else still references) on the main stream, i.e.
+    # before the branch has written it.
+
 
 def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

@@ -27,9 +27,10 @@ elif what in ("gemm_bf_ip0", "gemm_bf_ip1"):
     # split-precision input projections of a 20-batch look-ahead super-batch (1280 sequences): phone_rnn0 (T=300, K=60),
     # phone_rnn1 (T=150, K=256); three bf16 planes in, fp32 out
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 1280
+    NS = int(os.environ.get("RUN_ONE_NSPLIT", "3"))           # 2: the f16x2 scheme of the default path
     M, N, K = (300 * S, 768, 60) if what == "gemm_bf_ip0" else (150 * S, 768, 256)
     a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.1; bias = torch.randn(N, device="cuda")
-    planes = ops.split_bf16(a, 3); packed = ops.gemm_bf16_pack(w, 3); out = torch.empty(M, N, device="cuda")
+    planes = ops.split_bf16(a, NS); packed = ops.gemm_bf16_pack(w, NS); out = torch.empty(M, N, device="cuda")
     for _ in range(5):
         ops.gemm_bf16(planes, packed, bias, N, K, out=out)
 elif what == "gru_bf":
