@@ -71,8 +71,28 @@ json.dump(j, open(O + "/pmc_traffic.json", "w"), indent=1)
 PY
 rm -rf $O/pmc_gru_bf_pool*
 cat $O/pmc_gru_bf.txt
+# the Sinc launch's SQ / memory counters (1024 sequences, whole chip)
+bash tools/pmc_kernel.sh gpurun_out/$TAG/pmc_sinc wconv_sinc 1024 wconv_bf_fwd > $O/pmc_wconv_sinc.txt 2>&1
+rm -rf $O/pmc_sinc
+# the convolution launches at 1024 sequences on the look-ahead partition
+python tools/wconv_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-330 > $O/wconv_probe.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?"
 timeout 400 python bench.py --no-cpu-baseline --no-large-batch --no-side-runs > $O/bench_512.json 2> $O/bench_512.err; echo "bench512 rc=$?"
+if [ "${TRACE_OTHERS:-1}" = "1" ]; then
+  # fully trainable step, ASR pre-training: kernel tables of the traced runs; configs[4] shape in both arithmetics
+  for w in unfreeze_all asr_pretrain; do
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$w -o u -- python $R/bench.py $B --workload $w --steps 100 --warmup 10 > $O/bench_${w}_under_rocprofv3.json 2> $O/bench_${w}_prof.err
+    cd $R
+    f=$(find $O/trace_$w -name "*kernel_trace.csv" | head -1)
+    python tools/rocprof_summary.py $f 34 > $O/${w}_kernel_stats.txt
+    python tools/rocprof_summary.py $f 50 --by-shape > $O/${w}_kernel_stats_by_shape.txt
+    rm -rf $O/trace_$w
+  done
+  for d in bf16 f32; do
+    timeout 300 python bench.py --dtype $d --workload unfreeze_all --seconds 10 --batch 32 --steps 40 --warmup 10 --no-cpu-baseline --no-kernel-table > $O/bench_cfg4_$d.json 2> $O/bench_cfg4_$d.err; echo "cfg4 $d rc=$?"
+  done
+fi
 head -20 $O/default_kernel_stats.txt | cut -c1-160
 python - <<PY
 import json
