@@ -29,9 +29,7 @@ def _single_rank_dp():
 
 def data_parallel():
     """Does a training step of this process contain a gradient collective?"""
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
-    return dist.get_world_size() > 1 or _single_rank_dp()
+    return world()[1] > 1 or (dist.is_available() and dist.is_initialized() and _single_rank_dp())
 
 
 def init_from_env(backend=None):
@@ -189,8 +187,9 @@ class GradBucket:
         """Can the step's all-reduce be a node of the step's hipGraph?  (pipeline.StepGraph: ONE graph per step under data
         parallelism — forward, backward, bucket packing, all-reduce, Adam — instead of graph / eager collective / graph;
         the collective is then ordered by the graph on the CU-masked training stream and costs no host call per step.)
-        SLU_DP_GRAPH: "0" never, "1" without the self-test, "auto" (default): backend nccl (RCCL collectives are
-        capturable; gloo stages through the host) AND a self-test passes on every rank — a tiny all-reduce captured on a
+        SLU_DP_GRAPH: "0" never, "1" without the self-test, "auto" (default): torch.distributed's own communicator on
+        backend nccl (RCCL collectives are capturable; gloo stages through the host; not with SLU_COMM=rccl, see below)
+        AND a self-test passes on every rank — a tiny all-reduce captured on a
         side stream and replayed twice must give the known sum.  The ranks agree on the verdict with an eager MIN
         all-reduce BEFORE any replay (a rank whose capture failed must not leave the others waiting inside a captured
         collective), so they all build the same kind of step."""
@@ -198,6 +197,13 @@ class GradBucket:
             return self._in_graph
         mode = os.environ.get("SLU_DP_GRAPH", "auto")
         ok = data_parallel() and mode != "0" and device.type == "cuda" and (self.comm is not None or dist.get_backend() == "nccl")
+        if ok and self.comm is not None and mode != "1":
+            # SLU_COMM=rccl: a SECOND RCCL communicator beside torch.distributed's.  RCCL orders the launches of a device's
+            # communicators among themselves with events; with this communicator's collective captured and
+            # torch.distributed's next one eager, that event is one "last recorded in a capturing stream" — seen once on
+            # MI355X as an abort of torch's NCCL watchdog thread (hipErrorCapturedEvent).  With two communicators the
+            # all-reduce therefore stays an eager call between two graphs unless SLU_DP_GRAPH=1 insists.
+            ok = False
         if ok and mode != "1":
             ok = self._capture_selftest(device)
         self._in_graph = bool(ok)

@@ -171,6 +171,7 @@ def test_data_parallel_step_graph_logic_with_emulated_second_rank(tmp_path, monk
     torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
     ds = data.SyntheticSLUDataset(12, 8, 6000, cfg.values_per_slot, seed=5)
     monkeypatch.setenv("SLU_LOOKAHEAD", "4")
+    monkeypatch.setenv("SLU_DP_GRAPH", "0")         # the emulated collective is a host function: eager between the two graphs
     results = {}
     calls = {"n": 0}
     for world in (1, 2):
