@@ -50,12 +50,12 @@ def _param_signature(model):
 
 def _lookahead_width(depth, batch_size):
     """Batches per look-ahead super-batch: explicit, or eight sequences per CU the side streams may use — one
-    16-sequence workgroup of the split-precision recurrence per direction and CU: 1024 sequences = 16 batches of 64 on
-    the 128 CUs of the default partition (slu_hip/pipeline.cu_split has the round-3 sweep).  Measured on MI355X (bench.py,
-    512 steps, round 2, 96 + 160 CUs): 18 / 19 / 20 / 21 / 22 batches -> 272 / 265 / 272-282 / 232 / 238 k utt/s — one
-    batch more and the recurrences need a second round of workgroups.  Wider super-batches make the frozen stages more efficient, but the two partitions share the
-    power budget (with all 256 CUs busy the clock drops to ~1.8 GHz and the latency-bound trainable step slows by
-    20-30 %), and a wider first super-batch is a longer pipeline fill."""
+    16-sequence workgroup of the split-precision recurrence per direction and CU: 1280 sequences = 20 batches of 64 on
+    the 160 CUs of the default partition (slu_hip/pipeline.cu_split has the sweeps).  One batch more and the recurrences
+    need a second round of workgroups (round 2, 96 + 160 CUs: 18 / 19 / 20 / 21 / 22 batches -> 272 / 265 / 272-282 / 232 /
+    238 k utt/s).  Wider super-batches make the frozen stages more efficient, but the two partitions share the power
+    budget (with all 256 CUs busy the clock drops to ~1.8 GHz and the latency-bound trainable step slows by 20-30 %), and
+    a wider first super-batch is a longer pipeline fill."""
     if depth > 0:
         return depth
     from slu_hip import pipeline
