@@ -575,6 +575,146 @@ gemm_tn_small_wide_kernel(const TnArgs a) {
 }
 
 
+// The 64 x 64 kernel with the k range ALSO split over workgroups, for the weight gradients of the long layers (K = T * B
+// = 2 400 ... 19 200 rows: a layer's 72 tiles alone leave most of the chip idle, and the generic k-slow GEMM + reduce
+// launches it replaced ran at 14 % of the fp32 MFMA peak).  Workgroup (tile, ks) multiplies k steps [ks, ks + 1) * sps of
+// its tile exactly as above (four waves, fixed-order LDS sum) and writes the 64 x 64 partial to the workspace; the LAST
+// workgroup of a tile to arrive (ticket) adds the ksplit partials in the order ks = 0, 1, ... — the same sum whichever
+// workgroup it is — and stores C.  One launch per layer, deterministic, no reduce launch.
+// workspace: ksplit * tiles partial tiles of 4096 floats; tickets: one zero word per tile, left zero.
+__global__ void __launch_bounds__(256)
+gemm_tn_wide_splitk_kernel(const TnArgs a, const int ksplit, float* __restrict__ ws, unsigned* __restrict__ tickets) {
+  __shared__ float red[4][16][256];                    // [wave][tile][lane*4 + r]
+  __shared__ int s_last;
+  if ((int)blockIdx.x < a.rs_blocks) {                 // the row-sum job
+    tn_rowsum(a, (int)blockIdx.x * 256 + threadIdx.x);
+    return;
+  }
+  const int bid = (int)blockIdx.x - a.rs_blocks;
+  const int gtile = bid / ksplit, ks = bid - gtile * ksplit;
+  int q = 0;
+  while (q + 1 < a.count && gtile >= a.p[q].tile_end) ++q;
+  const TnProblem& P = a.p[q];
+  const int tile = gtile - (q ? a.p[q - 1].tile_end : 0);
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = lane & 15, kg = lane >> 4;
+  // this workgroup's k steps (4 rows each): a multiple of 32 per split, so that every wave runs whole batches of U = 8
+  const int steps = P.K >> 2;
+  const int sps = ((((steps + ksplit - 1) / ksplit) + 31) >> 5) << 5;
+  const int g0 = min(steps, ks * sps), g1 = min(steps, g0 + sps);
+  const int per = sps >> 2;                            // a multiple of 8
+  const int s0 = min(g1, g0 + w * per), s1 = min(g1, s0 + per);
+  const float* __restrict__ pa = P.A + (m0 + 4 * i + 3 < P.M ? m0 + 4 * i : 0);
+  const float* __restrict__ pb = P.B + (n0 + 4 * i + 3 < P.N ? n0 + 4 * i : 0);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;
+  const int nb = (s1 > s0) ? (s1 - s0) / U : 0;
+  float4 avA[U], avB[U];
+  float4 bvA[U], bvB[U];
+#define TN_LOAD(av, bv, batch)                                                        \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                      \
+    const long long k = 4 * (s0 + (batch) * U + u) + kg;                               \
+    av[u] = *reinterpret_cast<const float4*>(pa + k * P.lda);                          \
+    bv[u] = *reinterpret_cast<const float4*>(pb + k * P.ldb);                          \
+  }                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+#define TN_ROW(x_, av_, b_)                                                            \
+  acc[x_][0] = mfma16(av_, b_.x, acc[x_][0]); acc[x_][1] = mfma16(av_, b_.y, acc[x_][1]); \
+  acc[x_][2] = mfma16(av_, b_.z, acc[x_][2]); acc[x_][3] = mfma16(av_, b_.w, acc[x_][3]);
+#define TN_STEP(a_, b_) TN_ROW(0, a_.x, b_) TN_ROW(1, a_.y, b_) TN_ROW(2, a_.z, b_) TN_ROW(3, a_.w, b_)
+#define TN_MFMA(av, bv)                                                                \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) { TN_STEP(av[u], bv[u]) }              \
+  __builtin_amdgcn_sched_barrier(0);
+  if (nb > 0) {
+    TN_LOAD(avA, bvA, 0)
+    for (int bt = 0; bt < nb; bt += 2) {
+      TN_LOAD(avB, bvB, min(bt + 1, nb - 1))
+      TN_MFMA(avA, bvA)
+      TN_LOAD(avA, bvA, min(bt + 2, nb - 1))
+      if (bt + 1 < nb) { TN_MFMA(avB, bvB) }
+    }
+  }
+  int sb = s0 + nb * U;
+  for (; sb < s1; ++sb) {                              // fewer than U full steps left
+    const long long k = 4 * sb + kg;
+    const float4 av = *reinterpret_cast<const float4*>(pa + k * P.lda);
+    const float4 bv = *reinterpret_cast<const float4*>(pb + k * P.ldb);
+    TN_STEP(av, bv)
+  }
+  if (ks == ksplit - 1 && w == 3 && (P.K & 3)) {       // partial last step of the whole k range: zero the rows past K
+    const long long k = 4 * steps + kg;
+    const bool kok = k < P.K;
+    const long long kc = kok ? k : 0;
+    float4 av = *reinterpret_cast<const float4*>(pa + kc * P.lda);
+    const float4 bv = *reinterpret_cast<const float4*>(pb + kc * P.ldb);
+    av.x = kok ? av.x : 0.0f; av.y = kok ? av.y : 0.0f; av.z = kok ? av.z : 0.0f; av.w = kok ? av.w : 0.0f;
+    TN_STEP(av, bv)
+  }
+#undef TN_MFMA
+#undef TN_STEP
+#undef TN_ROW
+#undef TN_LOAD
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][4 * x + y][lane * 4 + r] = acc[x][y][r];
+  __syncthreads();
+  // wave w finishes the four 16 x 16 tiles of row-tile x = w: element (lane, r) is row 4*kg + r, column i
+  float4 part[4];
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    const int t = 4 * w + y;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane * 4 + r;
+      v[r] = ((red[0][t][e] + red[1][t][e]) + red[2][t][e]) + red[3][t][e];
+    }
+    part[y] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (ksplit > 1) {
+    // partial tile -> workspace, [16 sub-tiles][256] in the layout of `red`: 16 bytes per lane, 1 KB per wave and store
+    float* mine = ws + ((size_t)gtile * ksplit + ks) * 4096;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) *reinterpret_cast<float4*>(mine + (4 * w + y) * 256 + lane * 4) = part[y];
+    __threadfence();                                   // this workgroup's partial visible device-wide before its ticket
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(tickets + gtile, 1u) == (unsigned)(ksplit - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                   // acquire: the other workgroups' partials
+    const float* all = ws + (size_t)gtile * ksplit * 4096;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+      float4 s4 = *reinterpret_cast<const float4*>(all + (4 * w + y) * 256 + lane * 4);
+      for (int k2 = 1; k2 < ksplit; ++k2) {
+        const float4 o = *reinterpret_cast<const float4*>(all + (size_t)k2 * 4096 + (4 * w + y) * 256 + lane * 4);
+        s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+      }
+      part[y] = s4;
+    }
+    if (tid == 0) tickets[gtile] = 0u;                 // ready for the next launch (stream order)
+  }
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {
+    const float v[4] = {part[y].x, part[y].y, part[y].z, part[y].w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 4 * (4 * kg + r) + w, n = n0 + 4 * i + y;
+      if (m < P.M && n < P.N) P.C[(long long)m * P.ldc + n] = v[r];
+    }
+  }
+}
+
+
 // The same kernel with MT floats of A per lane and k row: 3 -> 48 x 32 output tiles, 12-byte loads, for matrices whose
 // M is not a multiple of 4 (or whose A is not 16-byte aligned).  A tile's k range is summed exactly as above.  Kept
 // apart from the 64-row kernel: writing that one as the MT = 4 instance of this template cost it 14 us (53 -> 67 us
@@ -977,6 +1117,80 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
   else
     hipLaunchKernelGGL(gemm_tn_small_mt_kernel<3>, dim3((unsigned)(tiles + extra)), dim3(256), 0, (hipStream_t)stream, a);
   SLU_CHECK_LAUNCH("gemm_tn_small_kernel");
+  return SLU_OK;
+}
+
+// Split-K form of slu_gemm_tn_batched for long k ranges (include/slu_hip.h).
+static int tn_splitk_factor(int64_t tiles, int64_t kmin) {
+  // ONE round of workgroups: two fit a CU (64 KB of LDS each), 512 on the chip — 654 workgroups (nine splits of a layer's
+  // 72 tiles) ran as two rounds, the second a quarter full: 168 us per launch; at least 256 k rows per split, at most 16
+  int64_t ks = 512 / tiles;
+  ks = ks < 1 ? 1 : ks;
+  if (ks > 16) ks = 16;
+  const int64_t by_k = kmin / 256 < 1 ? 1 : kmin / 256;
+  return (int)(ks < by_k ? ks : by_k);
+}
+
+static bool tn_splitk_shapes_ok(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                const int64_t* M, const int64_t* N, int64_t count) {
+  for (int q = 0; q < (int)count; ++q) {
+    if (((M[q] | lda[q]) & 3) || ((uintptr_t)A[q] & 15)) return false;
+    if (((N[q] | ldb[q]) & 3) || ((uintptr_t)B[q] & 15)) return false;
+  }
+  return true;
+}
+
+extern "C" size_t slu_gemm_tn_splitk_workspace_bytes(const int64_t* M, const int64_t* N, const int64_t* K, int64_t count) {
+  if (!M || !N || !K || count < 1 || count > 4) return 0;
+  int64_t tiles = 0, kmin = K[0];
+  for (int q = 0; q < (int)count; ++q) {
+    tiles += cdiv(M[q], 64) * cdiv(N[q], 64);
+    kmin = K[q] < kmin ? K[q] : kmin;
+  }
+  return (size_t)tiles * tn_splitk_factor(tiles, kmin) * 4096 * sizeof(float);
+}
+
+extern "C" int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                          float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
+                                          const int64_t* K, int64_t count, const float* rowsum_src, int64_t rowsum_rows,
+                                          int64_t rowsum_cols, float* rowsum_dst, void* workspace, size_t workspace_bytes,
+                                          uint32_t* tickets, int64_t n_tickets, void* stream) {
+  SLU_REQUIRE(A && B && C && lda && ldb && ldc && M && N && K, "slu_gemm_tn_batched_splitk: null pointer");
+  SLU_REQUIRE((rowsum_src == nullptr) == (rowsum_dst == nullptr), "slu_gemm_tn_batched_splitk: rowsum_src and rowsum_dst go together");
+  SLU_REQUIRE(!rowsum_src || (rowsum_rows >= 1 && rowsum_cols >= 1 && rowsum_rows < (1LL << 30) && rowsum_cols < (1LL << 30)),
+              "slu_gemm_tn_batched_splitk: bad row-sum size");
+  SLU_REQUIRE(count >= 1 && count <= 4, "slu_gemm_tn_batched_splitk: 1..4 problems per call");
+  if (!tn_splitk_shapes_ok(A, lda, B, ldb, M, N, count))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gemm_tn_batched_splitk: M, lda, N, ldb must be multiples of 4 and A, B 16-byte aligned");
+  TnArgs a;
+  int tiles = 0;
+  int64_t kmin = K[0];
+  for (int q = 0; q < (int)count; ++q) {
+    SLU_REQUIRE(A[q] && B[q] && C[q] && M[q] > 0 && N[q] > 0 && K[q] > 0, "slu_gemm_tn_batched_splitk: bad problem %d", q);
+    SLU_REQUIRE(M[q] < (1LL << 30) && N[q] < (1LL << 30) && K[q] < (1LL << 30), "slu_gemm_tn_batched_splitk: size overflow");
+    a.p[q].A = A[q]; a.p[q].B = B[q]; a.p[q].C = C[q];
+    a.p[q].lda = lda[q]; a.p[q].ldb = ldb[q]; a.p[q].ldc = ldc[q];
+    a.p[q].M = (int)M[q]; a.p[q].N = (int)N[q]; a.p[q].K = (int)K[q];
+    a.p[q].tiles_n = (int)cdiv(N[q], 64);
+    tiles += (int)(cdiv(M[q], 64) * cdiv(N[q], 64));
+    a.p[q].tile_end = tiles;
+    kmin = K[q] < kmin ? K[q] : kmin;
+  }
+  const int ksplit = tn_splitk_factor(tiles, kmin);
+  if (ksplit > 1) {
+    const size_t need = (size_t)tiles * ksplit * 4096 * sizeof(float);
+    if (!workspace || workspace_bytes < need)
+      SLU_FAIL(SLU_ERR_WORKSPACE, "slu_gemm_tn_batched_splitk: workspace too small (%zu < %zu)", workspace_bytes, need);
+    SLU_REQUIRE(tickets && n_tickets >= tiles, "slu_gemm_tn_batched_splitk: needs %d zeroed ticket words", tiles);
+  }
+  a.count = (int)count;
+  a.tiles = tiles;
+  a.rs_src = rowsum_src; a.rs_dst = rowsum_dst; a.rs_rows = (int)rowsum_rows; a.rs_cols = (int)rowsum_cols;
+  const int extra = rowsum_src ? (int)cdiv(rowsum_cols, 256) : 0;
+  a.rs_blocks = extra;
+  hipLaunchKernelGGL(gemm_tn_wide_splitk_kernel, dim3((unsigned)(tiles * ksplit + extra)), dim3(256), 0, (hipStream_t)stream,
+                     a, ksplit, reinterpret_cast<float*>(workspace), (unsigned*)tickets);
+  SLU_CHECK_LAUNCH("gemm_tn_wide_splitk_kernel");
   return SLU_OK;
 }
 

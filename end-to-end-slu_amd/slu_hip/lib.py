@@ -82,6 +82,8 @@ SIGNATURES = {
     "slu_comm_allreduce_f64": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_destroy": (c_int, [vp]),
     "slu_gemm_tn_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp]),
+    "slu_gemm_tn_splitk_workspace_bytes": (c_sz, [vp, vp, vp, c_i64]),
+    "slu_gemm_tn_batched_splitk": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp, c_sz, vp, c_i64, vp]),
     "slu_gemm_small_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
@@ -105,7 +107,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 6          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

@@ -758,6 +758,52 @@ def gemm_tn_batched(problems, rowsum=None):
                                      _stream()), "slu_gemm_tn_batched")
 
 
+_TN_TICKETS = {}          # (device, stream) -> zeroed ticket words of slu_gemm_tn_batched_splitk (the kernel leaves them zero)
+TN_SPLITK_MIN_ROWS = 2048
+
+
+def gemm_tn_splitk_ok(operands):
+    """operands: [(A (K, M), B (K, N)), ...] — shapes slu_gemm_tn_batched_splitk takes: every M, N and row stride a
+    multiple of 4, unit column strides, 16-byte aligned operands."""
+    return all(A.shape[1] % 4 == 0 and B.shape[1] % 4 == 0 and A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0
+               and A.stride(1) == 1 and B.stride(1) == 1 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+               for A, B in operands)
+
+
+def gemm_tn_batched_splitk(problems, rowsum=None):
+    """gemm_tn_batched for long k ranges (the weight gradients of a GRU layer with thousands of rows): one launch, the k
+    range split over workgroups, partial tiles folded in a fixed order by each tile's last workgroup."""
+    import ctypes
+    L = _lib.load()
+    n = len(problems)
+    for A, B, C in problems:
+        assert A.shape[0] == B.shape[0] and C.shape == (A.shape[1], B.shape[1])
+    assert gemm_tn_splitk_ok([(A, B) for A, B, _ in problems]) and all(C.stride(1) == 1 for _, _, C in problems)
+    if rowsum:
+        src, dst = rowsum
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32
+        assert src.numel() == src.shape[0] * dst.numel()
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    arr = lambda ty, vals: (ty * n)(*vals)
+    Ms, Ns, Ks = (arr(i64, [p[2].shape[0] for p in problems]), arr(i64, [p[2].shape[1] for p in problems]),
+                  arr(i64, [p[0].shape[0] for p in problems]))
+    dev = problems[0][0].device
+    wsb = L.slu_gemm_tn_splitk_workspace_bytes(Ms, Ns, Ks, n)
+    ws = _workspace(wsb, dev)
+    tiles = sum(-(-p[2].shape[0] // 64) * -(-p[2].shape[1] // 64) for p in problems)
+    key = (dev.index, _stream())
+    tk = _TN_TICKETS.get(key)
+    if tk is None or tk.numel() < tiles:
+        tk = _TN_TICKETS[key] = torch.zeros(max(1024, tiles), dtype=torch.int32, device=dev)
+    _lib.check(L.slu_gemm_tn_batched_splitk(arr(vp, [p[0].data_ptr() for p in problems]), arr(i64, [p[0].stride(0) for p in problems]),
+                                            arr(vp, [p[1].data_ptr() for p in problems]), arr(i64, [p[1].stride(0) for p in problems]),
+                                            arr(vp, [p[2].data_ptr() for p in problems]), arr(i64, [p[2].stride(0) for p in problems]),
+                                            Ms, Ns, Ks, n,
+                                            rowsum[0].data_ptr() if rowsum else None, rowsum[0].shape[0] if rowsum else 0,
+                                            rowsum[1].numel() if rowsum else 0, rowsum[1].data_ptr() if rowsum else None,
+                                            ws.data_ptr(), wsb, tk.data_ptr(), tk.numel(), _stream()), "slu_gemm_tn_batched_splitk")
+
+
 def colsum(x2d, out=None, accumulate=False):
     L = _lib.load()
     M, N = x2d.shape
@@ -1193,6 +1239,17 @@ class GRULayerFn(torch.autograd.Function):
         dev = x.device
         small = (T * B <= TN_SMALL_ROWS and T > 1 and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
                  and I % 4 == 0 and H % 4 == 0)
+        # long layers (thousands of rows) in exact-fp32 training: the same ONE launch with the k range split over workgroups
+        # (slu_gemm_tn_batched_splitk) instead of three k-slow GEMMs + three reduce launches + a column sum
+        long_rows = (not small and T * B >= TN_SPLITK_MIN_ROWS and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
+                     and I % 4 == 0 and H % 4 == 0 and train_nsplit(True) == 0
+                     and os.environ.get("SLU_TN_SPLITK", "1") != "0")
+        if long_rows:
+            n = (T - 1) * B
+            long_rows = gemm_tn_splitk_ok([(g2, x2)] + [
+                ((h2[:, d * 3 * H:(d + 1) * 3 * H][B:], r2[:n, :H]) if d == 0
+                 else (h2[:, d * 3 * H:(d + 1) * 3 * H][:n], r2[B:, H:])) for d in range(D)])
+        small = small or long_rows
         if need_bias and not small:
             # (tiles, D, 6H) per-tile partials -> (D, 6H): [d(b_ih) (3H) | d(b_hh) (3H)]  (slu_colsum_f32, deterministic)
             dbp = colsum(dbp.view(dbp.shape[0], D * 6 * H)).view(D, 6 * H)
@@ -1214,7 +1271,7 @@ class GRULayerFn(torch.autograd.Function):
                 db = torch.empty(dbp.shape[1:], dtype=torch.float32, device=dev)
                 rowsum = (dbp.contiguous(), db)
                 dbp = db
-            gemm_tn_batched(probs, rowsum)
+            (gemm_tn_batched_splitk if long_rows else gemm_tn_batched)(probs, rowsum)
             grads[3] = dW[:3 * H]
             if D == 2:
                 grads[4] = dW[3 * H:]

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 5
+#define SLU_ABI_VERSION 6
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -146,6 +146,19 @@ int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, const float* 
                         float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K,
                         int64_t count, const float* rowsum_src, int64_t rowsum_rows, int64_t rowsum_cols,
                         float* rowsum_dst, void* stream);
+/* The same contract for LONG k ranges (K = T * B of several thousand rows: the weight gradients of the phoneme / word GRU
+ * layers when they train — reference models.py:232 / :262 through autograd): 64 x 64 output tiles whose k range is also
+ * split over workgroups; a tile's last workgroup to arrive adds the partial tiles in a fixed order (deterministic, no
+ * reduce launch).  Every M, lda, N, ldb a multiple of 4, A and B 16-byte aligned.  workspace: at least
+ * slu_gemm_tn_splitk_workspace_bytes(M, N, K, count) bytes (uninitialised); tickets: one 32-bit word per 64 x 64 output
+ * tile of the call (sum over problems of ceil(M / 64) * ceil(N / 64)), ZERO at entry and left zero — a buffer the caller
+ * zeroes once and reuses for launches on ONE stream.                                                                 */
+size_t slu_gemm_tn_splitk_workspace_bytes(const int64_t* M, const int64_t* N, const int64_t* K, int64_t count);
+int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                               float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K,
+                               int64_t count, const float* rowsum_src, int64_t rowsum_rows, int64_t rowsum_cols,
+                               float* rowsum_dst, void* workspace, size_t workspace_bytes, uint32_t* tickets,
+                               int64_t n_tickets, void* stream);
 /* out[n] = [out[n] if accumulate] + sum_m X[m*x_rs + n]   (bias gradients)                       */
 /* Up to four independent SMALL-M products in one launch (latency-bound shapes: the seq2seq decoder's per-step Linear /
  * GRUCell products and their data gradients, models.py:427-485): C_q (M x N) = [C_q +] A_q (M x K, row stride lda, k fast)

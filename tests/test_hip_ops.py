@@ -198,6 +198,46 @@ def test_gemm_tn_batched_vs_float64(ops, shapes):
     assert torch.equal(dst, seq)                      # rows added in order
 
 
+@pytest.mark.parametrize("shapes", [[(9600, 768, 256), (9536, 384, 128), (9536, 384, 128)],       # a word-layer-sized GRU layer
+                                    [(19200, 768, 60), (19136, 384, 128)],                          # first layer: N = 60
+                                    [(2050, 64, 64), (4099, 132, 68)]])                             # K % 4 != 0, partial tiles
+def test_gemm_tn_batched_splitk_vs_float64(ops, shapes):
+    """slu_gemm_tn_batched_splitk: the batched A^T B launch with the k range split over workgroups (the weight gradients of
+    the long GRU layers) against float64, on strided views as GRULayerFn.backward passes them; bit-identical from run to
+    run (the partial tiles are folded in a fixed order by whichever workgroup arrives last) and the ticket words are left
+    zero for the next launch."""
+    torch.manual_seed(11)
+    probs, want = [], []
+    for K, M, N in shapes:
+        big_a = torch.randn(K + 2, M + 8, device="cuda")
+        big_b = torch.randn(K + 2, N + 4, device="cuda")
+        A, B = big_a[1:K + 1, 4:M + 4], big_b[2:K + 2, :N]
+        assert A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+        C = torch.full((M, N), float("nan"), device="cuda")
+        probs.append((A, B, C))
+        want.append(A.double().t() @ B.double())
+    part = torch.randn(16, 2, 96, device="cuda")
+    dst = torch.empty(2, 96, device="cuda")
+    ops.gemm_tn_batched_splitk(probs, (part, dst))
+    first = [C.clone() for _, _, C in probs]
+    for (A, B, C), w in zip(probs, want):
+        assert torch.isfinite(C).all()
+        err = (C.double() - w).abs().max().item()
+        assert err <= 3e-5 * max(1.0, w.abs().max().item()), err
+    seq = part[0].clone()
+    for r in range(1, 16):
+        seq += part[r]
+    assert torch.equal(dst, seq)
+    for _ in range(3):
+        for _, _, C in probs:
+            C.fill_(float("nan"))
+        ops.gemm_tn_batched_splitk(probs, None)
+        for (_, _, C), f in zip(probs, first):
+            assert torch.equal(C, f)
+    for tk in ops._TN_TICKETS.values():
+        assert int(tk.abs().sum()) == 0
+
+
 def test_colsum(ops):
     x = torch.randn(1000, 130)
     out = ops.colsum(cu(x))
