@@ -53,3 +53,13 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(lib.SluHipError, match="no CPU fallback"):
         lib.load()
+
+
+def test_graft_entry_build_checks_the_current_abi_version():
+    """__graft_entry__.build() is the driver's "does it build" check: it must accept whatever SLU_ABI_VERSION the header
+    carries (a hard-coded number there went stale once), and the library on disk must be the one the binding expects."""
+    import re
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "lib.ABI_VERSION" in src and not re.search(r"ABI_VERSION\s*==\s*\d", src)
+    header = open(os.path.join(ROOT, "include", "slu_hip.h")).read()
+    assert int(re.search(r"#define\s+SLU_ABI_VERSION\s+(\d+)", header).group(1)) == lib.ABI_VERSION
