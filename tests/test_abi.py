@@ -58,7 +58,7 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 def test_graft_entry_build_checks_the_current_abi_version():
     """__graft_entry__.build() is the driver's "does it build" check: it must accept whatever SLU_ABI_VERSION the header
     carries (a hard-coded number there went stale once), and the library on disk must be the one the binding expects."""
-    import re
+    from slu_hip import lib
     src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
     assert "lib.ABI_VERSION" in src and not re.search(r"ABI_VERSION\s*==\s*\d", src)
     header = open(os.path.join(ROOT, "include", "slu_hip.h")).read()
