@@ -299,7 +299,8 @@ def _timed_graph(fn, stream, reps=20):
         fn()
         stream.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+        from slu_hip import pipeline as _pl
+        with _pl.capture(graph, stream):
             for _ in range(reps):
                 fn()
         graph.replay()                              # warm replay

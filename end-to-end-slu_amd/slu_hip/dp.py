@@ -184,27 +184,25 @@ class GradBucket:
         self.allreduce_flats()
 
     def collective_in_graph(self, device):
-        """Can the step's all-reduce be a node of the step's hipGraph?  (pipeline.StepGraph: ONE graph per step under data
+        """Is the step's all-reduce a node of the step's hipGraph?  (pipeline.StepGraph: ONE graph per step under data
         parallelism — forward, backward, bucket packing, all-reduce, Adam — instead of graph / eager collective / graph;
-        the collective is then ordered by the graph on the CU-masked training stream and costs no host call per step.)
-        SLU_DP_GRAPH: "0" never, "1" without the self-test, "auto" (default): torch.distributed's own communicator on
-        backend nccl (RCCL collectives are capturable; gloo stages through the host; not with SLU_COMM=rccl, see below)
-        AND a self-test passes on every rank — a tiny all-reduce captured on a
-        side stream and replayed twice must give the known sum.  The ranks agree on the verdict with an eager MIN
-        all-reduce BEFORE any replay (a rank whose capture failed must not leave the others waiting inside a captured
-        collective), so they all build the same kind of step."""
+        the collective is then ordered by the graph on the CU-masked training stream and costs no host call per step:
+        measured with one rank on MI355X, 0.172 instead of 0.189 ms per step.)
+        OFF by default (SLU_DP_GRAPH=0).  With this torch / ROCm stack a process that captures RCCL collectives while
+        torch.distributed's NCCL watchdog thread is polling earlier, eager collectives aborts now and then — 2 of 18 runs
+        of the one-rank test, with either communicator: "Process group watchdog thread terminated with exception: HIP
+        error: operation not permitted on an event last recorded in a capturing stream" (hipErrorCapturedEvent from the
+        watchdog's event query; the capture forks torch's collective stream, and the watchdog polls every 100 ms).  An
+        abort of one rank in eight is not a risk a default may carry; the eager collective between two graphs has run
+        clean in every test.  SLU_DP_GRAPH=1: captured after a self-test — a tiny all-reduce captured on a side stream
+        and replayed twice must give the known sum, the ranks agreeing on the verdict with an eager MIN all-reduce BEFORE
+        any replay (a rank whose capture failed must not leave the others waiting inside a captured collective)."""
         if self._in_graph is not None:
             return self._in_graph
-        mode = os.environ.get("SLU_DP_GRAPH", "auto")
-        ok = data_parallel() and mode != "0" and device.type == "cuda" and (self.comm is not None or dist.get_backend() == "nccl")
-        if ok and self.comm is not None and mode != "1":
-            # SLU_COMM=rccl: a SECOND RCCL communicator beside torch.distributed's.  RCCL orders the launches of a device's
-            # communicators among themselves with events; with this communicator's collective captured and
-            # torch.distributed's next one eager, that event is one "last recorded in a capturing stream" — seen once on
-            # MI355X as an abort of torch's NCCL watchdog thread (hipErrorCapturedEvent).  With two communicators the
-            # all-reduce therefore stays an eager call between two graphs unless SLU_DP_GRAPH=1 insists.
-            ok = False
-        if ok and mode != "1":
+        mode = os.environ.get("SLU_DP_GRAPH", "0")
+        ok = (mode == "1" and data_parallel() and device.type == "cuda"
+              and (self.comm is not None or dist.get_backend() == "nccl"))
+        if ok:
             ok = self._capture_selftest(device)
         self._in_graph = bool(ok)
         return self._in_graph
@@ -217,7 +215,8 @@ class GradBucket:
         graph, captured = torch.cuda.CUDAGraph(), 1.0
         torch.cuda.synchronize(device)
         try:
-            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            from . import pipeline as _pl
+            with _pl.capture(graph, side):
                 t.copy_(src)
                 if self.comm is not None:
                     self.comm.allreduce(t)

@@ -762,6 +762,21 @@ _TN_TICKETS = {}          # (device, stream) -> zeroed ticket words of slu_gemm_
 TN_SPLITK_MIN_ROWS = 2048
 
 
+def tn_tickets(dev, tiles=0):
+    """The zeroed ticket words of the CURRENT stream for slu_gemm_tn_batched_splitk (the kernel leaves them zero, so one
+    buffer serves every launch of a stream).  Created outside hipGraph capture only: a buffer allocated while capturing
+    would belong to that graph's private memory pool and die with it while this cache still hands it out —
+    pipeline.StepGraph calls this before it starts capturing."""
+    key = (dev.index, _stream())
+    tk = _TN_TICKETS.get(key)
+    if tk is None or tk.numel() < tiles:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("slu_gemm_tn_batched_splitk: no ticket buffer for this stream yet and the stream is capturing; "
+                               "call slu_hip.ops.tn_tickets(device) on this stream before the capture starts")
+        tk = _TN_TICKETS[key] = torch.zeros(max(1024, tiles), dtype=torch.int32, device=dev)
+    return tk
+
+
 def gemm_tn_splitk_ok(operands):
     """operands: [(A (K, M), B (K, N)), ...] — shapes slu_gemm_tn_batched_splitk takes: every M, N and row stride a
     multiple of 4, unit column strides, 16-byte aligned operands."""
@@ -791,10 +806,7 @@ def gemm_tn_batched_splitk(problems, rowsum=None):
     wsb = L.slu_gemm_tn_splitk_workspace_bytes(Ms, Ns, Ks, n)
     ws = _workspace(wsb, dev)
     tiles = sum(-(-p[2].shape[0] // 64) * -(-p[2].shape[1] // 64) for p in problems)
-    key = (dev.index, _stream())
-    tk = _TN_TICKETS.get(key)
-    if tk is None or tk.numel() < tiles:
-        tk = _TN_TICKETS[key] = torch.zeros(max(1024, tiles), dtype=torch.int32, device=dev)
+    tk = tn_tickets(dev, tiles)
     _lib.check(L.slu_gemm_tn_batched_splitk(arr(vp, [p[0].data_ptr() for p in problems]), arr(i64, [p[0].stride(0) for p in problems]),
                                             arr(vp, [p[1].data_ptr() for p in problems]), arr(i64, [p[1].stride(0) for p in problems]),
                                             arr(vp, [p[2].data_ptr() for p in problems]), arr(i64, [p[2].stride(0) for p in problems]),

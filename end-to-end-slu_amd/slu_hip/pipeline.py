@@ -14,12 +14,32 @@ occupy every CU and each small kernel of the training step queues behind them.  
 host a few microseconds instead of ~1 ms of Python dispatch.  Dropout inside a captured prefix reads
 its Philox offset (step*16) from device memory, so every replay draws the masks of its own step.
 """
+import contextlib
 import os
 
 import torch
 
 from . import ops
 
+
+
+@contextlib.contextmanager
+def capture(graph, stream):
+    """torch.cuda.graph(...) in thread-local capture mode WITH THE GARBAGE COLLECTOR OFF.  A captured step runs its
+    backward pass in autograd's worker thread; a collection that starts there (or anywhere) during the capture may
+    finalise objects whose destructors talk to the runtime — a pinned host buffer returning to torch's host allocator
+    (event record / query), a graph of an earlier trainer — which is illegal while a capture is in progress and ends in
+    an abort of the process (seen once: "Fatal Python error: Aborted ... Garbage-collecting" inside a captured backward).
+    torch.cuda.graph collects once before the capture starts; nothing may be collected until it has ended."""
+    import gc
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, stream=stream, capture_error_mode="thread_local"):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 def cu_split(device=None):
     """CUs [0, n) of the device are reserved for the trainable part of the step, the look-ahead
@@ -243,7 +263,7 @@ class PrefixSlot:
         try:
             # thread-local capture mode: other threads (e.g. the RCCL watchdog) may keep calling the
             # runtime while this thread captures
-            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local"):
+            with capture(graph, self.stream):
                 if guard is not None:
                     guard.arm()                     # memset node
                 feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)
@@ -270,10 +290,9 @@ class RangeTrip(RuntimeError):
 
 class StepGraph:
     """One optimisation step captured as hipGraph(s).  Single process: ONE graph (forward, loss, backward, Adam).
-    Data parallel: ONE graph as well when the collective can be a graph node (backend nccl = RCCL; dp.GradBucket.
-    collective_in_graph) — forward, loss, backward, packing the gradients into the flat bucket, the RCCL all-reduce
-    and Adam, all ordered by the graph on the CU-masked training stream, no host call between them; otherwise (gloo,
-    SLU_DP_GRAPH=0, a failed self-test) two graphs around an eager collective:
+    Data parallel: two graphs around an eager collective by default; ONE graph with the RCCL all-reduce as a node when
+    SLU_DP_GRAPH=1 asks for it and the self-test passes (dp.GradBucket.collective_in_graph has the measurement and the
+    reason it is opt-in):
     G1 = forward, loss, backward, packing;  [all-reduce, eager];  G2 = Adam.  Used for the trainable remainder of an SLU
     step (inputs = prefix features + labels), for a fully trainable SLU step (waveforms + labels) and
     for an ASR pre-training step (waveforms + phoneme / word labels): a B = 64 step is ~100 short
@@ -309,9 +328,11 @@ class StepGraph:
         self.one = torch.ones((), dtype=torch.float32, device=dev)      # root gradient (no per-step fill)
         self.g1 = torch.cuda.CUDAGraph()
         ops._aux_streams(dev, 3)                    # created before the capture starts
+        with torch.cuda.stream(stream):
+            ops.tn_tickets(dev)                     # likewise: the split-K weight-gradient launch's ticket words of this stream
         ops._Fork.capture_forks = bool(forks)
         try:
-            with torch.cuda.graph(self.g1, stream=stream, capture_error_mode="thread_local"):
+            with capture(self.g1, stream):
                 if guard is not None:
                     guard.arm()
                 with _models.frozen_math_scope(guard):
@@ -334,7 +355,7 @@ class StepGraph:
         one = (self.collective_in_graph if self.dp else _one_graph()) and guard is None
         if not one:
             self.g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g2, stream=stream, capture_error_mode="thread_local"):
+            with capture(self.g2, stream):
                 if self.collective_in_graph:        # guarded step: the range check sits between backward and the collective
                     bucket.allreduce_flats()
                 trainer.optimizer.step()

@@ -87,27 +87,30 @@ def test_two_ranks_on_one_gpu_over_gloo(tmp_path, single):
 
 
 @pytest.mark.parametrize("comm", ["torch", "rccl"])
-def test_one_rank_rccl_collective_inside_the_step_graph(tmp_path, single, comm):
+def test_one_rank_rccl_data_parallel_step(tmp_path, single, comm):
     """What a ONE-GPU box can run of the real thing: a one-rank RCCL group treated as data parallel (SLU_DP_SINGLE=1) —
-    bucket packing, the RCCL all-reduce as a NODE OF THE STEP'S hipGraph (torch.distributed's collective captured), 1 / N
-    in Adam.  A one-rank sum is the identity and N = 1 divides exactly, so the run must equal the plain single-process
-    run bit for bit — captured == eager, and nothing of the step was lost around the collective.  SLU_COMM=rccl (a second
-    communicator, slu_comm_* on the training stream) keeps its collective eager between two graphs (slu_hip/dp.py)."""
+    bucket packing inside the captured step, the RCCL all-reduce (torch.distributed's, or slu_comm_* on the training
+    stream) as an eager call between the two graphs, 1 / N in Adam.  A one-rank sum is the identity and N = 1 divides
+    exactly, so the run must equal the plain single-process run bit for bit — nothing of the step was lost around the
+    collective."""
     (a,) = _run(tmp_path, 1, comm, extra_env={"SLU_DP_SINGLE": "1"})
     assert a["backend"] == "nccl"
     assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
-    want = "a node of the step's hipGraph" if comm == "torch" else "eager call between two hipGraphs"
-    assert a["collective"] == [want] * 3, a["collective"]
+    assert a["collective"] == ["eager call between two hipGraphs"] * 3, a["collective"]
     for k, v in single["sd"].items():
         assert torch.equal(v, a["sd"][k]), k
     assert a["epochs"] == single["epochs"] and a["payloads"] == single["payloads"]
 
 
-def test_one_rank_rccl_collective_eager_between_graphs(tmp_path, single):
-    """SLU_DP_GRAPH=0: the round-3 shape of the step (graph, eager all-reduce, graph) stays available and gives the same
-    parameters."""
-    (a,) = _run(tmp_path, 1, "torch", extra_env={"SLU_DP_SINGLE": "1", "SLU_DP_GRAPH": "0"})
-    assert a["collective"] == ["eager call between two hipGraphs"] * 3, a["collective"]
+@pytest.mark.skipif(os.environ.get("SLU_TEST_DP_GRAPH", "0") != "1",
+                    reason="SLU_DP_GRAPH=1 (the all-reduce captured inside the step graph) is opt-in: torch's NCCL watchdog "
+                           "aborts the process now and then when collectives are captured (slu_hip/dp.py); run with "
+                           "SLU_TEST_DP_GRAPH=1 to exercise it")
+@pytest.mark.parametrize("comm", ["torch", "rccl"])
+def test_one_rank_rccl_collective_inside_the_step_graph(tmp_path, single, comm):
+    """SLU_DP_GRAPH=1: the all-reduce as a NODE OF THE STEP'S hipGraph — same parameters, bit for bit."""
+    (a,) = _run(tmp_path, 1, comm, extra_env={"SLU_DP_SINGLE": "1", "SLU_DP_GRAPH": "1"})
+    assert a["collective"] == ["a node of the step's hipGraph"] * 3, a["collective"]
     for k, v in single["sd"].items():
         assert torch.equal(v, a["sd"][k]), k
 
@@ -121,6 +124,5 @@ def test_rccl_data_parallel_training(tmp_path, single, world, comm):
     a = ranks[0]
     assert a["backend"] == "nccl"
     assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
-    want = "a node of the step's hipGraph" if comm == "torch" else "eager call between two hipGraphs"
-    assert a["collective"] == [want] * 3, a["collective"]
+    assert a["collective"] == ["eager call between two hipGraphs"] * 3, a["collective"]
     _check(ranks, single, world, comm)
