@@ -1122,8 +1122,12 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
 
 // Split-K form of slu_gemm_tn_batched for long k ranges (include/slu_hip.h).
 static int tn_splitk_factor(int64_t tiles, int64_t kmin) {
-  // ONE round of workgroups: two fit a CU (64 KB of LDS each), 512 on the chip — 654 workgroups (nine splits of a layer's
-  // 72 tiles) ran as two rounds, the second a quarter full: 168 us per launch; at least 256 k rows per split, at most 16
+  // ONE round of workgroups: two fit a CU (216 VGPRs), 512 on the chip — 654 workgroups (nine splits of a layer's 72 tiles)
+  // ran as two rounds, the second a quarter full: 168 us per launch against 141-150 with seven; at least 256 k rows per
+  // split, at most 16.  (Eight splits put split ks on XCD ks — linear id tile * 8 + ks — so that a k row crosses HBM -> L2
+  // once: FETCH_SIZE 266 -> 91 MB per launch, L2 hits 39 -> 75 %, and the launch got SLOWER, 174 us: nine eighths of a round,
+  // and the bound is not HBM but the L1's outstanding requests — k-slow 16-byte loads, 8 MAC per operand byte, ~16 B/clk per
+  // CU needed at the MFMA peak; profiles/r04_am_pmc_tn_splitk.txt.)
   int64_t ks = 512 / tiles;
   ks = ks < 1 ? 1 : ks;
   if (ks > 16) ks = 16;

@@ -103,6 +103,15 @@ elif what == "tn":
     probs = [(g2, x, dW), (h2[B:, :3 * H], r2[:n, :H], dWf), (h2[:n, 3 * H:], r2[B:, H:], dWr)]
     for _ in range(10):
         ops.gemm_tn_batched(probs)
+elif what == "tn_long":
+    # a word-layer-sized GRU layer's three weight gradients in one split-K launch (T = 150, B = 64: K = 9600 rows)
+    T, B, I, H, D = 150, 64, 256, 128, 2
+    x = torch.randn(T * B, I, device="cuda"); g2 = torch.randn(T * B, D * 3 * H, device="cuda"); h2 = torch.randn(T * B, D * 3 * H, device="cuda")
+    r2 = torch.randn(T * B, D * H, device="cuda"); n = (T - 1) * B
+    dW = torch.empty(D * 3 * H, I, device="cuda"); dWf = torch.empty(3 * H, H, device="cuda"); dWr = torch.empty(3 * H, H, device="cuda")
+    probs = [(g2, x, dW), (h2[B:, :3 * H], r2[:n, :H], dWf), (h2[:n, 3 * H:], r2[B:, H:], dWr)]
+    for _ in range(10):
+        ops.gemm_tn_batched_splitk(probs)
 elif what == "gru":
     T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 64), 128
     gx = torch.randn(T, B, 6 * H, device="cuda")
