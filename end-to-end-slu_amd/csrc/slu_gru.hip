@@ -38,15 +38,7 @@ struct GruFwdParams {
   float* out;             // (T, B, D*H)
   float* reserve;         // [D][T][NBT][NW][5][64][4] or null
   int T, B, D;
-#ifdef SLU_GRU_PROBE
-  int dbg;                // ablation mask of the probe build (tools/gru_probe.py): never compiled into the product
-#endif
 };
-#ifdef SLU_GRU_PROBE
-#define SLU_DBG(bit) (p.dbg & (bit))
-#else
-#define SLU_DBG(bit) 0
-#endif
 
 template <int H>
 __global__ void __launch_bounds__(H * 4)
@@ -244,7 +236,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     const int t = dir ? T - 1 - s : s;
     const int cur = s & 1;
     float ngr[2], ngz[2], ngn[2];
-    if (s + 1 < T && !SLU_DBG(1)) {
+    if (s + 1 < T) {
       const int tn = dir ? t - 1 : t + 1;
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -257,10 +249,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     }
 
     float af[NQ];
-    if (SLU_DBG(32 | 64)) {       // probe: no LDS read (values from registers: wrong results, timing only)
-#pragma unroll
-      for (int v = 0; v < NQ; ++v) af[v] = hprev[v & 1] + (float)v;
-    } else {
+    {
       const float* __restrict__ hrow = &hbuf[cur][si * LD + half * KS + 4 * blk];
 #pragma unroll
       for (int v = 0; v < NQ / 4; ++v) {
@@ -269,7 +258,6 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
       }
     }
     f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = {0.f, 0.f, 0.f, 0.f}, an = {0.f, 0.f, 0.f, 0.f};
-    if (!SLU_DBG(16))
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int kb = (q / 4) * 32 + (q % 4);
@@ -296,24 +284,19 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     float rr[2], zz[2], nn[2], qq[2], hn[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (SLU_DBG(8)) {      // probe: gate math without the transcendentals
-        rr[e] = 0.5f + 0.01f * (gr[e] + (hr[e] + bhr)); zz[e] = 0.5f + 0.01f * (gz[e] + (hz[e] + bhz));
-        qq[e] = hq[e] + bhn; nn[e] = 0.01f * (gn[e] + rr[e] * qq[e]);
-      } else {
       rr[e] = act_sigmoid(gr[e] + (hr[e] + bhr));
       zz[e] = act_sigmoid(gz[e] + (hz[e] + bhz));
       qq[e] = hq[e] + bhn;
       nn[e] = act_tanh(gn[e] + rr[e] * qq[e]);
-      }
       hn[e] = (1.0f - zz[e]) * nn[e] + zz[e] * hprev[e];
     }
     float* __restrict__ hnext = &hbuf[cur ^ 1][0];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      if (!SLU_DBG(32 | 64)) hnext[(2 * half + e) * LD + j] = hn[e];
-      if (rowok[e] && !SLU_DBG(2)) outd[(size_t)t * out_ts + grow[e] * D * H] = hn[e];
+      hnext[(2 * half + e) * LD + j] = hn[e];
+      if (rowok[e]) outd[(size_t)t * out_ts + grow[e] * D * H] = hn[e];
     }
-    if (p.reserve && !SLU_DBG(4)) {
+    if (p.reserve) {
       float* __restrict__ rs = p.reserve + ((((size_t)dir * T + t) * NBT16) * NW16 + rsv_wave) * (5 * 256) + rsv_lane;
       *reinterpret_cast<float2*>(rs + 0 * 256) = make_float2(rr[0], rr[1]);
       *reinterpret_cast<float2*>(rs + 1 * 256) = make_float2(zz[0], zz[1]);
@@ -323,7 +306,7 @@ gru_seq_fwd4_kernel(const GruFwdParams p, const int NBT16) {
     }
 #pragma unroll
     for (int e = 0; e < 2; ++e) { hprev[e] = hn[e]; gr[e] = ngr[e]; gz[e] = ngz[e]; gn[e] = ngn[e]; }
-    if (!SLU_DBG(32)) __syncthreads();
+    __syncthreads();
   }
 }
 
@@ -731,9 +714,6 @@ extern "C" int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const flo
   GruFwdParams p;
   p.gx = gx; p.w_hh[0] = w_hh_fwd; p.w_hh[1] = w_hh_rev; p.b_hh[0] = b_hh_fwd; p.b_hh[1] = b_hh_rev;
   p.out = out; p.reserve = reserve; p.T = (int)T; p.B = (int)B; p.D = (int)D;
-#ifdef SLU_GRU_PROBE
-  { const char* e = getenv("SLU_GRU_DBG"); p.dbg = e ? atoi(e) : 0; }
-#endif
   hipStream_t st = (hipStream_t)stream;
   if (!gru_persistent(H)) return gru_step_fwd(gx, p.w_hh, p.b_hh, out, reserve, T, B, H, D, st);
   if (gru_use_seq4(B, H, D)) {

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "SLU_HIP_LIB" not in os.environ:
-    lib = os.path.join(ROOT, "end-to-end-slu_amd", "lib", "libslu_hip_probe.so")
+    lib = os.path.join(ROOT, "end-to-end-slu_amd", "lib_alt", "libslu_hip_probe.so")
     for mask in [int(m) for m in os.environ.get('PROBE_MASKS', '0,7,16,31,39,63,71,95').split(',')]:
         env = dict(os.environ, SLU_HIP_LIB=lib, SLU_GRU_DBG=str(mask))
         out = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, capture_output=True, text=True)
