@@ -8,11 +8,11 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${SLU_EXTRA_FLAGS:-}"
 JOBS="${SLU_BUILD_JOBS:-$(( $(nproc) < 16 ? $(nproc) : 16 ))}"
-UNITS="slu_api slu_sinc slu_wconv slu_wconv_bf16 slu_gemm slu_gemm_bf16 slu_gru slu_gru_step slu_gru_bf16 slu_pool slu_head slu_optim slu_framece slu_comm slu_seq2seq"
+UNITS="slu_api slu_sinc slu_wconv slu_wconv_bf16 slu_gemm slu_gemm_bf16 slu_gru slu_gru_step slu_gru_bf16 slu_gru_proj slu_pool slu_head slu_optim slu_framece slu_comm slu_seq2seq"
 OBJS=()
 STALE=()
 for f in $UNITS; do
-  if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/slu_common.h" -nt "$OUT/$f.o" ] || [ "$HERE/slu_bf16.h" -nt "$OUT/$f.o" ] || [ "$HERE/slu_philox.h" -nt "$OUT/$f.o" ] \
+  if [ ! -f "$OUT/$f.o" ] || [ "$HERE/$f.hip" -nt "$OUT/$f.o" ] || [ "$HERE/slu_common.h" -nt "$OUT/$f.o" ] || [ "$HERE/slu_bf16.h" -nt "$OUT/$f.o" ] || [ "$HERE/slu_philox.h" -nt "$OUT/$f.o" ] || [ "$HERE/slu_gemm_tile.h" -nt "$OUT/$f.o" ] \
      || [ "$HERE/../../include/slu_hip.h" -nt "$OUT/$f.o" ]; then
     STALE+=("$f")
   fi

@@ -81,6 +81,9 @@ SIGNATURES = {
     "slu_comm_allreduce_f32": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_allreduce_f64": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_destroy": (c_int, [vp]),
+    "slu_gru_proj_supported": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "slu_gru_proj_state_words": (c_i64, [c_i64, c_i64]),
+    "slu_gru_proj_seq_fwd": (c_int, [vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp]),
     "slu_gemm_tn_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp]),
     "slu_gemm_tn_splitk_workspace_bytes": (c_sz, [vp, vp, vp, c_i64]),
     "slu_gemm_tn_batched_splitk": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp, c_sz, vp, c_i64, vp]),
@@ -107,7 +110,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 6          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 7          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

@@ -839,6 +839,48 @@ def gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, want_reserve):
     return out, reserve
 
 
+_PROJ_STATE = {}          # (device, stream, T, B) -> hand-off counters of slu_gru_proj_seq_fwd (zeroed once, then launch-owned)
+
+
+def gru_proj_fused_ok(x2, w_ih, T, B, I, H, D):
+    """Can the layer's input projection and recurrence share one launch (slu_gru_proj_seq_fwd)?  Exact-fp32 training
+    arithmetic, a shape the kernel takes, plain row-major operands — and, while a hipGraph is being captured, hand-off
+    counters that already exist for this (shape, stream) (they are created by the eager steps that precede every capture;
+    a buffer allocated during the capture would belong to the graph's private pool).
+    OPT-IN (SLU_FUSE_PROJ_GRU=1): bit-identical to the two launches, but measured SLOWER on MI355X — intent layer (T = 19,
+    B = 64) 57.7 us against 51.0 for projection + recurrence on the 96-CU training partition, T = 300: 523 against 427
+    (profiles/r04_ap_proj_gru_fused.txt): the consumer's write-through loads and counter reads cost more per step than the
+    overlap with the projection returns.  Kept as the tested starting point of that fusion."""
+    if os.environ.get("SLU_FUSE_PROJ_GRU", "0") != "1" or not x2.is_cuda or train_nsplit(False) != 0:
+        return False
+    if not (x2.stride(1) == 1 and w_ih.stride(1) == 1 and x2.dtype == w_ih.dtype == torch.float32):
+        return False
+    if not _lib.load().slu_gru_proj_supported(T, B, I, H, D):
+        return False
+    key = (x2.device.index, _stream(), T, B)
+    return key in _PROJ_STATE or not torch.cuda.is_current_stream_capturing()
+
+
+def gru_proj_seq_fwd(x2, w_ih, b_ih, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, I, H, D, want_reserve):
+    """gx = x2 w_ih^T + b_ih and the recurrence over it in ONE launch; -> (out (T, B, D*H), reserve or None).  Bit-identical
+    to gemm + gru_seq_fwd."""
+    L = _lib.load()
+    dev = x2.device
+    key = (dev.index, _stream(), T, B)
+    st = _PROJ_STATE.get(key)
+    if st is None:
+        st = _PROJ_STATE[key] = torch.zeros(L.slu_gru_proj_state_words(T, B), dtype=torch.int32, device=dev)
+    gx = torch.empty(T * B, D * 3 * H, dtype=torch.float32, device=dev)
+    out = torch.empty(T, B, D * H, dtype=torch.float32, device=dev)
+    reserve = None
+    if want_reserve:
+        reserve = torch.empty(L.slu_gru_reserve_bytes(T, B, H, D) // 4, dtype=torch.float32, device=dev)
+    _lib.check(L.slu_gru_proj_seq_fwd(x2.data_ptr(), x2.stride(0), w_ih.data_ptr(), w_ih.stride(0), _ptr(b_ih), gx.data_ptr(),
+                                      w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r), out.data_ptr(),
+                                      _ptr(reserve), T, B, I, H, D, st.data_ptr(), st.numel(), _stream()), "slu_gru_proj_seq_fwd")
+    return out, reserve
+
+
 def gru_seq_bwd(d_out, reserve, w_hh_f, w_hh_r, T, B, H, D):
     L = _lib.load()
     d_out = _f32c(d_out, "d_out")
@@ -1216,8 +1258,13 @@ class GRULayerFn(torch.autograd.Function):
             gx = gemm_bf16(planes, packed, b_ih, D * 3 * H, I)
             raw, reserve = gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, need)
         else:
-            gx = gemm_nt(x.view(T * B, I), w_ih, b_ih)                    # (T*B, D*3H); train_nsplit arithmetic
-            raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
+            x2 = x.view(T * B, I)
+            if gru_proj_fused_ok(x2, w_ih, T, B, I, H, D):
+                # projection tiles and recurrence in one launch: the recurrence starts as soon as its first rows exist
+                raw, reserve = gru_proj_seq_fwd(x2, w_ih, b_ih, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, I, H, D, need)
+            else:
+                gx = gemm_nt(x2, w_ih, b_ih)                              # (T*B, D*3H); train_nsplit arithmetic
+                raw, reserve = gru_seq_fwd(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, need)
         offset, offset_dev, sub_batch = offset if isinstance(offset, tuple) else (offset, None, 0)
         if p == 0.0 and (factor == 1):
             y = raw

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 6
+#define SLU_ABI_VERSION 7
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -284,6 +284,22 @@ size_t slu_gru_reserve_bytes(int64_t T, int64_t B, int64_t H, int64_t D);
 int slu_gru_seq_fwd(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
                     const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
                     int64_t T, int64_t B, int64_t H, int64_t D, void* stream);
+/* Input projection + recurrence of a TRAINABLE layer in ONE launch (exact fp32; reference models.py:232 / :262: nn.GRU's
+ * x W_ih^T + b_ih followed by its T-step loop): workgroups of the same grid compute gx = x W_ih^T + b_ih tile by tile in
+ * time order and run slu_gru_seq_fwd's 4-sequence recurrence, which picks up each step's rows as soon as their tiles are
+ * published (write-through stores + a per-row-tile counter; see csrc/slu_gru_proj.hip).  Results are bit-identical to
+ * slu_gemm_f32 followed by slu_gru_seq_fwd.  x: (T*B, I) rows of stride x_rs; w_ih: direction-stacked (D*3H, I), row
+ * stride w_rs; b_ih (D*3H) or NULL; gx_scratch: T*B*D*3H floats (contents undefined afterwards); out / reserve as
+ * slu_gru_seq_fwd.  state: slu_gru_proj_state_words(T, B) 32-bit words, ZERO before the first launch, then owned by the
+ * launches of ONE (shape, stream) pair (counters accumulate across launches).  slu_gru_proj_supported: 1 if the shape is
+ * taken (H = 128, B % 4 == 0, the 4-sequence geometry), else use the two calls.                                     */
+int slu_gru_proj_supported(int64_t T, int64_t B, int64_t I, int64_t H, int64_t D);
+int64_t slu_gru_proj_state_words(int64_t T, int64_t B);
+int slu_gru_proj_seq_fwd(const float* x, int64_t x_rs, const float* w_ih, int64_t w_rs, const float* b_ih,
+                         float* gx_scratch, const float* w_hh_fwd, const float* w_hh_rev,
+                         const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
+                         int64_t T, int64_t B, int64_t I, int64_t H, int64_t D,
+                         int32_t* state, int64_t state_words, void* stream);
 /* Back-propagation through time.
  *   d_out   (T, B, D*H)  gradient w.r.t. `out`
  *   d_gx    (T, B, D*3H) gradient w.r.t. gx = x W_ih^T + b_ih          [dr_pre, dz_pre, dn_pre]

@@ -238,6 +238,43 @@ def test_gemm_tn_batched_splitk_vs_float64(ops, shapes):
         assert int(tk.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("T,B,I,D", [(19, 64, 256, 2), (5, 8, 60, 1), (7, 12, 256, 2), (150, 64, 256, 2), (300, 64, 60, 2), (2, 4, 64, 2), (1, 64, 256, 2)])
+def test_gru_projection_and_recurrence_in_one_launch_equal_the_two_launches(ops, monkeypatch, T, B, I, D):
+    """slu_gru_proj_seq_fwd: the input projection's tiles and the 4-sequence recurrence in ONE launch (producer / consumer
+    workgroups, per-row-tile counters, write-through stores and loads) must give exactly what slu_gemm_f32 followed by
+    slu_gru_seq_fwd give — output and saved gates, bit for bit — launch after launch on the same hand-off state (the
+    counters accumulate; a stale cross-XCD read would show as a mismatch in one of the repeats)."""
+    H = 128
+    monkeypatch.setenv("SLU_FUSE_PROJ_GRU", "1")             # opt-in path (slower than the two launches today)
+    torch.manual_seed(T * 31 + B)
+    x = torch.randn(T * B, I, device="cuda")
+    w_ih = torch.randn(D * 3 * H, I, device="cuda") * 0.1
+    b_ih = torch.randn(D * 3 * H, device="cuda") * 0.1
+    wf, bf = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, device="cuda") * 0.1
+    wr, br = (torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, device="cuda") * 0.1) if D == 2 else (None, None)
+    assert ops.gru_proj_fused_ok(x, w_ih, T, B, I, H, D)
+    gx = ops.gemm(x, w_ih.t(), b_ih)
+    want, want_rs = ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, True)
+    reps = 40 if T * B <= 2048 else 6
+    for rep in range(reps):
+        if rep % 3 == 1:                                     # new inputs at the same addresses: stale lines would be OLD values
+            x.normal_()
+            gx = ops.gemm(x, w_ih.t(), b_ih)
+            want, want_rs = ops.gru_seq_fwd(gx, wf, wr, bf, br, T, B, H, D, True)
+        got, got_rs = ops.gru_proj_seq_fwd(x, w_ih, b_ih, wf, wr, bf, br, T, B, I, H, D, True)
+        assert torch.equal(got, want), "output, repeat %d" % rep
+        if B % 16 == 0:
+            assert torch.equal(got_rs, want_rs), "saved gates, repeat %d" % rep
+        elif rep < 2:      # slots of absent sequences are never written: compare what the BPTT kernel makes of the saved gates
+            d_out = torch.randn(T, B, D * H, device="cuda")
+            for a, b in zip(ops.gru_seq_bwd(d_out, got_rs, wf, wr, T, B, H, D), ops.gru_seq_bwd(d_out, want_rs, wf, wr, T, B, H, D)):
+                assert torch.equal(a, b), "BPTT on the saved gates, repeat %d" % rep
+    got, none = ops.gru_proj_seq_fwd(x, w_ih, None, wf, wr, bf, br, T, B, I, H, D, False)
+    gx0 = ops.gemm(x, w_ih.t(), None)
+    want0, _ = ops.gru_seq_fwd(gx0, wf, wr, bf, br, T, B, H, D, False)
+    assert none is None and torch.equal(got, want0)
+
+
 def test_colsum(ops):
     x = torch.randn(1000, 130)
     out = ops.colsum(cu(x))
