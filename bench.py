@@ -758,8 +758,12 @@ def claim_stdout():
     global _JSON_FD
     if _JSON_FD is None:
         sys.stdout.flush()
-        _JSON_FD = os.dup(1)
-        os.dup2(2, 1)
+        try:
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            _JSON_FD = saved
+        except OSError:                  # no usable stderr (or stdout): leave the descriptors alone, print as usual
+            _JSON_FD = None
 
 
 def emit_json(out):
