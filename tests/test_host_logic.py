@@ -167,3 +167,18 @@ def test_committed_profile_tables_cover_the_default_dominant_kernel():
     assert inloop[name]["avg_us"] > 0 and os.path.exists(os.path.join(ROOT, inloop[name]["source"]))
     assert 0.9 <= pmc[name]["traffic_over_algorithmic"] <= 1.5
     assert os.path.exists(os.path.join(ROOT, pmc[name]["source"]))
+
+
+def test_bench_stdout_carries_the_json_line_only(tmp_path):
+    """The contract is ONE JSON line on stdout: whatever libraries (config messages, RCCL's banner) or child processes
+    print after bench.claim_stdout() must land on stderr — Python-level and C-level output alike."""
+    import subprocess
+    code = ("import bench, os\n"
+            "bench.claim_stdout()\n"
+            "print('noise from a library')\n"
+            "os.system('echo noise from a child process')\n"
+            "bench.emit_json({'metric': 'x', 'value': 1})\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout == '{"metric": "x", "value": 1}\n'
+    assert "noise from a library" in r.stderr and "noise from a child process" in r.stderr
