@@ -483,18 +483,23 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
         byts = sum(s["bytes"] for s in shapes)
         ms = sum(s["ms"] for s in shapes)
         peak = shapes[0]["peak"]
-        tf_mfma = mfma / (ms * 1e-3) / 1e12
+        tf_mfma = mfma / (ms * 1e-3) / 1e12              # 16-bit MFMA products actually issued (x 3 / x 6 on the split schemes)
+        tf_alg = flops / (ms * 1e-3) / 1e12              # algorithmic (fp32-equivalent) work rate
         tbs = byts / (ms * 1e-3) / 1e12
-        f_mfma, f_hbm = tf_mfma / peak, tbs / PEAK_HBM_TBS
+        # `frac` prices ALGORITHMIC work: fp32-equivalent flops against the peak of the MFMA unit the kernel issues to, and
+        # algorithmic bytes against HBM; the issued-product utilisation of the unit is reported beside it
+        f_mfma, f_issued, f_hbm = tf_alg / peak, tf_mfma / peak, tbs / PEAK_HBM_TBS
         # the kernel runs on its stream's CU partition only: its MFMA fraction of THAT partition's share of the peak
         # (HBM is shared by the whole chip: no such rescaling)
         n_cu, split = _n_cus(), _cu_split()
         cus = (n_cu - split if "look-ahead" in shapes[0]["shape"] else split) if 0 < split < n_cu else n_cu
         out.append({"kernel": name, "launches_per_cycle": len(shapes), "algorithmic_gflop": round(flops / 1e9, 2),
-                    "cus": cus, "mfma_frac_of_partition_peak": round(f_mfma * n_cu / cus, 4),
+                    "cus": cus, "mfma_issued_frac_of_partition_peak": round(f_issued * n_cu / cus, 4),
                     "avg_us": round(1e3 * ms / len(shapes), 2),
-                    "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),       # fp32-equivalent work rate
+                    "algorithmic_tflops": round(tf_alg, 2),                           # fp32-equivalent work rate
                     "mfma_tflops": round(tf_mfma, 2), "mfma_peak": peak, "mfma_frac": round(f_mfma, 4),
+                    "mfma_issued_frac": round(f_issued, 4),
+                    "frac_of_fp32_mfma_peak": round(tf_alg / PEAK_FP32_MFMA_TFLOPS, 4),
                     "hbm_tbs": round(tbs, 3), "hbm_frac": round(f_hbm, 4),
                     "bound": "mfma" if f_mfma >= f_hbm else "hbm", "frac": round(max(f_mfma, f_hbm), 4),
                     "gpu_ms_per_step": round(t_step, 4),
@@ -513,12 +518,13 @@ def dtype_label():
         return ("bf16 (operands of every forward contraction - convolutions, input projections, recurrences - and of the "
                 "data-gradient contractions on bf16 MFMA; fp32 accumulation, gate math, weight gradients, master weights, Adam)")
     if models.guarded_frozen_nsplit() == 2:
-        return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
-                "operands split into 2 fp16 terms (22-bit significand), 3 fp16 MFMA products, fp32 accumulation - "
-                "fp32-class: same deviation from float64 as an fp32 fmaf chain, parity <= 1e-4)")
+        return ("f32 with 22-bit frozen operands (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN "
+                "stages: f16x2 = fp32 operands as 2 fp16 terms, 22-bit significand - NARROWER than the reference's fp32 -, 3 fp16 "
+                "MFMA products, fp32 accumulation; opt-in, SLU_FROZEN_MATH=auto)")
     if models.guarded_frozen_nsplit() == 3:
-        return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: fp32 "
-                "operands split into 3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation - fp32-class, parity <= 1e-4)")
+        return ("f32 (trainable stages: exact fp32 MFMA; convolutions and GRU contractions of FROZEN stages: bf16x3 = every fp32 "
+                "operand split EXACTLY into 3 bf16 terms (3 x 8 = 24 significand bits, fp32's exponent range), 6 bf16 MFMA "
+                "products per fp32 product (only terms below 2^-24 |a b| dropped), fp32 accumulation)")
     return "f32"
 
 
@@ -532,25 +538,9 @@ def _n_cus():
     return pipeline.n_compute_units(torch.cuda.current_device())
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc pass (separate run,
-    FETCH_SIZE x 2 correction of MI355X_MICROARCH.md): profiles/pmc_traffic.json, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(kernel)
-    except (OSError, ValueError):
-        return None
-
-
-def inloop_kernel_us():
-    """Average duration of each kernel INSIDE the real pipelined loop (beside the other partition's traffic), from the
-    committed rocprofv3 --kernel-trace run of this very command: profiles/inloop_kernel_us.json
-    ({kernel: {"avg_us": ..., "source": ...}}), or {}."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "inloop_kernel_us.json")) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return {}
+# Committed evidence for the numbers this process cannot measure itself (it has no profiler): named as `source`, never read.
+PMC_SOURCE = "profiles/r05_z_pmc_gru_bf.txt"                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (HBM bytes per launch)
+INLOOP_SOURCE = "profiles/r05_z_default_kernel_stats_by_shape.txt"  # rocprofv3 --kernel-trace of the default command (in-loop durations)
 
 
 def side_run(extra_args, env_extra=None, timeout=600):
@@ -628,11 +618,12 @@ def feature_parity(model, config, batch, samples, n_batches=16):
     old = os.environ.get("SLU_FROZEN_MATH")
     xd = x.cuda()
     try:
-        for mode in ("auto", "bf16x3", "fp32"):
+        for mode in ("bf16x3", "fp32", "auto"):
             os.environ["SLU_FROZEN_MATH"] = mode
             with torch.no_grad():
                 got = pm.compute_features(xd).float().cpu()
-            label = mode if mode != "auto" else "default (f16x2 under the range guard)"
+            label = {"bf16x3": "default (bf16x3)", "fp32": "exact fp32 MFMA",
+                     "auto": "f16x2 under the range guard (opt-in, 22-bit operands)"}[mode]
             out["max_abs_dev"][label] = float((got - ref).abs().max())
         out["guard_trips"] = pm.range_guard().trips
     finally:
@@ -641,7 +632,7 @@ def feature_parity(model, config, batch, samples, n_batches=16):
         else:
             os.environ["SLU_FROZEN_MATH"] = old
         model.train(was_training)
-    out["frozen_arithmetic_after"] = {2: "f16x2", 3: "bf16x3", 0: "fp32"}.get(models.guarded_frozen_nsplit(model))
+    out["default_frozen_arithmetic"] = {2: "f16x2", 3: "bf16x3", 0: "fp32"}.get(models.guarded_frozen_nsplit(model))
     del xd
     return out
 
@@ -650,8 +641,8 @@ def frontend_fwd_point(model, config, batch, samples):
     """BASELINE.json configs[1]: the SincNet + Conv1d front end of the phoneme module alone (reference models.py:77-110,
     180-220: sinc -> abs -> pool -> LeakyReLU -> conv -> LeakyReLU -> conv -> LeakyReLU), B = 64 x 3 s, forward only, on
     the whole device: time per batch, utterances/s, algorithmic HBM GB/s (waveform in + conv2 output out = SURVEY 8(d)'s
-    minimum for these stages) and MFMA rate, in the default arithmetic of frozen stages and on the exact fp32 kernels,
-    with the CPU oracle's front end timed beside it."""
+    minimum for these stages) and MFMA rate, in the default arithmetic of frozen stages (bf16x3), on the exact fp32 kernels
+    and on guarded f16x2, with the CPU oracle's front end timed beside it."""
     import copy
     import models
     from oracle import slu_oracle as O
@@ -678,7 +669,7 @@ def frontend_fwd_point(model, config, batch, samples):
            "algorithmic_gflop": round(flops / 1e9, 3), "algorithmic_MB": round(nbytes / 1e6, 2)}
     old = os.environ.get("SLU_FROZEN_MATH")
     try:
-        for mode, label in (("auto", "default"), ("fp32", "exact_fp32")):
+        for mode, label in (("bf16x3", "default"), ("fp32", "exact_fp32"), ("auto", "f16x2_guarded")):
             os.environ["SLU_FROZEN_MATH"] = mode
             with torch.no_grad():
                 if mode == "auto":
@@ -690,9 +681,11 @@ def frontend_fwd_point(model, config, batch, samples):
             res[label] = {"ms": round(ms, 4), "utterances_per_s": round(batch / (ms * 1e-3), 1),
                           "algorithmic_hbm_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
                           "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-                          "frac_of_fp16_mfma_peak" if mode == "auto" else "frac_of_fp32_mfma_peak":
-                              round(flops * (MFMA_PRODUCTS[2] if mode == "auto" else 1.0) / (ms * 1e-3) / 1e12
-                                    / (PEAK_BF16_MFMA_TFLOPS if mode == "auto" else PEAK_FP32_MFMA_TFLOPS), 4)}
+                          "frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            if mode != "fp32":
+                ns = 3 if mode == "bf16x3" else 2
+                res[label]["mfma_issued_frac_of_16bit_peak"] = round(flops * MFMA_PRODUCTS[ns] / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
+                res[label]["mfma_algorithmic_frac_of_16bit_peak"] = round(flops / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)
     finally:
         if old is None:
             os.environ.pop("SLU_FROZEN_MATH", None)
@@ -927,7 +920,10 @@ def main():
         note("parity on the golden batch")
         parity = parity_check(dev)
     note("setup")
-    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, 4, args.hidden)
+    # >= one look-ahead super-batch of DISTINCT synthetic batches (32 x 64 x 3 s = 393 MB resident): no super-batch holds a
+    # batch twice
+    n_distinct = int(os.environ.get("SLU_BENCH_DISTINCT", "32" if samples * args.batch <= 64 * 48000 else "8"))
+    config, model, trainer, train_ds, work = setup(args.workload, rank, args.batch, samples, n_distinct, args.hidden)
     batches = [tuple(t.to(dev) for t in b) for b in train_ds.loader]       # inputs resident in HBM
     model.train()
 
@@ -1021,52 +1017,43 @@ def main():
             top = table[0]
             is_mfma = top["bound"] == "mfma"
             alg_per_launch = round(sum(s["algorithmic_MB"] for s in top["shapes"]) * 1e6 / len(top["shapes"]))
-            pmc = pmc_traffic(top["kernel"])
-            # the same kernel inside the real loop (rocprofv3 kernel trace of this command, committed): the other
-            # partition's traffic, the shared power budget and the profiler make it slower than the isolated replay
-            # (the committed trace is of the DEFAULT command: its durations say nothing about other workloads / shapes)
-            default_shape = (args.workload == "no_unfreezing" and not args.hidden and args.batch == 64 and args.seconds == 3.0
-                             and width > 1 and os.environ.get("SLU_DTYPE", "f32") != "bf16")
-            inloop = inloop_kernel_us() if default_shape else {}
-            il = inloop.get(top["kernel"])
-            frac_inloop = None
-            if il and il.get("avg_us"):
-                frac_inloop = round(top["frac"] * top["avg_us"] / il["avg_us"], 4)
             # all bytes the frozen-prefix kernels move per super-batch against SURVEY 8(d)'s minimum (0.914 MB / utterance)
             prefix_bytes = sum(sh["algorithmic_MB"] * 1e6 for k in table for sh in k["shapes"] if "look-ahead" in sh["shape"])
             prefix_ms = sum(sh["us"] * 1e-3 for k in table for sh in k["shapes"] if "look-ahead" in sh["shape"])
             prefix_gflop = sum(sh["gflop"] for k in table for sh in k["shapes"] if "look-ahead" in sh["shape"])
             n_utt = args.batch * width
-            # HBM bytes per launch: the PMC passes measure the largest launch shape(s) of the kernel; their
-            # measured / algorithmic ratio is applied to the per-launch mean `achieved` is quoted on
-            ratio = (pmc or {}).get("traffic_over_algorithmic")
             out["roofline"] = {
+                # the dominant kernel of the timed steps (largest share of a step's GPU time), measured by THIS process:
+                # ALGORITHMIC work (SURVEY 8(d) flops / bytes of its launch shapes) / the average launch duration between two
+                # HIP events on the CU-masked stream it runs on
                 "bound": top["bound"],
-                "achieved": top["mfma_tflops"] if is_mfma else top["hbm_tbs"] * 1e3,
+                "achieved": top["algorithmic_tflops"] if is_mfma else top["hbm_tbs"] * 1e3,
                 "peak": top["mfma_peak"] if is_mfma else PEAK_HBM_TBS * 1e3,
                 "unit": "TFLOP/s" if is_mfma else "GB/s",
-                "frac": frac_inloop if frac_inloop is not None else top["frac"],
-                "frac_isolated": top["frac"], "frac_in_loop": frac_inloop,
-                "in_loop": il,
+                "frac": top["frac"],
+                "frac_hbm": top["hbm_frac"], "frac_mfma_algorithmic": top["mfma_frac"],
+                "mfma_issued_frac": top["mfma_issued_frac"],           # utilisation of the unit by the 16-bit products issued
+                "frac_of_fp32_mfma_peak": top["frac_of_fp32_mfma_peak"],
+                "traffic": None,                                        # PMC counters need the profiler: see traffic_source
+                "traffic_source": PMC_SOURCE, "in_loop_source": INLOOP_SOURCE,
+                "algorithmic_bytes_per_launch": alg_per_launch,
+                "algorithmic_gflop_per_launch": round(top["algorithmic_gflop"] / top["launches_per_cycle"], 3),
+                "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
                 "prefix_traffic_over_8d": round(prefix_bytes / (0.914e6 * n_utt), 2) if width > 1 else None,
                 "prefix_bytes_per_super_batch": round(prefix_bytes) if width > 1 else None,
                 "prefix_ms_per_super_batch_isolated": round(prefix_ms, 3) if width > 1 else None,
-                # the frozen stages as a whole against the roofline of an exact-fp32 implementation: their algorithmic
-                # (fp32-equivalent) flops per super-batch / the sum of their isolated kernel times, of the whole chip's
-                # fp32 MFMA peak (they run on the look-ahead partition only; the split schemes are why this can pass 1)
+                # the frozen stages as a whole: their algorithmic (fp32-equivalent) flops per super-batch / the sum of their
+                # isolated kernel times, against the whole chip's fp32 MFMA peak (they run on the look-ahead partition only)
                 "prefix_fp32_equiv_tflops_isolated": round(prefix_gflop / prefix_ms, 1) if width > 1 and prefix_ms else None,
                 "prefix_frac_of_fp32_mfma_peak": round(prefix_gflop / prefix_ms / PEAK_FP32_MFMA_TFLOPS, 3) if width > 1 and prefix_ms else None,
-                "traffic": round(alg_per_launch * ratio) if ratio else None,
-                "algorithmic_bytes_per_launch": alg_per_launch, "traffic_pmc": pmc,
-                "kernel": top["kernel"], "launches": top["launches_per_cycle"], "avg_launch_ms": round(top["avg_us"] / 1e3, 5),
                 "kernels": table[:6],
-                "note": "per kernel: sums over its distinct launch shapes in one look-ahead cycle (%d steps) of the "
-                        "algorithmic fp32 flops (mfma_tflops counts the 16-bit MFMA products actually issued: 3 per fp32 "
-                        "product on the f16x2 kernels, 6 on bf16x3) and of the algorithmic HBM bytes / sum of the average "
-                        "durations; each shape is launched 20x back to back (one hipGraph) on the CU-masked stream it "
-                        "runs on during the timed steps (frozen stages: %d sequences on CUs [%d,%d); trainable stages: "
-                        "%d sequences on CUs [0,%d)) between two HIP events on that stream.  Peaks are whole-chip: fp32 "
-                        "MFMA 157.3, dense bf16 / fp16 MFMA 2500 TFLOP/s, HBM 8 TB/s; `frac` is against the kernel's binding one."
+                "note": "per kernel: sums over its distinct launch shapes in one look-ahead cycle (%d steps) of the ALGORITHMIC fp32 "
+                        "flops and HBM bytes / sum of the average durations; `frac` = max(algorithmic flops / peak of the MFMA unit "
+                        "the kernel issues to, algorithmic bytes / HBM peak); mfma_issued_frac counts the 16-bit products actually "
+                        "issued (6 per fp32 product on bf16x3, 3 on f16x2).  Each shape is launched 20x back to back (one hipGraph) on "
+                        "the CU-masked stream it runs on during the timed steps (frozen stages: %d sequences on CUs [%d,%d); trainable "
+                        "stages: %d sequences on CUs [0,%d)) between two HIP events on that stream.  Peaks are whole-chip: fp32 MFMA "
+                        "157.3, dense bf16 / fp16 MFMA 2500 TFLOP/s, HBM 8 TB/s."
                         % (width, args.batch * width, _cu_split(), _n_cus(), args.batch, _cu_split())}
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
@@ -1098,9 +1085,12 @@ def main():
             torch.cuda.empty_cache()
             note("side runs")
             common = ["--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--seconds", str(args.seconds)]
+            # the other arithmetics of the frozen stages, each at the driver's K and in the 512-step steady state (`value` /
+            # `steady_state` of the sub-line): exact fp32 MFMA; f16x2 under its range guard (22-bit operands: NARROWER than
+            # the reference's fp32, opt-in, never the headline)
             out["exact_fp32"] = side_run(common, {"SLU_FROZEN_MATH": "fp32"})
-            note("side run: frozen stages on bf16x3")
-            out["frozen_bf16x3"] = side_run(common, {"SLU_FROZEN_MATH": "bf16x3"})
+            note("side run: frozen stages on guarded f16x2")
+            out["frozen_f16x2"] = side_run(common, {"SLU_FROZEN_MATH": "auto"})
             short = ["--steps", "40", "--warmup", "10", "--batch", str(args.batch), "--seconds", str(args.seconds)]
             out.setdefault("other_workloads", {}).update({w: side_run(short + ["--workload", w]) for w in ("unfreeze_all", "asr_pretrain", "seq2seq")})
         emit_json(out)

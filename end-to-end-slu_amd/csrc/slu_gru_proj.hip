@@ -295,6 +295,11 @@ extern "C" int slu_gru_proj_supported(int64_t T, int64_t B, int64_t I, int64_t H
   if (H != 128 || (D != 1 && D != 2) || T < 1 || B < 1 || I < 1) return 0;
   if ((D * 3 * H) % 64 != 0 || B % 4 != 0) return 0;
   if (cdiv(B, 16) * D >= 256) return 0;                       // the 16-sequence kernel's territory (gru_use_seq4)
+  // the recurrence workgroups [0, nrec) SPIN on counters the projection workgroups behind them publish: both sets must
+  // be resident together.  The smallest CU partition a stream of this package gets is 64 CUs at one workgroup per CU
+  // (pipeline.cu_split: multiples of 16, the opt-in is refused below 64), so at most 32 consumers may be launched — the
+  // other half of the slots is then always free for producers (B <= 64 bidirectional: the intent layer's shape)
+  if (cdiv(B, 4) * D > 32) return 0;
   if (T * B * D * 3 * H * 4 >= (1LL << 31)) return 0;          // gx through one buffer descriptor
   return 1;
 }

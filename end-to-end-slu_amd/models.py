@@ -104,7 +104,7 @@ def _site(module, idx):
 
 
 class _FrozenMath:
-    """State of the frozen stages' arithmetic in the default mode (SLU_FROZEN_MATH=auto; slu_hip/guard.py)."""
+    """State of the frozen stages' arithmetic in the guarded mode (SLU_FROZEN_MATH=auto; slu_hip/guard.py)."""
     scope = None        # the RangeGuard watching the evaluation that is running now: only then auto = f16x2
 
 
@@ -119,8 +119,16 @@ def frozen_math_scope(guard):
         _FrozenMath.scope = prev
 
 
+# Round 5: the DEFAULT arithmetic of frozen stages is as wide as the reference's fp32 ATen kernels (models.py:108, 200,
+# 232): bf16x3 = every fp32 operand as three bf16 terms (3 x 8 significand bits = fp32's 24, fp32's exponent range, so
+# the split is EXACT), six bf16 MFMA products per fp32 product (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; what is
+# dropped is below 2^-24 |a b| per product, the size of one fp32 rounding), fp32 accumulation.  The 22-bit f16x2 scheme
+# under its range guard ("auto") is faster and opt-in: narrower than the reference's arithmetic, it is not the default.
+DEFAULT_FROZEN_MATH = "bf16x3"
+
+
 def frozen_math_mode():
-    mode = os.environ.get("SLU_FROZEN_MATH", "auto")
+    mode = os.environ.get("SLU_FROZEN_MATH", DEFAULT_FROZEN_MATH)
     if mode not in _FROZEN_MATH:
         raise ValueError("SLU_FROZEN_MATH=%r: expected one of %s" % (mode, sorted(_FROZEN_MATH)))
     return mode
@@ -343,6 +351,11 @@ class GRU(torch.nn.Module):
             if getattr(self, "_packed_ih", (None, None))[0] != key:
                 self._packed_ih = (key, _ops.gemm_bf16_pack(w_ih.detach(), nsplit))
             packed = self._packed_ih[1]
+            if nsplit == 2 and _FrozenMath.scope is not None and not isinstance(xt, _ops.SplitAct):
+                # guarded f16x2 fed by an fp32 tensor no convolution launch has watched (a last CNN block with dropout,
+                # pool 2 or a channel count without plane output hands fp32 over): raise the guard's last word to this
+                # input's largest |value| before split_bf16 turns it into fp16 terms
+                _ops.absmax_into(xt, _FrozenMath.scope.word(1 << 20))
             if isinstance(xt, _ops.SplitAct) or not xt.requires_grad:
                 # nothing to differentiate: the whole layer outside autograd, activations may stay in bf16 planes
                 rev = (self.weight_hh_l0_reverse, self.bias_hh_l0_reverse) if self.bidirectional else (None, None)

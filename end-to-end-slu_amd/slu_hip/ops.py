@@ -691,6 +691,19 @@ def gru_layer_frozen(x, w_ih, b_ih, packed_ih, w_hh_f, b_hh_f, w_hh_r, b_hh_r, p
     return dropout_pool_fwd(raw, mask, p, seed, off, method, factor, off_dev, sub, keep_bits=keep)
 
 
+def absmax_into(t, word_ptr):
+    """atomicMax of the IEEE bit pattern of max |t| into the uint32 device word at `word_ptr` (the f16x2 range guard's
+    words, slu_hip/guard.py): one small launch on the current stream."""
+    import ctypes
+    t = t.detach()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    assert t.dtype == torch.float32 and t.is_cuda
+    ptrs = (ctypes.c_void_p * 1)(t.data_ptr())
+    numel = (ctypes.c_int64 * 1)(t.numel())
+    _lib.check(_lib.load().slu_absmax_multi(ptrs, numel, 1, word_ptr, _stream()), "slu_absmax_multi")
+
+
 def split_path_supported(H, D):
     """Shapes the split-precision kernels are instantiated for (else the exact fp32 kernels run)."""
     return H in (64, 128) and (D * 3 * H) % 64 == 0
@@ -759,6 +772,7 @@ def gemm_tn_batched(problems, rowsum=None):
 
 
 _TN_TICKETS = {}          # (device, stream) -> zeroed ticket words of slu_gemm_tn_batched_splitk (the kernel leaves them zero)
+_TN_RETIRED = []          # outgrown ticket buffers, kept alive for the graphs that captured their addresses
 TN_SPLITK_MIN_ROWS = 2048
 
 
@@ -773,6 +787,8 @@ def tn_tickets(dev, tiles=0):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("slu_gemm_tn_batched_splitk: no ticket buffer for this stream yet and the stream is capturing; "
                                "call slu_hip.ops.tn_tickets(device) on this stream before the capture starts")
+        if tk is not None:
+            _TN_RETIRED.append(tk)      # a hipGraph captured earlier may still address the smaller buffer: never freed
         tk = _TN_TICKETS[key] = torch.zeros(max(1024, tiles), dtype=torch.int32, device=dev)
     return tk
 
@@ -856,6 +872,9 @@ def gru_proj_fused_ok(x2, w_ih, T, B, I, H, D):
     if not (x2.stride(1) == 1 and w_ih.stride(1) == 1 and x2.dtype == w_ih.dtype == torch.float32):
         return False
     if not _lib.load().slu_gru_proj_supported(T, B, I, H, D):
+        return False
+    from . import pipeline as _pl
+    if 0 < _pl.cu_split() < 64:         # consumers (<= 32 workgroups) + producers must be co-resident on the training partition
         return False
     key = (x2.device.index, _stream(), T, B)
     return key in _PROJ_STATE or not torch.cuda.is_current_stream_capturing()
@@ -1300,7 +1319,7 @@ class GRULayerFn(torch.autograd.Function):
                  and I % 4 == 0 and H % 4 == 0)
         # long layers (thousands of rows) in exact-fp32 training: the same ONE launch with the k range split over workgroups
         # (slu_gemm_tn_batched_splitk) instead of three k-slow GEMMs + three reduce launches + a column sum
-        long_rows = (not small and T * B >= TN_SPLITK_MIN_ROWS and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
+        long_rows = (not small and T > 1 and T * B >= TN_SPLITK_MIN_ROWS and (ng[3] or ng[4]) and all(ng[7 + 2 * d] for d in range(D))
                      and I % 4 == 0 and H % 4 == 0 and train_nsplit(True) == 0
                      and os.environ.get("SLU_TN_SPLITK", "1") != "0")
         if long_rows:

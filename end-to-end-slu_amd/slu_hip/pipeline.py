@@ -234,6 +234,10 @@ class PrefixSlot:
     def _fill(x_cat, xs):
         B = xs[0].shape[0]
         for k, x in enumerate(xs):
+            if x.dtype != x_cat.dtype:
+                # copy_ would CONVERT: float [-1, 1) samples into an int16 buffer are all zeros, int16 PCM into a float
+                # buffer is 32768 times too large — a super-batch holds one sample format (training.launch_next)
+                raise TypeError("look-ahead super-batch of %s batches received a %s batch" % (x_cat.dtype, x.dtype))
             x_cat[k * B:(k + 1) * B].copy_(x, non_blocking=True)
 
     def _table_ok(self, model, xs):
@@ -364,6 +368,9 @@ class StepGraph:
 
     def run(self, inputs, step):
         # static inputs + dropout-stream offset in ONE launch (device-resident sources; others fall back to copy_)
+        for dst, src in zip(self.inputs, inputs):
+            if dst.dtype != src.dtype:          # the graph was captured for one sample format (float32 or PCM16)
+                raise TypeError("captured step expects %s inputs, got %s" % (dst.dtype, src.dtype))
         for dst, src in ops.stage_inputs(list(zip(self.inputs, inputs)), self.rng, step * 16):
             dst.copy_(src, non_blocking=True)
         self.g1.replay()

@@ -65,6 +65,28 @@ def _lookahead_width(depth, batch_size):
     return max(2, min(32, (8 * cus) // max(1, batch_size)))
 
 
+def _ramp_plan(n_run, width, n_slots):
+    """Sizes of the FIRST super-batches of a run of n_run batches (the rest are `width` batches each), and how many of
+    them are started side by side.  The first super-batch of a run is pure pipeline fill: nothing can train until its
+    frozen prefix is through ~560 dependent recurrence steps, whatever its size — so the run starts with a SMALL
+    super-batch and two larger ones launched AT THE SAME TIME on the look-ahead partition (together at most `width`
+    batches = one recurrence workgroup per look-ahead CU, so they really run side by side): sizes ~ 1 : 2 : 4.  The
+    training stream starts after the small one's latency and finds the second and third ready when it needs them.
+    Round 5, bf16x3 frozen stages, the driver's 20-step command: 12 + 8 chained (rounds 2-4) -> 3 + 6 + 11 side by side.
+    SLU_RAMP=0 (or fewer than three look-ahead slots): the old plan, one capped first super-batch (3/5 of a run that
+    fits in two).  SLU_RAMP=a,b,c: explicit sizes."""
+    env = os.environ.get("SLU_RAMP", "auto")
+    T = min(n_run, width)
+    if env not in ("auto", "0"):
+        sizes = [max(1, int(v)) for v in env.split(",") if v.strip()]
+        return sizes, len(sizes)
+    if env == "0" or n_slots < 3 or T < 9:
+        return ([max(2, -(-3 * n_run // 5))] if n_run < 2 * width else []), 0
+    a = max(2, int(T / 7.0 + 0.5))
+    b = max(a, int(2 * T / 7.0 + 0.5))
+    return [a, b, T - a - b], 3
+
+
 class Trainer:
     def __init__(self, model, config):
         self.model = model
@@ -356,7 +378,7 @@ class Trainer:
                     guard = step_guard()
                     fused_now = fused and guard is None
                     fwd = forward if (fused_now or not fused) else forward_plain
-                    key = ("full", asr, trainable, fused_now) + tuple(tuple(t.shape) for t in ins)
+                    key = ("full", asr, trainable, fused_now) + tuple((tuple(t.shape), t.dtype) for t in ins)
                     vals = self._graph_step(key, ins, next_rng_step(), fwd, main,
                                             forks=os.environ.get("SLU_GRAPH_FORKS", "1") != "0", guard=guard)
                     if sums is not None and not fused_now:
@@ -395,7 +417,7 @@ class Trainer:
                 return out
 
             for batch in loader:
-                if group and (tuple(batch[0].shape) != tuple(group[0][0].shape)
+                if group and (tuple(batch[0].shape) != tuple(group[0][0].shape) or batch[0].dtype != group[0][0].dtype
                               or len(group) == _lookahead_width(_lookahead_env(), len(group[0][0]))):
                     yield from flush()
                 group.append(batch)
@@ -432,7 +454,9 @@ class Trainer:
         main = self._train_stream
         main.wait_stream(outer)
         if getattr(self, "_slots", None) is None:
-            n_slots = max(2, int(os.environ.get("SLU_LOOKAHEAD_SLOTS", "2")))
+            # three slots: the first three super-batches of a run start side by side (_ramp_plan); afterwards one is
+            # being consumed, one computed and one queued behind it
+            n_slots = max(2, int(os.environ.get("SLU_LOOKAHEAD_SLOTS", "3")))
             self._slots = [pipeline.PrefixSlot(dev) for _ in range(n_slots)]   # in-flight super-batches
         pm = self.model.pretrained_model
         with torch.cuda.stream(main):
@@ -449,10 +473,7 @@ class Trainer:
         fused = step_graphs and self._fused_sums()
         forward = self._slu_forward(n_prefix, sums if fused else None)
         trainable = _param_signature(self.model)
-        # short runs (an epoch of a few dozen batches): the first super-batch is pure pipeline fill, so a run that
-        # fits in two super-batches is split 60 : 40 — the second, smaller one (its encoder runs beside the first
-        # one's steps, ~5 % slower than alone) is then ready when the first one's steps end (20 batches: 12 + 8;
-        # measured prefix times 0.94 + 0.153 ms per batch, 0.2 ms per step: 7.3 ms against 7.6 for 10 + 10)
+        # the first super-batches of a run are sized and started by _ramp_plan (pipeline fill)
         try:
             n_run = len(loader)
         except TypeError:
@@ -462,6 +483,7 @@ class Trainer:
         carry = []                                    # a batch read ahead that did not fit its group
         launched = 0
         last_done = [None]
+        ramp = [[], 0]                                # [sizes of the first super-batches, how many start side by side]
 
         def launch_next():
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
@@ -469,25 +491,23 @@ class Trainer:
             group = [carry.pop()] if carry else []
             ver = lambda b: b[0]._version if b[0].is_cuda else None
             versions = [ver(b) for b in group]                 # tensor version of every batch WHEN IT WAS READ
-            cap = [1 << 30]
-
             wcache = {}
 
             def width():
                 bs = len(group[0][0])
                 if bs not in wcache:
                     w = _lookahead_width(depth, bs)
-                    if launched == 0 and n_run < 2 * w:
-                        cap[0] = max(2, -(-3 * n_run // 5))
-                    wcache[bs] = min(cap[0], w)
+                    if launched == 0:
+                        ramp[0], ramp[1] = _ramp_plan(n_run, w, len(self._slots))
+                    wcache[bs] = min(ramp[0][launched], w) if launched < len(ramp[0]) else w
                 return wcache[bs]
             while not group or len(group) < width():
                 try:
                     batch = next(it)
                 except StopIteration:
                     break
-                if group and tuple(batch[0].shape) != tuple(group[0][0].shape):
-                    carry.append(batch)
+                if group and (tuple(batch[0].shape) != tuple(group[0][0].shape) or batch[0].dtype != group[0][0].dtype):
+                    carry.append(batch)          # a super-batch holds ONE shape and ONE sample format (float32 or PCM16)
                     break
                 group.append(batch)
                 versions.append(ver(batch))
@@ -496,8 +516,10 @@ class Trainer:
             slot = self._slots[launched % len(self._slots)]
             launched += 1
             steps = [next_rng_step() for _ in group]                        # consecutive by construction
+            # the first ramp[1] super-batches of the run start side by side; from then on each waits for its predecessor
+            # (two full-width super-batches side by side would only delay the one the training stream is waiting for)
             feats, done, guard = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
-                                          after=last_done[0])
+                                          after=None if launched <= ramp[1] else last_done[0])
             last_done[0] = done
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on

@@ -1,5 +1,5 @@
-"""The default arithmetic of the frozen stages (SLU_FROZEN_MATH=auto: f16x2 under a range guard, bf16x3 otherwise —
-slu_hip/guard.py) must have fp32's DOMAIN, like the reference's plain fp32 ATen kernels (models.py:108, :200, :232):
+"""The GUARDED fast arithmetic of the frozen stages (SLU_FROZEN_MATH=auto, opt-in since round 5 — the default is bf16x3
+everywhere: f16x2 under a range guard, bf16x3 otherwise — slu_hip/guard.py) must have fp32's DOMAIN, like the reference's plain fp32 ATen kernels (models.py:108, :200, :232):
 whatever the scale of the waveforms or of the checkpoint, the encoder's output stays within the parity bound of the CPU
 ORACLE (not merely of the package's own exact kernels), through every entry point that evaluates frozen stages —
 compute_features / predict_intents (eager, guarded), the look-ahead training loop (guard read when a slot is consumed)."""
@@ -48,12 +48,12 @@ def _model(tmp_path, cfg, scale_weights=None):
 @pytest.mark.parametrize("amp", [1e-6, 1e-5, 1e-3, 0.1, 30.0, 1e3, 32768.0])
 def test_default_arithmetic_over_the_input_dynamic_range_vs_oracle(tmp_path, monkeypatch, amp):
     """Waveform amplitudes from 1e-6 (every sample far below fp16's smallest normal) to 32768 (un-normalised int16
-    audio: the Sinc layer's output reaches 1e6, beyond fp16): encoder features in the DEFAULT mode against the CPU
+    audio: the Sinc layer's output reaches 1e6, beyond fp16): encoder features in the GUARDED mode (SLU_FROZEN_MATH=auto) against the CPU
     oracle, eval mode, full-size architecture, 8 x 1 s.  Which arithmetic ran is asserted too: f16x2 for ordinary audio,
     bf16x3 after a quiet-input trip (no pin) or an overflow trip (pinned) — and SLU_FROZEN_MATH=f16x2, the UNGUARDED form,
     does break at 32768, which is what the guard is for."""
     import models
-    monkeypatch.delenv("SLU_FROZEN_MATH", raising=False)
+    monkeypatch.setenv("SLU_FROZEN_MATH", "auto")
     cfg = _cfg(tmp_path)
     model, pre = _model(tmp_path, cfg)
     model.eval()
@@ -115,7 +115,7 @@ def _assert_as_close_as_exact_fp32(monkeypatch, pm, x, ref, got, slack=0.002):
     monkeypatch.setenv("SLU_FROZEN_MATH", "bf16x3")
     with torch.no_grad():
         b3 = pm.compute_features(x).float().cpu()
-    monkeypatch.delenv("SLU_FROZEN_MATH")
+    monkeypatch.setenv("SLU_FROZEN_MATH", "auto")
     frac = lambda a: ((a - ref).abs() > TOL).float().mean().item()
     print("   fraction of features further than 1e-4 from the oracle: default %.4f, exact fp32 kernels %.4f" % (frac(got), frac(exact)))
     assert not switched or torch.equal(b3, got)
@@ -136,7 +136,7 @@ def test_default_arithmetic_with_a_scaled_checkpoint_vs_oracle(tmp_path, monkeyp
         kernels, and agreement with the explicit bf16x3 mode bit for bit (the guard switched)."""
     import models
     from slu_hip import guard as G
-    monkeypatch.delenv("SLU_FROZEN_MATH", raising=False)
+    monkeypatch.setenv("SLU_FROZEN_MATH", "auto")
     cfg = _cfg(tmp_path)
     if case == "conv1_x1e5_conv2_x1e-5":
         model, pre = _model(tmp_path, cfg)
@@ -193,7 +193,7 @@ def test_lookahead_loop_reads_the_guard_before_it_uses_a_super_batch(tmp_path, m
         monkeypatch.setenv("SLU_LOOKAHEAD", lookahead)
         monkeypatch.setenv("SLU_GRAPHS", graphs)
         if math is None:
-            monkeypatch.delenv("SLU_FROZEN_MATH", raising=False)
+            monkeypatch.setenv("SLU_FROZEN_MATH", "auto")
         else:
             monkeypatch.setenv("SLU_FROZEN_MATH", math)
         model, _ = _model(tmp_path, cfg)

@@ -40,14 +40,20 @@ def test_lookahead_width_rules(monkeypatch):
 
 def test_arithmetic_mode_switches(monkeypatch):
     """SLU_FROZEN_MATH / SLU_TRAIN_MATH / SLU_DTYPE -> the split scheme of each class of contraction (csrc/slu_bf16.h):
-    frozen stages default to "auto" — f16x2 (2) ONLY inside a guarded evaluation (slu_hip/guard.py), bf16x3 (3: fp32's
-    range) wherever no guard is active —, trainable GEMMs to exact fp32 (0); bf16 mode (BASELINE configs[4]) overrides
-    both; unknown values are rejected instead of silently running another arithmetic."""
+    frozen stages default to bf16x3 (3: fp32's 24 significand bits and exponent range — as wide as the reference's fp32
+    kernels); "auto" is the OPT-IN guarded mode — f16x2 (2) ONLY inside a guarded evaluation (slu_hip/guard.py), bf16x3
+    wherever no guard is active —, trainable GEMMs exact fp32 (0); bf16 mode (BASELINE configs[4]) overrides both;
+    unknown values are rejected instead of silently running another arithmetic."""
     import pytest
     import models
     from slu_hip import ops
     for k in ("SLU_FROZEN_MATH", "SLU_TRAIN_MATH", "SLU_DTYPE"):
         monkeypatch.delenv(k, raising=False)
+    assert models.frozen_math_mode() == "bf16x3"               # the default is reference-width
+    assert models.contraction_nsplit(True) == 3 and models.guarded_frozen_nsplit() == 3
+    with models.frozen_math_scope(object()):                   # a guard scope changes nothing outside the "auto" mode
+        assert models.contraction_nsplit(True) == 3
+    monkeypatch.setenv("SLU_FROZEN_MATH", "auto")
     assert models.frozen_math_mode() == "auto"
     assert models.contraction_nsplit(True) == 3 and models.contraction_nsplit(False) == 0      # no guard: fp32's range
     with models.frozen_math_scope(object()):                                                   # a guard is watching
