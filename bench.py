@@ -785,7 +785,6 @@ def self_launch(args):
             raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (--share-gpu runs all ranks on the "
                              "visible GPUs over gloo: a functional check of the multi-process path, not a measurement)"
                              % (n, visible))
-        env["SLU_DIST_BACKEND"] = "gloo"
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -814,26 +813,50 @@ def self_launch(args):
     sys.exit(rc)
 
 
+def _time_collective(call, stream, reps=50):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            call()
+        e0.record(stream)
+        for _ in range(reps):
+            call()
+        e1.record(stream)
+    e1.synchronize()
+    return round(1e3 * e0.elapsed_time(e1) / reps, 2)
+
+
 def dp_point(model, trainer, batches, steps, asr, fence):
     """Data parallel runs, EVERY rank (collectives inside): (1) the step's gradient all-reduce alone — the flat bucket(s),
-    50 back-to-back calls on the training stream between two HIP events; (2) the timed loop once more with the collective
-    stubbed out (each rank applies its local gradients: the replicas diverge, nothing is measured after this) — the
-    difference to the headline's ms_per_step is what the collective costs INSIDE the loop."""
+    50 back-to-back calls on the training stream between two HIP events — through the communicator the loop used AND
+    through the other data plane (hand-written IPC all-reduce / RCCL via the C ABI), so that one line carries both;
+    (2) the timed loop once more with the collective stubbed out (each rank applies its local gradients: the replicas
+    diverge, nothing is measured after this) — the difference to the headline's ms_per_step is what the collective costs
+    INSIDE the loop."""
+    from slu_hip import dp
     b = trainer.bucket
     stream = getattr(trainer, "_train_stream", None) or getattr(trainer, "_full_stream", None) or torch.cuda.current_stream()
     for f in b.flats.values():
         f.zero_()                                    # repeated in-place sums of real gradients would overflow
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(stream):
-        for _ in range(5):
-            b.allreduce_flats()
-        e0.record(stream)
-        for _ in range(50):
-            b.allreduce_flats()
-        e1.record(stream)
-    e1.synchronize()
-    out = {"allreduce_us_alone": round(1e3 * e0.elapsed_time(e1) / 50, 2), "allreduce_bytes": b.nbytes(),
-           "collectives_per_step": len(b.flats)}
+    used = getattr(b.comm, "kind", "torch.distributed (%s)" % torch.distributed.get_backend())
+    out = {"data_plane": used, "allreduce_us_alone": _time_collective(b.allreduce_flats, stream),
+           "allreduce_bytes": b.nbytes(), "collectives_per_step": 1 if b.comm is not None else len(b.flats)}
+    alone = {used: out["allreduce_us_alone"]}
+    dev = next(model.parameters()).device
+    rank, world = dp.world()
+    others = [("ipc", dp.IpcComm)] + ([] if dp._shared_device() else [("rccl", dp.DirectComm)])
+    for kind, ctor in others:
+        if kind == used or b.comm is None and os.environ.get("SLU_COMM") == "torch" and False:
+            continue
+        try:                                          # construction is collective: every rank walks this list in order
+            other = ctor(rank, world, dev)
+            alone[kind] = _time_collective(lambda: other.allreduce_flats(b.flats), stream)
+            if kind == "ipc" and other.status() != 0:
+                alone[kind] = "timed out"
+            other.close()
+        except Exception as e:                        # noqa: BLE001 - a side measurement never takes the headline down
+            alone[kind] = "unavailable: %s" % str(e)[:120]
+    out["allreduce_us_alone_by_data_plane"] = alone
     b.stub = True
     trainer._step_graphs.clear()
     try:
@@ -846,21 +869,34 @@ def dp_point(model, trainer, batches, steps, asr, fence):
     finally:
         b.stub = False
         trainer._step_graphs.clear()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=next(model.parameters()).device)
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    if torch.distributed.get_backend() == "nccl":
+        tmax = tmax.to(dev)
     torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     out["ms_per_step_without_collective"] = round(1e3 * tmax.item() / steps, 4)
     return out
 
 
-def rccl_info(world):
+def rccl_info(world, trainer):
+    """How the ranks talk: control plane (torch.distributed backend) and data plane (the gradient collective)."""
     if not torch.distributed.is_initialized():
         return None
     import torch.distributed as dist
+    from slu_hip import lib
     backend = dist.get_backend()
-    info = {"ranks": world, "backend": backend + (" (= RCCL on ROCm)" if backend == "nccl" else ""),
-            "algo": os.environ.get("NCCL_ALGO", "default"), "proto": os.environ.get("NCCL_PROTO", "default")}
+    comm = trainer.bucket.comm if trainer.bucket is not None else None
+    kind = getattr(comm, "kind", None)
+    info = {"ranks": world,
+            "control_plane": "torch.distributed backend %s%s" % (backend, " (= RCCL on ROCm)" if backend == "nccl" else ""),
+            "data_plane": {"ipc": "slu_comm_allreduce_ipc: hand-written two-shot all-reduce over peer-mapped windows (xGMI)",
+                           "rccl": "RCCL through the C ABI (slu_comm_allreduce_group) on the training stream",
+                           None: "torch.distributed's collective on the flat buckets (%s)" % backend}[kind],
+            "backend": backend, "algo": os.environ.get("NCCL_ALGO", "default"), "proto": os.environ.get("NCCL_PROTO", "default")}
+    if getattr(comm, "selftest_us", None) is not None:
+        info["ipc_selftest_us_per_call"] = round(comm.selftest_us, 2)
     try:
-        info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        v = lib.load().slu_comm_version()
+        info["version"] = "RCCL %d.%d.%d" % (v // 10000, v // 100 % 100, v % 100) if v else "no RCCL mapped"
     except Exception as e:
         info["version"] = "unknown (%s)" % (e,)
     return info
@@ -951,8 +987,10 @@ def main():
     elapsed = time.perf_counter() - t0
     fill_ms = ev0.elapsed_time(ev_first)
     note("timed region done: %.3f s" % elapsed)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64)          # control plane: a host tensor over gloo
     if world > 1:
+        if torch.distributed.get_backend() == "nccl":
+            tmax = tmax.to(dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed = tmax.item()
     loss_mean = (sums[0] / (args.steps * args.batch)).item()
@@ -964,6 +1002,11 @@ def main():
             dp_costs = dp_point(model, trainer, batches, args.steps, asr, fence)
         except Exception as e:                                   # a side measurement never takes the headline down
             dp_costs = {"error": str(e)[:200]}
+
+    comm_info = rccl_info(world, trainer) if trainer.data_parallel else None
+    graphs_dp = trainer.graph_stats() if trainer.data_parallel else {}
+    if world > 1:
+        trainer.close()                      # collective (the IPC windows are unmapped behind a barrier): every rank, now
 
     # steady state of the same loop (long run), reported beside `value` when K is short: the first
     # super-batch of a run has to be computed before its first step can start (pipeline fill)
@@ -1004,13 +1047,13 @@ def main():
         if steady:
             out["steady_state"] = steady
         if trainer.data_parallel:
-            out["rccl"] = rccl_info(world)
+            out["rccl"] = comm_info
             if dp_costs:
                 # per step: where the all-reduce sits, what it costs alone and what the loop costs without it
                 out["rccl"].update(dp_costs)
-                out["rccl"]["collective"] = graphs.get("collective")
-            if os.environ.get("SLU_DIST_BACKEND") == "gloo":
-                out["config"]["parallelism"] += " (ranks share the visible GPU(s) over gloo: functional check only)"
+            out["rccl"]["collective"] = graphs.get("collective")
+            if "SLU_LOCAL_DEVICE" in os.environ:
+                out["config"]["parallelism"] += " (ranks share the visible GPU(s): functional check only)"
         if world == 1 and not args.no_kernel_table:
             note("kernel table")
             table = kernel_table(model, trainer, args.batch, samples, width, asr)

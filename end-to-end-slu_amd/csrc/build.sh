@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${SLU_EXTRA_FLAGS:-}"
 JOBS="${SLU_BUILD_JOBS:-$(( $(nproc) < 16 ? $(nproc) : 16 ))}"
-UNITS="slu_api slu_sinc slu_wconv slu_wconv_bf16 slu_gemm slu_gemm_bf16 slu_gru slu_gru_step slu_gru_bf16 slu_gru_proj slu_pool slu_head slu_optim slu_framece slu_comm slu_seq2seq"
+UNITS="slu_api slu_sinc slu_wconv slu_wconv_bf16 slu_gemm slu_gemm_bf16 slu_gru slu_gru_step slu_gru_bf16 slu_gru_proj slu_pool slu_head slu_optim slu_framece slu_comm slu_comm_ipc slu_seq2seq"
 OBJS=()
 STALE=()
 for f in $UNITS; do

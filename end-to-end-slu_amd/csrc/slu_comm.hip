@@ -20,6 +20,7 @@ typedef int (*CommInitRankFn)(NcclComm*, int, NcclId, int);
 typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*AllReduceFn)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
 typedef const char* (*GetErrorStringFn)(int);
+typedef int (*GroupFn)(void);
 
 struct Rccl {
   void* handle = nullptr;
@@ -29,6 +30,7 @@ struct Rccl {
   CommDestroyFn comm_destroy = nullptr;
   AllReduceFn all_reduce = nullptr;
   GetErrorStringFn error_string = nullptr;
+  GroupFn group_start = nullptr, group_end = nullptr;
 };
 
 static Rccl* rccl() {
@@ -51,6 +53,8 @@ static Rccl* rccl() {
   r.comm_destroy = (CommDestroyFn)dlsym(r.handle, "ncclCommDestroy");
   r.all_reduce = (AllReduceFn)dlsym(r.handle, "ncclAllReduce");
   r.error_string = (GetErrorStringFn)dlsym(r.handle, "ncclGetErrorString");
+  r.group_start = (GroupFn)dlsym(r.handle, "ncclGroupStart");
+  r.group_end = (GroupFn)dlsym(r.handle, "ncclGroupEnd");
   if (!r.get_version || !r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce) r.handle = nullptr;
   return r.handle ? &r : nullptr;
 }
@@ -109,6 +113,26 @@ extern "C" int slu_comm_allreduce_f32(void* comm, float* buf, int64_t count, voi
 
 extern "C" int slu_comm_allreduce_f64(void* comm, double* buf, int64_t count, void* stream) {
   return comm_allreduce(comm, buf, count, /*ncclFloat64*/ 8, stream, "slu_comm_allreduce_f64");
+}
+
+// Both gradient buckets of a step (fp32 + the Sinc layer's 160 float64 values) as ONE grouped RCCL operation: one
+// launch on the stream instead of two dependent collectives.  Either bucket may be absent (count 0).
+extern "C" int slu_comm_allreduce_group(void* comm, float* f32, int64_t n32, double* f64, int64_t n64, void* stream) {
+  SLU_REQUIRE(comm && n32 >= 0 && n64 >= 0 && n32 + n64 > 0 && (n32 == 0 || f32) && (n64 == 0 || f64),
+              "slu_comm_allreduce_group: bad argument");
+  Rccl* R = rccl();
+  if (!R) SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_comm_allreduce_group: no RCCL library in this process");
+  const bool group = n32 > 0 && n64 > 0 && R->group_start && R->group_end;
+  if (group) SLU_RCCL(R->group_start(), "ncclGroupStart");
+  int rc = 0;
+  if (n32 > 0) rc = R->all_reduce(f32, f32, (size_t)n32, /*ncclFloat32*/ 7, /*ncclSum*/ 0, (NcclComm)comm, (hipStream_t)stream);
+  if (rc == 0 && n64 > 0) rc = R->all_reduce(f64, f64, (size_t)n64, /*ncclFloat64*/ 8, 0, (NcclComm)comm, (hipStream_t)stream);
+  if (group) {
+    const int rc_end = R->group_end();
+    if (rc == 0) rc = rc_end;
+  }
+  SLU_RCCL(rc, "slu_comm_allreduce_group");
+  return SLU_OK;
 }
 
 extern "C" int slu_comm_destroy(void* comm) {

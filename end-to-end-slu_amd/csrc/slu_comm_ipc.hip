@@ -1,0 +1,271 @@
+// slu_comm_ipc_*: the data-parallel step's gradient all-reduce as ONE hand-written kernel over peer-mapped device
+// memory — the xGMI-native shape SURVEY §5 / §8(e) names — instead of a library collective.  The reference has no
+// distributed code at all: new design.
+//
+// Why: the payload is 1.2 MB (frozen encoder) … 5.5 MB (everything trainable) per 0.15–2.7 ms step, i.e. the
+// collective is LATENCY-bound.  xGMI is point to point (7 links per GPU), so a two-shot all-reduce can use all links at
+// once with two flag hand-offs, where a ring pays 2 (N − 1) hops:
+//   window of rank r (fine-grained device memory, exported with hipIpcGetMemHandle, mapped by every peer):
+//       [flags 4 KiB | `in` staging (cap bytes) | `out` staging (cap bytes)]
+//   1. every rank copies its bucket into its own `in` (local), releases at system scope, raises flag_in[r] on every peer;
+//   2. waits for all peers' flag_in; rank r then OWNS chunk r: it reads chunk r of every rank's `in` over the links
+//      (N − 1 remote reads of payload / N each, all links busy at once), adds them IN RANK ORDER 0 … N−1 (one rank
+//      computes each element, so the replicas receive bit-identical sums) and WRITES the sum into chunk r of every
+//      rank's `out` (N − 1 remote writes); releases; raises flag_out[r] on every peer;
+//   3. waits for all peers' flag_out, copies its own `out` back into the bucket (local).
+// The fp32 bucket and the 160-element float64 bucket of the Sinc parameters travel as TYPED SEGMENTS of the same
+// payload: one launch, one collective per step whatever the trainable set.
+// Flags hold a monotonically increasing epoch (never reset), the epoch counter lives in device memory: the launch has
+// no per-call host argument and replays as a node of the step's hipGraph.  Every wait is bounded: a peer that never
+// arrives raises the window's status word instead of hanging the GPU (slu_comm_ipc_status).
+// A rank's `in` may be overwritten by its next call only after every peer has read it: a peer raises flag_out AFTER
+// its reads, and a rank leaves step 3 only after it has seen every peer's flag_out.  A rank's `out` is written by the
+// peers of call k + 1 only after they saw its flag_in of call k + 1, which it raises after finishing call k.
+#include "slu_common.h"
+#include <string.h>
+
+namespace slu {
+
+constexpr int IPC_MAX_RANKS = 8;
+constexpr long long IPC_FLAG_BYTES = 4096;
+constexpr int IPC_WGS = 32;                 // all resident at once on any partition of this package (>= 16 CUs)
+constexpr unsigned IPC_SPIN_LIMIT = 1u << 21;   // polls of ~1 us: a peer that is two seconds late is not coming
+
+// window-relative offsets of the control words (each on a 64-byte line of its own)
+//   flag_in[src]  at 64 * src            flag_out[src] at 64 * (8 + src)
+//   epoch         at 64 * 16             arrive[0..2]  at 64 * (17 + k)           status at 64 * 20
+__device__ __forceinline__ unsigned long long* ipc_word(unsigned char* win, int line) {
+  return reinterpret_cast<unsigned long long*>(win + 64 * line);
+}
+
+struct IpcArgs {
+  unsigned char* win[IPC_MAX_RANKS];        // every rank's window in THIS process' address space; win[rank] = own
+  int rank, nranks;
+  long long cap;                            // capacity of each staging area (bytes, multiple of 256)
+  float* f32; long long n32;                // the fp32 bucket (reduced in place)
+  double* f64; long long n64;               // the float64 bucket or null
+};
+
+// wait until flag word `line + src` of the own window has reached `epoch`, for every peer src (threads 0 .. nranks-1 poll
+// one peer each), then acquire at system scope.  Returns with the whole workgroup synchronised.
+__device__ __forceinline__ void ipc_wait_all(const IpcArgs& a, int line, unsigned long long epoch) {
+  unsigned char* own = a.win[a.rank];
+  if ((int)threadIdx.x < a.nranks && (int)threadIdx.x != a.rank) {
+    unsigned long long* f = ipc_word(own, line + (int)threadIdx.x);
+    unsigned spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > IPC_SPIN_LIMIT) {
+        __hip_atomic_store(ipc_word(own, 20), 1ull + (unsigned long long)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: peers' writes behind their flags are visible now
+  __syncthreads();
+}
+
+// every wave has drained its stores; the workgroup's lane 0 releases at system scope and arrives on `arrive_line`; the
+// LAST workgroup of the launch raises flag `flag_line + rank` (= epoch) on every peer's window.
+__device__ __forceinline__ void ipc_publish(const IpcArgs& a, int arrive_line, int flag_line, unsigned long long epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* cnt = ipc_word(a.win[a.rank], arrive_line);
+    const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned long long)gridDim.x - 1) {
+      __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = 0; q < a.nranks; ++q)
+        if (q != a.rank)
+          __hip_atomic_store(ipc_word(a.win[q], flag_line + a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+allreduce_ipc_kernel(const IpcArgs a) {
+  unsigned char* own = a.win[a.rank];
+  const unsigned long long epoch =
+      __hip_atomic_load(ipc_word(own, 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+  const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nthr = (long long)gridDim.x * 256;
+  const long long u32 = (a.n32 + 3) / 4;                   // 16-byte units of the fp32 segment (tail padded with zeros)
+  const long long u64 = (a.n64 + 1) / 2;                   // 16-byte units of the float64 segment
+
+  // ---- 1. bucket -> own `in` ----
+  {
+    float4* in = reinterpret_cast<float4*>(own + IPC_FLAG_BYTES);
+    for (long long u = tid; u < u32; u += nthr) {
+      float4 v;
+      if (4 * u + 3 < a.n32) v = reinterpret_cast<const float4*>(a.f32)[u];
+      else {
+        v.x = 4 * u + 0 < a.n32 ? a.f32[4 * u + 0] : 0.f; v.y = 4 * u + 1 < a.n32 ? a.f32[4 * u + 1] : 0.f;
+        v.z = 4 * u + 2 < a.n32 ? a.f32[4 * u + 2] : 0.f; v.w = 0.f;
+      }
+      in[u] = v;
+    }
+    double2* in64 = reinterpret_cast<double2*>(own + IPC_FLAG_BYTES + 16 * u32);
+    for (long long u = tid; u < u64; u += nthr) {
+      double2 v;
+      v.x = a.f64[2 * u]; v.y = 2 * u + 1 < a.n64 ? a.f64[2 * u + 1] : 0.0;
+      in64[u] = v;
+    }
+  }
+  ipc_publish(a, 17, 0, epoch);
+  ipc_wait_all(a, 0, epoch);
+
+  // ---- 2. reduce this rank's chunk over all ranks (rank order), push the sum into every rank's `out` ----
+  {
+    const long long c0 = u32 * a.rank / a.nranks, c1 = u32 * (a.rank + 1) / a.nranks;
+    for (long long u = c0 + tid; u < c1; u += nthr) {
+      float4 v[IPC_MAX_RANKS];
+#pragma unroll
+      for (int q = 0; q < IPC_MAX_RANKS; ++q)
+        if (q < a.nranks) v[q] = reinterpret_cast<const float4*>(a.win[q] + IPC_FLAG_BYTES)[u];
+      float4 s = v[0];
+#pragma unroll
+      for (int q = 1; q < IPC_MAX_RANKS; ++q)
+        if (q < a.nranks) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
+#pragma unroll
+      for (int q = 0; q < IPC_MAX_RANKS; ++q)
+        if (q < a.nranks) reinterpret_cast<float4*>(a.win[q] + IPC_FLAG_BYTES + a.cap)[u] = s;
+    }
+    // the float64 segment (160 values when the Sinc layer trains) is rank 0's
+    if (a.rank == 0) {
+      for (long long u = tid; u < u64; u += nthr) {
+        double2 s = reinterpret_cast<const double2*>(a.win[0] + IPC_FLAG_BYTES + 16 * u32)[u];
+        for (int q = 1; q < a.nranks; ++q) {
+          const double2 v = reinterpret_cast<const double2*>(a.win[q] + IPC_FLAG_BYTES + 16 * u32)[u];
+          s.x += v.x; s.y += v.y;
+        }
+        for (int q = 0; q < a.nranks; ++q)
+          reinterpret_cast<double2*>(a.win[q] + IPC_FLAG_BYTES + a.cap + 16 * u32)[u] = s;
+      }
+    }
+  }
+  ipc_publish(a, 18, 8, epoch);
+  ipc_wait_all(a, 8, epoch);
+
+  // ---- 3. own `out` -> bucket ----
+  {
+    const float4* out = reinterpret_cast<const float4*>(own + IPC_FLAG_BYTES + a.cap);
+    for (long long u = tid; u < u32; u += nthr) {
+      const float4 v = out[u];
+      if (4 * u + 3 < a.n32) reinterpret_cast<float4*>(a.f32)[u] = v;
+      else {
+        if (4 * u + 0 < a.n32) a.f32[4 * u + 0] = v.x;
+        if (4 * u + 1 < a.n32) a.f32[4 * u + 1] = v.y;
+        if (4 * u + 2 < a.n32) a.f32[4 * u + 2] = v.z;
+      }
+    }
+    const double2* out64 = reinterpret_cast<const double2*>(own + IPC_FLAG_BYTES + a.cap + 16 * u32);
+    for (long long u = tid; u < u64; u += nthr) {
+      const double2 v = out64[u];
+      a.f64[2 * u] = v.x;
+      if (2 * u + 1 < a.n64) a.f64[2 * u + 1] = v.y;
+    }
+  }
+  // the launch's last workgroup advances the epoch (every workgroup has read it by now)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* cnt = ipc_word(own, 19);
+    const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned long long)gridDim.x - 1) {
+      __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ipc_word(own, 16), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace slu
+
+using namespace slu;
+
+extern "C" int64_t slu_comm_ipc_window_bytes(int64_t payload_bytes) {
+  if (payload_bytes < 0) return 0;
+  const long long cap = (payload_bytes + 32 + 255) / 256 * 256;      // + one padded 16-byte unit per typed segment
+  return IPC_FLAG_BYTES + 2 * cap;
+}
+
+extern "C" int slu_comm_ipc_window_create(int64_t window_bytes, int64_t fine_grained, void** window_out, void* handle64) {
+  SLU_REQUIRE(window_out && handle64 && window_bytes > IPC_FLAG_BYTES && (window_bytes - IPC_FLAG_BYTES) % 512 == 0,
+              "slu_comm_ipc_window_create: bad argument (size from slu_comm_ipc_window_bytes)");
+  void* p = nullptr;
+  hipError_t e = fine_grained ? hipExtMallocWithFlags(&p, (size_t)window_bytes, hipDeviceMallocFinegrained)
+                              : hipMalloc(&p, (size_t)window_bytes);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_comm_ipc_window_create: allocation of %lld bytes: %s", (long long)window_bytes, hipGetErrorString(e));
+  e = hipMemset(p, 0, (size_t)window_bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    SLU_FAIL(SLU_ERR_HIP, "slu_comm_ipc_window_create: %s", hipGetErrorString(e));
+  }
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  memcpy(handle64, &h, 64);
+  *window_out = p;
+  return SLU_OK;
+}
+
+extern "C" int slu_comm_ipc_window_open(const void* handle64, void** window_out) {
+  SLU_REQUIRE(handle64 && window_out, "slu_comm_ipc_window_open: null pointer");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+  *window_out = p;
+  return SLU_OK;
+}
+
+extern "C" int slu_comm_ipc_window_close(void* peer_window) {
+  if (!peer_window) return SLU_OK;
+  const hipError_t e = hipIpcCloseMemHandle(peer_window);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "hipIpcCloseMemHandle: %s", hipGetErrorString(e));
+  return SLU_OK;
+}
+
+extern "C" int slu_comm_ipc_window_destroy(void* own_window) {
+  if (!own_window) return SLU_OK;
+  const hipError_t e = hipFree(own_window);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "hipFree: %s", hipGetErrorString(e));
+  return SLU_OK;
+}
+
+extern "C" int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes,
+                                      float* f32, int64_t n32, double* f64, int64_t n64, void* stream) {
+  SLU_REQUIRE(windows && nranks >= 1 && nranks <= IPC_MAX_RANKS && rank >= 0 && rank < nranks,
+              "slu_comm_allreduce_ipc: 1..%d ranks", IPC_MAX_RANKS);
+  SLU_REQUIRE(n32 >= 0 && n64 >= 0 && n32 + n64 > 0 && (n32 == 0 || f32) && (n64 == 0 || f64),
+              "slu_comm_allreduce_ipc: empty payload or null bucket");
+  SLU_REQUIRE(((uintptr_t)f32 & 15) == 0 && ((uintptr_t)f64 & 15) == 0, "slu_comm_allreduce_ipc: buckets must be 16-byte aligned");
+  IpcArgs a;
+  a.cap = (window_bytes - IPC_FLAG_BYTES) / 2;
+  SLU_REQUIRE(window_bytes > IPC_FLAG_BYTES && 16 * ((n32 + 3) / 4) + 16 * ((n64 + 1) / 2) <= a.cap,
+              "slu_comm_allreduce_ipc: payload of %lld + %lld elements exceeds the window's staging capacity (%lld bytes)",
+              (long long)n32, (long long)n64, (long long)a.cap);
+  for (int q = 0; q < IPC_MAX_RANKS; ++q) {
+    a.win[q] = q < nranks ? (unsigned char*)windows[q] : nullptr;
+    SLU_REQUIRE(q >= nranks || a.win[q], "slu_comm_allreduce_ipc: window of rank %d is null", q);
+  }
+  a.rank = (int)rank; a.nranks = (int)nranks;
+  a.f32 = f32; a.n32 = n32; a.f64 = f64; a.n64 = n64;
+  hipLaunchKernelGGL(allreduce_ipc_kernel, dim3(IPC_WGS), dim3(256), 0, (hipStream_t)stream, a);
+  SLU_CHECK_LAUNCH("allreduce_ipc_kernel");
+  return SLU_OK;
+}
+
+// status word of the own window: 0 = every wait of every call so far was answered; 1 + q = a wait for rank q timed out
+// (the results of that call are garbage, the ranks are out of step).  Synchronises the device.
+extern "C" int slu_comm_ipc_status(void* own_window, int64_t* status_out) {
+  SLU_REQUIRE(own_window && status_out, "slu_comm_ipc_status: null pointer");
+  unsigned long long v = 0;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(&v, (unsigned char*)own_window + 64 * 20, 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_comm_ipc_status: %s", hipGetErrorString(e));
+  *status_out = (int64_t)v;
+  return SLU_OK;
+}

@@ -1,12 +1,21 @@
-"""Data parallelism for the training loop: one process per GPU, gradients averaged with ONE RCCL
-all-reduce per step over a flat bucket (torch.distributed backend "nccl" is RCCL on ROCm; xGMI
-between the 8 GPUs of a node).  The reference has no distributed code at all — this is new design
-(SURVEY.md §8e).
+"""Data parallelism for the training loop: one process per GPU, gradients averaged with ONE collective per step over
+flat buckets.  The reference has no distributed code at all — this is new design.
 
-Per step the payload is small (1.2 MB with a frozen encoder, 5.5 MB fully unfrozen), i.e. the
-collective is latency-bound: a single collective over one contiguous buffer is the shape that
-matters, not bandwidth tuning.  The bucket is rebuilt when the set of parameters that receive
-gradients changes (the gradual-unfreezing schedule changes it once per epoch).
+Per step the payload is small (1.2 MB with a frozen encoder, 5.5 MB fully unfrozen), i.e. the collective is
+latency-bound: a single operation over one contiguous buffer, issued from the training stream as a node of the step's
+hipGraph, is the shape that matters, not bandwidth tuning.  The bucket is rebuilt when the set of parameters that
+receive gradients changes (the gradual-unfreezing schedule changes it once per epoch).
+
+Round 5: CONTROL PLANE AND DATA PLANE ARE SEPARATE.  torch.distributed is initialised with the **gloo** backend and
+carries only host-side traffic (the RCCL unique id / IPC handles at start-up, epoch-metric sums, barriers, the
+agreement flags of the self-tests).  Every gradient collective goes through the C ABI on the training stream:
+  * `IpcComm`   — slu_comm_allreduce_ipc: the hand-written two-shot all-reduce over peer-mapped windows (xGMI point to
+                  point, all links at once; csrc/slu_comm_ipc.hip), fp32 + float64 buckets as typed segments of one launch;
+  * `DirectComm` — RCCL driven directly (slu_comm_allreduce_group: both buckets in one ncclGroup), the fallback.
+No ProcessGroupNCCL exists in the process, hence no NCCL watchdog thread — the thread that aborted processes in round 4
+when collectives were captured — and the all-reduce is a NODE OF THE STEP'S hipGraph by default (SLU_DP_GRAPH=0 turns
+that off).  SLU_DIST_BACKEND=nccl restores torch's own backend (collectives then stay eager between two graphs unless
+SLU_DP_GRAPH=1 insists).  SLU_COMM = auto | ipc | rccl | torch selects the data plane (make_comm).
 """
 import os
 
@@ -45,7 +54,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = os.environ.get("SLU_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # gloo: the CONTROL plane only (module docstring); the gradient collectives run on the C ABI's communicators
+            backend = os.environ.get("SLU_DIST_BACKEND") or "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=ws, device_id=torch.device("cuda", local))
@@ -69,17 +79,26 @@ class DirectComm:
             _lib.check(self._L.slu_comm_unique_id(buf), "slu_comm_unique_id")
         if world_size > 1:
             box = [bytes(buf)]
-            dist.broadcast_object_list(box, src=0)
+            dist.broadcast_object_list(box, src=0)          # host bytes: any backend (gloo is the control plane)
             buf = (ctypes.c_char * 128).from_buffer_copy(box[0])
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(device):
             _lib.check(self._L.slu_comm_init(ctypes.byref(self._handle), buf, world_size, rank), "slu_comm_init")
         self.world_size = world_size
 
+    kind = "rccl"
+
     def allreduce(self, flat):
         fn = {torch.float32: self._L.slu_comm_allreduce_f32, torch.float64: self._L.slu_comm_allreduce_f64}[flat.dtype]
         self._lib.check(fn(self._handle, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream),
                         "slu_comm_allreduce")
+
+    def allreduce_flats(self, flats):
+        """Every gradient bucket of the step ({dtype: flat}) as ONE grouped RCCL operation."""
+        f32, f64 = _typed_flats(flats)
+        self._lib.check(self._L.slu_comm_allreduce_group(self._handle, _ptr_or_none(f32), 0 if f32 is None else f32.numel(),
+                                                         _ptr_or_none(f64), 0 if f64 is None else f64.numel(),
+                                                         torch.cuda.current_stream().cuda_stream), "slu_comm_allreduce_group")
 
     def close(self):
         if getattr(self, "_handle", None):
@@ -92,6 +111,199 @@ class DirectComm:
             self.close()
         except Exception:                         # interpreter shutdown: the runtime may be gone already
             pass
+
+
+def _flag_device(device):
+    """Where a control-plane flag lives: the host, unless torch.distributed itself runs on RCCL."""
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _ptr_or_none(t):
+    return None if t is None else t.data_ptr()
+
+
+def _typed_flats(flats):
+    """{dtype: flat} -> (fp32 flat or None, float64 flat or None); any other gradient dtype is refused."""
+    extra = [d for d in flats if d not in (torch.float32, torch.float64)]
+    if extra:
+        raise TypeError("gradient buckets of dtype %s: the communicators reduce float32 and float64" % extra)
+    return flats.get(torch.float32), flats.get(torch.float64)
+
+
+class IpcComm:
+    """The hand-written all-reduce over peer-mapped windows (slu_comm_ipc_* of include/slu_hip.h, protocol in
+    csrc/slu_comm_ipc.hip): every rank owns a window of fine-grained device memory, exports it with a 64-byte IPC handle
+    (exchanged over the gloo control plane) and maps every peer's.  One launch per step on the CURRENT stream reduces the
+    fp32 and the float64 bucket (typed segments), with no host argument per call — a plain kernel node under capture.
+    Works between the GPUs of a node (xGMI) and between processes that share one GPU (same-device IPC: how the one-GPU
+    boxes of this environment test it)."""
+    kind = "ipc"
+
+    def __init__(self, rank, world_size, device, payload_bytes=None):
+        import ctypes
+        from . import lib as _lib
+        self._lib, self._L = _lib, _lib.load()
+        if payload_bytes is None:
+            payload_bytes = int(os.environ.get("SLU_IPC_PAYLOAD_MB", "8")) << 20      # everything trainable: 5.5 MB
+        self.rank, self.world_size, self.device = rank, world_size, device
+        self.window_bytes = int(self._L.slu_comm_ipc_window_bytes(payload_bytes))
+        fine = 0 if os.environ.get("SLU_IPC_COARSE", "0") == "1" else 1
+        own, handle = ctypes.c_void_p(), (ctypes.c_char * 64)()
+        with torch.cuda.device(device):
+            _lib.check(self._L.slu_comm_ipc_window_create(self.window_bytes, fine, ctypes.byref(own), handle),
+                       "slu_comm_ipc_window_create")
+        self._own = own
+        self._peers = {}
+        handles = [bytes(handle)]
+        if world_size > 1:
+            handles = [None] * world_size
+            dist.all_gather_object(handles, bytes(handle))
+        self._windows = (ctypes.c_void_p * world_size)()
+        with torch.cuda.device(device):
+            for q in range(world_size):
+                if q == rank:
+                    self._windows[q] = own.value
+                else:
+                    w = ctypes.c_void_p()
+                    _lib.check(self._L.slu_comm_ipc_window_open((ctypes.c_char * 64).from_buffer_copy(handles[q]),
+                                                                ctypes.byref(w)), "slu_comm_ipc_window_open")
+                    self._peers[q] = w
+                    self._windows[q] = w.value
+        if world_size > 1:
+            dist.barrier()                       # every window is mapped everywhere before the first launch
+
+    def _launch(self, f32, f64):
+        self._lib.check(self._L.slu_comm_allreduce_ipc(self._windows, self.rank, self.world_size, self.window_bytes,
+                                                       _ptr_or_none(f32), 0 if f32 is None else f32.numel(),
+                                                       _ptr_or_none(f64), 0 if f64 is None else f64.numel(),
+                                                       torch.cuda.current_stream().cuda_stream), "slu_comm_allreduce_ipc")
+
+    def allreduce(self, flat):
+        if flat.dtype == torch.float32:
+            self._launch(flat, None)
+        elif flat.dtype == torch.float64:
+            self._launch(None, flat)
+        else:
+            raise TypeError("IpcComm reduces float32 and float64 buckets")
+
+    def allreduce_flats(self, flats):
+        f32, f64 = _typed_flats(flats)
+        self._launch(f32, f64)
+
+    def status(self):
+        """0, or 1 + q when a wait for rank q timed out in some call (synchronises the device)."""
+        import ctypes
+        v = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            self._lib.check(self._L.slu_comm_ipc_status(self._own, ctypes.byref(v)), "slu_comm_ipc_status")
+        return int(v.value)
+
+    def close(self):
+        if getattr(self, "_own", None):
+            torch.cuda.synchronize()
+            if self.world_size > 1 and dist.is_initialized():
+                dist.barrier()                   # no peer may still be inside a launch that reads this window
+            with torch.cuda.device(self.device):
+                for w in self._peers.values():
+                    self._lib.check(self._L.slu_comm_ipc_window_close(w), "slu_comm_ipc_window_close")
+                self._lib.check(self._L.slu_comm_ipc_window_destroy(self._own), "slu_comm_ipc_window_destroy")
+            self._peers, self._own = {}, None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_own", None) and self.world_size == 1:
+                self.close()                     # (with peers, close() is collective: the owner calls it explicitly)
+        except Exception:
+            pass
+
+
+def _selftest(comm, rank, world_size, device, rounds=12, n=70001):
+    """A communicator must PROVE itself before it carries gradients: `rounds` all-reduces of rank- and round-dependent
+    fp32 + float64 patterns (odd length: exercises the padded tail and the typed float64 segment), every word compared
+    with the known sum; the ranks agree on the verdict over the control plane.  -> (ok, microseconds per call)."""
+    ok = 1.0
+    us = 0.0
+    try:
+        base = torch.arange(n, dtype=torch.float32, device=device) % 251.0
+        b64 = torch.arange(161, dtype=torch.float64, device=device)
+        f32, f64 = torch.empty_like(base), torch.empty_like(b64)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(rounds):
+            f32.copy_(base * float(rank + 1) + float(it))
+            f64.copy_(b64 * float(rank + 1) + 0.5 * it)
+            if it == 2:
+                e0.record()
+            comm.allreduce_flats({torch.float32: f32, torch.float64: f64})
+            want32 = base * (world_size * (world_size + 1) / 2.0) + float(it * world_size)
+            want64 = b64 * (world_size * (world_size + 1) / 2.0) + 0.5 * it * world_size
+            if not (torch.equal(f32, want32) and torch.equal(f64, want64)):
+                ok = 0.0
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = 1e3 * e0.elapsed_time(e1) / max(1, rounds - 2)
+        if hasattr(comm, "status") and comm.status() != 0:
+            ok = 0.0
+    except Exception as e:                                   # noqa: BLE001 - any failure means "not this communicator"
+        print("data parallel: %s self-test failed on rank %d: %s" % (type(comm).__name__, rank, str(e)[:300]))
+        ok = 0.0
+    if world_size > 1:
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # control plane: host tensor
+        ok = flag.item()
+    return ok >= 1.0, us
+
+
+def _shared_device():
+    """Do several ranks of this job sit on ONE GPU (the --share-gpu / SLU_LOCAL_DEVICE test set-up)?  RCCL refuses
+    duplicate devices; same-device IPC works."""
+    return "SLU_LOCAL_DEVICE" in os.environ
+
+
+def make_comm(rank, world_size, device):
+    """The data plane of this trainer's gradient collectives, by SLU_COMM:
+      auto (default)  IpcComm if it passes its self-test (every word of 12 patterned all-reduces right on every rank,
+                      no timed-out wait), else DirectComm (RCCL; needs one GPU per rank), else None;
+      ipc | rccl      that one, unconditionally (an exception if it cannot be built);
+      torch           None: torch.distributed's own collective on the buckets (gloo stages device tensors through the
+                      host — the functional fallback; backend nccl = ProcessGroupNCCL).
+    With SLU_DIST_BACKEND=nccl and SLU_COMM unset the round-4 behaviour is kept (torch.distributed's collective)."""
+    mode = os.environ.get("SLU_COMM", "auto")
+    if mode not in ("auto", "ipc", "rccl", "torch"):
+        raise ValueError("SLU_COMM=%r: expected auto, ipc, rccl or torch" % mode)
+    if mode == "torch" or device.type != "cuda" or not dist.is_initialized():
+        return None
+    if mode == "auto" and dist.get_backend() == "nccl":
+        return None
+    if mode == "rccl":
+        return DirectComm(rank, world_size, device)
+    if mode == "ipc":
+        return IpcComm(rank, world_size, device)
+    comm = None
+    try:
+        comm = IpcComm(rank, world_size, device)
+        built = 1.0
+    except Exception as e:                                   # noqa: BLE001
+        print("data parallel: no IPC windows on rank %d (%s)" % (rank, str(e)[:300]))
+        built = 0.0
+    if world_size > 1:
+        flag = torch.tensor([built])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        built = flag.item()
+    if built >= 1.0:
+        ok, us = _selftest(comm, rank, world_size, device)
+        if ok:
+            comm.selftest_us = us
+            return comm
+        if rank == 0:
+            print("data parallel: the hand-written IPC all-reduce failed its self-test; falling back to RCCL")
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:                                    # noqa: BLE001
+            pass
+    if _shared_device():
+        return None                                          # RCCL refuses duplicate devices: gloo carries the buckets
+    return DirectComm(rank, world_size, device)
 
 
 class GradBucket:
@@ -167,12 +379,13 @@ class GradBucket:
         ws = world()[1]
         if self.stub:
             return
-        for flat in self.flats.values():
-            if self.comm is not None:
-                self.comm.allreduce(flat)
-            else:
+        if self.comm is not None and self.flats:
+            self.comm.allreduce_flats(self.flats)       # ONE launch: fp32 + float64 buckets (typed segments / one ncclGroup)
+        else:
+            for flat in self.flats.values():
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            if self.divide:
+        if self.divide:
+            for flat in self.flats.values():
                 flat.div_(ws)
 
     def allreduce_mean(self):
@@ -187,21 +400,24 @@ class GradBucket:
         """Is the step's all-reduce a node of the step's hipGraph?  (pipeline.StepGraph: ONE graph per step under data
         parallelism — forward, backward, bucket packing, all-reduce, Adam — instead of graph / eager collective / graph;
         the collective is then ordered by the graph on the CU-masked training stream and costs no host call per step:
-        measured with one rank on MI355X, 0.172 instead of 0.189 ms per step.)
-        OFF by default (SLU_DP_GRAPH=0).  With this torch / ROCm stack a process that captures RCCL collectives while
-        torch.distributed's NCCL watchdog thread is polling earlier, eager collectives aborts now and then — 2 of 18 runs
-        of the one-rank test, with either communicator: "Process group watchdog thread terminated with exception: HIP
-        error: operation not permitted on an event last recorded in a capturing stream" (hipErrorCapturedEvent from the
-        watchdog's event query; the capture forks torch's collective stream, and the watchdog polls every 100 ms).  An
-        abort of one rank in eight is not a risk a default may carry; the eager collective between two graphs has run
-        clean in every test.  SLU_DP_GRAPH=1: captured after a self-test — a tiny all-reduce captured on a side stream
-        and replayed twice must give the known sum, the ranks agreeing on the verdict with an eager MIN all-reduce BEFORE
-        any replay (a rank whose capture failed must not leave the others waiting inside a captured collective)."""
+        measured with one rank on MI355X in round 4, 0.172 instead of 0.189 ms per step.)
+        Round 5: ON by default whenever the bucket has a communicator of its own (IpcComm / DirectComm) and
+        torch.distributed runs on gloo.  Round 4 had to leave it off: with backend "nccl" torch's ProcessGroupNCCL
+        watchdog thread polls the events of earlier eager collectives every 100 ms, and that query aborted 2 of 18
+        processes while a capture was in progress ("operation not permitted on an event last recorded in a capturing
+        stream").  With gloo as the control plane the process has no ProcessGroupNCCL and no such thread; the IPC
+        all-reduce is a plain kernel anyway.  SLU_DP_GRAPH=0 turns the graph node off; with SLU_DIST_BACKEND=nccl it
+        stays off unless SLU_DP_GRAPH=1 insists.  Either way it is captured only after a self-test — a small all-reduce
+        captured on a side stream and replayed twice must give the known sum, the ranks agreeing on "captured" over the
+        control plane BEFORE any replay (a rank whose capture failed must not leave the others waiting inside a captured
+        collective)."""
         if self._in_graph is not None:
             return self._in_graph
-        mode = os.environ.get("SLU_DP_GRAPH", "0")
-        ok = (mode == "1" and data_parallel() and device.type == "cuda"
-              and (self.comm is not None or dist.get_backend() == "nccl"))
+        mode = os.environ.get("SLU_DP_GRAPH", "auto")
+        ok = mode != "0" and data_parallel() and device.type == "cuda"
+        if ok:
+            nccl = dist.get_backend() == "nccl"
+            ok = (self.comm is not None and not nccl) or (mode == "1" and (self.comm is not None or nccl))
         if ok:
             ok = self._capture_selftest(device)
         self._in_graph = bool(ok)
@@ -227,7 +443,7 @@ class GradBucket:
                   "between two graphs" % (str(e)[:200],))
             captured = 0.0
         torch.cuda.synchronize(device)
-        flag = torch.tensor([captured], dtype=torch.float32, device=device)
+        flag = torch.tensor([captured], dtype=torch.float32, device=_flag_device(device))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # eager: every rank reaches this whatever its capture did
         if flag.item() < 1.0:
             return False
@@ -239,18 +455,22 @@ class GradBucket:
             side.synchronize()
             if not bool((t == want).all()):
                 good = 0.0
-        flag = torch.tensor([good], dtype=torch.float32, device=device)
+        flag = torch.tensor([good], dtype=torch.float32, device=_flag_device(device))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return flag.item() >= 1.0
 
 
 def allreduce_sums(values, device, comm=None):
-    """Sum a short list of Python floats over ranks (epoch metrics); identity for one process.  comm: the step's
-    DirectComm (SLU_COMM=rccl) — the reduction then goes through the same communicator, on the current stream, so
-    that every collective of the process is ordered by one stream."""
+    """Sum a short list of Python floats over ranks (epoch metrics); identity for one process.  Control-plane traffic:
+    a host tensor over gloo (or, with SLU_DIST_BACKEND=nccl, a device tensor through the step's communicator / torch's
+    collective as in round 4)."""
     rank, ws = world()
     if ws == 1:
         return list(values)
+    if dist.get_backend() != "nccl":
+        t = torch.tensor(list(values), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.tolist()
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     if comm is not None and t.is_cuda:
         comm.allreduce(t)

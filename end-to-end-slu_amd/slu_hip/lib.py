@@ -81,6 +81,14 @@ SIGNATURES = {
     "slu_comm_allreduce_f32": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_allreduce_f64": (c_int, [vp, vp, c_i64, vp]),
     "slu_comm_destroy": (c_int, [vp]),
+    "slu_comm_allreduce_group": (c_int, [vp, vp, c_i64, vp, c_i64, vp]),
+    "slu_comm_ipc_window_bytes": (c_i64, [c_i64]),
+    "slu_comm_ipc_window_create": (c_int, [c_i64, c_i64, vp, vp]),
+    "slu_comm_ipc_window_open": (c_int, [vp, vp]),
+    "slu_comm_ipc_window_close": (c_int, [vp]),
+    "slu_comm_ipc_window_destroy": (c_int, [vp]),
+    "slu_comm_allreduce_ipc": (c_int, [vp, c_i64, c_i64, c_i64, vp, c_i64, vp, c_i64, vp]),
+    "slu_comm_ipc_status": (c_int, [vp, vp]),
     "slu_gru_proj_supported": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),
     "slu_gru_proj_state_words": (c_i64, [c_i64, c_i64]),
     "slu_gru_proj_seq_fwd": (c_int, [vp, c_i64, vp, c_i64, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp]),
@@ -110,7 +118,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 7          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 8          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

@@ -119,9 +119,9 @@ class Trainer:
             # data-parallel mean: the all-reduce delivers the SUM, Adam divides by the world size in-kernel
             self.optimizer.grad_div = float(self.world_size)
             self.bucket.divide = False
-            if os.environ.get("SLU_COMM", "torch") == "rccl" and torch.distributed.get_backend() == "nccl":
-                dev = next(model.parameters()).device
-                self.bucket.comm = dp.DirectComm(self.rank, self.world_size, dev)
+            # the data plane of the gradient collective (slu_hip/dp.make_comm): the hand-written IPC all-reduce after its
+            # self-test, else RCCL through the C ABI, else (None) torch.distributed's collective on the buckets
+            self.bucket.comm = dp.make_comm(self.rank, self.world_size, next(model.parameters()).device)
 
     # -- checkpoints / log (reference training.py:23-45) -------------------------------------------
     def load_checkpoint(self):

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 7
+#define SLU_ABI_VERSION 8
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -482,6 +482,31 @@ int slu_comm_init(void** comm_out, const void* id128, int64_t nranks, int64_t ra
 int slu_comm_allreduce_f32(void* comm, float* buf, int64_t count, void* stream);
 int slu_comm_allreduce_f64(void* comm, double* buf, int64_t count, void* stream);
 int slu_comm_destroy(void* comm);
+/* Both gradient buckets of a step as ONE grouped RCCL operation (ncclGroupStart / End around the fp32 and the float64
+ * all-reduce): one launch per step whatever the trainable set.  Either count may be 0.  (ABI 8)                       */
+int slu_comm_allreduce_group(void* comm, float* f32, int64_t n32, double* f64, int64_t n64, void* stream);
+
+/* -------- hand-written all-reduce over peer-mapped device memory (xGMI within a node) — ABI 8 ------------------
+ * the collective of a data-parallel step is latency-bound (1.2 - 5.5 MB per 0.15 - 2.7 ms
+ * step), and xGMI is point to point: a two-shot all-reduce written as ONE kernel uses all links at once with two
+ * flag hand-offs where a ring pays 2 (N - 1) hops (csrc/slu_comm_ipc.hip has the protocol).  No library collective
+ * is involved: every rank creates a WINDOW (fine-grained device memory; slu_comm_ipc_window_bytes(payload) bytes),
+ * sends its 64-byte hipIpcMemHandle to the peers over any side channel (torch.distributed / gloo here), maps theirs,
+ * and calls slu_comm_allreduce_ipc with the N window pointers in rank order (windows[rank] = its own).  The fp32
+ * bucket and the float64 bucket are typed segments of one payload: ONE launch per step, in place, SUM, added in rank
+ * order by one rank per element (replicas receive bit-identical sums); asynchronous on `stream`, no host argument per
+ * call (flags carry a device-resident epoch), so the launch replays as a node of the step's hipGraph.  All ranks must
+ * call it the same number of times with the same sizes.  Waits are bounded (~2 s): slu_comm_ipc_status (synchronises
+ * the device) returns 0, or 1 + q when a wait for rank q timed out.  window_create / open / close / destroy allocate,
+ * map and release (never under capture).                                                                          */
+int64_t slu_comm_ipc_window_bytes(int64_t payload_bytes);
+int slu_comm_ipc_window_create(int64_t window_bytes, int64_t fine_grained, void** window_out, void* handle64);
+int slu_comm_ipc_window_open(const void* handle64, void** window_out);
+int slu_comm_ipc_window_close(void* peer_window);
+int slu_comm_ipc_window_destroy(void* own_window);
+int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes,
+                           float* f32, int64_t n32, double* f64, int64_t n64, void* stream);
+int slu_comm_ipc_status(void* own_window, int64_t* status_out);
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,33 @@ def sinc_mel_init(N_filt, fs):
     return b1 / freq_scale, (b2 - b1) / freq_scale
 
 
+# Working precision of the restatement.  float32 = the reference's own arithmetic (every cast point below is the
+# reference's; this is the mode every golden fixture pins).  float64_evaluation() switches the same formulas to float64
+# WITHOUT the intermediate float32 roundings: the rounding-free value of the function the reference computes, which the
+# gradient-parity tests use as the arbiter between two fp32 evaluations (|gpu - f64| against |oracle_fp32 - f64|).
+WORK_DTYPE = torch.float32
+
+
+class float64_evaluation:
+    """with O.float64_evaluation(): ... — evaluate the oracle in float64 (pass float64 weights and inputs: to_float64)."""
+
+    def __enter__(self):
+        global WORK_DTYPE
+        self._old, WORK_DTYPE = WORK_DTYPE, torch.float64
+        return self
+
+    def __exit__(self, *exc):
+        global WORK_DTYPE
+        WORK_DTYPE = self._old
+        return False
+
+
+def to_float64(sd, requires_grad=True):
+    """A float64 copy of a state_dict (floating tensors only are converted), as fresh leaves."""
+    return {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()).requires_grad_(requires_grad and v.is_floating_point())
+            for k, v in sd.items()}
+
+
 def sinc_filters(filt_b1, filt_band, Filt_dim, fs):
     """models.py:79-106 (+ flip/sinc models.py:7-24), vectorised over the 80 filters.
 
@@ -58,24 +85,24 @@ def sinc_filters(filt_b1, filt_band, Filt_dim, fs):
     N = Filt_dim
     freq_scale = fs * 1.0
     half = int((N - 1) / 2)
-    t_right = torch.linspace(1, (N - 1) / 2, steps=half) / fs            # :82 (float32)
+    t_right = torch.linspace(1, (N - 1) / 2, steps=half, dtype=WORK_DTYPE) / fs   # :82 (float32)
     min_freq = 50.0
     min_band = 50.0
     beg = torch.abs(filt_b1) + min_freq / freq_scale                      # :88 (float64)
     end = beg + (torch.abs(filt_band) + min_band / freq_scale)            # :89 (float64)
-    n = torch.linspace(0, N, steps=N)                                     # :91
-    window = (0.54 - 0.46 * torch.cos(2 * math.pi * n / N)).float()       # :94-95
+    n = torch.linspace(0, N, steps=N, dtype=WORK_DTYPE)                   # :91
+    window = (0.54 - 0.46 * torch.cos(2 * math.pi * n / N)).to(WORK_DTYPE)   # :94-95 (.float())
 
     def low_pass(f32_freq):                                               # :99-100 with sinc() :17-24
         band = (f32_freq * freq_scale).unsqueeze(1)                       # (N_filt,1) float32
         arg = 2 * math.pi * band * t_right.unsqueeze(0)                   # :18
         y_right = torch.sin(arg) / arg
         y_left = torch.flip(y_right, dims=[1])                            # :19 (flip() :7-14)
-        ones = torch.ones(y_right.shape[0], 1)
+        ones = torch.ones(y_right.shape[0], 1, dtype=WORK_DTYPE)
         y = torch.cat([y_left, ones, y_right], dim=1)                     # :22
         return 2 * f32_freq.unsqueeze(1) * y
 
-    band_pass = low_pass(end.float()) - low_pass(beg.float())             # :99-101
+    band_pass = low_pass(end.to(WORK_DTYPE)) - low_pass(beg.to(WORK_DTYPE))   # :99-101 (.float())
     band_pass = band_pass / band_pass.max(dim=1, keepdim=True)[0]         # :103
     return band_pass * window.unsqueeze(0)                                # :106
 

@@ -46,6 +46,7 @@ losses = [float(v[0]) for v, _ in trainer._iterate(batches, True, False)]
 torch.cuda.synchronize()
 torch.save({"losses": losses, "sd": {k: v.detach().cpu() for k, v in model.state_dict().items()},
             "payload": trainer.bucket.nbytes(), "dtypes": sorted(str(d) for d in trainer.bucket.flats)}, out)
+trainer.close()
 if ws > 1:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -1,5 +1,6 @@
-"""Worker of tests/test_hip_multigpu.py: one rank of a REAL multi-GPU data-parallel run (one process per GPU, backend
-"nccl" = RCCL over xGMI), or the single-process reference run on the full batches.
+"""Worker of tests/test_hip_multigpu.py: one rank of a data-parallel run (one process per GPU — or several ranks on one
+GPU —, control plane gloo, gradient collective by SLU_COMM: the hand-written IPC all-reduce, RCCL through the C ABI, or
+torch.distributed's own), or the single-process reference run on the full batches.
     python dp_rccl_worker.py <out.pt> <world_size>
 Two epochs of Trainer.train on a frozen pre-trained encoder with gradual unfreezing (unfreezing_type 2): the set of
 trainable parameters — and with it the flat gradient bucket — changes between the epochs."""
@@ -63,6 +64,7 @@ torch.cuda.synchronize()
 torch.save({"epochs": epochs, "payloads": payloads, "live": live, "collective": collective,
             "sd": {k: v.detach().cpu() for k, v in model.state_dict().items()},
             "comm": type(trainer.bucket.comm).__name__ if trainer.bucket.comm is not None else "torch.distributed",
+            "ipc_status": trainer.bucket.comm.status() if hasattr(trainer.bucket.comm, "status") else 0,
             "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"}, out)
 trainer.close()
 if torch.distributed.is_initialized():

@@ -98,6 +98,11 @@ def test_tiny_model_eval_and_train_vs_reference(models_mod, tmp_path):
     logits, pred = model.predict_intents(x)
     assert maxerr(logits, T(d["eval.logits"])) <= 1e-5
     assert np.array_equal(pred.cpu().numpy(), d["eval.pred"])
+    # decode_intents (reference models.py:853-865: the nested scan of Sy_intent for the value whose index was predicted),
+    # non-seq2seq: the strings of the REFERENCE's predicted intents (fixture g5), utterance by utterance
+    want = [[value for idx, slot in enumerate(model.Sy_intent) for value in model.Sy_intent[slot]
+             if int(row[idx]) == model.Sy_intent[slot][value]] for row in d["eval.pred"]]
+    assert model.decode_intents(x) == want and all(len(w) == len(cfg.values_per_slot) for w in want)
     feats = model.pretrained_model.compute_features(x)
     assert tuple(feats.shape) == d["eval.features"].shape
     assert maxerr(feats, T(d["eval.features"])) <= 1e-5
@@ -228,6 +233,27 @@ def test_baseline_config0_full_size_vs_reference(models_mod, tmp_path):
     assert a[0] == b[0] and a[3] == b[3] and abs(float(a[1]) - float(b[1])) <= 1e-4 and float(a[2]) == float(b[2])
 
 
+def assert_grads_vs_float64(named_gpu_grads, sd32, sd64, what, rel=1e-4):
+    """gradients within 1e-4 of the per-tensor max-abs.  Two correct fp32 evaluations of a long recurrence /
+    a heavily cancelling sum (the float64 Sinc parameters; a LeakyReLU input within round-off of its kink) can differ from
+    EACH OTHER by more than that, so the arbiter is a float64 evaluation of the oracle (O.float64_evaluation: the same
+    formulas without intermediate fp32 rounding): per tensor, the GPU may be off the float64 value by rel * max|grad| — or,
+    where the fp32 ORACLE itself is further off than half of that, by twice the oracle's own deviation.
+    -> (worst gpu deviation / scale, worst oracle deviation / scale, name of the worst)."""
+    worst = (0.0, 0.0, "")
+    for k, g in named_gpu_grads:
+        if sd64[k].grad is None:
+            continue
+        ref64 = sd64[k].grad
+        scale = max(ref64.abs().max().item(), 1e-9)
+        e_gpu = (g.detach().cpu().double() - ref64).abs().max().item()
+        e_ref = (sd32[k].grad.double() - ref64).abs().max().item()
+        assert e_gpu <= max(rel * scale, 2.0 * e_ref), "%s %s: |gpu - f64| = %.3e, |oracle_fp32 - f64| = %.3e, scale %.3e" % (
+            what, k, e_gpu, e_ref, scale)
+        worst = max(worst, (e_gpu / scale, e_ref / scale, k))
+    return worst
+
+
 @pytest.mark.parametrize("B,seconds,train_math", [(64, 3, "fp32"), (5, 1, "fp32"), (64, 3, "split")])
 def test_full_size_batch_vs_oracle(models_mod, tmp_path, monkeypatch, B, seconds, train_math):
     """BASELINE.json configs[2]/[3] shape: B=64 synthetic 3 s utterances through the whole SLU model,
@@ -268,6 +294,16 @@ def test_full_size_batch_vs_oracle(models_mod, tmp_path, monkeypatch, B, seconds
     rloss, racc, _, _ = O.slu_forward(sdg, x, y, cfg, masks, explicit_gru=False)
     rloss.backward()
     assert abs(loss.item() - rloss.item()) <= 1e-4 and acc.item() == racc.item()
+    if train_math == "fp32":
+        # the default arithmetic: SURVEY 8(c)'s 1e-4, arbitrated by a float64 evaluation of the oracle
+        sd64 = O.to_float64(sd)
+        with O.float64_evaluation():
+            l64, _, _, _ = O.slu_forward(sd64, x.double(), y, cfg, {k: v.double() for k, v in masks.items()}, explicit_gru=False)
+        l64.backward()
+        w = assert_grads_vs_float64(((k, p.grad) for k, p in model.named_parameters()), sdg, sd64, "B=%d" % B)
+        print("B=%d exact fp32: worst gradient deviation from the float64 oracle %.3e of the tensor's max (fp32 oracle: %.3e) at %s"
+              % ((B,) + w))
+        return
     worst = 0.0
     for k, p in model.named_parameters():
         if sdg[k].grad is None:
@@ -275,7 +311,7 @@ def test_full_size_batch_vs_oracle(models_mod, tmp_path, monkeypatch, B, seconds
         scale = max(sdg[k].grad.abs().max().item(), 1e-6)
         e = maxerr(p.grad, sdg[k].grad) / scale
         worst = max(worst, e)
-        assert e <= 2e-4, (k, e)
+        assert e <= 2e-4, (k, e)      # opt-in split-precision GEMMs of trainable layers: against the fp32 oracle
     print("B=%d SLU_TRAIN_MATH=%s worst relative gradient deviation: %.3e" % (B, train_math, worst))
 
 
@@ -421,10 +457,13 @@ def test_ten_second_utterances_vs_oracle(models_mod, tmp_path):
     rloss, _, _, _ = O.slu_forward(sdg, x, y, cfg, masks, explicit_gru=False)
     rloss.backward()
     assert abs(loss.item() - rloss.item()) <= 1e-4
-    for k, p in model.named_parameters():
-        if sdg[k].grad is not None:
-            scale = max(sdg[k].grad.abs().max().item(), 1e-6)
-            assert maxerr(p.grad, sdg[k].grad) <= 3e-4 * scale, k
+    # 1000 dependent recurrence steps: arbitrated by the float64 evaluation (1e-4, or twice the fp32 oracle's own deviation)
+    sd64 = O.to_float64(sd)
+    with O.float64_evaluation():
+        l64, _, _, _ = O.slu_forward(sd64, x.double(), y, cfg, {k: v.double() for k, v in masks.items()}, explicit_gru=False)
+    l64.backward()
+    w = assert_grads_vs_float64(((k, p.grad) for k, p in model.named_parameters()), sdg, sd64, "10 s")
+    print("10 s: worst gradient deviation from the float64 oracle %.3e of the tensor's max (fp32 oracle: %.3e) at %s" % w)
 
 
 def test_full_size_asr_pretraining_step_vs_oracle(models_mod, tmp_path):
@@ -457,24 +496,19 @@ def test_full_size_asr_pretraining_step_vs_oracle(models_mod, tmp_path):
     (rpl + rwl).backward()
     assert abs(pl.item() - rpl.item()) <= 1e-4 and abs(wl.item() - rwl.item()) <= 1e-4, (pl.item(), rpl.item(), wl.item(), rwl.item())
     assert abs(pa.item() - rpa.item()) <= 1e-6 and abs(wa.item() - rwa.item()) <= 1e-6
-    # LeakyReLU kinks: a convolution output within fp32 round-off of ZERO may land on either side of the kink in two
-    # correct fp32 evaluations (this draw has one: conv1 at (33, ch 1, frame 95) is -1.3e-7 in the oracle, +2.2e-7 on
-    # the GPU), and its upstream gradient then differs by the slope ratio 1 : 0.2 in BOTH implementations' own right.
-    # One such element among 1.15 M moves the (tiny, heavily cancelling) Sinc-parameter gradients by ~1e-3 and nothing
-    # else measurably; parameters UPSTREAM of a kink-adjacent element get the wider bound, everything else 2e-4.
-    with torch.no_grad():
-        st = O.encoder_stages({k: v.detach() for k, v in sd.items()}, x, cfg, masks, explicit_gru=False, upto="phoneme_features")
-    kink_stage = max([c for c in (1, 2) if int((st["conv%d" % c].abs() < 1e-6).sum()) > 0], default=0)
-    upstream = {0: (), 1: ("phoneme_layers.0.",), 2: ("phoneme_layers.0.", "phoneme_layers.5.")}[kink_stage]
-    worst, n = (0.0, ""), 0
+    # The arbiter is a float64 evaluation of the oracle.  (Round 3 found one conv1 output of 1.15 M within fp32 round-off of
+    # the LeakyReLU kink — -1.3e-7 in the fp32 oracle, +2.2e-7 on the GPU — which moves the tiny, heavily cancelling
+    # float64 Sinc-parameter gradients by ~1e-3 in EITHER fp32 evaluation; rounds 3-4 widened the bound for parameters
+    # upstream of such an element.  Against float64 the statement is sharper: the GPU must be within 1e-4 of the float64
+    # gradient, or no further from it than twice the fp32 oracle is.)
+    sd64 = O.to_float64({k: v.detach() for k, v in sd.items()})
+    with O.float64_evaluation():
+        p64, w64, _, _ = O.asr_forward(sd64, x.double(), yp, yw, cfg, {k: v.double() for k, v in masks.items()}, explicit_gru=False)
+    (p64 + w64).backward()
     for k, p in pm.named_parameters():
-        ref = sd[k].grad
-        assert ref is not None and p.grad is not None, k
-        assert p.grad.dtype == ref.dtype, k
-        e = maxerr(p.grad, ref) / max(ref.abs().max().item(), 1e-9)
-        assert e <= (3e-3 if k.startswith(upstream) and upstream else 2e-4), (k, e, kink_stage)
-        worst = max(worst, (e, k))
-        n += 1
-    print("full-size ASR step: losses %.5f / %.5f (oracle %.5f / %.5f), %d gradients, worst relative deviation %.2e (%s); "
-          "conv outputs within 1e-6 of the LeakyReLU kink up to stage conv%d"
-          % (pl.item(), wl.item(), rpl.item(), rwl.item(), n, worst[0], worst[1], kink_stage))
+        assert sd[k].grad is not None and p.grad is not None and p.grad.dtype == sd[k].grad.dtype, k
+    worst = assert_grads_vs_float64(((k, p.grad) for k, p in pm.named_parameters()), sd, sd64, "ASR")
+    n = sum(1 for _ in pm.named_parameters())
+    print("full-size ASR step: losses %.5f / %.5f (oracle %.5f / %.5f), %d gradients, worst deviation from the float64 oracle "
+          "%.2e of the tensor's max (fp32 oracle %.2e) at %s"
+          % (pl.item(), wl.item(), rpl.item(), rwl.item(), n, worst[0], worst[1], worst[2]))

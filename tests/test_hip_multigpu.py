@@ -1,7 +1,8 @@
-"""GPU: REAL multi-GPU data parallelism — one process per GPU, backend "nccl" (= RCCL over xGMI) — for N in {2, 4, 8},
-both collective paths (torch.distributed's own stream; SLU_COMM=rccl = slu_comm_* on the training stream).  Each case
-skips itself on a box with fewer than N GPUs (the single-GPU gpurun boxes run none of them; the driver's 8-GPU node
-runs all).  Checked: replicas stay bit-identical, equal the single-process run on the full batches up to summation
+"""GPU: multi-process data parallelism.  Control plane: torch.distributed on gloo; data plane (SLU_COMM): the hand-written
+IPC all-reduce (slu_comm_allreduce_ipc), RCCL through the C ABI (slu_comm_allreduce_group), or torch.distributed's own
+collective.  REAL multi-GPU cases — one process per GPU — for N in {2, 4, 8} skip themselves on a box with fewer than N
+GPUs (the single-GPU gpurun boxes run none of them; the driver's 8-GPU node runs all); what a ONE-GPU box can run of the
+same code runs there: several ranks sharing GPU 0 (same-device IPC windows), one-rank groups treated as data parallel.  Checked: replicas stay bit-identical, equal the single-process run on the full batches up to summation
 order, epoch metrics are the reduced (full-batch) ones, the flat bucket is rebuilt across unfreeze_one_layer().
 SURVEY.md 4(ii), 8(e)."""
 import os
@@ -28,8 +29,9 @@ def _run(tmp_path, world, comm, shared_gpu=False, extra_env=None):
         env.pop("SLU_DIST_BACKEND", None)
         env.pop("SLU_LOCAL_DEVICE", None)
         env.pop("SLU_DP_SINGLE", None)
-        if shared_gpu:                       # all ranks on GPU 0 over gloo (RCCL refuses duplicate devices)
-            env.update(SLU_DIST_BACKEND="gloo", SLU_LOCAL_DEVICE="0")
+        env.pop("SLU_DP_GRAPH", None)
+        if shared_gpu:                       # all ranks on GPU 0 (RCCL refuses duplicate devices; same-device IPC works)
+            env.update(SLU_LOCAL_DEVICE="0")
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_rccl_worker.py"), out, str(world)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -76,53 +78,68 @@ def _check(ranks, single, world, comm):
         assert abs(loss1 - lossn) <= 1e-3 * max(1.0, abs(loss1))
 
 
-def test_two_ranks_on_one_gpu_over_gloo(tmp_path, single):
-    """The same worker and checks on a ONE-GPU box: two ranks share GPU 0 over gloo — everything of the multi-process
-    path except RCCL itself (bucket packing with slu_copy_multi, the collective between the two captured graphs, 1/N in
-    Adam, reduced epoch metrics, bucket rebuild across unfreeze_one_layer(), look-ahead pipeline per rank)."""
-    ranks = _run(tmp_path, 2, "torch", shared_gpu=True)
+NODE = "a node of the step's hipGraph"
+EAGER = "eager call between two hipGraphs"
+
+
+@pytest.mark.parametrize("comm", ["ipc", "torch"])
+def test_two_ranks_on_one_gpu(tmp_path, single, comm):
+    """The same worker and checks on a ONE-GPU box: two ranks share GPU 0.  comm "ipc": the hand-written all-reduce over
+    same-device IPC windows as a node of each rank's step graph — the whole multi-process step exactly as on a node of
+    several GPUs (bucket packing with slu_copy_multi, ONE collective launch for the fp32 + float64 buckets, 1/N in Adam,
+    reduced epoch metrics over the gloo control plane, bucket rebuild across unfreeze_one_layer(), look-ahead pipeline per
+    rank).  comm "torch": gloo carries the buckets (staged through the host), an eager call between two graphs."""
+    ranks = _run(tmp_path, 2, comm, shared_gpu=True)
     assert ranks[0]["backend"] == "gloo"
-    assert ranks[0]["collective"] == ["eager call between two hipGraphs"] * 3        # gloo stages through the host
-    _check(ranks, single, 2, "gloo on one GPU")
+    assert ranks[0]["comm"] == ("IpcComm" if comm == "ipc" else "torch.distributed")
+    assert ranks[0]["collective"] == [NODE if comm == "ipc" else EAGER] * 3, ranks[0]["collective"]
+    assert all(r["ipc_status"] == 0 for r in ranks)
+    _check(ranks, single, 2, comm + " on one GPU")
 
 
-@pytest.mark.parametrize("comm", ["torch", "rccl"])
-def test_one_rank_rccl_data_parallel_step(tmp_path, single, comm):
-    """What a ONE-GPU box can run of the real thing: a one-rank RCCL group treated as data parallel (SLU_DP_SINGLE=1) —
-    bucket packing inside the captured step, the RCCL all-reduce (torch.distributed's, or slu_comm_* on the training
-    stream) as an eager call between the two graphs, 1 / N in Adam.  A one-rank sum is the identity and N = 1 divides
-    exactly, so the run must equal the plain single-process run bit for bit — nothing of the step was lost around the
-    collective."""
+def test_auto_picks_the_ipc_all_reduce_after_its_self_test(tmp_path, single):
+    """SLU_COMM unset: the IPC all-reduce proves itself (12 patterned all-reduces, every word checked on every rank) and
+    carries the gradients; the collective is a graph node by default."""
+    ranks = _run(tmp_path, 2, "auto", shared_gpu=True)
+    assert ranks[0]["comm"] == "IpcComm" and ranks[0]["collective"] == [NODE] * 3
+    _check(ranks, single, 2, "auto on one GPU")
+
+
+@pytest.mark.parametrize("comm", ["ipc", "rccl"])
+def test_one_rank_data_parallel_step_with_the_collective_in_the_graph(tmp_path, single, comm):
+    """A one-rank group treated as data parallel (SLU_DP_SINGLE=1), control plane gloo: bucket packing, the all-reduce
+    (the IPC kernel, or RCCL's through slu_comm_allreduce_group) AS A NODE OF THE STEP'S hipGraph — the round-5 default;
+    there is no ProcessGroupNCCL and no watchdog thread in the process —, 1 / N in Adam.  A one-rank sum is the identity
+    and N = 1 divides exactly, so the run must equal the plain single-process run bit for bit."""
     (a,) = _run(tmp_path, 1, comm, extra_env={"SLU_DP_SINGLE": "1"})
-    assert a["backend"] == "nccl"
-    assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
-    assert a["collective"] == ["eager call between two hipGraphs"] * 3, a["collective"]
+    assert a["backend"] == "gloo"
+    assert a["comm"] == ("DirectComm" if comm == "rccl" else "IpcComm")
+    assert a["collective"] == [NODE] * 3, a["collective"]
+    assert a["ipc_status"] == 0
     for k, v in single["sd"].items():
         assert torch.equal(v, a["sd"][k]), k
     assert a["epochs"] == single["epochs"] and a["payloads"] == single["payloads"]
 
 
-@pytest.mark.skipif(os.environ.get("SLU_TEST_DP_GRAPH", "0") != "1",
-                    reason="SLU_DP_GRAPH=1 (the all-reduce captured inside the step graph) is opt-in: torch's NCCL watchdog "
-                           "aborts the process now and then when collectives are captured (slu_hip/dp.py); run with "
-                           "SLU_TEST_DP_GRAPH=1 to exercise it")
-@pytest.mark.parametrize("comm", ["torch", "rccl"])
-def test_one_rank_rccl_collective_inside_the_step_graph(tmp_path, single, comm):
-    """SLU_DP_GRAPH=1: the all-reduce as a NODE OF THE STEP'S hipGraph — same parameters, bit for bit."""
-    (a,) = _run(tmp_path, 1, comm, extra_env={"SLU_DP_SINGLE": "1", "SLU_DP_GRAPH": "1"})
-    assert a["collective"] == ["a node of the step's hipGraph"] * 3, a["collective"]
+def test_one_rank_nccl_backend_keeps_the_eager_collective(tmp_path, single):
+    """SLU_DIST_BACKEND=nccl (torch's ProcessGroupNCCL, round 4's set-up): torch.distributed's collective between the two
+    graphs — captured collectives stay opt-in there because of the watchdog thread (slu_hip/dp.py)."""
+    (a,) = _run(tmp_path, 1, "torch", extra_env={"SLU_DP_SINGLE": "1", "SLU_DIST_BACKEND": "nccl"})
+    assert a["backend"] == "nccl" and a["comm"] == "torch.distributed"
+    assert a["collective"] == [EAGER] * 3, a["collective"]
     for k, v in single["sd"].items():
         assert torch.equal(v, a["sd"][k]), k
 
 
-@pytest.mark.parametrize("comm", ["torch", "rccl"])
+@pytest.mark.parametrize("comm", ["ipc", "rccl", "auto"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_rccl_data_parallel_training(tmp_path, single, world, comm):
+def test_multi_gpu_data_parallel_training(tmp_path, single, world, comm):
     if torch.cuda.device_count() < world:
         pytest.skip("needs %d GPUs (this box has %d)" % (world, torch.cuda.device_count()))
     ranks = _run(tmp_path, world, comm)
     a = ranks[0]
-    assert a["backend"] == "nccl"
-    assert a["comm"] == ("DirectComm" if comm == "rccl" else "torch.distributed")
-    assert a["collective"] == ["eager call between two hipGraphs"] * 3, a["collective"]
+    assert a["backend"] == "gloo"
+    assert a["comm"] in ({"ipc": ("IpcComm",), "rccl": ("DirectComm",), "auto": ("IpcComm", "DirectComm")}[comm])
+    assert a["collective"] == [NODE] * 3, a["collective"]
+    assert all(r["ipc_status"] == 0 for r in ranks)
     _check(ranks, single, world, comm)

@@ -647,3 +647,65 @@ def test_slu_comm_single_rank_allreduce():
     st.synchronize()
     assert torch.equal(a, a0) and torch.equal(b, b0)
     comm.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own stage outputs (fixtures g2, g4: written by importing the reference) straight through the HIP kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("math", ["exact", "bf16x3", "f16x2"])
+def test_frontend_stages_vs_reference_fixture_g2(ops, math):
+    """g2 = the reference's SincLayer / abs / pool / LeakyReLU / Conv1d x 2 outputs on x = randn(2, 8000) (models.py:77-110,
+    163-168, 194-220).  The HIP front end — the trainable kernels (exact fp32 MFMA) and the frozen stages' split-precision
+    kernels in both schemes — against those tensors directly, stage by stage."""
+    d = load("g2_frontend.npz")
+    x = cu(d["x"])
+    b1, band = cu(d["phoneme_layers.0.filt_b1"]), cu(d["phoneme_layers.0.filt_band"])
+    w1, c1 = cu(d["phoneme_layers.5.weight"]), cu(d["phoneme_layers.5.bias"])
+    w2, c2 = cu(d["phoneme_layers.9.weight"]), cu(d["phoneme_layers.9.bias"])
+    B, T = x.shape
+    ns = {"exact": 0, "bf16x3": 3, "f16x2": 2}[math]
+
+    def conv(h, w, bias, l_in, c_in, stride, do_abs, pool, slope):
+        if ns:
+            assert ops.wconv_bf16_supported(c_in, stride, pool, w.shape[2], ns)
+            return ops.wconv_fwd_bf16(h, w, bias, B, l_in, c_in, stride, do_abs, pool, slope, False, ns)
+        return ops.wconv_fwd(h, w, bias, B, l_in, c_in, stride, do_abs, pool, slope, False, False)[0]
+
+    # fp32 round-off of a 401-tap sum in another summation order (the Sinc output reaches 2.6: one ulp there is 2.4e-7);
+    # the north star's bound for the whole network is 1e-4
+    tol = 5e-6
+    filters = ops.sinc_filters(b1, band, 401, 16000).view(80, 1, 401)
+    # the bare SincLayer output (no abs, no pool, slope 1 = identity): reference `after_sinc0`, (B, C, L)
+    h = conv(x, filters, None, T, 1, 80, False, 1, 1.0)
+    assert_close(h.transpose(1, 2), torch.from_numpy(d["after_sinc0"]), tol, "sinc0 (%s)" % math)
+    # the fused block: |.| -> MaxPool1d(2, ceil) -> LeakyReLU(0.2) -> Dropout(0)
+    h = conv(x, filters, None, T, 1, 80, True, 2, 0.2)
+    assert_close(h.transpose(1, 2), torch.from_numpy(d["after_dropout0"]), tol, "block 0 (%s)" % math)
+    h = conv(h, w1, c1, h.shape[1], 80, 1, False, 1, 0.2)
+    assert_close(h.transpose(1, 2), torch.from_numpy(d["after_dropout1"]), tol, "block 1 (%s)" % math)
+    h = conv(h, w2, c2, h.shape[1], 60, 1, False, 1, 0.2)
+    assert_close(h.transpose(1, 2), torch.from_numpy(d["after_dropout2"]), tol, "block 2 (%s)" % math)
+
+
+def test_downsample_and_dropout_vs_reference_fixture_g4(ops):
+    """g4 = the reference's Downsample (models.py:26-46) for T = 25 / 75 / 6 / 1, methods none / avg / max, factors 1-3
+    (ceil-mode partial last windows) and torch.nn.Dropout(0.5) outputs for two seeds: slu_dropout_pool_fwd against those
+    tensors directly, and through models.Downsample (the module surface the reference's callers use)."""
+    import models
+    d = load("g4_downsample.npz")
+    for T_ in (25, 75, 6, 1):
+        x = cu(d["x_T%d" % T_])                                   # (B, T, C)
+        xt = x.transpose(0, 1).contiguous()                       # kernels are time-major
+        for method in ("none", "avg", "max"):
+            for factor in (1, 2, 3):
+                ref = torch.from_numpy(d["y_T%d_%s_%d" % (T_, method, factor)])
+                y = ops.dropout_pool_fwd(xt, None, 0.0, 0, 0, method, factor).transpose(0, 1)
+                assert_close(y, ref, 1e-7, "T=%d %s/%d" % (T_, method, factor))
+                y = models.Downsample(method, factor)(x)
+                assert_close(y, ref, 1e-7, "module T=%d %s/%d" % (T_, method, factor))
+    for seed in (11, 12):
+        torch.manual_seed(seed)
+        mask = torch.empty(4, 9, 16).bernoulli_(0.5)              # the draw nn.Dropout made in the reference run
+        ones = torch.ones(9, 4, 16, device="cuda")
+        y = ops.dropout_pool_fwd(ones, cu(mask).transpose(0, 1), 0.5, 0, 0, "none", 1).transpose(0, 1)
+        assert np.array_equal(y.cpu().numpy(), d["dropout_seed%d" % seed])

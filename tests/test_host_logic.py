@@ -188,3 +188,37 @@ def test_bench_stdout_carries_the_json_line_only(tmp_path):
     assert r.returncode == 0, r.stderr[-500:]
     assert r.stdout == '{"metric": "x", "value": 1}\n'
     assert "noise from a library" in r.stderr and "noise from a child process" in r.stderr
+
+
+def test_ramp_plan_of_the_first_super_batches(monkeypatch):
+    """training._ramp_plan: a run starts with three super-batches side by side, ~1 : 2 : 4, together at most one
+    look-ahead width (one recurrence workgroup per look-ahead CU); short runs and two-slot set-ups keep the old plan."""
+    import training
+    monkeypatch.delenv("SLU_RAMP", raising=False)
+    assert training._ramp_plan(20, 20, 3) == ([3, 6, 11], 3)            # the driver's 20-step command
+    assert training._ramp_plan(512, 20, 3) == ([3, 6, 11], 3)           # long runs: the same start, then full width
+    assert training._ramp_plan(512, 24, 3) == ([3, 7, 14], 3)
+    sizes, side = training._ramp_plan(12, 20, 3)
+    assert sum(sizes) == 12 and side == 3 and sizes[0] <= sizes[1] <= sizes[2]
+    assert training._ramp_plan(5, 20, 3) == ([3], 0)                    # too short to ramp: one capped super-batch
+    assert training._ramp_plan(20, 20, 2) == ([12], 0)                  # two slots: rounds 2-4's 60 : 40 split
+    assert training._ramp_plan(100, 20, 2) == ([], 0)
+    monkeypatch.setenv("SLU_RAMP", "0")
+    assert training._ramp_plan(20, 20, 3) == ([12], 0)
+    monkeypatch.setenv("SLU_RAMP", "2,4,8")
+    assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 3)
+
+
+def test_data_plane_selection_without_a_gpu(monkeypatch):
+    """dp.make_comm: no communicator of its own for host tensors / without torch.distributed; unknown modes are refused."""
+    import pytest
+    from slu_hip import dp
+    monkeypatch.delenv("SLU_COMM", raising=False)
+    assert dp.make_comm(0, 1, torch.device("cpu")) is None
+    monkeypatch.setenv("SLU_COMM", "nvlink")
+    with pytest.raises(ValueError):
+        dp.make_comm(0, 1, torch.device("cpu"))
+    with pytest.raises(TypeError):
+        dp._typed_flats({torch.float16: torch.zeros(2, dtype=torch.float16)})
+    a, b = torch.zeros(3), torch.zeros(2, dtype=torch.float64)
+    assert dp._typed_flats({torch.float64: b, torch.float32: a}) == (a, b) and dp._typed_flats({}) == (None, None)
