@@ -7,12 +7,13 @@
 // once with two flag hand-offs, where a ring pays 2 (N − 1) hops:
 //   window of rank r (fine-grained device memory, exported with hipIpcGetMemHandle, mapped by every peer):
 //       [flags 4 KiB | `in` staging (cap bytes) | `out` staging (cap bytes)]
-//   1. every rank copies its bucket into its own `in` (local), releases at system scope, raises flag_in[r] on every peer;
-//   2. waits for all peers' flag_in; rank r then OWNS chunk r: it reads chunk r of every rank's `in` over the links
+//   1. every rank copies its bucket into its own `in` (local), releases at system scope, raises flag_in[r] on every
+//      window (its own too: a workgroup reads what the rank's other workgroups wrote only behind the rank's own flag);
+//   2. waits for all N flag_in; rank r then OWNS chunk r: it reads chunk r of every rank's `in` over the links
 //      (N − 1 remote reads of payload / N each, all links busy at once), adds them IN RANK ORDER 0 … N−1 (one rank
 //      computes each element, so the replicas receive bit-identical sums) and WRITES the sum into chunk r of every
 //      rank's `out` (N − 1 remote writes); releases; raises flag_out[r] on every peer;
-//   3. waits for all peers' flag_out, copies its own `out` back into the bucket (local).
+//   3. waits for all N flag_out, copies its own `out` back into the bucket (local).
 // The fp32 bucket and the 160-element float64 bucket of the Sinc parameters travel as TYPED SEGMENTS of the same
 // payload: one launch, one collective per step whatever the trainable set.
 // Flags hold a monotonically increasing epoch (never reset), the epoch counter lives in device memory: the launch has
@@ -50,7 +51,7 @@ struct IpcArgs {
 // one peer each), then acquire at system scope.  Returns with the whole workgroup synchronised.
 __device__ __forceinline__ void ipc_wait_all(const IpcArgs& a, int line, unsigned long long epoch) {
   unsigned char* own = a.win[a.rank];
-  if ((int)threadIdx.x < a.nranks && (int)threadIdx.x != a.rank) {
+  if ((int)threadIdx.x < a.nranks) {              // the own flag too: the other workgroups of THIS rank publish behind it
     unsigned long long* f = ipc_word(own, line + (int)threadIdx.x);
     unsigned spins = 0;
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
@@ -78,9 +79,10 @@ __device__ __forceinline__ void ipc_publish(const IpcArgs& a, int arrive_line, i
     const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned long long)gridDim.x - 1) {
       __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // every rank's window, the own one included: a workgroup of this rank reads what this rank's OTHER workgroups
+      // staged / reduced (its own chunk of `in`, its own chunk of `out`) only behind the own flag
       for (int q = 0; q < a.nranks; ++q)
-        if (q != a.rank)
-          __hip_atomic_store(ipc_word(a.win[q], flag_line + a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ipc_word(a.win[q], flag_line + a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

@@ -54,8 +54,11 @@ __device__ __forceinline__ void head_reduce_body(const float* row_stats, float* 
   float a = 0.0f, c = 0.0f;
   for (int b = threadIdx.x; b < B; b += 256) {
     if (COHERENT) {
-      a += __hip_atomic_load(row_stats + 2 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c += __hip_atomic_load(row_stats + 2 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // one 8-byte agent-scope load per utterance: the granule its workgroup published with ONE 8-byte agent-scope store
+      const unsigned long long g = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(row_stats) + b,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a += __uint_as_float((unsigned)(g & 0xffffffffull));
+      c += __uint_as_float((unsigned)(g >> 32));
     } else {
       a += row_stats[2 * b]; c += row_stats[2 * b + 1];
     }
@@ -236,20 +239,23 @@ head_fwd_kernel(const HeadParams p) {
       loss += s_part[p.slot_begin[s2]];
       all_ok = all_ok && (s_ok[p.slot_begin[s2]] != 0);
     }
-    p.row_stats[2 * b] = loss;
-    p.row_stats[2 * b + 1] = all_ok ? 1.0f : 0.0f;
+    // (loss, all-correct) as ONE naturally aligned 8-byte granule, written through (agent scope = sc1): the last
+    // workgroup reads it with an 8-byte agent-scope load — 8-byte agent atomics on both sides need no fence (round 5:
+    // the two __threadfence() of the ticket epilogue, a full L2 write-back + invalidate each, cost more than the reduce)
+    const unsigned long long g = (unsigned long long)__float_as_uint(loss) |
+                                 ((unsigned long long)__float_as_uint(all_ok ? 1.0f : 0.0f) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.row_stats) + b, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // batch loss / accuracy by the last workgroup to get here (same summation as head_reduce_kernel, whichever
   // workgroup runs it): saves the 1-workgroup reduce launch of every training step
   if (p.ticket && p.y) {
     __shared__ int s_last;
     if (tid == 0) {
-      __threadfence();                                   // this utterance's row_stats visible device-wide first
-      s_last = (atomicAdd(p.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the granule has left this CU before the ticket is drawn
+      s_last = (__hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
     if (s_last) {
-      __threadfence();
       head_reduce_body<true>(p.row_stats, p.loss_acc, p.epoch_sums, p.B);
       if (tid == 0) *p.ticket = 0u;
     }

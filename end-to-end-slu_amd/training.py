@@ -67,19 +67,22 @@ def _lookahead_width(depth, batch_size):
 
 def _ramp_plan(n_run, width, n_slots):
     """Sizes of the FIRST super-batches of a run of n_run batches (the rest are `width` batches each), and how many of
-    them are started side by side.  The first super-batch of a run is pure pipeline fill: nothing can train until its
-    frozen prefix is through ~560 dependent recurrence steps, whatever its size — so the run starts with a SMALL
-    super-batch and two larger ones launched AT THE SAME TIME on the look-ahead partition (together at most `width`
-    batches = one recurrence workgroup per look-ahead CU, so they really run side by side): sizes ~ 1 : 2 : 4.  The
-    training stream starts after the small one's latency and finds the second and third ready when it needs them.
-    Round 5, bf16x3 frozen stages, the driver's 20-step command: 12 + 8 chained (rounds 2-4) -> 3 + 6 + 11 side by side.
-    SLU_RAMP=0 (or fewer than three look-ahead slots): the old plan, one capped first super-batch (3/5 of a run that
-    fits in two).  SLU_RAMP=a,b,c: explicit sizes."""
-    env = os.environ.get("SLU_RAMP", "auto")
-    T = min(n_run, width)
+    them are started side by side instead of one behind the other.  Default: ONE capped first super-batch — a run that
+    fits in two super-batches is split 60 : 40 (20 batches: 12 + 8; the second one's encoder runs beside the first one's
+    steps and is ready when they end) —, nothing side by side.
+    SLU_RAMP=a,b,c: explicit sizes, started side by side (needs as many look-ahead slots, SLU_LOOKAHEAD_SLOTS).  Round 5
+    measured the obvious refinement and it is SLOWER (profiles/r05_a_sweep.txt, bf16x3 frozen stages, the driver's 20-step
+    command): 3 + 6 + 11 side by side 181.9 k utt/s, 2 + 5 + 13: 184.3 k, 4 + 6 + 10: 186.4 k, against 194.2 k for 12 + 8
+    chained; time to the first step 3.0 - 4.0 ms against 3.3.  The look-ahead streams have no priorities
+    (hipExtStreamCreateWithCUMask takes none), so super-batches side by side share the partition evenly: the small one's
+    latency chain (~560 dependent recurrence steps) waits behind the big ones' convolutions and GEMMs and ALL of them
+    finish late.  A frozen prefix is ~1.4 ms of latency + ~0.12 ms per batch of throughput on 160 CUs in this arithmetic;
+    short runs are bound by that sum, whatever the split."""
+    env = os.environ.get("SLU_RAMP", "0")
     if env not in ("auto", "0"):
         sizes = [max(1, int(v)) for v in env.split(",") if v.strip()]
-        return sizes, len(sizes)
+        return sizes, (len(sizes) if n_slots >= len(sizes) else 0)
+    T = min(n_run, width)
     if env == "0" or n_slots < 3 or T < 9:
         return ([max(2, -(-3 * n_run // 5))] if n_run < 2 * width else []), 0
     a = max(2, int(T / 7.0 + 0.5))
@@ -454,9 +457,9 @@ class Trainer:
         main = self._train_stream
         main.wait_stream(outer)
         if getattr(self, "_slots", None) is None:
-            # three slots: the first three super-batches of a run start side by side (_ramp_plan); afterwards one is
-            # being consumed, one computed and one queued behind it
-            n_slots = max(2, int(os.environ.get("SLU_LOOKAHEAD_SLOTS", "3")))
+            # two slots: one super-batch is consumed while the next is computed (a third slot only reads further ahead:
+            # 342 -> 323 k utt/s steady state, profiles/r05_a_sweep.txt)
+            n_slots = max(2, int(os.environ.get("SLU_LOOKAHEAD_SLOTS", "2")))
             self._slots = [pipeline.PrefixSlot(dev) for _ in range(n_slots)]   # in-flight super-batches
         pm = self.model.pretrained_model
         with torch.cuda.stream(main):
@@ -484,6 +487,8 @@ class Trainer:
         launched = 0
         last_done = [None]
         ramp = [[], 0]                                # [sizes of the first super-batches, how many start side by side]
+        # SLU_PREFIX_CHAIN=0 (experiment): super-batches of different slots never wait for each other
+        chain = os.environ.get("SLU_PREFIX_CHAIN", "1") != "0"
 
         def launch_next():
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
@@ -519,7 +524,7 @@ class Trainer:
             # the first ramp[1] super-batches of the run start side by side; from then on each waits for its predecessor
             # (two full-width super-batches side by side would only delay the one the training stream is waiting for)
             feats, done, guard = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
-                                          after=None if launched <= ramp[1] else last_done[0])
+                                          after=None if (launched <= ramp[1] or not chain) else last_done[0])
             last_done[0] = done
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on
