@@ -7,12 +7,12 @@
 // once with two flag hand-offs, where a ring pays 2 (N − 1) hops:
 //   window of rank r (fine-grained device memory, exported with hipIpcGetMemHandle, mapped by every peer):
 //       [flags 4 KiB | `in` staging (cap bytes) | `out` staging (cap bytes)]
-//   1. every rank copies its bucket into its own `in` (local), releases at system scope, raises flag_in[r] on every
+//   1. every rank copies its bucket into its own `in` (local, written through), raises flag_in[r] on every
 //      window (its own too: a workgroup reads what the rank's other workgroups wrote only behind the rank's own flag);
 //   2. waits for all N flag_in; rank r then OWNS chunk r: it reads chunk r of every rank's `in` over the links
 //      (N − 1 remote reads of payload / N each, all links busy at once), adds them IN RANK ORDER 0 … N−1 (one rank
 //      computes each element, so the replicas receive bit-identical sums) and WRITES the sum into chunk r of every
-//      rank's `out` (N − 1 remote writes); releases; raises flag_out[r] on every peer;
+//      rank's `out` (N − 1 remote writes, written through); raises flag_out[r] on every window;
 //   3. waits for all N flag_out, copies its own `out` back into the bucket (local).
 // The fp32 bucket and the 160-element float64 bucket of the Sinc parameters travel as TYPED SEGMENTS of the same
 // payload: one launch, one collective per step whatever the trainable set.
@@ -29,7 +29,7 @@ namespace slu {
 
 constexpr int IPC_MAX_RANKS = 8;
 constexpr long long IPC_FLAG_BYTES = 4096;
-constexpr int IPC_WGS = 32;                 // all resident at once on any partition of this package (>= 16 CUs)
+constexpr int IPC_WGS = 64;                 // all resident at once on any partition of this package (>= 16 CUs, 8 per CU)
 constexpr unsigned IPC_SPIN_LIMIT = 1u << 21;   // polls of ~1 us: a peer that is two seconds late is not coming
 
 // window-relative offsets of the control words (each on a 64-byte line of its own)
@@ -47,11 +47,37 @@ struct IpcArgs {
   double* f64; long long n64;               // the float64 bucket or null
 };
 
-// wait until flag word `line + src` of the own window has reached `epoch`, for every peer src (threads 0 .. nranks-1 poll
-// one peer each), then acquire at system scope.  Returns with the whole workgroup synchronised.
+// Staging traffic is SYSTEM-SCOPE on both sides: 8-byte relaxed atomic stores / loads (global_store / load_dwordx2 sc0
+// sc1: written through, never served from a stale cache line) — "sc0 sc1 stores and loads on both sides" needs no release
+// / acquire fence, whatever memory type the exporting and the importing process map the window with.  (The first version
+// used plain 16-byte accesses between system-scope release / acquire fences: on ranks sharing one GPU it returned stale
+// words in the first large all-reduce after small ones — lines of `in` still cached from the previous call — and its four
+// fences cost 7 of its 16 us.)
+__device__ __forceinline__ void st_sys(void* p, float a, float b) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
+                     (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float2 ld_sys(const void* p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_float2(__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32)));
+}
+__device__ __forceinline__ void st_sys64(void* p, double a) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(a),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double ld_sys64(const void* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+// wait until flag word `line + src` of the own window has reached `epoch`, for EVERY rank src (the own one too: the other
+// workgroups of this rank publish behind it); threads 0 .. nranks-1 poll one flag each.  Returns with the workgroup
+// synchronised.  No acquire: everything read behind the flags is read with system-scope loads.
 __device__ __forceinline__ void ipc_wait_all(const IpcArgs& a, int line, unsigned long long epoch) {
   unsigned char* own = a.win[a.rank];
-  if ((int)threadIdx.x < a.nranks) {              // the own flag too: the other workgroups of THIS rank publish behind it
+  if ((int)threadIdx.x < a.nranks) {
     unsigned long long* f = ipc_word(own, line + (int)threadIdx.x);
     unsigned spins = 0;
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
@@ -63,26 +89,21 @@ __device__ __forceinline__ void ipc_wait_all(const IpcArgs& a, int line, unsigne
     }
   }
   __syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // system scope: peers' writes behind their flags are visible now
-  __syncthreads();
 }
 
-// every wave has drained its stores; the workgroup's lane 0 releases at system scope and arrives on `arrive_line`; the
-// LAST workgroup of the launch raises flag `flag_line + rank` (= epoch) on every peer's window.
+// every wave drains its (written-through) stores; the workgroup's lane 0 arrives on `arrive_line`; the LAST workgroup of the
+// launch — every workgroup's stores have been acknowledged by then — raises flag `flag_line + rank` (= epoch) on every
+// rank's window, the own one included.
 __device__ __forceinline__ void ipc_publish(const IpcArgs& a, int arrive_line, int flag_line, unsigned long long epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned long long* cnt = ipc_word(a.win[a.rank], arrive_line);
-    const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned long long)gridDim.x - 1) {
       __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // every rank's window, the own one included: a workgroup of this rank reads what this rank's OTHER workgroups
-      // staged / reduced (its own chunk of `in`, its own chunk of `out`) only behind the own flag
       for (int q = 0; q < a.nranks; ++q)
-        __hip_atomic_store(ipc_word(a.win[q], flag_line + a.rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ipc_word(a.win[q], flag_line + a.rank), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -93,57 +114,41 @@ allreduce_ipc_kernel(const IpcArgs a) {
   const unsigned long long epoch =
       __hip_atomic_load(ipc_word(own, 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
   const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nthr = (long long)gridDim.x * 256;
-  const long long u32 = (a.n32 + 3) / 4;                   // 16-byte units of the fp32 segment (tail padded with zeros)
-  const long long u64 = (a.n64 + 1) / 2;                   // 16-byte units of the float64 segment
+  const long long p32 = (a.n32 + 1) / 2;                   // 8-byte pairs of the fp32 segment (an odd tail is padded with 0)
+  const long long seg64 = 16 * ((a.n32 + 3) / 4);          // byte offset of the float64 segment inside a staging area
 
   // ---- 1. bucket -> own `in` ----
   {
-    float4* in = reinterpret_cast<float4*>(own + IPC_FLAG_BYTES);
-    for (long long u = tid; u < u32; u += nthr) {
-      float4 v;
-      if (4 * u + 3 < a.n32) v = reinterpret_cast<const float4*>(a.f32)[u];
-      else {
-        v.x = 4 * u + 0 < a.n32 ? a.f32[4 * u + 0] : 0.f; v.y = 4 * u + 1 < a.n32 ? a.f32[4 * u + 1] : 0.f;
-        v.z = 4 * u + 2 < a.n32 ? a.f32[4 * u + 2] : 0.f; v.w = 0.f;
-      }
-      in[u] = v;
-    }
-    double2* in64 = reinterpret_cast<double2*>(own + IPC_FLAG_BYTES + 16 * u32);
-    for (long long u = tid; u < u64; u += nthr) {
-      double2 v;
-      v.x = a.f64[2 * u]; v.y = 2 * u + 1 < a.n64 ? a.f64[2 * u + 1] : 0.0;
-      in64[u] = v;
-    }
+    unsigned char* in = own + IPC_FLAG_BYTES;
+    for (long long u = tid; u < p32; u += nthr)
+      st_sys(in + 8 * u, a.f32[2 * u], 2 * u + 1 < a.n32 ? a.f32[2 * u + 1] : 0.f);
+    for (long long u = tid; u < a.n64; u += nthr) st_sys64(in + seg64 + 8 * u, a.f64[u]);
   }
   ipc_publish(a, 17, 0, epoch);
   ipc_wait_all(a, 0, epoch);
 
   // ---- 2. reduce this rank's chunk over all ranks (rank order), push the sum into every rank's `out` ----
   {
-    const long long c0 = u32 * a.rank / a.nranks, c1 = u32 * (a.rank + 1) / a.nranks;
+    const long long c0 = p32 * a.rank / a.nranks, c1 = p32 * (a.rank + 1) / a.nranks;
     for (long long u = c0 + tid; u < c1; u += nthr) {
-      float4 v[IPC_MAX_RANKS];
+      float2 v[IPC_MAX_RANKS];
 #pragma unroll
       for (int q = 0; q < IPC_MAX_RANKS; ++q)
-        if (q < a.nranks) v[q] = reinterpret_cast<const float4*>(a.win[q] + IPC_FLAG_BYTES)[u];
-      float4 s = v[0];
+        if (q < a.nranks) v[q] = ld_sys(a.win[q] + IPC_FLAG_BYTES + 8 * u);
+      float2 s = v[0];
 #pragma unroll
       for (int q = 1; q < IPC_MAX_RANKS; ++q)
-        if (q < a.nranks) { s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w; }
+        if (q < a.nranks) { s.x += v[q].x; s.y += v[q].y; }
 #pragma unroll
       for (int q = 0; q < IPC_MAX_RANKS; ++q)
-        if (q < a.nranks) reinterpret_cast<float4*>(a.win[q] + IPC_FLAG_BYTES + a.cap)[u] = s;
+        if (q < a.nranks) st_sys(a.win[q] + IPC_FLAG_BYTES + a.cap + 8 * u, s.x, s.y);
     }
     // the float64 segment (160 values when the Sinc layer trains) is rank 0's
     if (a.rank == 0) {
-      for (long long u = tid; u < u64; u += nthr) {
-        double2 s = reinterpret_cast<const double2*>(a.win[0] + IPC_FLAG_BYTES + 16 * u32)[u];
-        for (int q = 1; q < a.nranks; ++q) {
-          const double2 v = reinterpret_cast<const double2*>(a.win[q] + IPC_FLAG_BYTES + 16 * u32)[u];
-          s.x += v.x; s.y += v.y;
-        }
-        for (int q = 0; q < a.nranks; ++q)
-          reinterpret_cast<double2*>(a.win[q] + IPC_FLAG_BYTES + a.cap + 16 * u32)[u] = s;
+      for (long long u = tid; u < a.n64; u += nthr) {
+        double s = ld_sys64(a.win[0] + IPC_FLAG_BYTES + seg64 + 8 * u);
+        for (int q = 1; q < a.nranks; ++q) s += ld_sys64(a.win[q] + IPC_FLAG_BYTES + seg64 + 8 * u);
+        for (int q = 0; q < a.nranks; ++q) st_sys64(a.win[q] + IPC_FLAG_BYTES + a.cap + seg64 + 8 * u, s);
       }
     }
   }
@@ -152,31 +157,22 @@ allreduce_ipc_kernel(const IpcArgs a) {
 
   // ---- 3. own `out` -> bucket ----
   {
-    const float4* out = reinterpret_cast<const float4*>(own + IPC_FLAG_BYTES + a.cap);
-    for (long long u = tid; u < u32; u += nthr) {
-      const float4 v = out[u];
-      if (4 * u + 3 < a.n32) reinterpret_cast<float4*>(a.f32)[u] = v;
-      else {
-        if (4 * u + 0 < a.n32) a.f32[4 * u + 0] = v.x;
-        if (4 * u + 1 < a.n32) a.f32[4 * u + 1] = v.y;
-        if (4 * u + 2 < a.n32) a.f32[4 * u + 2] = v.z;
-      }
+    const unsigned char* out = own + IPC_FLAG_BYTES + a.cap;
+    for (long long u = tid; u < p32; u += nthr) {
+      const float2 v = ld_sys(out + 8 * u);
+      a.f32[2 * u] = v.x;
+      if (2 * u + 1 < a.n32) a.f32[2 * u + 1] = v.y;
     }
-    const double2* out64 = reinterpret_cast<const double2*>(own + IPC_FLAG_BYTES + a.cap + 16 * u32);
-    for (long long u = tid; u < u64; u += nthr) {
-      const double2 v = out64[u];
-      a.f64[2 * u] = v.x;
-      if (2 * u + 1 < a.n64) a.f64[2 * u + 1] = v.y;
-    }
+    for (long long u = tid; u < a.n64; u += nthr) a.f64[u] = ld_sys64(out + seg64 + 8 * u);
   }
   // the launch's last workgroup advances the epoch (every workgroup has read it by now)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long* cnt = ipc_word(own, 19);
-    const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long old = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned long long)gridDim.x - 1) {
       __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ipc_word(own, 16), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ipc_word(own, 16), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -233,22 +233,41 @@ def test_baseline_config0_full_size_vs_reference(models_mod, tmp_path):
     assert a[0] == b[0] and a[3] == b[3] and abs(float(a[1]) - float(b[1])) <= 1e-4 and float(a[2]) == float(b[2])
 
 
-def assert_grads_vs_float64(named_gpu_grads, sd32, sd64, what, rel=1e-4):
+def assert_grads_vs_float64(named_gpu_grads, sd32, sd64, what, rel=1e-4, kink_grads=None):
     """gradients within 1e-4 of the per-tensor max-abs.  Two correct fp32 evaluations of a long recurrence /
-    a heavily cancelling sum (the float64 Sinc parameters; a LeakyReLU input within round-off of its kink) can differ from
-    EACH OTHER by more than that, so the arbiter is a float64 evaluation of the oracle (O.float64_evaluation: the same
-    formulas without intermediate fp32 rounding): per tensor, the GPU may be off the float64 value by rel * max|grad| — or,
-    where the fp32 ORACLE itself is further off than half of that, by twice the oracle's own deviation.
+    a heavily cancelling sum (the float64 Sinc parameters) can differ from EACH OTHER by more than that, so the arbiter is
+    a float64 evaluation of the oracle (O.float64_evaluation: the same formulas without intermediate fp32 rounding): per
+    tensor, the GPU may be off the float64 value by rel * max|grad| — or, where the fp32 ORACLE itself is further off than
+    half of that, by twice the oracle's own deviation.
+    kink_grads: None, or a callable -> (n, gA, gB): the float64 gradients with the n LeakyReLU inputs that lie within
+    fp32 round-off of the kink forced to the positive (gA) and to the negative (gB) branch.  Such an input lands on either
+    side in a correct fp32 evaluation, so |gA - gB| (element by element) is granted on top — evaluated only if the plain
+    bound fails, and only if n > 0.
     -> (worst gpu deviation / scale, worst oracle deviation / scale, name of the worst)."""
     worst = (0.0, 0.0, "")
+    kinks = None
     for k, g in named_gpu_grads:
         if sd64[k].grad is None:
             continue
         ref64 = sd64[k].grad
         scale = max(ref64.abs().max().item(), 1e-9)
-        e_gpu = (g.detach().cpu().double() - ref64).abs().max().item()
+        d_gpu = (g.detach().cpu().double() - ref64).abs()
+        e_gpu = d_gpu.max().item()
         e_ref = (sd32[k].grad.double() - ref64).abs().max().item()
-        assert e_gpu <= max(rel * scale, 2.0 * e_ref), "%s %s: |gpu - f64| = %.3e, |oracle_fp32 - f64| = %.3e, scale %.3e" % (
+        bound = max(rel * scale, 2.0 * e_ref)
+        if e_gpu > bound and kink_grads is not None:
+            if kinks is None:
+                kinks = kink_grads()
+                print("%s: %d activation input(s) within fp32 round-off of the kink" % (what, kinks[0]))
+            n, gA, gB = kinks
+            if n > 0:
+                slack = (gA[k] - gB[k]).abs()
+                excess = (d_gpu - slack).max().item()
+                assert excess <= bound, "%s %s: |gpu - f64| exceeds the kink slack by %.3e (bound %.3e, scale %.3e)" % (
+                    what, k, excess, bound, scale)
+                worst = max(worst, (max(excess, 0.0) / scale, e_ref / scale, k + " (beyond the kink slack)"))
+                continue
+        assert e_gpu <= bound, "%s %s: |gpu - f64| = %.3e, |oracle_fp32 - f64| = %.3e, scale %.3e" % (
             what, k, e_gpu, e_ref, scale)
         worst = max(worst, (e_gpu / scale, e_ref / scale, k))
     return worst
@@ -496,18 +515,37 @@ def test_full_size_asr_pretraining_step_vs_oracle(models_mod, tmp_path):
     (rpl + rwl).backward()
     assert abs(pl.item() - rpl.item()) <= 1e-4 and abs(wl.item() - rwl.item()) <= 1e-4, (pl.item(), rpl.item(), wl.item(), rwl.item())
     assert abs(pa.item() - rpa.item()) <= 1e-6 and abs(wa.item() - rwa.item()) <= 1e-6
-    # The arbiter is a float64 evaluation of the oracle.  (Round 3 found one conv1 output of 1.15 M within fp32 round-off of
-    # the LeakyReLU kink — -1.3e-7 in the fp32 oracle, +2.2e-7 on the GPU — which moves the tiny, heavily cancelling
-    # float64 Sinc-parameter gradients by ~1e-3 in EITHER fp32 evaluation; rounds 3-4 widened the bound for parameters
-    # upstream of such an element.  Against float64 the statement is sharper: the GPU must be within 1e-4 of the float64
-    # gradient, or no further from it than twice the fp32 oracle is.)
+    # The arbiter is a float64 evaluation of the oracle: the GPU must be within 1e-4 of the float64 gradient, or no further
+    # from it than twice the fp32 oracle is.  Round 3 found one conv1 output of 1.15 M within fp32 round-off of the
+    # LeakyReLU kink in this draw (-1.3e-7 in the fp32 oracle, +2.2e-7 on the GPU): the two fp32 evaluations then take
+    # different branches THERE, both legitimately, and the tiny float64 Sinc-parameter gradients move by ~1e-3 of their
+    # max (round 5, measured against float64: GPU 8.2e-4 off, fp32 oracle 5e-6 off — the oracle happens to share float64's
+    # branch).  Rounds 3-4 widened the bound to 3e-3 for parameters upstream of such an element; now the claim is PROVEN:
+    # where the plain bound fails, float64 gradients are evaluated with the kink-adjacent inputs (|x| < 1e-6) forced to
+    # either branch, and only their element-wise difference is granted on top of the plain bound.
     sd64 = O.to_float64({k: v.detach() for k, v in sd.items()})
     with O.float64_evaluation():
         p64, w64, _, _ = O.asr_forward(sd64, x.double(), yp, yw, cfg, {k: v.double() for k, v in masks.items()}, explicit_gru=False)
     (p64 + w64).backward()
     for k, p in pm.named_parameters():
         assert sd[k].grad is not None and p.grad is not None and p.grad.dtype == sd[k].grad.dtype, k
-    worst = assert_grads_vs_float64(((k, p.grad) for k, p in pm.named_parameters()), sd, sd64, "ASR")
+
+    def kink_grads():
+        """float64 gradients with every activation input within 1e-6 of the kink forced to one side, then to the other"""
+        out = []
+        for side in (+1, -1):
+            sdk = O.to_float64({k: v.detach() for k, v in sd.items()})
+            O.KINK, O.KINK_SEEN[0] = (1e-6, side), 0
+            try:
+                with O.float64_evaluation():
+                    a, b, _, _ = O.asr_forward(sdk, x.double(), yp, yw, cfg, {k: v.double() for k, v in masks.items()}, explicit_gru=False)
+                (a + b).backward()
+            finally:
+                O.KINK = None
+            out.append({k: v.grad for k, v in sdk.items() if v.grad is not None})
+        return O.KINK_SEEN[0], out[0], out[1]
+
+    worst = assert_grads_vs_float64(((k, p.grad) for k, p in pm.named_parameters()), sd, sd64, "ASR", kink_grads=kink_grads)
     n = sum(1 for _ in pm.named_parameters())
     print("full-size ASR step: losses %.5f / %.5f (oracle %.5f / %.5f), %d gradients, worst deviation from the float64 oracle "
           "%.2e of the tensor's max (fp32 oracle %.2e) at %s"
