@@ -130,24 +130,11 @@ def max_pool_ceil(x_ncl, k):
     return F.max_pool1d(x_ncl, kernel_size=k, ceil_mode=True)
 
 
-# Test aid for the gradient-parity arbiter (tests/test_hip_model.py): LeakyReLU / ReLU have a KINK at 0, and an input
-# within fp32 round-off of 0 lands on either side of it in two correct fp32 evaluations — the gradients upstream then
-# differ by the slope ratio, legitimately.  KINK = (delta, side): inputs with |x| < delta take the slope of the positive
-# (side > 0) or the negative (side < 0) branch; KINK_SEEN[0] counts them.  None (default): the plain function.
-KINK = None
-KINK_SEEN = [0]
-
-
 def activation(x, name):
     """models.py:210-213 — LeakyReLU(0.2) when cfg says "leaky_relu", else ReLU."""
-    neg = 0.2 if name == "leaky_relu" else 0.0
-    y = F.leaky_relu(x, 0.2) if name == "leaky_relu" else F.relu(x)
-    if KINK is not None:
-        delta, side = KINK
-        near = x.detach().abs() < delta
-        KINK_SEEN[0] += int(near.sum())
-        y = torch.where(near, x * (1.0 if side > 0 else neg), y)
-    return y
+    if name == "leaky_relu":
+        return F.leaky_relu(x, 0.2)
+    return F.relu(x)
 
 
 def dropout_with_mask(x, p, mask):
@@ -357,11 +344,14 @@ def slu_forward(sd, x_bt, y_intent, cfg, masks=None, explicit_gru=True, faithful
     return loss, acc, logits, pred
 
 
-def asr_forward(sd, x_bt, y_phoneme, y_word, cfg, masks=None, explicit_gru=True):
+def asr_forward(sd, x_bt, y_phoneme, y_word, cfg, masks=None, explicit_gru=True, stages_out=None):
     """PretrainedModel.forward (models.py:291-331): phoneme/word cross-entropy with
-    ignore_index=-1 and frame accuracies over the non-ignored frames."""
+    ignore_index=-1 and frame accuracies over the non-ignored frames.
+    stages_out: optional dict that receives the encoder's named stage outputs (tests that inspect intermediates)."""
     upto = "phoneme_features" if cfg.pretraining_type == 1 else "features"
     st = encoder_stages(sd, x_bt, cfg, masks, prefix="", explicit_gru=explicit_gru, upto=upto)
+    if stages_out is not None:
+        stages_out.update(st)
     ph = st["phoneme_features"] @ sd["phoneme_linear.weight"].t() + sd["phoneme_linear.bias"]
     ph = ph.reshape(ph.shape[0] * ph.shape[1], -1)
     yp = y_phoneme.reshape(-1)

@@ -77,7 +77,15 @@ def case(name, n32, n64, seed, graph_replays=0, straggler=False):
             else:
                 comm.allreduce_flats(flats)
         stream.synchronize()
-        ok = ok and torch.equal(f32.cpu(), want32) and torch.equal(f64.cpu(), want64)
+        got32, got64 = f32.cpu(), f64.cpu()
+        good = torch.equal(got32, want32) and torch.equal(got64, want64)
+        if not good and "diag" not in res:
+            bad = (got32 != want32).nonzero().flatten()
+            res["diag"] = {"case": name, "round": it, "rank": rank, "bad32": int(bad.numel()), "bad64": int((got64 != want64).sum()),
+                           "first": int(bad[0]) if bad.numel() else -1, "last": int(bad[-1]) if bad.numel() else -1,
+                           "got": [float(v) for v in got32[bad[:4]]], "want": [float(v) for v in want32[bad[:4]]],
+                           "own_input": [float(v) for v in h32[bad[:4]]]}
+        ok = ok and good
     res["cases"].append({"name": name, "ok": bool(ok), "rounds": rounds})
 
 

@@ -53,7 +53,7 @@ def _check(results, world, where):
         assert r["status"] == 0, r                              # no wait timed out
         assert r["oversize_refused"]
         bad = [c["name"] for c in r["cases"] if not c["ok"]]
-        assert not bad, bad
+        assert not bad, (bad, [q.get("diag") for q in results])
         assert len(r["cases"]) == 9
     print("%d ranks %s: 1.21 MB all-reduce %s us per call" % (world, where, [r["us_per_call_1p21MB"] for r in results]))
 

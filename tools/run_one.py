@@ -41,6 +41,17 @@ elif what == "gru_bf":
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
         ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS)
+elif what in ("gru_bf3_pool_300", "gru_bf3_pool_150"):
+    # round 5, the DEFAULT arithmetic (bf16x3): a frozen GRU layer as the look-ahead super-batch launches it — gx in (the
+    # projection GEMM wrote it), recurrence + Dropout(0.5) + avg-pool(2) epilogue, three bf16 planes out; T = 300 / 150
+    T, B, H = (300 if what.endswith("300") else 150), (int(sys.argv[2]) if len(sys.argv) > 2 else 1280), 128
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    keep = ops.dropout_bits(T, B, 2 * H, 0.5, 1234, 19, None, 64, "cuda")
+    gx = torch.randn(T, B, 6 * H, device="cuda")
+    for _ in range(5):
+        ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, 3, keep, 0.5, True)
+    torch.cuda.synchronize()
 elif what in ("gru_bf_pool_fused", "gru_bf_pool"):
     # the product form of a frozen GRU layer (round 4): recurrence + Dropout(0.5) + avg-pool(2) in one launch, plane output;
     # _fused: the first layer (K = 60, input projection inside the kernel, T = 300); else a K = 256 layer reading gx (T = 150)
@@ -58,23 +69,6 @@ elif what in ("gru_bf_pool_fused", "gru_bf_pool"):
         gx = torch.randn(T, B, 6 * H, device="cuda")
         for _ in range(5):
             ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, 2, keep, 0.5, True)
-    torch.cuda.synchronize()
-elif what == "gru_bf_r3":
-    # the round-3 kernel from the alt library (tools/build_alt.sh EXTRA_UNITS=tools/probes/slu_gru_bf16_r3.hip; SLU_HIP_LIB)
-    import ctypes
-    from slu_hip import lib as _lib
-    T, B, H = 300, (int(sys.argv[2]) if len(sys.argv) > 2 else 1024), 128
-    gx = torch.randn(T, B, 6 * H, device="cuda")
-    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
-    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
-    out = torch.empty(T, B, 2 * H, device="cuda")
-    fn = _lib.load().slu_gru_seq_fwd_bf16_r3
-    vp, i64 = ctypes.c_void_p, ctypes.c_int64
-    fn.restype = ctypes.c_int
-    fn.argtypes = [vp] * 8 + [i64, i64, vp, vp, i64, i64, i64, i64, ctypes.c_int, vp]
-    for _ in range(5):
-        assert fn(gx.data_ptr(), wf.data_ptr(), wr.data_ptr(), bf.data_ptr(), br.data_ptr(), out.data_ptr(), None, None, 0, 0,
-                  None, None, T, B, H, 2, 2, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
 elif what in ("wconv_sinc", "wconv_conv1"):
     # frozen CNN blocks of a 1024-sequence super-batch on the split-precision kernel (f16x2)
