@@ -47,29 +47,17 @@ struct IpcArgs {
   double* f64; long long n64;               // the float64 bucket or null
 };
 
-// Staging traffic is SYSTEM-SCOPE on both sides: 8-byte relaxed atomic stores / loads (global_store / load_dwordx2 sc0
-// sc1: written through, never served from a stale cache line) — "sc0 sc1 stores and loads on both sides" needs no release
-// / acquire fence, whatever memory type the exporting and the importing process map the window with.  (The first version
-// used plain 16-byte accesses between system-scope release / acquire fences: on ranks sharing one GPU it returned stale
-// words in the first large all-reduce after small ones — lines of `in` still cached from the previous call — and its four
-// fences cost 7 of its 16 us.)
-__device__ __forceinline__ void st_sys(void* p, float a, float b) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
-                     (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ float2 ld_sys(const void* p) {
-  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM);
-  return make_float2(__uint_as_float((unsigned)(v & 0xffffffffull)), __uint_as_float((unsigned)(v >> 32)));
-}
-__device__ __forceinline__ void st_sys64(void* p, double a) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(a),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double ld_sys64(const void* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_SYSTEM));
+// Staging traffic is SYSTEM-SCOPE on both sides: 16-byte buffer stores / loads with sc0 sc1 (aux 17: written through, never
+// served from a stale cache line) — "sc0 sc1 stores and loads on both sides" needs no release / acquire fence, whatever
+// memory type the exporting and the importing process map the window with.  (The first version used plain 16-byte
+// accesses between system-scope release / acquire fences: its four fences cost 7 of its 16 us.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int IPC_SYS = 17;                                 // aux bits: sc0 (1) | sc1 (16) = system scope
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ipc_rsrc(unsigned char* win, long long bytes) {
+  const unsigned long long b = (unsigned long long)win;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 
 // wait until flag word `line + src` of the own window has reached `epoch`, for EVERY rank src (the own one too: the other
@@ -114,41 +102,71 @@ allreduce_ipc_kernel(const IpcArgs a) {
   const unsigned long long epoch =
       __hip_atomic_load(ipc_word(own, 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
   const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, nthr = (long long)gridDim.x * 256;
-  const long long p32 = (a.n32 + 1) / 2;                   // 8-byte pairs of the fp32 segment (an odd tail is padded with 0)
-  const long long seg64 = 16 * ((a.n32 + 3) / 4);          // byte offset of the float64 segment inside a staging area
+  const long long u32 = (a.n32 + 3) / 4;                   // 16-byte units of the fp32 segment (tail padded with zeros)
+  const long long u64 = (a.n64 + 1) / 2;                   // 16-byte units of the float64 segment
+  const long long ua = u32 + u64;                          // the float64 units follow the fp32 units in a staging area
+  const long long wbytes = IPC_FLAG_BYTES + 2 * a.cap;     // < 2^31 (checked by the launcher)
+  const int IN = (int)IPC_FLAG_BYTES, OUT = (int)(IPC_FLAG_BYTES + a.cap);
+  __amdgpu_buffer_rsrc_t rs[IPC_MAX_RANKS];
+#pragma unroll
+  for (int q = 0; q < IPC_MAX_RANKS; ++q) rs[q] = ipc_rsrc(a.win[q < a.nranks ? q : a.rank], wbytes);
+  const __amdgpu_buffer_rsrc_t rown = ipc_rsrc(own, wbytes);
 
   // ---- 1. bucket -> own `in` ----
-  {
-    unsigned char* in = own + IPC_FLAG_BYTES;
-    for (long long u = tid; u < p32; u += nthr)
-      st_sys(in + 8 * u, a.f32[2 * u], 2 * u + 1 < a.n32 ? a.f32[2 * u + 1] : 0.f);
-    for (long long u = tid; u < a.n64; u += nthr) st_sys64(in + seg64 + 8 * u, a.f64[u]);
+  for (long long u = tid; u < ua; u += nthr) {
+    u32x4 o;
+    if (u < u32) {
+      if (4 * u + 3 < a.n32) {
+        const float4 v = reinterpret_cast<const float4*>(a.f32)[u];
+        o = u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      } else {
+        o = u32x4{4 * u + 0 < a.n32 ? __float_as_uint(a.f32[4 * u + 0]) : 0u, 4 * u + 1 < a.n32 ? __float_as_uint(a.f32[4 * u + 1]) : 0u,
+                  4 * u + 2 < a.n32 ? __float_as_uint(a.f32[4 * u + 2]) : 0u, 0u};
+      }
+    } else {
+      const long long e = 2 * (u - u32);
+      const unsigned long long d0 = (unsigned long long)__double_as_longlong(a.f64[e]);
+      const unsigned long long d1 = e + 1 < a.n64 ? (unsigned long long)__double_as_longlong(a.f64[e + 1]) : 0ull;
+      o = u32x4{(unsigned)d0, (unsigned)(d0 >> 32), (unsigned)d1, (unsigned)(d1 >> 32)};
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(o, rown, IN + (int)(16 * u), 0, IPC_SYS);
   }
   ipc_publish(a, 17, 0, epoch);
   ipc_wait_all(a, 0, epoch);
 
   // ---- 2. reduce this rank's chunk over all ranks (rank order), push the sum into every rank's `out` ----
   {
-    const long long c0 = p32 * a.rank / a.nranks, c1 = p32 * (a.rank + 1) / a.nranks;
+    const long long c0 = u32 * a.rank / a.nranks, c1 = u32 * (a.rank + 1) / a.nranks;
     for (long long u = c0 + tid; u < c1; u += nthr) {
-      float2 v[IPC_MAX_RANKS];
+      u32x4 v[IPC_MAX_RANKS];
 #pragma unroll
       for (int q = 0; q < IPC_MAX_RANKS; ++q)
-        if (q < a.nranks) v[q] = ld_sys(a.win[q] + IPC_FLAG_BYTES + 8 * u);
-      float2 s = v[0];
+        if (q < a.nranks) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs[q], IN + (int)(16 * u), 0, IPC_SYS);
+      float s0 = __uint_as_float(v[0][0]), s1 = __uint_as_float(v[0][1]), s2 = __uint_as_float(v[0][2]), s3 = __uint_as_float(v[0][3]);
 #pragma unroll
       for (int q = 1; q < IPC_MAX_RANKS; ++q)
-        if (q < a.nranks) { s.x += v[q].x; s.y += v[q].y; }
+        if (q < a.nranks) {
+          s0 += __uint_as_float(v[q][0]); s1 += __uint_as_float(v[q][1]);
+          s2 += __uint_as_float(v[q][2]); s3 += __uint_as_float(v[q][3]);
+        }
+      const u32x4 o = {__float_as_uint(s0), __float_as_uint(s1), __float_as_uint(s2), __float_as_uint(s3)};
 #pragma unroll
       for (int q = 0; q < IPC_MAX_RANKS; ++q)
-        if (q < a.nranks) st_sys(a.win[q] + IPC_FLAG_BYTES + a.cap + 8 * u, s.x, s.y);
+        if (q < a.nranks) __builtin_amdgcn_raw_buffer_store_b128(o, rs[q], OUT + (int)(16 * u), 0, IPC_SYS);
     }
     // the float64 segment (160 values when the Sinc layer trains) is rank 0's
     if (a.rank == 0) {
-      for (long long u = tid; u < a.n64; u += nthr) {
-        double s = ld_sys64(a.win[0] + IPC_FLAG_BYTES + seg64 + 8 * u);
-        for (int q = 1; q < a.nranks; ++q) s += ld_sys64(a.win[q] + IPC_FLAG_BYTES + seg64 + 8 * u);
-        for (int q = 0; q < a.nranks; ++q) st_sys64(a.win[q] + IPC_FLAG_BYTES + a.cap + seg64 + 8 * u, s);
+      for (long long u = u32 + tid; u < ua; u += nthr) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int q = 0; q < a.nranks; ++q) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs[q], IN + (int)(16 * u), 0, IPC_SYS);
+          const double d0 = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
+          const double d1 = __longlong_as_double((long long)(((unsigned long long)v[3] << 32) | v[2]));
+          if (q == 0) { t0 = d0; t1 = d1; } else { t0 += d0; t1 += d1; }
+        }
+        const unsigned long long b0 = (unsigned long long)__double_as_longlong(t0), b1 = (unsigned long long)__double_as_longlong(t1);
+        const u32x4 o = {(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)};
+        for (int q = 0; q < a.nranks; ++q) __builtin_amdgcn_raw_buffer_store_b128(o, rs[q], OUT + (int)(16 * u), 0, IPC_SYS);
       }
     }
   }
@@ -156,14 +174,21 @@ allreduce_ipc_kernel(const IpcArgs a) {
   ipc_wait_all(a, 8, epoch);
 
   // ---- 3. own `out` -> bucket ----
-  {
-    const unsigned char* out = own + IPC_FLAG_BYTES + a.cap;
-    for (long long u = tid; u < p32; u += nthr) {
-      const float2 v = ld_sys(out + 8 * u);
-      a.f32[2 * u] = v.x;
-      if (2 * u + 1 < a.n32) a.f32[2 * u + 1] = v.y;
+  for (long long u = tid; u < ua; u += nthr) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rown, OUT + (int)(16 * u), 0, IPC_SYS);
+    if (u < u32) {
+      if (4 * u + 3 < a.n32) {
+        reinterpret_cast<float4*>(a.f32)[u] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+      } else {
+        if (4 * u + 0 < a.n32) a.f32[4 * u + 0] = __uint_as_float(v[0]);
+        if (4 * u + 1 < a.n32) a.f32[4 * u + 1] = __uint_as_float(v[1]);
+        if (4 * u + 2 < a.n32) a.f32[4 * u + 2] = __uint_as_float(v[2]);
+      }
+    } else {
+      const long long e = 2 * (u - u32);
+      a.f64[e] = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
+      if (e + 1 < a.n64) a.f64[e + 1] = __longlong_as_double((long long)(((unsigned long long)v[3] << 32) | v[2]));
     }
-    for (long long u = tid; u < a.n64; u += nthr) a.f64[u] = ld_sys64(out + seg64 + 8 * u);
   }
   // the launch's last workgroup advances the epoch (every workgroup has read it by now)
   __syncthreads();
@@ -242,6 +267,7 @@ extern "C" int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_
   SLU_REQUIRE(((uintptr_t)f32 & 15) == 0 && ((uintptr_t)f64 & 15) == 0, "slu_comm_allreduce_ipc: buckets must be 16-byte aligned");
   IpcArgs a;
   a.cap = (window_bytes - IPC_FLAG_BYTES) / 2;
+  SLU_REQUIRE(window_bytes < (1LL << 31), "slu_comm_allreduce_ipc: windows above 2 GiB are not addressable by one buffer descriptor");
   SLU_REQUIRE(window_bytes > IPC_FLAG_BYTES && 16 * ((n32 + 3) / 4) + 16 * ((n64 + 1) / 2) <= a.cap,
               "slu_comm_allreduce_ipc: payload of %lld + %lld elements exceeds the window's staging capacity (%lld bytes)",
               (long long)n32, (long long)n64, (long long)a.cap);
