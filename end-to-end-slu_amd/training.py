@@ -68,9 +68,12 @@ def _lookahead_width(depth, batch_size):
 def _ramp_plan(n_run, width, n_slots):
     """Sizes of the FIRST super-batches of a run of n_run batches (the rest are `width` batches each), and how many of
     them are started side by side instead of one behind the other.  Default: ONE capped first super-batch — a run that
-    fits in two super-batches is split 60 : 40 (20 batches: 12 + 8; the second one's encoder runs beside the first one's
-    steps and is ready when they end) —, nothing side by side.
-    SLU_RAMP=a,b,c: explicit sizes, started side by side (needs as many look-ahead slots, SLU_LOOKAHEAD_SLOTS).  Round 5
+    fits in two super-batches is split 70 : 30 (20 batches: 14 + 6; the second one's encoder runs beside the first one's
+    steps and is ready when they end; rounds 2-4, f16x2 frozen stages: 60 : 40.  Round 5, bf16x3, the driver's 20-step
+    command, profiles/r05_g_first_sb.txt: first 10 / 12 / 14 / 16 / 20 batches -> 188.3 / 194.9 / 201.8 / 189.6 / 176.3 k
+    utt/s; running the first super-batch on an unmasked stream — the training partition is idle until it is through —
+    changed nothing: 190.1 / 196.5 / 187.2 / 180.3 for 12 / 14 / 16 / 20) —, nothing side by side.
+    SLU_RAMP=a,b,c: explicit sizes, one behind the other (SLU_RAMP_SIDE=1 with as many look-ahead slots: side by side).  Round 5
     measured the obvious refinement and it is SLOWER (profiles/r05_a_sweep.txt, bf16x3 frozen stages, the driver's 20-step
     command): 3 + 6 + 11 side by side 181.9 k utt/s, 2 + 5 + 13: 184.3 k, 4 + 6 + 10: 186.4 k, against 194.2 k for 12 + 8
     chained; time to the first step 3.0 - 4.0 ms against 3.3.  The look-ahead streams have no priorities
@@ -81,10 +84,11 @@ def _ramp_plan(n_run, width, n_slots):
     env = os.environ.get("SLU_RAMP", "0")
     if env not in ("auto", "0"):
         sizes = [max(1, int(v)) for v in env.split(",") if v.strip()]
-        return sizes, (len(sizes) if n_slots >= len(sizes) else 0)
+        side = os.environ.get("SLU_RAMP_SIDE", "0") == "1" and n_slots >= len(sizes)
+        return sizes, (len(sizes) if side else 0)
     T = min(n_run, width)
     if env == "0" or n_slots < 3 or T < 9:
-        return ([max(2, -(-3 * n_run // 5))] if n_run < 2 * width else []), 0
+        return ([max(2, -(-7 * n_run // 10))] if n_run < 2 * width else []), 0
     a = max(2, int(T / 7.0 + 0.5))
     b = max(a, int(2 * T / 7.0 + 0.5))
     return [a, b, T - a - b], 3

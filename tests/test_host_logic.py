@@ -192,21 +192,23 @@ def test_bench_stdout_carries_the_json_line_only(tmp_path):
 
 def test_ramp_plan_of_the_first_super_batches(monkeypatch):
     """training._ramp_plan: by default one capped first super-batch (a run that fits in two is split 60 : 40), nothing side
-    by side; SLU_RAMP=a,b,c / auto = the measured-and-slower side-by-side start, kept as an option."""
+    by side (70 : 30 for a run that fits in two); SLU_RAMP = explicit sizes / auto = the measured-and-slower side-by-side start."""
     import training
     monkeypatch.delenv("SLU_RAMP", raising=False)
-    assert training._ramp_plan(20, 20, 2) == ([12], 0)                  # the driver's 20-step command: 12 + 8
-    assert training._ramp_plan(5, 20, 2) == ([3], 0)
+    assert training._ramp_plan(20, 20, 2) == ([14], 0)                  # the driver's 20-step command: 14 + 6
+    assert training._ramp_plan(5, 20, 2) == ([4], 0)
     assert training._ramp_plan(100, 20, 2) == ([], 0) and training._ramp_plan(100, 20, 3) == ([], 0)
     monkeypatch.setenv("SLU_RAMP", "auto")
     assert training._ramp_plan(20, 20, 3) == ([3, 6, 11], 3)
     assert training._ramp_plan(512, 24, 3) == ([3, 7, 14], 3)
     sizes, side = training._ramp_plan(12, 20, 3)
     assert sum(sizes) == 12 and side == 3 and sizes[0] <= sizes[1] <= sizes[2]
-    assert training._ramp_plan(5, 20, 3) == ([3], 0) and training._ramp_plan(20, 20, 2) == ([12], 0)
+    assert training._ramp_plan(5, 20, 3) == ([4], 0) and training._ramp_plan(20, 20, 2) == ([14], 0)
     monkeypatch.setenv("SLU_RAMP", "2,4,8")
-    assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 3)
-    assert training._ramp_plan(20, 20, 2) == ([2, 4, 8], 0)             # too few slots: the sizes, one behind the other
+    assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 0)             # explicit sizes: one behind the other ...
+    monkeypatch.setenv("SLU_RAMP_SIDE", "1")
+    assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 3)             # ... side by side on request,
+    assert training._ramp_plan(20, 20, 2) == ([2, 4, 8], 0)             # if there are enough slots
 
 
 def test_data_plane_selection_without_a_gpu(monkeypatch):
