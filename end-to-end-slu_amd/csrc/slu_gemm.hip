@@ -1031,14 +1031,16 @@ extern "C" int slu_gemm_tn_batched(const float* const* A, const int64_t* lda, co
 }
 
 // Split-K form of slu_gemm_tn_batched for long k ranges (include/slu_hip.h).
-static int tn_splitk_factor(int64_t tiles, int64_t kmin) {
+static int tn_splitk_factor(int64_t tiles, int64_t kmin, int64_t max_wg = 0) {
   // ONE round of workgroups: two fit a CU (216 VGPRs), 512 on the chip — 654 workgroups (nine splits of a layer's 72 tiles)
   // ran as two rounds, the second a quarter full: 168 us per launch against 141-150 with seven; at least 256 k rows per
   // split, at most 16.  (Eight splits put split ks on XCD ks — linear id tile * 8 + ks — so that a k row crosses HBM -> L2
   // once: FETCH_SIZE 266 -> 91 MB per launch, L2 hits 39 -> 75 %, and the launch got SLOWER, 174 us: nine eighths of a round,
   // and the bound is not HBM but the L1's outstanding requests — k-slow 16-byte loads, 8 MAC per operand byte, ~16 B/clk per
   // CU needed at the MFMA peak; profiles/r04_am_pmc_tn_splitk.txt.)
-  int64_t ks = 512 / tiles;
+  // max_wg > 0 (slu_gemm_tn_batched_splitk_wg): a smaller budget — a launch that runs BESIDE a latency-bound recurrence on a
+  // branch of its own must leave whole CUs empty for it (192-216 workgroups spread one per CU)
+  int64_t ks = (max_wg > 0 ? max_wg : 512) / tiles;
   ks = ks < 1 ? 1 : ks;
   if (ks > 16) ks = 16;
   const int64_t by_k = kmin / 256 < 1 ? 1 : kmin / 256;
@@ -1054,21 +1056,26 @@ static bool tn_splitk_shapes_ok(const float* const* A, const int64_t* lda, const
   return true;
 }
 
-extern "C" size_t slu_gemm_tn_splitk_workspace_bytes(const int64_t* M, const int64_t* N, const int64_t* K, int64_t count) {
+extern "C" size_t slu_gemm_tn_splitk_workspace_bytes_wg(const int64_t* M, const int64_t* N, const int64_t* K, int64_t count,
+                                                        int64_t max_workgroups) {
   if (!M || !N || !K || count < 1 || count > 4) return 0;
   int64_t tiles = 0, kmin = K[0];
   for (int q = 0; q < (int)count; ++q) {
     tiles += cdiv(M[q], 64) * cdiv(N[q], 64);
     kmin = K[q] < kmin ? K[q] : kmin;
   }
-  return (size_t)tiles * tn_splitk_factor(tiles, kmin) * 4096 * sizeof(float);
+  return (size_t)tiles * tn_splitk_factor(tiles, kmin, max_workgroups) * 4096 * sizeof(float);
 }
 
-extern "C" int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
-                                          float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
-                                          const int64_t* K, int64_t count, const float* rowsum_src, int64_t rowsum_rows,
-                                          int64_t rowsum_cols, float* rowsum_dst, void* workspace, size_t workspace_bytes,
-                                          uint32_t* tickets, int64_t n_tickets, void* stream) {
+extern "C" size_t slu_gemm_tn_splitk_workspace_bytes(const int64_t* M, const int64_t* N, const int64_t* K, int64_t count) {
+  return slu_gemm_tn_splitk_workspace_bytes_wg(M, N, K, count, 0);
+}
+
+extern "C" int slu_gemm_tn_batched_splitk_wg(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                             float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
+                                             const int64_t* K, int64_t count, const float* rowsum_src, int64_t rowsum_rows,
+                                             int64_t rowsum_cols, float* rowsum_dst, void* workspace, size_t workspace_bytes,
+                                             uint32_t* tickets, int64_t n_tickets, int64_t max_workgroups, void* stream) {
   SLU_REQUIRE(A && B && C && lda && ldb && ldc && M && N && K, "slu_gemm_tn_batched_splitk: null pointer");
   SLU_REQUIRE((rowsum_src == nullptr) == (rowsum_dst == nullptr), "slu_gemm_tn_batched_splitk: rowsum_src and rowsum_dst go together");
   SLU_REQUIRE(!rowsum_src || (rowsum_rows >= 1 && rowsum_cols >= 1 && rowsum_rows < (1LL << 30) && rowsum_cols < (1LL << 30)),
@@ -1090,7 +1097,8 @@ extern "C" int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* 
     a.p[q].tile_end = tiles;
     kmin = K[q] < kmin ? K[q] : kmin;
   }
-  const int ksplit = tn_splitk_factor(tiles, kmin);
+  SLU_REQUIRE(max_workgroups >= 0, "slu_gemm_tn_batched_splitk: negative workgroup budget");
+  const int ksplit = tn_splitk_factor(tiles, kmin, max_workgroups);
   if (ksplit > 1) {
     const size_t need = (size_t)tiles * ksplit * 4096 * sizeof(float);
     if (!workspace || workspace_bytes < need)
@@ -1106,6 +1114,15 @@ extern "C" int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* 
                      a, ksplit, reinterpret_cast<float*>(workspace), (unsigned*)tickets);
   SLU_CHECK_LAUNCH("gemm_tn_wide_splitk_kernel");
   return SLU_OK;
+}
+
+extern "C" int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                          float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
+                                          const int64_t* K, int64_t count, const float* rowsum_src, int64_t rowsum_rows,
+                                          int64_t rowsum_cols, float* rowsum_dst, void* workspace, size_t workspace_bytes,
+                                          uint32_t* tickets, int64_t n_tickets, void* stream) {
+  return slu_gemm_tn_batched_splitk_wg(A, lda, B, ldb, C, ldc, M, N, K, count, rowsum_src, rowsum_rows, rowsum_cols, rowsum_dst,
+                                       workspace, workspace_bytes, tickets, n_tickets, 0, stream);
 }
 
 extern "C" int slu_colsum_f32(const float* X, int64_t x_rs, float* out, int64_t M, int64_t N,

@@ -95,6 +95,8 @@ SIGNATURES = {
     "slu_gemm_tn_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp]),
     "slu_gemm_tn_splitk_workspace_bytes": (c_sz, [vp, vp, vp, c_i64]),
     "slu_gemm_tn_batched_splitk": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp, c_sz, vp, c_i64, vp]),
+    "slu_gemm_tn_splitk_workspace_bytes_wg": (c_sz, [vp, vp, vp, c_i64, c_i64]),
+    "slu_gemm_tn_batched_splitk_wg": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_i64, c_i64, vp, vp, c_sz, vp, c_i64, c_i64, vp]),
     "slu_gemm_small_batched": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, c_i64, vp]),
     "slu_colsum_f32": (c_int, [vp, c_i64, vp, c_i64, c_i64, c_int, vp]),
     "slu_gru_reserve_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),

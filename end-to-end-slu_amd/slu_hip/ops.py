@@ -87,6 +87,11 @@ class _Fork:
     _used = {}
 
     capture_forks = False     # set by pipeline.StepGraph while it captures a step with nothing running beside it
+    # Round 5: set by training.Trainer._iterate_full_steps for the steps of a FULLY trainable loop (nothing runs beside them):
+    # the batched weight-gradient launch of a GRU layer with thousands of rows goes to an auxiliary stream / graph branch
+    # (ops.wgrad_branch: joined at the end of the layer's backward, or — mode "pass" — left open until the trainer's single
+    # join after loss.backward()).
+    defer = False
 
     def __init__(self, device, i):
         # Inside a captured step of the look-ahead pipeline the branches land on extra hardware queues that
@@ -793,6 +798,25 @@ def tn_tickets(dev, tiles=0):
     return tk
 
 
+def wgrad_branch():
+    """-> (mode, workgroup budget) of the batched weight-gradient launch of a long GRU layer inside a FULLY trainable loop
+    (GRULayerFn.backward under _Fork.defer).  SLU_WGRAD_BRANCH:
+      layer (default)  on an auxiliary stream / graph branch beside the layer's data-gradient GEMM, joined at the end of the
+                       layer's backward, with a budget of SLU_WGRAD_WGS = 216 workgroups (of the 512 a full round has);
+      pass             the same launch left open until the whole backward pass has ended (beside the BPTT of the layer
+                       below; the trainer joins once) — bit-identical, measured slower;
+      0                in line on the main stream, full round (rounds 3-4).
+    Measured on MI355X (profiles/r05_hi_wgrad_branch.txt; B = 64 x 3 s, every layer trainable, ms per step, same box): in line
+    2.780 | layer 2.620 | pass 2.697 (budget 144: 2.707, 288: 2.687, 512: 2.838); second box: in line 2.945 | layer with
+    budget 72 / 144 / 216 / 288 / 360 / 512: 2.979 / 2.855 / 2.804 / 2.939 / 2.968 / 2.969.  Beside the data-gradient GEMM the
+    weight gradients are free as long as they do not take every CU; beside the BPTT they still lengthen its dependent steps
+    by more than they save, budget or not."""
+    mode = os.environ.get("SLU_WGRAD_BRANCH", "layer")
+    if mode not in ("layer", "pass", "0"):
+        raise ValueError("SLU_WGRAD_BRANCH=%r: expected layer, pass or 0" % mode)
+    return mode, (0 if mode == "0" else int(os.environ.get("SLU_WGRAD_WGS", "216")))
+
+
 def gemm_tn_splitk_ok(operands):
     """operands: [(A (K, M), B (K, N)), ...] — shapes slu_gemm_tn_batched_splitk takes: every M, N and row stride a
     multiple of 4, unit column strides, 16-byte aligned operands."""
@@ -801,7 +825,7 @@ def gemm_tn_splitk_ok(operands):
                for A, B in operands)
 
 
-def gemm_tn_batched_splitk(problems, rowsum=None):
+def gemm_tn_batched_splitk(problems, rowsum=None, max_wg=0):
     """gemm_tn_batched for long k ranges (the weight gradients of a GRU layer with thousands of rows): one launch, the k
     range split over workgroups, partial tiles folded in a fixed order by each tile's last workgroup."""
     import ctypes
@@ -819,17 +843,18 @@ def gemm_tn_batched_splitk(problems, rowsum=None):
     Ms, Ns, Ks = (arr(i64, [p[2].shape[0] for p in problems]), arr(i64, [p[2].shape[1] for p in problems]),
                   arr(i64, [p[0].shape[0] for p in problems]))
     dev = problems[0][0].device
-    wsb = L.slu_gemm_tn_splitk_workspace_bytes(Ms, Ns, Ks, n)
+    wsb = L.slu_gemm_tn_splitk_workspace_bytes_wg(Ms, Ns, Ks, n, int(max_wg))    # max_wg: workgroup budget (0 = a full round)
     ws = _workspace(wsb, dev)
     tiles = sum(-(-p[2].shape[0] // 64) * -(-p[2].shape[1] // 64) for p in problems)
     tk = tn_tickets(dev, tiles)
-    _lib.check(L.slu_gemm_tn_batched_splitk(arr(vp, [p[0].data_ptr() for p in problems]), arr(i64, [p[0].stride(0) for p in problems]),
+    _lib.check(L.slu_gemm_tn_batched_splitk_wg(arr(vp, [p[0].data_ptr() for p in problems]), arr(i64, [p[0].stride(0) for p in problems]),
                                             arr(vp, [p[1].data_ptr() for p in problems]), arr(i64, [p[1].stride(0) for p in problems]),
                                             arr(vp, [p[2].data_ptr() for p in problems]), arr(i64, [p[2].stride(0) for p in problems]),
                                             Ms, Ns, Ks, n,
                                             rowsum[0].data_ptr() if rowsum else None, rowsum[0].shape[0] if rowsum else 0,
                                             rowsum[1].numel() if rowsum else 0, rowsum[1].data_ptr() if rowsum else None,
-                                            ws.data_ptr(), wsb, tk.data_ptr(), tk.numel(), _stream()), "slu_gemm_tn_batched_splitk")
+                                            ws.data_ptr(), wsb, tk.data_ptr(), tk.numel(), int(max_wg), _stream()),
+               "slu_gemm_tn_batched_splitk")
 
 
 def colsum(x2d, out=None, accumulate=False):
@@ -1335,9 +1360,23 @@ class GRULayerFn(torch.autograd.Function):
             # a few thousand rows (the intent layer of the look-ahead pipeline): every weight gradient of the layer
             # in ONE launch (no split-K workspaces, no reduce launches).  The choice depends on the shape only.
             n = (T - 1) * B
-            dW = torch.empty(D * 3 * H, I, dtype=torch.float32, device=dev)
-            probs = [(g2, x2, dW)]
+            # Round 5, fully trainable loops (_Fork.defer; wgrad_branch has the modes and the measurements): the launch goes to
+            # an auxiliary stream / graph branch with a workgroup budget, beside this layer's data-gradient GEMM — or, mode
+            # "pass", stays open until the trainer's single join after the whole backward pass.  What makes the open form safe:
+            #  * every gradient it writes is a tensor of its own (not a view of a stacked buffer): AccumulateGrad takes such
+            #    a tensor over without reading it — a view it would CLONE, on this stream, before the branch has written it;
+            #  * the bias sums (views of one small buffer) are formed on THIS stream by slu_colsum_f32;
+            #  * the operands are recorded on the branch's stream, so the allocator does not hand their memory out again
+            #    before the branch has read them.
+            mode, budget = wgrad_branch() if (long_rows and _Fork.defer) else ("0", 0)
+            join_here = False
             outs = []
+            if budget:
+                dWs = [torch.empty(3 * H, I, dtype=torch.float32, device=dev) for _ in range(D)]
+                probs = [(g2[:, d * 3 * H:(d + 1) * 3 * H], x2, dWs[d]) for d in range(D)]
+            else:
+                dW = torch.empty(D * 3 * H, I, dtype=torch.float32, device=dev)
+                probs = [(g2, x2, dW)]
             for d in range(D):
                 hd = h2[:, d * 3 * H:(d + 1) * 3 * H]
                 ga, hp = (hd[B:], r2[:n, :H]) if d == 0 else (hd[:n], r2[B:, H:])
@@ -1345,14 +1384,29 @@ class GRULayerFn(torch.autograd.Function):
                 probs.append((ga, hp, dWh))
                 outs.append(dWh)
             rowsum = None
-            if need_bias:                                  # the per-tile bias partial sums, summed by the same launch
+            if need_bias and budget:
+                dbp = colsum(dbp.view(dbp.shape[0], D * 6 * H)).view(D, 6 * H)
+            elif need_bias:                                # the per-tile bias partial sums, summed by the same launch
                 db = torch.empty(dbp.shape[1:], dtype=torch.float32, device=dev)
                 rowsum = (dbp.contiguous(), db)
                 dbp = db
-            (gemm_tn_batched_splitk if long_rows else gemm_tn_batched)(probs, rowsum)
-            grads[3] = dW[:3 * H]
-            if D == 2:
-                grads[4] = dW[3 * H:]
+            if budget:
+                fork = _Fork(dev, 0)
+                with fork:
+                    gemm_tn_batched_splitk(probs, None, max_wg=budget)
+                if fork.active:
+                    for t in (d_gx, d_gh, x, raw):
+                        t.record_stream(fork.side)
+                    if mode == "layer":
+                        join_here = True                 # after the data-gradient GEMM below
+                grads[3] = dWs[0]
+                if D == 2:
+                    grads[4] = dWs[1]
+            else:
+                (gemm_tn_batched_splitk if long_rows else gemm_tn_batched)(probs, rowsum)
+                grads[3] = dW[:3 * H]
+                if D == 2:
+                    grads[4] = dW[3 * H:]
             for d in range(D):
                 grads[7 + 2 * d] = outs[d]
                 if ng[8 + 2 * d]:
@@ -1363,6 +1417,8 @@ class GRULayerFn(torch.autograd.Function):
                 grads[5] = dbp[0, :3 * H]
             if D == 2 and ng[6]:
                 grads[6] = dbp[1, :3 * H]
+            if join_here:
+                _Fork.join(dev)
             return tuple(grads)
         # The weight-gradient GEMMs are independent of each other and of the data-gradient GEMM: they
         # run on auxiliary streams (graph branches under capture) while dx proceeds on this one.

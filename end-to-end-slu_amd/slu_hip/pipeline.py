@@ -331,9 +331,10 @@ class StepGraph:
         bucket.release_grads()
         self.one = torch.ones((), dtype=torch.float32, device=dev)      # root gradient (no per-step fill)
         self.g1 = torch.cuda.CUDAGraph()
-        ops._aux_streams(dev, 3)                    # created before the capture starts
-        with torch.cuda.stream(stream):
-            ops.tn_tickets(dev)                     # likewise: the split-K weight-gradient launch's ticket words of this stream
+        aux = ops._aux_streams(dev, 3)              # created before the capture starts
+        for st_ in [stream] + (aux[:1] if forks else []):
+            with torch.cuda.stream(st_):
+                ops.tn_tickets(dev)                 # likewise: the split-K weight-gradient launch's ticket words of this stream
         ops._Fork.capture_forks = bool(forks)
         try:
             with capture(self.g1, stream):
@@ -342,6 +343,7 @@ class StepGraph:
                 with _models.frozen_math_scope(guard):
                     self.metrics, self.loss = forward(self.inputs, self.rng)
                 self.loss.backward(self.one)
+                ops._Fork.join(dev)                 # branches the backward pass left open (ops._Fork.defer): joined ONCE, here
                 if guard is not None:
                     guard.collect()
                 if self.dp:

@@ -162,6 +162,9 @@ class Trainer:
     def _step(self, loss):
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if loss.is_cuda:
+            from slu_hip import ops
+            ops._Fork.join(loss.device)          # branches left open by the backward pass (ops._Fork.defer): one join
         if self.bucket is not None:
             self.bucket.allreduce_mean()
         self.optimizer.step()
@@ -375,6 +378,11 @@ class Trainer:
             if pm is None or not any(not any(q.requires_grad for q in st.parameters()) for st in pm._stages()):
                 return None
             return pm.range_guard() if pm.f16x2_allowed() else None
+        from slu_hip import ops as _ops
+        was_defer = _ops._Fork.defer
+        # nothing runs beside these steps: the weight-gradient launches of long GRU layers may stay open until the end of the
+        # backward pass (ops.GRULayerFn.backward)
+        _ops._Fork.defer = os.environ.get("SLU_GRAPH_FORKS", "1") != "0"
         try:
             with torch.cuda.stream(main):
                 pm.warm_weight_caches()
@@ -392,6 +400,7 @@ class Trainer:
                         self._accumulate(sums, vals, len(batch[0]))
                     yield vals, len(batch[0])
         finally:
+            _ops._Fork.defer = was_defer
             outer.wait_stream(main)
 
     def _iterate(self, loader, train, asr, accumulate=False):

@@ -159,6 +159,17 @@ int slu_gemm_tn_batched_splitk(const float* const* A, const int64_t* lda, const 
                                int64_t count, const float* rowsum_src, int64_t rowsum_rows, int64_t rowsum_cols,
                                float* rowsum_dst, void* workspace, size_t workspace_bytes, uint32_t* tickets,
                                int64_t n_tickets, void* stream);
+/* The same with a workgroup BUDGET (ABI 8): max_workgroups > 0 caps tiles x splits (default 512 = one round at two per CU).
+ * For a launch that runs on a graph branch of its own beside a latency-bound recurrence (the weight gradients of GRU layer
+ * l beside the BPTT of layer l - 1): 192 - 216 workgroups spread one per CU and leave whole CUs empty for the recurrence's
+ * 32 workgroups.  The split count decides the summation order: the same budget gives the same bits.                      */
+size_t slu_gemm_tn_splitk_workspace_bytes_wg(const int64_t* M, const int64_t* N, const int64_t* K, int64_t count,
+                                             int64_t max_workgroups);
+int slu_gemm_tn_batched_splitk_wg(const float* const* A, const int64_t* lda, const float* const* B, const int64_t* ldb,
+                                  float* const* C, const int64_t* ldc, const int64_t* M, const int64_t* N,
+                                  const int64_t* K, int64_t count, const float* rowsum_src, int64_t rowsum_rows,
+                                  int64_t rowsum_cols, float* rowsum_dst, void* workspace, size_t workspace_bytes,
+                                  uint32_t* tickets, int64_t n_tickets, int64_t max_workgroups, void* stream);
 /* out[n] = [out[n] if accumulate] + sum_m X[m*x_rs + n]   (bias gradients)                       */
 /* Up to four independent SMALL-M products in one launch (latency-bound shapes: the seq2seq decoder's per-step Linear /
  * GRUCell products and their data gradients, models.py:427-485): C_q (M x N) = [C_q +] A_q (M x K, row stride lda, k fast)

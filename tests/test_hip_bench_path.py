@@ -240,7 +240,7 @@ def test_captured_asr_pretraining_step_equals_eager(tmp_path, monkeypatch):
                 vals.append(v.clone() if torch.is_tensor(v) else
                             torch.stack([t.detach().float().reshape(()).cuda() for t in v]))
         torch.cuda.synchronize()
-        assert trainer.graph_stats()["step_graphs"] == (1 if graphs == "1" else 0)
+        assert trainer.graph_stats()["step_graphs"] == 1 and trainer.graph_stats()["capture_failures"] == 0
         assert trainer.graph_stats()["capture_failures"] == 0
         results[graphs] = (torch.stack(vals).cpu(), {k: v.detach().cpu().clone() for k, v in pm.state_dict().items()})
     assert torch.equal(results["0"][0], results["1"][0])
@@ -279,3 +279,54 @@ def test_split_schemes_hold_fp32_class_over_the_input_dynamic_range(tmp_path, mo
         err = (feats[math] - ref).abs().max().item()
         print("input amplitude %g, %s: max-abs deviation from the exact-fp32 kernels %.3e (feature range %.3f)" % (scale, math, err, span))
         assert err <= 2e-5 * max(span, 1.0)
+
+
+def test_weight_gradient_branches_of_fully_trainable_loops(tmp_path, monkeypatch):
+    """Fully trainable loops (round 5): the batched weight-gradient launch of every long GRU layer runs on an auxiliary stream
+    / graph branch with a workgroup budget.  SLU_WGRAD_BRANCH=layer (default) joins it at the end of its layer's backward
+    (beside the data-gradient GEMM); =pass leaves the very same launches open until ONE join after the whole backward pass
+    (beside the BPTT of the layer below).  If the open form had a hazard — a gradient cloned or packed before its branch wrote
+    it, an operand's memory handed out again too early — the two would differ: they must be BIT-IDENTICAL, losses and final
+    parameters, over eager steps, the capture and replays.  SLU_WGRAD_BRANCH=0 (in line, no budget: another split count, i.e.
+    another summation order) must agree to fp32 round-off."""
+    import data
+    import models
+    import training
+    cfg = _full_cfg(tmp_path)
+    torch.manual_seed(1)
+    torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
+    ds = data.SyntheticSLUDataset(2, 32, 48000, cfg.values_per_slot, seed=77)
+    dev_batches = [tuple(t.cuda() for t in b) for b in ds.batches]
+    n_steps = 7                                          # three eager steps, the capture, three replays
+    loader = [dev_batches[i % 2] for i in range(n_steps)]
+
+    def run(mode):
+        monkeypatch.setenv("SLU_WGRAD_BRANCH", mode)
+        monkeypatch.setenv("SLU_GRAPHS", "1")
+        monkeypatch.setenv("SLU_LOOKAHEAD", "auto")
+        torch.manual_seed(2)
+        model = models.Model(cfg)
+        for p in model.parameters():
+            p.requires_grad = True                        # unfreeze_all_layers end state: nothing to look ahead to
+        models.set_dropout_seed(99)
+        trainer = training.Trainer(model, cfg)
+        model.train()
+        losses = []
+        import contextlib
+        with contextlib.closing(trainer._iterate(loader, True, False)) as it:
+            for v, _ in it:
+                losses.append(float(v[0]))
+        torch.cuda.synchronize()
+        assert trainer.graph_stats()["step_graphs"] == 1 and trainer.graph_stats()["capture_failures"] == 0
+        return losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    l_def, sd_def = run("pass")
+    l_join, sd_join = run("layer")
+    assert l_def == l_join
+    for k, v in sd_join.items():
+        assert torch.equal(v, sd_def[k]), k
+    l_off, sd_off = run("0")
+    assert max(abs(a - b) for a, b in zip(l_def, l_off)) <= 1e-4
+    worst = max((sd_off[k].double() - sd_def[k].double()).abs().max().item() for k in sd_off)
+    print("branched vs in-line weight-gradient launches after %d steps: worst parameter difference %.2e" % (n_steps, worst))
+    assert worst <= 5e-3          # Adam normalises by |g|: a near-zero gradient entry may flip sign between summation orders
