@@ -846,7 +846,7 @@ def dp_point(model, trainer, batches, steps, asr, fence):
     rank, world = dp.world()
     others = [("ipc", dp.IpcComm)] + ([] if dp._shared_device() else [("rccl", dp.DirectComm)])
     for kind, ctor in others:
-        if kind == used or b.comm is None and os.environ.get("SLU_COMM") == "torch" and False:
+        if kind == used:
             continue
         try:                                          # construction is collective: every rank walks this list in order
             other = ctor(rank, world, dev)

@@ -70,15 +70,16 @@ rm -rf $O/pmc_gru_bf3_pool*
 cat $O/pmc_gru_bf.txt
 timeout 1200 python bench.py --steps 20 --warmup 5 > $O/bench_20.json 2> $O/bench_20.err; echo "bench20 rc=$?"
 timeout 400 python bench.py --no-cpu-baseline --no-large-batch --no-side-runs > $O/bench_512.json 2> $O/bench_512.err; echo "bench512 rc=$?"
+timeout 400 python bench.py --gpus 2 --share-gpu --steps 20 --warmup 5 --no-cpu-baseline --no-large-batch --no-side-runs --no-kernel-table > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err; echo "bench 2 ranks rc=$?"
 head -24 $O/default_kernel_stats.txt | cut -c1-170
 python - <<PY
 import json
-for f in ("bench_20", "bench_512"):
+for f in ("bench_20", "bench_512", "bench_2ranks_one_gpu"):
     try:
         d = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1])
         r = d.get("roofline") or {}
         print(f, d["value"], d["ms_per_step"], d.get("steady_state"), {k: r.get(k) for k in ("kernel", "bound", "frac", "frac_hbm", "frac_mfma_algorithmic", "mfma_issued_frac", "prefix_traffic_over_8d", "prefix_ms_per_super_batch_isolated")})
-        for k in ("exact_fp32", "frozen_f16x2", "host_inputs", "other_workloads", "cpu_baseline", "parity"):
+        for k in ("exact_fp32", "frozen_f16x2", "host_inputs", "other_workloads", "cpu_baseline", "parity", "rccl"):
             if d.get(k): print("   ", k, json.dumps(d[k])[:700])
     except Exception as e:
         print(f, "ERR", e)
