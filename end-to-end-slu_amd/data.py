@@ -279,6 +279,27 @@ def _loader_workers():
     return min(16, os.cpu_count() or 1)
 
 
+class ForkSafeDataLoader(torch.utils.data.DataLoader):
+    """DataLoader whose worker processes are forked from a process that holds GPU objects (hipGraphs, CU-masked streams,
+    events, IPC windows).  A forked child must never FINALISE such objects — their destructors call into a HIP runtime
+    that does not exist in the child — yet CPython may run a garbage collection right inside the child's fork bootstrap
+    (`threading._after_fork`), and any unreachable cycle that holds one of them is then destroyed there: seen once as
+    "Fatal Python error: Segmentation fault ... Garbage-collecting" in a worker of the ASR loader.  So: collect in the
+    PARENT (where the runtime is alive) right before the workers start, and freeze what exists (`gc.freeze`: the children
+    inherit a permanent generation their collections never visit); the parent unfreezes afterwards."""
+
+    def __iter__(self):
+        if self.num_workers <= 0:
+            return super().__iter__()
+        import gc
+        gc.collect()
+        gc.freeze()
+        try:
+            return super().__iter__()            # the workers are forked here
+        finally:
+            gc.unfreeze()
+
+
 def wav_num_samples(path):
     """Number of frames of a wav file from its header (falls back to decoding for non-PCM files)."""
     import wave
@@ -367,18 +388,18 @@ class SLUDataset(torch.utils.data.Dataset):
         seed = getattr(config, "seed", 0)
         if os.environ.get("SLU_BUCKET_BATCHES", "0") == "1" and collate.pad_multiple > 1:
             lengths = [wav_num_samples(p) for p in self._paths] * self.upsample_factor
-            self.loader = torch.utils.data.DataLoader(
+            self.loader = ForkSafeDataLoader(
                 self, num_workers=_loader_workers(), collate_fn=collate, pin_memory=pin,
                 batch_sampler=LengthBucketBatchSampler(lengths, config.training_batch_size, collate.pad_multiple,
                                                        rank=rank, world=world, seed=seed))
         elif world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self, num_replicas=world, rank=rank,
                                                                       shuffle=True, seed=seed)
-            self.loader = torch.utils.data.DataLoader(
+            self.loader = ForkSafeDataLoader(
                 self, batch_size=config.training_batch_size, num_workers=_loader_workers(), sampler=sampler,
                 collate_fn=collate, pin_memory=pin)
         else:
-            self.loader = torch.utils.data.DataLoader(
+            self.loader = ForkSafeDataLoader(
                 self, batch_size=config.training_batch_size, num_workers=_loader_workers(), shuffle=True,
                 collate_fn=collate, pin_memory=pin)
 
@@ -547,11 +568,11 @@ class ASRDataset(torch.utils.data.Dataset):
         if world > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self, num_replicas=world, rank=rank,
                                                                       shuffle=True, seed=getattr(config, "seed", 0))
-            self.loader = torch.utils.data.DataLoader(
+            self.loader = ForkSafeDataLoader(
                 self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), sampler=sampler,
                 collate_fn=CollateWavsASR(), pin_memory=torch.cuda.is_available())
         else:
-            self.loader = torch.utils.data.DataLoader(
+            self.loader = ForkSafeDataLoader(
                 self, batch_size=config.pretraining_batch_size, num_workers=_loader_workers(), shuffle=True,
                 collate_fn=CollateWavsASR(), pin_memory=torch.cuda.is_available())
 

@@ -65,11 +65,12 @@ def _lookahead_width(depth, batch_size):
     return max(2, min(32, (8 * cus) // max(1, batch_size)))
 
 
-def _ramp_plan(n_run, width, n_slots):
+def _ramp_plan(n_run, width, n_slots, first_share=0.7):
     """Sizes of the FIRST super-batches of a run of n_run batches (the rest are `width` batches each), and how many of
     them are started side by side instead of one behind the other.  Default: ONE capped first super-batch — a run that
-    fits in two super-batches is split 70 : 30 (20 batches: 14 + 6; the second one's encoder runs beside the first one's
-    steps and is ready when they end; rounds 2-4, f16x2 frozen stages: 60 : 40.  Round 5, bf16x3, the driver's 20-step
+    fits in two super-batches is split first_share : rest — 70 : 30 with the frozen stages on bf16x3 / exact fp32 (20
+    batches: 14 + 6), 60 : 40 on the faster f16x2 (12 + 8; with 14 + 6 its 20-step rate fell from 240 to 214 k utt/s) —: the
+    second one's encoder runs beside the first one's steps and is ready when they end.  Round 5, bf16x3, the driver's 20-step
     command, profiles/r05_g_first_sb.txt: first 10 / 12 / 14 / 16 / 20 batches -> 188.3 / 194.9 / 201.8 / 189.6 / 176.3 k
     utt/s; running the first super-batch on an unmasked stream — the training partition is idle until it is through —
     changed nothing: 190.1 / 196.5 / 187.2 / 180.3 for 12 / 14 / 16 / 20) —, nothing side by side.
@@ -88,7 +89,7 @@ def _ramp_plan(n_run, width, n_slots):
         return sizes, (len(sizes) if side else 0)
     T = min(n_run, width)
     if env == "0" or n_slots < 3 or T < 9:
-        return ([max(2, -(-7 * n_run // 10))] if n_run < 2 * width else []), 0
+        return ([max(2, int(math.ceil(first_share * n_run - 1e-9)))] if n_run < 2 * width else []), 0
     a = max(2, int(T / 7.0 + 0.5))
     b = max(a, int(2 * T / 7.0 + 0.5))
     return [a, b, T - a - b], 3
@@ -516,7 +517,9 @@ class Trainer:
                 if bs not in wcache:
                     w = _lookahead_width(depth, bs)
                     if launched == 0:
-                        ramp[0], ramp[1] = _ramp_plan(n_run, w, len(self._slots))
+                        import models as _models
+                        share = 0.6 if _models.guarded_frozen_nsplit(self.model) == 2 else 0.7
+                        ramp[0], ramp[1] = _ramp_plan(n_run, w, len(self._slots), share)
                     wcache[bs] = min(ramp[0][launched], w) if launched < len(ramp[0]) else w
                 return wcache[bs]
             while not group or len(group) < width():

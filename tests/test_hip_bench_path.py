@@ -240,7 +240,7 @@ def test_captured_asr_pretraining_step_equals_eager(tmp_path, monkeypatch):
                 vals.append(v.clone() if torch.is_tensor(v) else
                             torch.stack([t.detach().float().reshape(()).cuda() for t in v]))
         torch.cuda.synchronize()
-        assert trainer.graph_stats()["step_graphs"] == 1 and trainer.graph_stats()["capture_failures"] == 0
+        assert trainer.graph_stats()["step_graphs"] == (1 if graphs == "1" else 0)
         assert trainer.graph_stats()["capture_failures"] == 0
         results[graphs] = (torch.stack(vals).cpu(), {k: v.detach().cpu().clone() for k, v in pm.state_dict().items()})
     assert torch.equal(results["0"][0], results["1"][0])

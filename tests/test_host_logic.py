@@ -160,19 +160,19 @@ def test_head_dropout_fusion_rule(monkeypatch):
     assert not ops.head_dropout_fusable(w, 0.5, None, "none", 1)
 
 
-def test_committed_profile_tables_cover_the_default_dominant_kernel():
-    """bench.py turns roofline.frac_isolated into frac_in_loop / traffic with profiles/inloop_kernel_us.json and
-    profiles/pmc_traffic.json: both must carry the dominant kernel of the default command under the name bench.py's
-    kernel table gives it (the split scheme is part of the name)."""
-    import json
-    with open(os.path.join(ROOT, "profiles", "inloop_kernel_us.json")) as f:
-        inloop = json.load(f)
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-        pmc = json.load(f)
-    name = "gru_bf_fwd_kernel<128,2>"
-    assert inloop[name]["avg_us"] > 0 and os.path.exists(os.path.join(ROOT, inloop[name]["source"]))
-    assert 0.9 <= pmc[name]["traffic_over_algorithmic"] <= 1.5
-    assert os.path.exists(os.path.join(ROOT, pmc[name]["source"]))
+def test_committed_profile_evidence_named_by_the_bench_line_exists():
+    """bench.py measures `roofline` itself and reads nothing from profiles/ at run time; what it cannot measure without a
+    profiler (HBM bytes from the PMC counters, in-loop kernel durations) it NAMES as `traffic_source` / `in_loop_source`.
+    Those committed files must exist and be about the dominant kernel of the default arithmetic (bf16x3: the scheme is
+    part of the kernel's name)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for rel in (bench.PMC_SOURCE, bench.INLOOP_SOURCE):
+        path = os.path.join(ROOT, rel)
+        assert os.path.isfile(path), rel
+        text = open(path).read()
+        assert "gru_bf_fwd_kernel<128,3>" in text.replace(", ", ",") or "gru_bf_fwd_kernel<128,3," in text.replace(", ", ","), rel
+    assert "traffic / algorithmic" in open(os.path.join(ROOT, bench.PMC_SOURCE)).read()
 
 
 def test_bench_stdout_carries_the_json_line_only(tmp_path):
@@ -196,7 +196,8 @@ def test_ramp_plan_of_the_first_super_batches(monkeypatch):
     import training
     monkeypatch.delenv("SLU_RAMP", raising=False)
     assert training._ramp_plan(20, 20, 2) == ([14], 0)                  # the driver's 20-step command: 14 + 6
-    assert training._ramp_plan(5, 20, 2) == ([4], 0)
+    assert training._ramp_plan(20, 20, 2, 0.6) == ([12], 0)             # the opt-in f16x2 arithmetic: 12 + 8
+    assert training._ramp_plan(5, 20, 2) == ([4], 0) and training._ramp_plan(5, 20, 2, 0.6) == ([3], 0)
     assert training._ramp_plan(100, 20, 2) == ([], 0) and training._ramp_plan(100, 20, 3) == ([], 0)
     monkeypatch.setenv("SLU_RAMP", "auto")
     assert training._ramp_plan(20, 20, 3) == ([3, 6, 11], 3)
