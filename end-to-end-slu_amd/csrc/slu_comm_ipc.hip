@@ -202,6 +202,25 @@ allreduce_ipc_kernel(const IpcArgs a) {
   }
 }
 
+// Touch every page of every window once (one system-scope load per 4 KiB, the sum parked in the own window's scratch
+// line): peer windows are mapped lazily (hipIpcMemLazyEnablePeerAccess — the only mode hipIpcOpenMemHandle offers), so
+// the FIRST access to a page of a peer's window can stall its wave for a long time while the mapping is established.
+// Inside the all-reduce such a stall makes a rank miss its peers' bounded waits (seen: the first 1.21 MB call after a few
+// tiny ones timed out now and then on ranks sharing a GPU).  This kernel has no flags and no waits: it just pays the
+// first-touch cost up front, once per communicator.
+__global__ void __launch_bounds__(256)
+ipc_touch_kernel(const IpcArgs a, long long window_bytes) {
+  unsigned acc = 0;
+  const long long pages = (window_bytes + 4095) / 4096;
+  for (int q = 0; q < a.nranks; ++q) {
+    const __amdgpu_buffer_rsrc_t rs = ipc_rsrc(a.win[q], window_bytes);
+    for (long long pg = (long long)blockIdx.x * 256 + threadIdx.x; pg < pages; pg += (long long)gridDim.x * 256)
+      acc += __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(pg * 4096), 0, IPC_SYS);
+  }
+  if (acc == 0x9e3779b9u)        // never true for a zeroed / flag-only window: keeps the loads alive
+    __hip_atomic_store(ipc_word(a.win[a.rank], 21), (unsigned long long)acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace slu
 
 using namespace slu;
@@ -279,6 +298,23 @@ extern "C" int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_
   a.f32 = f32; a.n32 = n32; a.f64 = f64; a.n64 = n64;
   hipLaunchKernelGGL(allreduce_ipc_kernel, dim3(IPC_WGS), dim3(256), 0, (hipStream_t)stream, a);
   SLU_CHECK_LAUNCH("allreduce_ipc_kernel");
+  return SLU_OK;
+}
+
+extern "C" int slu_comm_ipc_window_touch(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes, void* stream) {
+  SLU_REQUIRE(windows && nranks >= 1 && nranks <= IPC_MAX_RANKS && rank >= 0 && rank < nranks,
+              "slu_comm_ipc_window_touch: 1..%d ranks", IPC_MAX_RANKS);
+  SLU_REQUIRE(window_bytes > IPC_FLAG_BYTES && window_bytes < (1LL << 31), "slu_comm_ipc_window_touch: bad window size");
+  IpcArgs a;
+  a.cap = (window_bytes - IPC_FLAG_BYTES) / 2;
+  for (int q = 0; q < IPC_MAX_RANKS; ++q) {
+    a.win[q] = q < nranks ? (unsigned char*)windows[q] : nullptr;
+    SLU_REQUIRE(q >= nranks || a.win[q], "slu_comm_ipc_window_touch: window of rank %d is null", q);
+  }
+  a.rank = (int)rank; a.nranks = (int)nranks;
+  a.f32 = nullptr; a.n32 = 0; a.f64 = nullptr; a.n64 = 0;
+  hipLaunchKernelGGL(ipc_touch_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, a, (long long)window_bytes);
+  SLU_CHECK_LAUNCH("ipc_touch_kernel");
   return SLU_OK;
 }
 

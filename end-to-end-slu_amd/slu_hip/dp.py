@@ -171,6 +171,17 @@ class IpcComm:
                     self._windows[q] = w.value
         if world_size > 1:
             dist.barrier()                       # every window is mapped everywhere before the first launch
+        # pay the first-touch cost of the lazily mapped peer windows now, not inside a call with bounded waits
+        import time
+        with torch.cuda.device(device):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _lib.check(self._L.slu_comm_ipc_window_touch(self._windows, rank, world_size, self.window_bytes,
+                                                         torch.cuda.current_stream().cuda_stream), "slu_comm_ipc_window_touch")
+            torch.cuda.synchronize()
+            self.first_touch_ms = 1e3 * (time.perf_counter() - t0)      # what the lazy mappings cost (reported by the tests)
+        if world_size > 1:
+            dist.barrier()
 
     def _launch(self, f32, f64):
         self._lib.check(self._L.slu_comm_allreduce_ipc(self._windows, self.rank, self.world_size, self.window_bytes,

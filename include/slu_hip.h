@@ -518,6 +518,10 @@ int slu_comm_ipc_window_destroy(void* own_window);
 int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes,
                            float* f32, int64_t n32, double* f64, int64_t n64, void* stream);
 int slu_comm_ipc_status(void* own_window, int64_t* status_out);
+/* One load per 4 KiB page of every window, no flags, no waits: peer windows are mapped lazily, and a first touch inside
+ * the all-reduce can stall a rank past its peers' bounded waits.  Call once after every window is open (then synchronise
+ * and barrier) — slu_hip/dp.IpcComm does.                                                                             */
+int slu_comm_ipc_window_touch(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ torch.cuda.set_device(local)
 lib.require_gfx950()
 dev = torch.device("cuda", local)
 comm = dp.IpcComm(rank, ws, dev)
-res = {"cases": [], "backend": dist.get_backend() if ws > 1 else "none"}
+res = {"cases": [], "backend": dist.get_backend() if ws > 1 else "none", "first_touch_ms": round(comm.first_touch_ms, 3)}
 
 
 def ordered_sum(t):
