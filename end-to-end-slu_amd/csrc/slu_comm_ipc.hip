@@ -17,7 +17,7 @@
 // The fp32 bucket and the 160-element float64 bucket of the Sinc parameters travel as TYPED SEGMENTS of the same
 // payload: one launch, one collective per step whatever the trainable set.
 // Flags hold a monotonically increasing epoch (never reset), the epoch counter lives in device memory: the launch has
-// no per-call host argument and replays as a node of the step's hipGraph.  Every wait is bounded: a peer that never
+// no per-call host argument and replays as a node of the step's hipGraph.  Every wait is bounded (about a minute): a peer that never
 // arrives raises the window's status word instead of hanging the GPU (slu_comm_ipc_status).
 // A rank's `in` may be overwritten by its next call only after every peer has read it: a peer raises flag_out AFTER
 // its reads, and a rank leaves step 3 only after it has seen every peer's flag_out.  A rank's `out` is written by the
@@ -30,7 +30,10 @@ namespace slu {
 constexpr int IPC_MAX_RANKS = 8;
 constexpr long long IPC_FLAG_BYTES = 4096;
 constexpr int IPC_WGS = 64;                 // all resident at once on any partition of this package (>= 16 CUs, 8 per CU)
-constexpr unsigned IPC_SPIN_LIMIT = 1u << 21;   // polls of ~1 us: a peer that is two seconds late is not coming
+// Polls of ~1 us each before a wait gives up and raises the status word: about a minute.  Not seconds: ranks that SHARE a
+// GPU (the test set-up) were seen to be descheduled for more than two seconds now and then (status raised in 1 of ~10
+// four-rank runs with a 2^21 limit; the longest wait of a call is kept in the window, slu_comm_ipc_max_wait).
+constexpr unsigned IPC_SPIN_LIMIT = 1u << 26;
 
 // window-relative offsets of the control words (each on a 64-byte line of its own)
 //   flag_in[src]  at 64 * src            flag_out[src] at 64 * (8 + src)
@@ -75,6 +78,8 @@ __device__ __forceinline__ void ipc_wait_all(const IpcArgs& a, int line, unsigne
         break;
       }
     }
+    if (spins > 4096)            // the longest wait so far, in polls (diagnostics: slu_comm_ipc_max_wait)
+      __hip_atomic_fetch_max(ipc_word(own, 22), (unsigned long long)spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
 }
@@ -298,6 +303,17 @@ extern "C" int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_
   a.f32 = f32; a.n32 = n32; a.f64 = f64; a.n64 = n64;
   hipLaunchKernelGGL(allreduce_ipc_kernel, dim3(IPC_WGS), dim3(256), 0, (hipStream_t)stream, a);
   SLU_CHECK_LAUNCH("allreduce_ipc_kernel");
+  return SLU_OK;
+}
+
+// The longest wait of any call so far, in polls (~1 us each; 0 = none above 4096).  Synchronises the device.
+extern "C" int slu_comm_ipc_max_wait(void* own_window, int64_t* polls_out) {
+  SLU_REQUIRE(own_window && polls_out, "slu_comm_ipc_max_wait: null pointer");
+  unsigned long long v = 0;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(&v, (unsigned char*)own_window + 64 * 22, 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_comm_ipc_max_wait: %s", hipGetErrorString(e));
+  *polls_out = (int64_t)v;
   return SLU_OK;
 }
 

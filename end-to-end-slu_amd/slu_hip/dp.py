@@ -209,6 +209,14 @@ class IpcComm:
             self._lib.check(self._L.slu_comm_ipc_status(self._own, ctypes.byref(v)), "slu_comm_ipc_status")
         return int(v.value)
 
+    def max_wait_polls(self):
+        """The longest flag wait of any call so far, in polls of ~1 us (diagnostics; synchronises the device)."""
+        import ctypes
+        v = ctypes.c_int64(0)
+        with torch.cuda.device(self.device):
+            self._lib.check(self._L.slu_comm_ipc_max_wait(self._own, ctypes.byref(v)), "slu_comm_ipc_max_wait")
+        return int(v.value)
+
     def close(self):
         if getattr(self, "_own", None):
             torch.cuda.synchronize()

@@ -507,7 +507,7 @@ int slu_comm_allreduce_group(void* comm, float* f32, int64_t n32, double* f64, i
  * bucket and the float64 bucket are typed segments of one payload: ONE launch per step, in place, SUM, added in rank
  * order by one rank per element (replicas receive bit-identical sums); asynchronous on `stream`, no host argument per
  * call (flags carry a device-resident epoch), so the launch replays as a node of the step's hipGraph.  All ranks must
- * call it the same number of times with the same sizes.  Waits are bounded (~2 s): slu_comm_ipc_status (synchronises
+ * call it the same number of times with the same sizes.  Waits are bounded (~1 min): slu_comm_ipc_status (synchronises
  * the device) returns 0, or 1 + q when a wait for rank q timed out.  window_create / open / close / destroy allocate,
  * map and release (never under capture).                                                                          */
 int64_t slu_comm_ipc_window_bytes(int64_t payload_bytes);
@@ -518,6 +518,7 @@ int slu_comm_ipc_window_destroy(void* own_window);
 int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes,
                            float* f32, int64_t n32, double* f64, int64_t n64, void* stream);
 int slu_comm_ipc_status(void* own_window, int64_t* status_out);
+int slu_comm_ipc_max_wait(void* own_window, int64_t* polls_out);   /* longest wait so far in ~1 us polls (diagnostics)   */
 /* One load per 4 KiB page of every window, no flags, no waits: peer windows are mapped lazily, and a first touch inside
  * the all-reduce can stall a rank past its peers' bounded waits.  Call once after every window is open (then synchronise
  * and barrier) — slu_hip/dp.IpcComm does.                                                                             */

@@ -110,6 +110,7 @@ e1.record()
 torch.cuda.synchronize()
 res["us_per_call_1p21MB"] = round(1e3 * e0.elapsed_time(e1) / 50, 2)
 res["status"] = comm.status()
+res["max_wait_polls"] = comm.max_wait_polls()
 # a payload beyond the window's capacity is refused before anything is launched
 try:
     comm.allreduce(torch.zeros((9 << 20) // 4, dtype=torch.float32, device=dev))
