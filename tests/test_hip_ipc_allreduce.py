@@ -63,9 +63,10 @@ def _check(results, world, where):
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_ipc_allreduce_ranks_sharing_one_gpu(tmp_path, world):
     """Up to FOUR ranks on one GPU: their kernels spin on each other's flags and must therefore run side by side.  Eight
-    processes oversubscribe the device's hardware queues, the scheduler time-slices them (measured: 22.8 ms per call
-    instead of 20 us, profiles/r05_e_ipc_shared_gpu.txt) and a bounded wait can expire — an artefact of the shared-GPU
-    test set-up that one rank per GPU does not have (the N = 8 case below runs there)."""
+    processes oversubscribe the device's hardware queues and the scheduler time-slices them (measured: 22.8 ms per call
+    instead of 20 us, profiles/r05_e_ipc_shared_gpu.txt) — an artefact of the shared-GPU test set-up that one rank per GPU
+    does not have (the N = 8 case below runs there).  The uneven-arrival cases make real stragglers: the rank whose first
+    matmul initialises rocBLAS arrives 1.5 - 5 s late (longest flag wait 0.6 - 2.1 M polls, printed below)."""
     _check(_run(tmp_path, world, shared=True), world, "sharing GPU 0")
 
 
