@@ -654,6 +654,12 @@ class Trainer:
                     self._say("acc: " + str(hit))
                     self._say("guess: " + guess[0])
                     self._say("truth: " + truth[0])
+        comm = self.bucket.comm if self.bucket is not None else None
+        if train and comm is not None and hasattr(comm, "status"):
+            st = comm.status()                 # the epoch statistics are read here anyway: the device is idle
+            if st != 0:
+                raise RuntimeError("data parallel: rank %d gave up waiting for rank %d inside the gradient all-reduce (bounded "
+                                   "wait, slu_comm_allreduce_ipc): the replicas are out of step" % (self.rank, st - 1))
         means = self._epoch_means(self.epoch_sums[:len(names)].tolist() + [string_acc], num_examples, dev)
         if not all(math.isfinite(float(m)) for m in means[:len(names)]):
             import models
