@@ -7,6 +7,7 @@ Layouts used between kernels (the host mirror in models.py converts at the modul
 torch is plumbing here: it owns the device buffers, the stream and the autograd tape.  All
 arithmetic of the hot path happens in libslu_hip.so; there is no fallback path.
 """
+import contextlib
 import os
 
 import torch
@@ -1368,7 +1369,11 @@ class GRULayerFn(torch.autograd.Function):
             #  * the bias sums (views of one small buffer) are formed on THIS stream by slu_colsum_f32;
             #  * the operands are recorded on the branch's stream, so the allocator does not hand their memory out again
             #    before the branch has read them.
-            mode, budget = wgrad_branch() if (long_rows and _Fork.defer) else ("0", 0)
+            # The budget (and with it the split count = the summation order) depends on the SHAPE only, so that every loop
+            # kind — captured, eager, look-ahead with trainable long layers — produces the same bits; the branch itself only
+            # where nothing runs beside the step (_Fork.defer).
+            mode, budget = wgrad_branch() if long_rows else ("0", 0)
+            branch = bool(budget) and _Fork.defer
             join_here = False
             outs = []
             if budget:
@@ -1391,10 +1396,10 @@ class GRULayerFn(torch.autograd.Function):
                 rowsum = (dbp.contiguous(), db)
                 dbp = db
             if budget:
-                fork = _Fork(dev, 0)
+                fork = _Fork(dev, 0) if branch else contextlib.nullcontext()
                 with fork:
                     gemm_tn_batched_splitk(probs, None, max_wg=budget)
-                if fork.active:
+                if branch and fork.active:
                     for t in (d_gx, d_gh, x, raw):
                         t.record_stream(fork.side)
                     if mode == "layer":

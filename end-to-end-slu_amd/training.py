@@ -381,9 +381,9 @@ class Trainer:
             return pm.range_guard() if pm.f16x2_allowed() else None
         from slu_hip import ops as _ops
         was_defer = _ops._Fork.defer
-        # nothing runs beside these steps: the weight-gradient launches of long GRU layers may stay open until the end of the
-        # backward pass (ops.GRULayerFn.backward)
-        _ops._Fork.defer = os.environ.get("SLU_GRAPH_FORKS", "1") != "0"
+        # nothing runs beside these steps: the weight-gradient launches of long GRU layers go to a graph branch
+        # (ops.GRULayerFn.backward, ops.wgrad_branch); the flag is raised per step, never across a yield
+        defer = os.environ.get("SLU_GRAPH_FORKS", "1") != "0"
         try:
             with torch.cuda.stream(main):
                 pm.warm_weight_caches()
@@ -395,8 +395,11 @@ class Trainer:
                     fused_now = fused and guard is None
                     fwd = forward if (fused_now or not fused) else forward_plain
                     key = ("full", asr, trainable, fused_now) + tuple((tuple(t.shape), t.dtype) for t in ins)
-                    vals = self._graph_step(key, ins, next_rng_step(), fwd, main,
-                                            forks=os.environ.get("SLU_GRAPH_FORKS", "1") != "0", guard=guard)
+                    _ops._Fork.defer = defer
+                    try:
+                        vals = self._graph_step(key, ins, next_rng_step(), fwd, main, forks=defer, guard=guard)
+                    finally:
+                        _ops._Fork.defer = was_defer
                     if sums is not None and not fused_now:
                         self._accumulate(sums, vals, len(batch[0]))
                     yield vals, len(batch[0])
@@ -445,14 +448,26 @@ class Trainer:
             if train and self._graphable():
                 yield from self._iterate_full_steps(loader, asr, sums)
                 return
-            for batch in loader:
-                with torch.set_grad_enabled(train):
-                    vals, loss = self._forward_losses(batch, asr)
-                    if train:
-                        self._step(loss)
-                if sums is not None:
-                    self._accumulate(sums, vals, len(batch[0]))
-                yield vals, len(batch[0])
+            # the same arithmetic as the captured loop (the weight-gradient branch of long GRU layers and its workgroup
+            # budget, ops.wgrad_branch): SLU_GRAPHS=0 and =1 stay bit-identical
+            from slu_hip import ops as _ops
+            was_defer = _ops._Fork.defer
+            on_gpu = train and all(p.is_cuda for p in self.model.parameters())
+            try:
+                for batch in loader:
+                    _ops._Fork.defer = on_gpu and os.environ.get("SLU_GRAPH_FORKS", "1") != "0"
+                    try:
+                        with torch.set_grad_enabled(train):
+                            vals, loss = self._forward_losses(batch, asr)
+                            if train:
+                                self._step(loss)
+                    finally:
+                        _ops._Fork.defer = was_defer
+                    if sums is not None:
+                        self._accumulate(sums, vals, len(batch[0]))
+                    yield vals, len(batch[0])
+            finally:
+                _ops._Fork.defer = was_defer
             return
         # ---- encoder look-ahead pipeline (slu_hip/pipeline.py) --------------------------------------
         import collections
