@@ -800,8 +800,10 @@ def tn_tickets(dev, tiles=0):
 
 
 def wgrad_branch():
-    """-> (mode, workgroup budget) of the batched weight-gradient launch of a long GRU layer inside a FULLY trainable loop
-    (GRULayerFn.backward under _Fork.defer).  SLU_WGRAD_BRANCH:
+    """-> (mode, workgroup budget) of the batched weight-gradient launch of a long GRU layer (>= 2048 rows).  The BUDGET
+    applies to every such launch (the split count decides the summation order: it must not depend on the loop kind); the
+    BRANCH only inside a fully trainable loop (GRULayerFn.backward under _Fork.defer), elsewhere the launch stays in line.
+    SLU_WGRAD_BRANCH:
       layer (default)  on an auxiliary stream / graph branch beside the layer's data-gradient GEMM, joined at the end of the
                        layer's backward, with a budget of SLU_WGRAD_WGS = 216 workgroups (of the 512 a full round has);
       pass             the same launch left open until the whole backward pass has ended (beside the BPTT of the layer
