@@ -149,28 +149,49 @@ class IpcComm:
         self.window_bytes = int(self._L.slu_comm_ipc_window_bytes(payload_bytes))
         fine = 0 if os.environ.get("SLU_IPC_COARSE", "0") == "1" else 1
         own, handle = ctypes.c_void_p(), (ctypes.c_char * 64)()
-        with torch.cuda.device(device):
-            _lib.check(self._L.slu_comm_ipc_window_create(self.window_bytes, fine, ctypes.byref(own), handle),
-                       "slu_comm_ipc_window_create")
-        self._own = own
-        self._peers = {}
-        handles = [bytes(handle)]
+        self._own, self._peers = None, {}
+        # Every step of the set-up that can fail on ONE rank is followed by an agreement over the control plane, so that
+        # all ranks raise together (a rank that raised alone would leave the others inside the next collective).
+        err = None
+        try:
+            with torch.cuda.device(device):
+                _lib.check(self._L.slu_comm_ipc_window_create(self.window_bytes, fine, ctypes.byref(own), handle),
+                           "slu_comm_ipc_window_create")
+            self._own = own
+        except Exception as e:                                # noqa: BLE001
+            err = str(e)
+        mine = (err is None, bytes(handle))
+        gathered = [mine]
         if world_size > 1:
-            handles = [None] * world_size
-            dist.all_gather_object(handles, bytes(handle))
+            gathered = [None] * world_size
+            dist.all_gather_object(gathered, mine)
+        if not all(ok for ok, _ in gathered):
+            self._release()
+            raise _lib.SluHipError("IpcComm: window creation failed on rank(s) %s%s"
+                                   % ([q for q, (ok, _) in enumerate(gathered) if not ok], "" if err is None else ": " + err))
         self._windows = (ctypes.c_void_p * world_size)()
-        with torch.cuda.device(device):
-            for q in range(world_size):
-                if q == rank:
-                    self._windows[q] = own.value
-                else:
-                    w = ctypes.c_void_p()
-                    _lib.check(self._L.slu_comm_ipc_window_open((ctypes.c_char * 64).from_buffer_copy(handles[q]),
-                                                                ctypes.byref(w)), "slu_comm_ipc_window_open")
-                    self._peers[q] = w
-                    self._windows[q] = w.value
+        try:
+            with torch.cuda.device(device):
+                for q in range(world_size):
+                    if q == rank:
+                        self._windows[q] = own.value
+                    else:
+                        w = ctypes.c_void_p()
+                        _lib.check(self._L.slu_comm_ipc_window_open((ctypes.c_char * 64).from_buffer_copy(gathered[q][1]),
+                                                                    ctypes.byref(w)), "slu_comm_ipc_window_open")
+                        self._peers[q] = w
+                        self._windows[q] = w.value
+        except Exception as e:                                # noqa: BLE001
+            err = str(e)
         if world_size > 1:
-            dist.barrier()                       # every window is mapped everywhere before the first launch
+            flag = torch.tensor([0.0 if err else 1.0])
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # also the barrier: every window is mapped everywhere
+            if flag.item() < 1.0:
+                self._release()
+                raise _lib.SluHipError("IpcComm: mapping a peer window failed on some rank%s" % ("" if err is None else ": " + err))
+        elif err:
+            self._release()
+            raise _lib.SluHipError("IpcComm: " + err)
         # pay the first-touch cost of the lazily mapped peer windows now, not inside a call with bounded waits
         import time
         with torch.cuda.device(device):
@@ -182,6 +203,15 @@ class IpcComm:
             self.first_touch_ms = 1e3 * (time.perf_counter() - t0)      # what the lazy mappings cost (reported by the tests)
         if world_size > 1:
             dist.barrier()
+
+    def _release(self):
+        """Unmap the peers' windows and free the own one (no collective; idempotent)."""
+        with torch.cuda.device(self.device):
+            for w in self._peers.values():
+                self._L.slu_comm_ipc_window_close(w)
+            if self._own:
+                self._L.slu_comm_ipc_window_destroy(self._own)
+        self._peers, self._own = {}, None
 
     def _launch(self, f32, f64):
         self._lib.check(self._L.slu_comm_allreduce_ipc(self._windows, self.rank, self.world_size, self.window_bytes,
@@ -217,16 +247,15 @@ class IpcComm:
             self._lib.check(self._L.slu_comm_ipc_max_wait(self._own, ctypes.byref(v)), "slu_comm_ipc_max_wait")
         return int(v.value)
 
-    def close(self):
+    def close(self, collective=True):
+        """collective (default): every rank calls it — a barrier first, so that no peer is still inside a launch that reads
+        this window.  collective=False: release without a barrier (a failed self-test: the ranks have agreed on the verdict
+        and nothing is in flight)."""
         if getattr(self, "_own", None):
             torch.cuda.synchronize()
-            if self.world_size > 1 and dist.is_initialized():
-                dist.barrier()                   # no peer may still be inside a launch that reads this window
-            with torch.cuda.device(self.device):
-                for w in self._peers.values():
-                    self._lib.check(self._L.slu_comm_ipc_window_close(w), "slu_comm_ipc_window_close")
-                self._lib.check(self._L.slu_comm_ipc_window_destroy(self._own), "slu_comm_ipc_window_destroy")
-            self._peers, self._own = {}, None
+            if collective and self.world_size > 1 and dist.is_initialized():
+                dist.barrier()
+            self._release()
 
     def __del__(self):
         try:
@@ -317,9 +346,11 @@ def make_comm(rank, world_size, device):
             print("data parallel: the hand-written IPC all-reduce failed its self-test; falling back to RCCL")
     if comm is not None:
         try:
-            comm.close()
+            comm.close(collective=False)                     # the verdict was agreed above: every rank is here, nothing in flight
         except Exception:                                    # noqa: BLE001
             pass
+        if world_size > 1:
+            dist.barrier()                                   # nobody unmaps a window a slower peer is still verifying against
     if _shared_device():
         return None                                          # RCCL refuses duplicate devices: gloo carries the buckets
     return DirectComm(rank, world_size, device)
