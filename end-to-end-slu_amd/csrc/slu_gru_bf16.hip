@@ -600,9 +600,13 @@ static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
 
 template <int H, int EPI>
 static int gru_bf_dispatch(int nsplit, int ki, dim3 grid, hipStream_t st, const GruBfParams& p) {
-  if (ki > 0) {        // fused input projection: f16x2, H = 128 (checked by the caller)
+  if (ki > 0) {        // fused input projection: f16x2 or bf16x3, H = 128 (checked by the caller)
     if constexpr (H == 128) {
-      if (ki == 1) gru_bf_launch<128, 2, 1, EPI>(grid, st, p); else gru_bf_launch<128, 2, 2, EPI>(grid, st, p);
+      if (nsplit == 3) {
+        if (ki == 1) gru_bf_launch<128, 3, 1, EPI>(grid, st, p); else gru_bf_launch<128, 3, 2, EPI>(grid, st, p);
+      } else {
+        if (ki == 1) gru_bf_launch<128, 2, 1, EPI>(grid, st, p); else gru_bf_launch<128, 2, 2, EPI>(grid, st, p);
+      }
     }
   } else if (nsplit == 3) {
     gru_bf_launch<H, 3, 0, EPI>(grid, st, p);
@@ -628,8 +632,8 @@ static int gru_bf_common(const char* who, GruBfParams& p, const float* gx, const
   if (fused) {
     SLU_REQUIRE(!gx && w_ih_packed && b_ih && !has_reserve, "%s: the fused input projection takes x_planes, "
                 "w_ih_packed and b_ih instead of gx, and no reserve (frozen layers only)", who);
-    if (!(nsplit == 2 && H == 128 && K >= 1 && K <= 64))
-      SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: the fused input projection is instantiated for f16x2 (nsplit 2), "
+    if (!((nsplit == 2 || nsplit == 3) && H == 128 && K >= 1 && K <= 64))
+      SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: the fused input projection is instantiated for f16x2 / bf16x3 (nsplit 2 / 3), "
                "H = 128 and at most 64 input channels (got nsplit %d, H %lld, K %lld)", who, nsplit, (long long)H, (long long)K);
     SLU_REQUIRE(x_plane_stride >= T * B * (cdiv(K, 32) * 32) && ((uintptr_t)x_planes & 15) == 0 && (x_plane_stride & 7) == 0,
                 "%s: x plane stride / alignment", who);

@@ -723,7 +723,13 @@ def gru_fused_input_ok(I, H, D, nsplit):
     largest layer is never written); the pipelined loop: 343-346 k against 325-336 k utt/s (same box).  The fused step costs
     1.70 instead of 1.27 us: its 18 extra MFMAs per wave run back to back at the end of the step (interleaving them with
     the gate math by scheduling hints made the step 2.2 us)."""
-    return nsplit == 2 and H == 128 and 1 <= I <= 64 and os.environ.get("SLU_FUSE_GRU_INPUT", "1") != "0"
+    if not (H == 128 and 1 <= I <= 64 and os.environ.get("SLU_FUSE_GRU_INPUT", "1") != "0"):
+        return False
+    # bf16x3 (round 5): instantiated and bit-identical to GEMM + recurrence (tests/test_hip_bf16.py), but with W_hh (144
+    # registers) AND the W_ih fragments (72 for K = 60) resident the kernel spills 40-49 VGPRs to scratch at two waves per
+    # SIMD, and the loop gets SLOWER: 160.3-160.7 against 190.7-196.8 k utt/s for the driver's 20-step command, 292-293
+    # against 345 k steady (same box, alternating runs).  Only when SLU_FUSE_GRU_INPUT3=1 asks for it.
+    return nsplit == 2 or (nsplit == 3 and os.environ.get("SLU_FUSE_GRU_INPUT3", "0") == "1")
 
 
 def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False, fused=None):

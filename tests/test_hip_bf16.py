@@ -146,13 +146,14 @@ def test_gru_bf16_vs_exact_fp32_kernel(ops, T, B, H, nsplit):
     assert err <= (5e-6 if nsplit >= 2 else 5e-2)
 
 
+@pytest.mark.parametrize("ns", [2, 3])
 @pytest.mark.parametrize("T,B,I", [(40, 64, 60), (23, 37, 60), (7, 16, 32), (300, 1024, 60)])
-def test_gru_fused_input_projection_equals_gemm_plus_recurrence(ops, T, B, I):
+def test_gru_fused_input_projection_equals_gemm_plus_recurrence(ops, T, B, I, ns):
     """slu_gru_seq_fwd_bf16(x_planes): the recurrence computes x W_ih^T + b_ih itself (first GRU layer, K <= 64, f16x2) with
     the projection GEMM's accumulation order — bit-identical to slu_gemm_bf16 followed by the plain recurrence, for both
     directions, ragged batches (B not a multiple of the 16-sequence tile) and the 1024-sequence super-batch."""
     torch.manual_seed(T + B)
-    H, D, ns = 128, 2, 2
+    H, D = 128, 2
     x = torch.randn(T * B, I, device="cuda")
     w_ih = torch.randn(D * 3 * H, I, device="cuda") * 0.1
     b_ih = torch.randn(D * 3 * H, device="cuda") * 0.1
