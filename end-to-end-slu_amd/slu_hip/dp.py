@@ -214,9 +214,23 @@ class IpcComm:
         self._peers, self._own = {}, None
 
     def _launch(self, f32, f64):
+        # a payload beyond the window's staging capacity (a model much larger than the reference's: 5.5 MB at most there)
+        # goes in several launches of whole 16-byte units; the float64 segment rides with the first one
+        cap = (self.window_bytes - 4096) // 2 - 64
+        n64 = 0 if f64 is None else f64.numel()
+        n32 = 0 if f32 is None else f32.numel()
+        if 4 * n32 + 8 * n64 + 32 > cap and f32 is not None:
+            if 8 * n64 + 32 > cap:
+                raise self._lib.SluHipError("slu_comm_allreduce_ipc: a float64 bucket of %d elements exceeds the window" % n64)
+            step = max(4, ((cap - 8 * n64 - 32) // 4) // 4 * 4)
+            for off in range(0, n32, step):
+                piece = f32[off:off + step]
+                self._launch(piece, f64 if off == 0 else None)
+                cap_left = cap
+                step = max(4, ((cap_left - 32) // 4) // 4 * 4)
+            return
         self._lib.check(self._L.slu_comm_allreduce_ipc(self._windows, self.rank, self.world_size, self.window_bytes,
-                                                       _ptr_or_none(f32), 0 if f32 is None else f32.numel(),
-                                                       _ptr_or_none(f64), 0 if f64 is None else f64.numel(),
+                                                       _ptr_or_none(f32), n32, _ptr_or_none(f64), n64,
                                                        torch.cuda.current_stream().cuda_stream), "slu_comm_allreduce_ipc")
 
     def allreduce(self, flat):

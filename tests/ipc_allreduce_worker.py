@@ -111,12 +111,13 @@ torch.cuda.synchronize()
 res["us_per_call_1p21MB"] = round(1e3 * e0.elapsed_time(e1) / 50, 2)
 res["status"] = comm.status()
 res["max_wait_polls"] = comm.max_wait_polls()
-# a payload beyond the window's capacity is refused before anything is launched
-try:
-    comm.allreduce(torch.zeros((9 << 20) // 4, dtype=torch.float32, device=dev))
-    res["oversize_refused"] = False
-except lib.SluHipError:
-    res["oversize_refused"] = True
+# a payload beyond the window's staging capacity (8 MB) goes in several launches; the C entry point itself refuses it
+case("20 MB bucket + 160 float64: three launches", 5000000, 160, 10)
+import ctypes  # noqa: E402
+big = torch.zeros((9 << 20) // 4, dtype=torch.float32, device=dev)
+rc = comm._L.slu_comm_allreduce_ipc(comm._windows, rank, ws, comm.window_bytes, big.data_ptr(), big.numel(), None, 0,
+                                    torch.cuda.current_stream().cuda_stream)
+res["oversize_refused"] = rc != 0 and b"capacity" in comm._L.slu_last_error()
 comm.close()
 json.dump(res, open(out, "w"))
 if ws > 1:

@@ -54,7 +54,7 @@ def _check(results, world, where):
         assert r["oversize_refused"]
         bad = [c["name"] for c in r["cases"] if not c["ok"]]
         assert not bad, (bad, [q.get("diag") for q in results])
-        assert len(r["cases"]) == 9
+        assert len(r["cases"]) == 10
     print("%d ranks %s: 1.21 MB all-reduce %s us per call; first touch of the mapped windows %s ms; longest flag wait %s polls"
           % (world, where, [r["us_per_call_1p21MB"] for r in results], [r["first_touch_ms"] for r in results],
              [r["max_wait_polls"] for r in results]))
