@@ -222,12 +222,11 @@ class IpcComm:
         if 4 * n32 + 8 * n64 + 32 > cap and f32 is not None:
             if 8 * n64 + 32 > cap:
                 raise self._lib.SluHipError("slu_comm_allreduce_ipc: a float64 bucket of %d elements exceeds the window" % n64)
-            step = max(4, ((cap - 8 * n64 - 32) // 4) // 4 * 4)
-            for off in range(0, n32, step):
-                piece = f32[off:off + step]
-                self._launch(piece, f64 if off == 0 else None)
-                cap_left = cap
-                step = max(4, ((cap_left - 32) // 4) // 4 * 4)
+            step, off = max(4, ((cap - 8 * n64 - 32) // 4) // 4 * 4), 0
+            while off < n32:
+                self._launch(f32[off:off + step], f64 if off == 0 else None)
+                off += step
+                step = max(4, ((cap - 32) // 4) // 4 * 4)
             return
         self._lib.check(self._L.slu_comm_allreduce_ipc(self._windows, self.rank, self.world_size, self.window_bytes,
                                                        _ptr_or_none(f32), n32, _ptr_or_none(f64), n64,
