@@ -894,6 +894,8 @@ def rccl_info(world, trainer):
             "backend": backend, "algo": os.environ.get("NCCL_ALGO", "default"), "proto": os.environ.get("NCCL_PROTO", "default")}
     if getattr(comm, "selftest_us", None) is not None:
         info["ipc_selftest_us_per_call"] = round(comm.selftest_us, 2)
+    if getattr(comm, "race_us", None) is not None:
+        info["start_up_race_us"] = comm.race_us       # both planes timed at start-up (1.21 MB): the faster one carries the gradients
     try:
         v = lib.load().slu_comm_version()
         info["version"] = "RCCL %d.%d.%d" % (v // 10000, v // 100 % 100, v % 100) if v else "no RCCL mapped"

@@ -314,6 +314,21 @@ def _selftest(comm, rank, world_size, device, rounds=12, n=70001):
     return ok >= 1.0, us
 
 
+def _time_plane(comm, device, n=302616, reps=30):
+    """Microseconds per all-reduce of the frozen-encoder step's payload (1.21 MB) through `comm`, back to back on the
+    current stream between two events (after 5 warm-up calls)."""
+    flat = torch.zeros(n, dtype=torch.float32, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        comm.allreduce(flat)
+    e0.record()
+    for _ in range(reps):
+        comm.allreduce(flat)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 1e3 * e0.elapsed_time(e1) / reps
+
+
 def _shared_device():
     """Do several ranks of this job sit on ONE GPU (the --share-gpu / SLU_LOCAL_DEVICE test set-up)?  RCCL refuses
     duplicate devices; same-device IPC works."""
@@ -323,7 +338,9 @@ def _shared_device():
 def make_comm(rank, world_size, device):
     """The data plane of this trainer's gradient collectives, by SLU_COMM:
       auto (default)  IpcComm if it passes its self-test (every word of 12 patterned all-reduces right on every rank,
-                      no timed-out wait), else DirectComm (RCCL; needs one GPU per rank), else None;
+                      no timed-out wait) — and, with one GPU per rank, if it is not slower than RCCL on the step's payload
+                      (both are timed once at start-up, the slowest rank's figures decide: `race_us`) —, else DirectComm
+                      (RCCL; needs one GPU per rank), else None;
       ipc | rccl      that one, unconditionally (an exception if it cannot be built);
       torch           None: torch.distributed's own collective on the buckets (gloo stages device tensors through the
                       host — the functional fallback; backend nccl = ProcessGroupNCCL).
@@ -354,6 +371,24 @@ def make_comm(rank, world_size, device):
         ok, us = _selftest(comm, rank, world_size, device)
         if ok:
             comm.selftest_us = us
+            if world_size > 1 and not _shared_device() and os.environ.get("SLU_COMM_RACE", "1") != "0":
+                # one GPU per rank: RCCL is available too — time both planes on the step's payload and keep the faster
+                # (the kernel has only ever run on ranks SHARING a GPU in this repository's test environment; on real links
+                # it must earn its place against the library)
+                rccl = None
+                try:
+                    rccl = DirectComm(rank, world_size, device)
+                    t_ipc, t_rccl = _time_plane(comm, device), _time_plane(rccl, device)
+                    both = torch.tensor([t_ipc, t_rccl], dtype=torch.float64)
+                    dist.all_reduce(both, op=dist.ReduceOp.MAX)          # the slowest rank's view, the same on every rank
+                    comm.race_us = {"ipc": round(both[0].item(), 2), "rccl": round(both[1].item(), 2)}
+                    if both[1].item() < both[0].item():
+                        rccl.race_us = comm.race_us
+                        comm.close()
+                        return rccl
+                    rccl.close()
+                except Exception as e:                           # noqa: BLE001 - RCCL unavailable: the proven kernel stays
+                    print("data parallel: no RCCL communicator to race against (%s)" % str(e)[:200])
             return comm
         if rank == 0:
             print("data parallel: the hand-written IPC all-reduce failed its self-test; falling back to RCCL")
