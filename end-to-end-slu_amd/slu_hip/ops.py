@@ -819,7 +819,8 @@ def wgrad_branch():
     2.780 | layer 2.620 | pass 2.697 (budget 144: 2.707, 288: 2.687, 512: 2.838); second box: in line 2.945 | layer with
     budget 72 / 144 / 216 / 288 / 360 / 512: 2.979 / 2.855 / 2.804 / 2.939 / 2.968 / 2.969.  Beside the data-gradient GEMM the
     weight gradients are free as long as they do not take every CU; beside the BPTT they still lengthen its dependent steps
-    by more than they save, budget or not."""
+    by more than they save, budget or not — and not by sharing its CUs: with BPTT workgroups that own their CU (a probe
+    build claiming all 512 registers per lane) the open form measured 2.686 against 2.683 ms."""
     mode = os.environ.get("SLU_WGRAD_BRANCH", "layer")
     if mode not in ("layer", "pass", "0"):
         raise ValueError("SLU_WGRAD_BRANCH=%r: expected layer, pass or 0" % mode)
