@@ -453,6 +453,348 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 6: TWO sequence tiles per workgroup, half a step apart (gru_bf2_fwd_kernel; opt-in: seq_tiles = 2).
+//
+// What bounds gru_bf_fwd_kernel is not a roofline but the issue of its own dependent chain (profiles/r05_z_pmc_gru_bf.txt):
+// per wave and step 1152 cycles of MFMA issue (72 x 16) and ~1080 cycles of gate / split VALU work that need each other's
+// results, and the SIMD's two waves sit in the same phase at the same time (one barrier per step): 2 x 1152 + 2 x 1080 of the
+// 4750 cycles of a step.  Here a workgroup owns 32 sequences = two tiles A, B that share the waves' resident W_hh slices, and
+// time is cut into PHASES of half a step:
+//     phase 2s    :  M(A, s)  ||  G(B, s-1)        M(X, s) = the 72 MFMAs  W_hh h_{s-1}  of tile X (needs all of h_{s-1}^X)
+//     phase 2s + 1:  M(B, s)  ||  G(A, s)          G(X, s) = gates, blend, split h_s -> LDS, Dropout + pooling, output tile
+// with one LDS barrier per phase.  M and G of a phase belong to DIFFERENT tiles, i.e. they are independent: they form ONE
+// scheduling region and the compiler interleaves the gate arithmetic of one tile with the MFMAs of the other.  Same products
+// in the same order, same gate formulas, same epilogue as gru_bf_fwd_kernel: the results are bit-identical
+// (tests/test_hip_bf16.py::test_gru_two_tiles_per_workgroup_equals_one_tile).
+//
+// MEASURED (profiles/r06_a_gru_two_tiles.txt, MI355X, T = 300, 2560 sequences on 160 CUs, bf16x3, pooled planes out): one tile
+// per workgroup 4.10 us per pair of tile-steps, this kernel 3.78 (- 8 %); f16x2: 2.80 -> 3.05 (slower).  The premise "one wave
+// on the matrix pipe while its SIMD neighbour does gate math doubles the throughput" does NOT hold on gfx950
+// (tools/probes/mfma_valu_overlap_probe2.cpp, profiles/r06_a_mfma_valu_coissue.txt): beside a wave that issues
+// v_mfma_f32_16x16x32_bf16 back to back, a second wave's v_fma / v_mul / v_sub stream hides 58 % of its time, v_and / v_mov /
+// v_perm 74 %, v_cvt_pk_bf16_f32 66 %, v_exp / v_rcp 50 %, and the packed fp32 operations (v_pk_fma / v_pk_add / v_pk_mul_f32)
+// NOTHING (0.07): an MFMA holds the SIMD's VALU issue port for about half of its 16 cycles.  The explicit form of the idea —
+// the first wave of every SIMD (HW_ID.SIMD_ID + an LDS ticket) runs M then G, the second G then M — was built and is SLOWER
+// than both waves in the same order (4.29 against 4.14 us; 3.94 against 3.53 with fp32 output): the wave that feeds the
+// matrix pipe starves its neighbour's VALU stream and the phase ends when the slower one does.  Letting the compiler
+// interleave inside one wave gives the 8 %.  Hence opt-in (SLU_GRU_TILES=2); the default stays one tile per workgroup.
+//
+// Memory: gx of chunk c (= tile c & 1, step c >> 1) is needed in phase c.  It is fetched by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, no ds_write) into a ring of THREE chunk buffers, two phases ahead; the keep bits of the chunk ride
+// along (one global_load_lds_dword).  The DMA is issued from inline assembly and awaited with an explicit
+// s_waitcnt vmcnt(4) at the end of each phase (a wave issues exactly four per phase, AFTER the phase's stores; memory
+// operations retire in order): the compiler would order EVERY later LDS read behind a pending LDS-DMA (vmcnt(0)), which
+// would put the memory latency on the chain.  There is no other vector-memory LOAD in the loop, so the compiler inserts no
+// waits of its own (a register spill would: the fp32 h_{s-1} and the pooling window's first frame therefore live in
+// private LDS slots, not in registers).  The LDS image of a chunk is dense (16 rows x 3H floats) with the 16-byte pieces of
+// row r XOR-swizzled by r — applied to the SOURCE address of the DMA — so that the compute layout's ds_read_b128
+// (lane = (sequence, unit quad)) is conflict-free.  Loads of rows past B are clamped to sequence B - 1 (they recompute that
+// row's values), stores of such rows are predicated off.
+template <int H, int NS, int EPI>
+struct Gru2Lds {
+  static constexpr int ROWB = H * 2;                        // bytes per h row (one sequence, one plane)
+  static constexpr int OROW = H + 4;                        // floats per staged fp32 output row
+  static constexpr int PROWB = H * 2 + 16;                  // bytes per staged plane row
+  static constexpr int HB = NS * 16 * ROWB;                 // h planes of ONE tile (single buffer: written in G, read in M)
+  static constexpr int GXB = 16 * 3 * H * 4;                // one gx chunk
+  static constexpr int KBB = 16 * (H / 32) * 4;             // keep words of one chunk (this direction's H / 32 words per sequence)
+  static constexpr int OSB = EPI == 1 ? NS * 16 * PROWB : 16 * OROW * 4;   // output tile of ONE sequence tile
+  static constexpr int HBUF = 0;
+  static constexpr int GXR = HBUF + 2 * HB;
+  static constexpr int KBR = GXR + 3 * GXB;
+  static constexpr int BIAS = KBR + 3 * KBB;
+  static constexpr int OST = BIAS + 3 * H * 4;
+  static constexpr int HP = OST + 2 * OSB;                   // fp32 h_{s-1} of the lane's four units (private slots)
+  static constexpr int HELD = HP + 2 * 16 * H * 4;          // EPI > 0: the masked h of a pooling window's first frame
+  static constexpr int BYTES = HELD + (EPI > 0 ? 2 * 16 * H * 4 : 0);
+};
+
+// LDS-DMA from inline assembly (see above): 64 lanes x 16 (4) bytes from base + voff (bytes) to LDS bytes [m0, m0 + 1024 (256))
+__device__ __forceinline__ void dma_b128(const void* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void* base, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(base), "s"(lds_addr) : "memory");
+}
+
+template <int H, int NS, int EPI>
+__global__ void __launch_bounds__(H * 4)
+gru_bf2_fwd_kernel(const GruBfParams p) {
+  static_assert(H == 128, "two-tile recurrence: H = 128 (8 waves = two per SIMD, one keep-word DMA per chunk)");
+  constexpr int NW = H / 16, KC = H / 32, SLOTS = H / 8;
+  typedef Split<NS> SP;
+  typedef Gru2Lds<H, NS, EPI> LD;
+  constexpr int ROWB = LD::ROWB, OROW = LD::OROW, PROWB = LD::PROWB;
+  constexpr int PCS = 3 * H / 4;                // 16-byte pieces per gx row (96)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  float* const bias_s = reinterpret_cast<float*>(smem + LD::BIAS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, kg = lane >> 4;      // compute layout: i = sequence of the tile (MFMA column), kg = unit quad
+  const int dir = blockIdx.y;
+  const int b0 = blockIdx.x * 32;
+  const int u0 = w * 16 + kg * 4;
+  const int T = p.T, B = p.B, D = p.D;
+
+  if constexpr (NS == 2) f16_denorm_flush();
+
+  // resident W_hh fragments, as in gru_bf_fwd_kernel
+  uint4 wb[3][KC][NS];
+  {
+    const float* __restrict__ W = p.w_hh[dir];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float* src = W + (size_t)(g * H + w * 16 + i) * H + c * 32 + kg * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned short s[8][NS];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split_terms<NS>(v[e], s[e]);
+#pragma unroll
+        for (int pl = 0; pl < NS; ++pl) {
+          uint4 o;
+          o.x = s[0][pl] | ((unsigned)s[1][pl] << 16); o.y = s[2][pl] | ((unsigned)s[3][pl] << 16);
+          o.z = s[4][pl] | ((unsigned)s[5][pl] << 16); o.w = s[6][pl] | ((unsigned)s[7][pl] << 16);
+          wb[g][c][pl] = o;
+        }
+      }
+  }
+  for (int x = tid; x < 3 * H; x += H * 4) bias_s[x] = p.b_hh[dir][x];
+  for (int x = tid; x < 2 * LD::HB / 4; x += H * 4) reinterpret_cast<unsigned*>(smem + LD::HBUF)[x] = 0u;   // h0 = 0
+  __syncthreads();
+
+  // ---- DMA side: this wave moves 1 KiB pieces 3w .. 3w + 2 of a chunk (gx) and the chunk's 256 bytes of keep words ----
+  const bool drop = EPI > 0 && p.keep != nullptr;
+  unsigned gv[2][3];                            // byte offsets inside a time step, per tile
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int P = (3 * w + j) * 64 + lane, row = P / PCS, q = P % PCS;
+      gv[x][j] = (unsigned)((min(b0 + 16 * x + row, B - 1) * D * 3 * H + dir * 3 * H) * 4 + (q ^ (row & 15)) * 16);
+    }
+  unsigned kv[2];
+  const int KW = (D * H) >> 5;                  // keep words per (t, sequence)
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+    kv[x] = drop ? (unsigned)((min(b0 + 16 * x + (lane >> 2), B - 1) * KW + dir * (H >> 5) + (lane & 3)) * 4) : (unsigned)(lane * 4);
+  const void* const kbase = drop ? (const void*)p.keep : (const void*)p.gx;      // no dropout: a harmless read (uniform counts)
+  const size_t gx_ts = (size_t)B * D * 3 * H * 4, kw_ts = drop ? (size_t)B * KW * 4 : 0, out_ts = (size_t)B * D * H;
+  const unsigned gx_m0 = lds0 + LD::GXR + 3 * w * 1024, kb_m0 = lds0 + LD::KBR;
+  // chunk (tile x, time t) -> ring slot
+  auto dma_chunk = [&](int x, int t_, int slot) {
+    const char* gb = reinterpret_cast<const char*>(p.gx) + (size_t)t_ * gx_ts;
+    const unsigned m = gx_m0 + slot * LD::GXB;
+    const unsigned v0 = x ? gv[1][0] : gv[0][0], v1 = x ? gv[1][1] : gv[0][1], v2 = x ? gv[1][2] : gv[0][2];
+    dma_b128(gb, v0, m);
+    dma_b128(gb, v1, m + 1024);
+    dma_b128(gb, v2, m + 2048);
+    dma_b32(reinterpret_cast<const char*>(kbase) + (size_t)t_ * kw_ts, x ? kv[1] : kv[0], kb_m0 + slot * LD::KBB);
+  };
+
+  // ---- compute-layout side ----
+  // h fragment (B operand) of chunk c: row i, slot (c*4 + kg) ^ i = ((kg ^ i) ^ 4c) — one register, c enters as an XOR of
+  // byte-offset bits 6-7 (register budget: 144 resident W_hh registers + two tiles' accumulators)
+  const int a_off0 = i * ROWB + ((kg ^ i) & (SLOTS - 1)) * 16;
+  const int h_off = i * ROWB + ((((u0 >> 3) ^ i) & (SLOTS - 1)) * 16) + (u0 & 7) * 2;
+  // gx seed read (bytes inside a chunk buffer): row i, piece (g*H/4 + u0/4) ^ i = ((u0/4) ^ i) + g*H/4 — gate g is an
+  // immediate offset of g * 4H bytes
+  const int gs_off0 = (i * PCS + ((u0 >> 2) ^ i)) * 16;
+  const int hp_off = (i * H + u0) * 4;          // private fp32 slot of (sequence i, units u0 .. u0 + 3)
+  const int kb_off = (i * (H >> 5) + (u0 >> 5)) * 4;
+  const int kb_sh = u0 & 31;
+  const int os_off = i * OROW + u0;             // fp32 output write (floats)
+  const int ps_off = i * PROWB + u0 * 2;        // plane output write (bytes)
+  // row-wise side of the output tiles (flush), rows clamped to B - 1
+  const int orow = (16 / NW) * w + lane / (H / 4), oc16 = lane % (H / 4);
+
+  f32x4 accs[2][SP::NACC][3];
+  float gn[2][4];
+  unsigned kb[2] = {0u, 0u};
+  int pend[2] = {-1, -1};
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gn[x][r] = 0.f;
+    *reinterpret_cast<float4*>(smem + LD::HP + x * (16 * H * 4) + hp_off) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (EPI > 0) *reinterpret_cast<float4*>(smem + LD::HELD + x * (16 * H * 4) + hp_off) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int a = 0; a < SP::NACC; ++a)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) accs[x][a][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // M(X): seed the chains of tile X with gx + b_hh from ring slot `slot`, then W_hh h_{s-1}
+#define SLU_G2_M(X, slot)                                                                                              \
+  do {                                                                                                                 \
+    const unsigned char* gxc__ = smem + LD::GXR + (slot) * LD::GXB;                                                    \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                                    \
+      const float4 v = *reinterpret_cast<const float4*>(gxc__ + gs_off0 + g * (4 * H));                                \
+      const float4 bb = *reinterpret_cast<const float4*>(&bias_s[g * H + u0]);                                         \
+      _Pragma("unroll") for (int a = 0; a < SP::NACC; ++a) accs[X][a][g] = f32x4{0.f, 0.f, 0.f, 0.f};                  \
+      if (g < 2) accs[X][0][g] = f32x4{v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w};                                \
+      else { accs[X][0][g] = f32x4{bb.x, bb.y, bb.z, bb.w}; gn[X][0] = v.x; gn[X][1] = v.y; gn[X][2] = v.z; gn[X][3] = v.w; } \
+    }                                                                                                                  \
+    kb[X] = *reinterpret_cast<const unsigned*>(smem + LD::KBR + (slot) * LD::KBB + kb_off) >> kb_sh;                   \
+    const unsigned char* hc__ = smem + LD::HBUF + (X) * LD::HB;                                                        \
+    _Pragma("unroll") for (int c = 0; c < KC; ++c) {                                                                   \
+      uint4 fa[NS];                                                                                                    \
+      _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) fa[pl] = *reinterpret_cast<const uint4*>(hc__ + pl * (16 * ROWB) + (a_off0 ^ (c * 64))); \
+      _Pragma("unroll") for (int q = 0; q < SP::NPAIR; ++q)                                                            \
+        _Pragma("unroll") for (int g = 0; g < 3; ++g)                                                                  \
+          accs[X][SP::ACC(q)][g] = mfma_split<NS>(wb[g][c][SP::PB(q)], fa[SP::PA(q)], accs[X][SP::ACC(q)][g]);         \
+    }                                                                                                                  \
+  } while (0)
+
+  // G(X) at time t_: gates, blend, split h -> LDS, Dropout + pooling, output tile (gru_bf_fwd_kernel's arithmetic)
+#define SLU_G2_G(X, t_)                                                                                                \
+  do {                                                                                                                 \
+    f32x4 acc[3];                                                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 3; ++g) acc[g] = split_result<NS>(accs[X][0][g], accs[X][SP::NACC - 1][g]);  \
+    float hn[4];                                                                                                       \
+    float4* const hp__ = reinterpret_cast<float4*>(smem + LD::HP + (X) * (16 * H * 4) + hp_off);                       \
+    const float4 hpv = *hp__;                                                                                          \
+    const float hprev[4] = {hpv.x, hpv.y, hpv.z, hpv.w};                                                               \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                    \
+      const float rr = bf_sigmoid(acc[0][r]);                                                                          \
+      const float zz = bf_sigmoid(acc[1][r]);                                                                          \
+      const float nn = bf_tanh(gn[X][r] + rr * acc[2][r]);                                                             \
+      hn[r] = nn + zz * (hprev[r] - nn);                                                                               \
+    }                                                                                                                  \
+    *hp__ = make_float4(hn[0], hn[1], hn[2], hn[3]);                                                                   \
+    {                                                                                                                  \
+      unsigned char* __restrict__ hx = smem + LD::HBUF + (X) * LD::HB;                                                 \
+      if constexpr (NS == 2) {                                                                                         \
+        unsigned hi01, lo01, hi23, lo23;                                                                               \
+        split_f16x2_pair_flush(hn[0], hn[1], hi01, lo01);                                                              \
+        split_f16x2_pair_flush(hn[2], hn[3], hi23, lo23);                                                              \
+        *reinterpret_cast<uint2*>(hx + h_off) = make_uint2(hi01, hi23);                                                \
+        *reinterpret_cast<uint2*>(hx + 16 * ROWB + h_off) = make_uint2(lo01, lo23);                                    \
+      } else {                                                                                                         \
+        unsigned short sp[4][NS];                                                                                      \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) split_terms<NS>(hn[r], sp[r]);                                   \
+        _Pragma("unroll") for (int pl = 0; pl < NS; ++pl)                                                              \
+          *reinterpret_cast<uint2*>(hx + pl * (16 * ROWB) + h_off) =                                                   \
+              make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));            \
+      }                                                                                                                \
+    }                                                                                                                  \
+    unsigned char* const ox__ = smem + LD::OST + (X) * LD::OSB;                                                        \
+    if constexpr (EPI == 0) {                                                                                          \
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(ox__) + os_off) = make_float4(hn[0], hn[1], hn[2], hn[3]);   \
+      pend[X] = (t_);                                                                                                  \
+    } else {                                                                                                           \
+      float m[4];                                                                                                      \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                    \
+        m[r] = drop ? __fmul_rn(hn[r], ((kb[X] >> r) & 1u) ? p.keep_scale : 0.0f) : hn[r];                             \
+      const bool even = ((t_) & 1) == 0;                                                                               \
+      const bool single = even && (t_) == T - 1;                                                                       \
+      const bool emit = dir ? even : (!even || single);                                                                \
+      pend[X] = -1;                                                                                                    \
+      float4* const hl__ = reinterpret_cast<float4*>(smem + LD::HELD + (X) * (16 * H * 4) + hp_off);                   \
+      if (!emit) {                                                                                                     \
+        float hd[4];                                                                                                   \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) hd[r] = dir ? m[r] : __fadd_rn(0.0f, m[r]);                      \
+        *hl__ = make_float4(hd[0], hd[1], hd[2], hd[3]);                                                               \
+      } else {                                                                                                         \
+        const float4 hlv = *hl__;                                                                                      \
+        const float held[4] = {hlv.x, hlv.y, hlv.z, hlv.w};                                                            \
+        float v[4];                                                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                \
+          const float first = dir ? __fadd_rn(0.0f, m[r]) : held[r];                                                   \
+          const float second = dir ? held[r] : m[r];                                                                   \
+          v[r] = single ? __fadd_rn(0.0f, m[r]) : __fmul_rn(__fadd_rn(first, second), 0.5f);                           \
+        }                                                                                                              \
+        pend[X] = (t_) >> 1;                                                                                           \
+        if constexpr (EPI == 2) {                                                                                      \
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(ox__) + os_off) = make_float4(v[0], v[1], v[2], v[3]);   \
+        } else if constexpr (NS == 2) {                                                                                \
+          unsigned hi01, lo01, hi23, lo23;                                                                             \
+          split_f16x2_pair_flush(v[0], v[1], hi01, lo01);                                                              \
+          split_f16x2_pair_flush(v[2], v[3], hi23, lo23);                                                              \
+          *reinterpret_cast<uint2*>(ox__ + ps_off) = make_uint2(hi01, hi23);                                           \
+          *reinterpret_cast<uint2*>(ox__ + 16 * PROWB + ps_off) = make_uint2(lo01, lo23);                              \
+        } else {                                                                                                       \
+          unsigned short sp[4][NS];                                                                                    \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);                                  \
+          _Pragma("unroll") for (int pl = 0; pl < NS; ++pl)                                                            \
+            *reinterpret_cast<uint2*>(ox__ + (pl * 16) * PROWB + ps_off) =                                             \
+                make_uint2(sp[0][pl] | ((unsigned)sp[1][pl] << 16), sp[2][pl] | ((unsigned)sp[3][pl] << 16));          \
+        }                                                                                                              \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+
+  // the output tile of tile X (assembled by G in the previous phase) -> global memory, whole rows.  EPI 1: NS planes x 16 rows
+  // x 2H bytes = NS * 4 wave-instructions of 1 KiB: wave w < NS * 4 moves piece w (plane w / 4, rows 4 (w % 4) ..) and, for w < NS * 4 - 8,
+  // piece w + 8.  Stores are issued BEFORE the phase's DMA, so their number does not enter the vmcnt(4) of the phase's end.
+#define SLU_G2_FLUSH(X)                                                                                                \
+  do {                                                                                                                 \
+    if (pend[X] >= 0) {                                                                                                \
+      const unsigned char* ox__ = smem + LD::OST + (X) * LD::OSB;                                                      \
+      if constexpr (EPI == 1) {                                                                                        \
+        const int r = (w & 3) * 4 + (lane >> 4), c16 = lane & 15;                                                      \
+        unsigned short* const gp__ = p.planes + (size_t)pend[X] * out_ts + (size_t)((b0 + 16 * (X) + r) * D * H + dir * H + c16 * 8); \
+        const bool ok__ = b0 + 16 * (X) + r < B;                                                                       \
+        if (w < NS * 4) {                                                                                              \
+          const int pl = w >> 2;                                                                                       \
+          const uint4 v = *reinterpret_cast<const uint4*>(ox__ + (pl * 16 + r) * PROWB + c16 * 16);                    \
+          if (ok__) *reinterpret_cast<uint4*>(gp__ + (size_t)pl * p.plane) = v;                                        \
+        }                                                                                                              \
+        if (w + 8 < NS * 4) {                                                                                          \
+          const int pl = (w >> 2) + 2;                                                                                 \
+          const uint4 v = *reinterpret_cast<const uint4*>(ox__ + (pl * 16 + r) * PROWB + c16 * 16);                    \
+          if (ok__) *reinterpret_cast<uint4*>(gp__ + (size_t)pl * p.plane) = v;                                        \
+        }                                                                                                              \
+      } else {                                                                                                         \
+        const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ox__) + orow * OROW + oc16 * 4); \
+        if (b0 + 16 * (X) + orow < B)                                                                                  \
+          *reinterpret_cast<float4*>(p.out + (size_t)pend[X] * out_ts + (b0 + 16 * (X) + orow) * D * H + dir * H + oc16 * 4) = v; \
+      }                                                                                                                \
+    }                                                                                                                  \
+  } while (0)
+
+  // one phase: X = the M tile (chunk in ring slot sl), 1 - X = the G tile (time tg); chunk (X, time tn) is requested into the
+  // slot two ahead.  doM / doG are literals (the first and the last phases of a launch lack one of the two).
+#define SLU_G2_PHASE(X, doM, doG, tg, tn)                                                                              \
+  do {                                                                                                                 \
+    SLU_G2_FLUSH(X);                                                                                                   \
+    dma_chunk(X, tn, sl == 0 ? 2 : sl - 1);                                                                            \
+    if constexpr (doM) SLU_G2_M(X, sl);          /* one scheduling region: the compiler interleaves M and G */         \
+    if constexpr (doG) SLU_G2_G(1 - (X), tg);                                                                          \
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                   \
+    lds_barrier();                                                                                                     \
+    sl = sl == 2 ? 0 : sl + 1;                                                                                         \
+  } while (0)
+
+  auto tt = [&](int s_) { const int c = s_ < T - 1 ? s_ : T - 1; return dir ? T - 1 - c : c; };   // time of step s_ (clamped)
+  dma_chunk(0, tt(0), 0);
+  dma_chunk(1, tt(0), 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int sl = 0;                                   // ring slot of the chunk the current phase reads: chunk c lives in slot c % 3
+  SLU_G2_PHASE(0, true, false, 0, tt(1));                       // phase 0: M(A, 0); requests chunk 2 = (A, 1)
+  for (int s = 0; s + 1 < T; ++s) {
+    SLU_G2_PHASE(1, true, true, tt(s), tt(s + 1));              // phase 2s + 1: M(B, s) || G(A, s); requests (B, s + 1)
+    SLU_G2_PHASE(0, true, true, tt(s), tt(s + 2));              // phase 2s + 2: M(A, s + 1) || G(B, s); requests (A, s + 2)
+  }
+  SLU_G2_PHASE(1, true, true, tt(T - 1), tt(T - 1));            // phase 2T - 1: M(B, T - 1) || G(A, T - 1)
+  SLU_G2_PHASE(0, false, true, tt(T - 1), tt(T - 1));           // phase 2T: G(B, T - 1); the last output of tile A leaves
+  SLU_G2_FLUSH(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may land after the workgroup has released its LDS
+#undef SLU_G2_PHASE
+#undef SLU_G2_FLUSH
+#undef SLU_G2_G
+#undef SLU_G2_M
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Round-3 geometry (A = h: a lane owns one hidden unit of four sequences), kept for the one caller that needs the saved
 // gates in the exact BPTT kernels' lane order: the bf16 forward of TRAINABLE layers (SLU_DTYPE=bf16; reserve != null).
 template <int H, int NS>
@@ -598,8 +940,28 @@ static void gru_bf_launch(dim3 grid, hipStream_t st, const GruBfParams& p) {
   hipLaunchKernelGGL((gru_bf_fwd_kernel<H, NS, KI, EPI>), grid, dim3(H * 4), lds, st, p);
 }
 
+template <int H, int NS, int EPI>
+static void gru_bf2_launch(hipStream_t st, const GruBfParams& p) {
+  constexpr int lds = Gru2Lds<H, NS, EPI>::BYTES;
+  static bool raised = false;
+  if (lds > 64 * 1024 && !raised) {
+    (void)hipFuncSetAttribute((const void*)gru_bf2_fwd_kernel<H, NS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    raised = true;
+  }
+  hipLaunchKernelGGL((gru_bf2_fwd_kernel<H, NS, EPI>), dim3((unsigned)cdiv(p.B, 32), (unsigned)p.D), dim3(H * 4), lds, st, p);
+}
+
 template <int H, int EPI>
-static int gru_bf_dispatch(int nsplit, int ki, dim3 grid, hipStream_t st, const GruBfParams& p) {
+static int gru_bf_dispatch(int nsplit, int ki, int seq_tiles, dim3 grid, hipStream_t st, const GruBfParams& p) {
+  if (seq_tiles == 2) {        // two sequence tiles per workgroup (checked by the caller: H = 128, no fused input)
+    if constexpr (H == 128) {
+      if (nsplit == 3) gru_bf2_launch<128, 3, EPI>(st, p);
+      else if (nsplit == 2) gru_bf2_launch<128, 2, EPI>(st, p);
+      else gru_bf2_launch<128, 1, EPI>(st, p);
+    }
+    SLU_CHECK_LAUNCH("gru_bf2_fwd_kernel");
+    return SLU_OK;
+  }
   if (ki > 0) {        // fused input projection: f16x2 or bf16x3, H = 128 (checked by the caller)
     if constexpr (H == 128) {
       if (nsplit == 3) {
@@ -626,8 +988,12 @@ using namespace slu;
 static int gru_bf_common(const char* who, GruBfParams& p, const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
                          const float* b_hh_fwd, const float* b_hh_rev, const void* x_planes, int64_t x_plane_stride,
                          int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D,
-                         int nsplit, bool has_reserve) {
+                         int nsplit, bool has_reserve, int seq_tiles) {
   SLU_REQUIRE((gx || x_planes) && w_hh_fwd && b_hh_fwd, "%s: null pointer", who);
+  SLU_REQUIRE(seq_tiles >= 0 && seq_tiles <= 2, "%s: seq_tiles must be 0 / 1 (one 16-sequence tile per workgroup) or 2", who);
+  if (seq_tiles == 2 && !(H == 128 && gx && !x_planes && !has_reserve && B * D * 3 * H < (1LL << 30)))
+    SLU_FAIL(SLU_ERR_UNSUPPORTED, "%s: two sequence tiles per workgroup are instantiated for H = 128, gx input (no fused "
+             "projection), no reserve, B * D * 3H < 2^30 (got H %lld, B %lld)", who, (long long)H, (long long)B);
   const bool fused = x_planes != nullptr;
   if (fused) {
     SLU_REQUIRE(!gx && w_ih_packed && b_ih && !has_reserve, "%s: the fused input projection takes x_planes, "
@@ -657,11 +1023,11 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
                                     const float* b_hh_fwd, const float* b_hh_rev, float* out, float* reserve,
                                     const void* x_planes, int64_t x_plane_stride, int64_t K, const void* w_ih_packed,
                                     const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D, int nsplit,
-                                    void* stream) {
+                                    int seq_tiles, void* stream) {
   SLU_REQUIRE(out, "slu_gru_seq_fwd_bf16: null pointer");
   GruBfParams p;
   int rc = gru_bf_common("slu_gru_seq_fwd_bf16", p, gx, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, x_planes, x_plane_stride, K,
-                         w_ih_packed, b_ih, T, B, H, D, nsplit, reserve != nullptr);
+                         w_ih_packed, b_ih, T, B, H, D, nsplit, reserve != nullptr, seq_tiles);
   if (rc) return rc;
   p.out = out; p.reserve = reserve;
   dim3 grid((unsigned)cdiv(B, 16), (unsigned)D);
@@ -676,7 +1042,7 @@ extern "C" int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, cons
   }
   SLU_REQUIRE(((uintptr_t)out & 15) == 0, "slu_gru_seq_fwd_bf16: out must be 16-byte aligned");
   const int ki = x_planes ? (K <= 32 ? 1 : 2) : 0;
-  return H == 128 ? gru_bf_dispatch<128, 0>(nsplit, ki, grid, st, p) : gru_bf_dispatch<64, 0>(nsplit, ki, grid, st, p);
+  return H == 128 ? gru_bf_dispatch<128, 0>(nsplit, ki, seq_tiles, grid, st, p) : gru_bf_dispatch<64, 0>(nsplit, ki, seq_tiles, grid, st, p);
 }
 
 extern "C" int slu_gru_seq_fwd_pool_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev,
@@ -684,14 +1050,14 @@ extern "C" int slu_gru_seq_fwd_pool_bf16(const float* gx, const float* w_hh_fwd,
                                          void* out_planes, int64_t out_plane_stride, const uint32_t* keep_bits, float p_drop,
                                          const void* x_planes, int64_t x_plane_stride, int64_t K, const void* w_ih_packed,
                                          const float* b_ih, int64_t T, int64_t B, int64_t H, int64_t D, int nsplit,
-                                         void* stream) {
+                                         int seq_tiles, void* stream) {
   SLU_REQUIRE((out_pooled != nullptr) != (out_planes != nullptr),
               "slu_gru_seq_fwd_pool_bf16: exactly one of out_pooled and out_planes");
   SLU_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f && (keep_bits || p_drop == 0.0f),
               "slu_gru_seq_fwd_pool_bf16: dropout p in [0, 1), with keep_bits when p > 0");
   GruBfParams p;
   int rc = gru_bf_common("slu_gru_seq_fwd_pool_bf16", p, gx, w_hh_fwd, w_hh_rev, b_hh_fwd, b_hh_rev, x_planes,
-                         x_plane_stride, K, w_ih_packed, b_ih, T, B, H, D, nsplit, false);
+                         x_plane_stride, K, w_ih_packed, b_ih, T, B, H, D, nsplit, false, seq_tiles);
   if (rc) return rc;
   if ((D * H) % 32 != 0)
     SLU_FAIL(SLU_ERR_UNSUPPORTED, "slu_gru_seq_fwd_pool_bf16: D * H must be a multiple of 32 (got %lld)", (long long)(D * H));
@@ -707,6 +1073,6 @@ extern "C" int slu_gru_seq_fwd_pool_bf16(const float* gx, const float* w_hh_fwd,
   hipStream_t st = (hipStream_t)stream;
   const int ki = x_planes ? (K <= 32 ? 1 : 2) : 0;
   if (out_planes)
-    return H == 128 ? gru_bf_dispatch<128, 1>(nsplit, ki, grid, st, p) : gru_bf_dispatch<64, 1>(nsplit, ki, grid, st, p);
-  return H == 128 ? gru_bf_dispatch<128, 2>(nsplit, ki, grid, st, p) : gru_bf_dispatch<64, 2>(nsplit, ki, grid, st, p);
+    return H == 128 ? gru_bf_dispatch<128, 1>(nsplit, ki, seq_tiles, grid, st, p) : gru_bf_dispatch<64, 1>(nsplit, ki, seq_tiles, grid, st, p);
+  return H == 128 ? gru_bf_dispatch<128, 2>(nsplit, ki, seq_tiles, grid, st, p) : gru_bf_dispatch<64, 2>(nsplit, ki, seq_tiles, grid, st, p);
 }

@@ -71,9 +71,9 @@ SIGNATURES = {
     "slu_wconv_fwd_bf16": (c_int, [vp, vp, c_i64, vp, vp, vp, vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32,
                                    c_i64, c_i64, vp, c_i64, vp, c_sz, c_int, c_int, vp, c_int, c_f32, vp]),
     "slu_gru_seq_fwd_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp, c_i64, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int,
-                                     vp]),
+                                     c_int, vp]),
     "slu_gru_seq_fwd_pool_bf16": (c_int, [vp, vp, vp, vp, vp, vp, vp, c_i64, vp, c_f32, vp, c_i64, c_i64, vp, vp, c_i64,
-                                          c_i64, c_i64, c_i64, c_int, vp]),
+                                          c_i64, c_i64, c_i64, c_int, c_int, vp]),
     "slu_dropout_bits": (c_int, [vp, c_f32, c_u64, c_u64, vp, c_i64, c_u64, c_i64, c_i64, c_i64, vp]),
     "slu_comm_version": (c_int, []),
     "slu_comm_unique_id": (c_int, [vp]),
@@ -122,7 +122,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8          # SLU_ABI_VERSION of include/slu_hip.h
+ABI_VERSION = 9          # SLU_ABI_VERSION of include/slu_hip.h
 
 
 class SluHipError(RuntimeError):

@@ -631,10 +631,36 @@ def gru_pool_fused_ok(H, D, T, p, mask, method, factor):
             and os.environ.get("SLU_FUSE_GRU_POOL", "1") != "0")
 
 
-def gru_seq_fwd_pool_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, keep, p, out_planes, fused=None):
+# CUs a CU-masked stream may use (pipeline.cu_range_stream registers its streams here): what decides between one and two
+# sequence tiles per recurrence workgroup
+STREAM_CUS = {}
+
+
+def gru_seq_tiles(B, H, D, fused=None, reserve=False, device=None):
+    """Sequence tiles (16 sequences each) per workgroup of the split-precision recurrence (slu_gru_seq_fwd[_pool]_bf16's
+    seq_tiles).  1 (default): gru_bf_fwd_kernel.  SLU_GRU_TILES=2: gru_bf2_fwd_kernel — two tiles half a step apart, the gate
+    arithmetic of one interleaved with the other's MFMAs; =auto: two tiles as soon as the one-tile grid (ceil(B / 16) x D
+    workgroups, one per CU) would not fit the stream's CUs in one round.  Both kernels produce the same bits.  Measured
+    (profiles/r06_a_gru_two_tiles.txt): 8 % faster on bf16x3 at 2560 sequences, slower on f16x2 — gfx950 overlaps a wave's MFMAs
+    with its neighbour's VALU work far less than the design assumed (csrc/slu_gru_bf16.hip) — hence opt-in."""
+    if H != 128 or fused is not None or reserve:
+        return 1
+    env = os.environ.get("SLU_GRU_TILES", "1")
+    if env in ("1", "2"):
+        return int(env)
+    cus = STREAM_CUS.get(torch.cuda.current_stream(device).cuda_stream)
+    if cus is None:
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device).multi_processor_count
+    return 2 if -(-B // 16) * D > cus else 1
+
+
+def gru_seq_fwd_pool_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, keep, p, out_planes, fused=None,
+                          seq_tiles=None):
     """Recurrence + Dropout(p; keep = dropout_bits or None) + avg-pool(2) in one launch -> SplitAct (out_planes) or fp32
-    (ceil(T/2), B, D*H).  fused as gru_seq_fwd_bf16."""
+    (ceil(T/2), B, D*H).  fused as gru_seq_fwd_bf16.  seq_tiles: None = gru_seq_tiles()."""
     L = _lib.load()
+    if seq_tiles is None:
+        seq_tiles = gru_seq_tiles(B, H, D, fused, False, w_hh_f.device)
     dev = w_hh_f.device
     T_out = -(-T // 2)
     if out_planes:
@@ -650,7 +676,7 @@ def gru_seq_fwd_pool_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit
     else:
         xa = (None, 0, 0, None, None)
     _lib.check(L.slu_gru_seq_fwd_pool_bf16(_ptr(gx), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r), *oa,
-                                           _ptr(keep), float(p), *xa, T, B, H, D, nsplit, _stream()),
+                                           _ptr(keep), float(p), *xa, T, B, H, D, nsplit, int(seq_tiles), _stream()),
                "slu_gru_seq_fwd_pool_bf16")
     return SplitAct(planes, T_out, B, D * H) if out_planes else out
 
@@ -732,12 +758,14 @@ def gru_fused_input_ok(I, H, D, nsplit):
     return nsplit == 2 or (nsplit == 3 and os.environ.get("SLU_FUSE_GRU_INPUT3", "0") == "1")
 
 
-def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False, fused=None):
+def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, want_reserve=False, fused=None, seq_tiles=None):
     """Recurrence on the split-precision MFMA kernels -> (out (T, B, D*H) fp32, reserve or None).
     fused = (planes (nsplit, T*B, round_up(K, 32)), K, packed W_ih, b_ih) with gx None: the kernel computes the input
     projection itself (gru_fused_input_ok shapes; bit-identical to gemm_bf16 + this call)."""
     L = _lib.load()
     dev = w_hh_f.device
+    if seq_tiles is None:
+        seq_tiles = gru_seq_tiles(B, H, D, fused, want_reserve, dev)
     out = torch.empty(T, B, D * H, dtype=torch.float32, device=dev)
     reserve = None
     if want_reserve:
@@ -749,7 +777,7 @@ def gru_seq_fwd_bf16(gx, w_hh_f, w_hh_r, b_hh_f, b_hh_r, T, B, H, D, nsplit, wan
     else:
         xa = (None, 0, 0, None, None)
     _lib.check(L.slu_gru_seq_fwd_bf16(_ptr(gx), w_hh_f.data_ptr(), _ptr(w_hh_r), b_hh_f.data_ptr(), _ptr(b_hh_r),
-                                      out.data_ptr(), _ptr(reserve), *xa, T, B, H, D, nsplit, _stream()),
+                                      out.data_ptr(), _ptr(reserve), *xa, T, B, H, D, nsplit, int(seq_tiles), _stream()),
                "slu_gru_seq_fwd_bf16")
     return out, reserve
 

@@ -85,6 +85,7 @@ def cu_range_stream(device, first, count, **stream_kw):
         with torch.cuda.device(device):
             rc = L.slu_stream_create_cu_range(first, count, ctypes.byref(h))
         if rc == 0 and h.value:
+            ops.STREAM_CUS[h.value] = int(count)
             return torch.cuda.ExternalStream(h.value, device=device)
         _CU_MASK_BROKEN[0] = True
         print("warning: CU-masked streams unavailable (%s); the look-ahead pipeline shares all CUs"

@@ -40,7 +40,7 @@ typedef enum {
   SLU_ERR_DEVICE = -5         /* current device is not gfx950                                */
 } slu_status;
 
-#define SLU_ABI_VERSION 8
+#define SLU_ABI_VERSION 9
 
 /* -------- library ------------------------------------------------------------------------- */
 int slu_version(void);                    /* returns SLU_ABI_VERSION                           */
@@ -262,7 +262,7 @@ int slu_wconv_fwd_bf16(const float* in, const float* const* in_table, int64_t ta
 int slu_gru_seq_fwd_bf16(const float* gx, const float* w_hh_fwd, const float* w_hh_rev, const float* b_hh_fwd,
                          const float* b_hh_rev, float* out, float* reserve, const void* x_planes,
                          int64_t x_plane_stride, int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T,
-                         int64_t B, int64_t H, int64_t D, int nsplit, void* stream);
+                         int64_t B, int64_t H, int64_t D, int nsplit, int seq_tiles, void* stream);
 /* The same recurrence of a FROZEN layer with the layer's Dropout(p) + Downsample("avg", 2) (models.py:246-251 / :276-281,
  * :26-46) applied in its epilogue (ABI 5): the lane that owns four consecutive hidden units of a sequence keeps the masked
  * h of a pooling window's first frame in registers and writes the average when the second frame arrives — the fp32
@@ -276,7 +276,7 @@ int slu_gru_seq_fwd_pool_bf16(const float* gx, const float* w_hh_fwd, const floa
                               const float* b_hh_rev, float* out_pooled, void* out_planes, int64_t out_plane_stride,
                               const uint32_t* keep_bits, float p_drop, const void* x_planes, int64_t x_plane_stride,
                               int64_t K, const void* w_ih_packed, const float* b_ih, int64_t T, int64_t B, int64_t H,
-                              int64_t D, int nsplit, void* stream);
+                              int64_t D, int nsplit, int seq_tiles, void* stream);
 
 /* -------- GRU recurrence: torch.nn.GRU (models.py:232, :262, :686), h0 = 0, gates [r; z; n] ----
  *   gx      (T, B, D*3H): x_t @ W_ih^T + b_ih for direction d in columns [d*3H, (d+1)*3H)

@@ -25,7 +25,7 @@ def test_library_loads_and_exports_every_symbol():
     L = lib.load()
     for name in header_functions():
         assert hasattr(L, name), name
-    assert L.slu_version() == lib.ABI_VERSION == 8
+    assert L.slu_version() == lib.ABI_VERSION == 9
     assert isinstance(L.slu_last_error(), bytes)
 
 

@@ -206,6 +206,44 @@ def test_gru_dropout_pool_epilogue_equals_the_two_launch_path(ops, T, B, H, D, s
                 assert torch.equal(alone, keep[:, sub:2 * sub])
 
 
+@pytest.mark.parametrize("T,B,D", [(75, 128, 2), (38, 37, 2), (1, 70, 2), (2, 33, 1), (301, 2560, 2), (150, 1296, 2)])
+@pytest.mark.parametrize("nsplit", [3, 2, 1])
+def test_gru_two_tiles_per_workgroup_equals_one_tile(ops, T, B, D, nsplit):
+    """gru_bf2_fwd_kernel (round 6: two 16-sequence tiles per workgroup half a step apart, gx and keep bits by LDS-DMA through a
+    ring of three chunk buffers; slu_gru_seq_fwd[_pool]_bf16(seq_tiles = 2)) against gru_bf_fwd_kernel (seq_tiles = 1): same
+    products in the same order, same gate formulas, same epilogue -> BIT-IDENTICAL outputs, for all three output forms
+    (fp32 every step; Dropout + avg-pool -> fp32; -> planes), odd T (partial last pooling window), T = 1 / 2 (no steady-state
+    loop iteration), ragged batches (the last workgroup's second tile partly or wholly past B), a unidirectional layer, and
+    the 40-batch super-batch of the benchmarked loop (2560 sequences, T = 301)."""
+    torch.manual_seed(T * 11 + B)
+    H = 128
+    gx = torch.randn(T, B, D * 3 * H, device="cuda")
+    wf, bf = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, device="cuda") * 0.1
+    wr, br = (torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, device="cuda") * 0.1) if D == 2 else (None, None)
+    one, _ = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, seq_tiles=1)
+    two, _ = ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, seq_tiles=2)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), "fp32 output of every step: %.3e" % (one - two).abs().max().item()
+    for p, offset in ((0.5, 7 * 16 + 3), (0.0, 0)):
+        keep = ops.dropout_bits(T, B, D * H, p, 1234, offset, None, 64 if B % 64 == 0 else 0, gx.device) if p > 0 else None
+        a_f = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, False, seq_tiles=1)
+        b_f = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, False, seq_tiles=2)
+        a_p = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, True, seq_tiles=1).planes
+        b_p = ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, D, nsplit, keep, p, True, seq_tiles=2).planes
+        torch.cuda.synchronize()
+        assert torch.equal(a_f, b_f), "pooled fp32 output, p = %g: %.3e" % (p, (a_f - b_f).abs().max().item())
+        assert torch.equal(a_p.view(torch.int16), b_p.view(torch.int16)), "plane output, p = %g" % p
+    # opt-in: the default is one tile; SLU_GRU_TILES=auto takes two as soon as the one-tile grid exceeds the device's CUs
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert ops.gru_seq_tiles(B, H, D) == 1
+    os.environ["SLU_GRU_TILES"] = "auto"
+    try:
+        assert ops.gru_seq_tiles(B, H, D) == (2 if -(-B // 16) * D > cus else 1)
+        assert ops.gru_seq_tiles(B, 64, D) == 1 and ops.gru_seq_tiles(B, H, D, reserve=True) == 1
+    finally:
+        del os.environ["SLU_GRU_TILES"]
+
+
 def test_bf16_mode_full_model_vs_fp32_oracle(tmp_path, monkeypatch):
     """BASELINE configs[4] arithmetic (SLU_DTYPE=bf16: the GRU layers' forward contractions on bf16 MFMA with
     fp32 accumulation and gate math, exact-fp32 backward on the saved gates).  The reference has no reduced

@@ -5,7 +5,7 @@
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 UNIT=$1; shift
-SRC="$ROOT/end-to-end-slu_amd/csrc"; LIB="$ROOT/end-to-end-slu_amd/lib"; ALT="$ROOT/end-to-end-slu_amd/lib_alt"
+SRC="$ROOT/end-to-end-slu_amd/csrc"; LIB="$ROOT/end-to-end-slu_amd/lib"; ALT="${ALT_DIR:-$ROOT/end-to-end-slu_amd/lib_alt}"
 mkdir -p "$ALT"
 bash "$SRC/build.sh" > /dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$SRC/$UNIT.hip" -o "$ALT/$UNIT.o"

@@ -41,6 +41,16 @@ elif what == "gru_bf":
     bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
     for _ in range(5):
         ops.gru_seq_fwd_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS)
+elif what in ("gru_bf3_pool_300_t2", "gru_bf3_pool_150_t2"):
+    # round 6: the same product form on gru_bf2_fwd_kernel (two sequence tiles per workgroup), 40-batch super-batch by default
+    T, B, H = (300 if "300" in what else 150), (int(sys.argv[2]) if len(sys.argv) > 2 else 2560), 128
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    keep = ops.dropout_bits(T, B, 2 * H, 0.5, 1234, 19, None, 64, "cuda")
+    gx = torch.randn(T, B, 6 * H, device="cuda")
+    for _ in range(5):
+        ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, 3, keep, 0.5, True, seq_tiles=2)
+    torch.cuda.synchronize()
 elif what in ("gru_bf3_pool_300", "gru_bf3_pool_150"):
     # round 5, the DEFAULT arithmetic (bf16x3): a frozen GRU layer as the look-ahead super-batch launches it — gx in (the
     # projection GEMM wrote it), recurrence + Dropout(0.5) + avg-pool(2) epilogue, three bf16 planes out; T = 300 / 150
