@@ -64,6 +64,30 @@ def init_from_env(backend=None):
     return rank, ws, local
 
 
+def _agree(ok):
+    """Control-plane agreement on a step that can fail on ONE rank: True iff it succeeded on EVERY rank (a MIN all-reduce of a
+    host flag; also a barrier).  Every fallible step of a communicator's set-up goes through it, so that the ranks raise —
+    or fall back — TOGETHER: a rank that raised alone would leave its peers inside the next control-plane collective."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        flag = torch.tensor([1.0 if ok else 0.0])
+        if dist.get_backend() == "nccl":
+            flag = flag.cuda()
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return flag.item() >= 1.0
+    return bool(ok)
+
+
+def agreed_status(status):
+    """MAX over the ranks of a non-negative status word (0 = fine): every rank sees the worst one."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([float(status)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+    return int(status)
+
+
 class DirectComm:
     """RCCL communicator driven through the C ABI (slu_comm_* of include/slu_hip.h): the all-reduce is enqueued on
     the CURRENT stream (the training stream, between the captured backward and Adam graphs) instead of going
@@ -75,15 +99,38 @@ class DirectComm:
         from . import lib as _lib
         self._lib, self._L = _lib, _lib.load()
         buf = (ctypes.c_char * 128)()
+        self._handle = None
+        # Both fallible steps are AGREED over the control plane (as in IpcComm): rank 0 broadcasts (ok, id) even when it
+        # could not draw an id, and the ranks compare notes after slu_comm_init — they all raise, or none does.
+        err = None
         if rank == 0:
-            _lib.check(self._L.slu_comm_unique_id(buf), "slu_comm_unique_id")
+            try:
+                _lib.check(self._L.slu_comm_unique_id(buf), "slu_comm_unique_id")
+            except Exception as e:                        # noqa: BLE001
+                err = str(e)
         if world_size > 1:
-            box = [bytes(buf)]
+            box = [(err is None, bytes(buf), err)]
             dist.broadcast_object_list(box, src=0)          # host bytes: any backend (gloo is the control plane)
-            buf = (ctypes.c_char * 128).from_buffer_copy(box[0])
-        self._handle = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            _lib.check(self._L.slu_comm_init(ctypes.byref(self._handle), buf, world_size, rank), "slu_comm_init")
+            ok0, raw, err0 = box[0]
+            if not ok0:
+                raise _lib.SluHipError("DirectComm: rank 0 could not create an RCCL unique id: %s" % err0)
+            buf = (ctypes.c_char * 128).from_buffer_copy(raw)
+        elif err is not None:
+            raise _lib.SluHipError("DirectComm: " + err)
+        handle = ctypes.c_void_p()
+        try:
+            with torch.cuda.device(device):
+                _lib.check(self._L.slu_comm_init(ctypes.byref(handle), buf, world_size, rank), "slu_comm_init")
+        except Exception as e:                            # noqa: BLE001
+            err = str(e)
+        if not _agree(err is None):
+            if err is None:                               # this rank's communicator exists, a peer's does not
+                try:
+                    self._L.slu_comm_destroy(handle)
+                except Exception:                         # noqa: BLE001
+                    pass
+            raise _lib.SluHipError("DirectComm: slu_comm_init failed on some rank%s" % ("" if err is None else ": " + err))
+        self._handle = handle
         self.world_size = world_size
 
     kind = "rccl"
@@ -194,15 +241,21 @@ class IpcComm:
             raise _lib.SluHipError("IpcComm: " + err)
         # pay the first-touch cost of the lazily mapped peer windows now, not inside a call with bounded waits
         import time
-        with torch.cuda.device(device):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _lib.check(self._L.slu_comm_ipc_window_touch(self._windows, rank, world_size, self.window_bytes,
-                                                         torch.cuda.current_stream().cuda_stream), "slu_comm_ipc_window_touch")
-            torch.cuda.synchronize()
-            self.first_touch_ms = 1e3 * (time.perf_counter() - t0)      # what the lazy mappings cost (reported by the tests)
-        if world_size > 1:
-            dist.barrier()
+        err = None
+        try:
+            with torch.cuda.device(device):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _lib.check(self._L.slu_comm_ipc_window_touch(self._windows, rank, world_size, self.window_bytes,
+                                                             torch.cuda.current_stream().cuda_stream), "slu_comm_ipc_window_touch")
+                torch.cuda.synchronize()
+                self.first_touch_ms = 1e3 * (time.perf_counter() - t0)  # what the lazy mappings cost (reported by the tests)
+        except Exception as e:                                # noqa: BLE001
+            err = str(e)
+        if not _agree(err is None):                           # (also the barrier: every rank has touched every window)
+            self._release()
+            raise _lib.SluHipError("IpcComm: the first touch of the peer windows failed on some rank%s"
+                                   % ("" if err is None else ": " + err))
 
     def _release(self):
         """Unmap the peers' windows and free the own one (no collective; idempotent)."""
@@ -314,19 +367,36 @@ def _selftest(comm, rank, world_size, device, rounds=12, n=70001):
     return ok >= 1.0, us
 
 
-def _time_plane(comm, device, n=302616, reps=30):
+def _time_plane(comm, device, n=302616, reps=30, world_size=1):
     """Microseconds per all-reduce of the frozen-encoder step's payload (1.21 MB) through `comm`, back to back on the
-    current stream between two events (after 5 warm-up calls)."""
-    flat = torch.zeros(n, dtype=torch.float32, device=device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    current stream between two events (after 5 warm-up calls).  The payload is VERIFIED: every word starts as 1 and must
+    be world_size ** (5 + reps) afterwards (exact in fp32 while that is below 2^24, which bounds the calls counted)."""
+    import time
+    gpu = torch.device(device).type == "cuda"            # (host tensors: the gloo tests of the race's control flow)
+    flat = torch.ones(n, dtype=torch.float32, device=device)
+    if gpu:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    calls = 0
     for _ in range(5):
         comm.allreduce(flat)
-    e0.record()
+        calls += 1
+    if gpu:
+        e0.record()
+    t0 = time.perf_counter()
     for _ in range(reps):
         comm.allreduce(flat)
-    e1.record()
-    torch.cuda.synchronize(device)
-    return 1e3 * e0.elapsed_time(e1) / reps
+        calls += 1
+        if world_size > 1 and float(world_size) ** (calls + 1) >= 2.0 ** 24:
+            flat.fill_(1.0)
+            calls = 0
+    if gpu:
+        e1.record()
+        torch.cuda.synchronize(device)
+    us = 1e3 * e0.elapsed_time(e1) / reps if gpu else 1e6 * (time.perf_counter() - t0) / reps
+    want = float(world_size) ** calls
+    if not bool((flat == want).all()):
+        raise RuntimeError("%s: wrong sums on the %d-element payload (expected %g everywhere)" % (type(comm).__name__, n, want))
+    return us
 
 
 def _shared_device():
@@ -358,37 +428,20 @@ def make_comm(rank, world_size, device):
         return IpcComm(rank, world_size, device)
     comm = None
     try:
-        comm = IpcComm(rank, world_size, device)
-        built = 1.0
+        comm = IpcComm(rank, world_size, device)             # (its own set-up failures are agreed: all ranks raise together)
     except Exception as e:                                   # noqa: BLE001
         print("data parallel: no IPC windows on rank %d (%s)" % (rank, str(e)[:300]))
-        built = 0.0
-    if world_size > 1:
-        flag = torch.tensor([built])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        built = flag.item()
-    if built >= 1.0:
-        ok, us = _selftest(comm, rank, world_size, device)
+    built = _agree(comm is not None)
+    if built:
+        ok, us = _selftest(comm, rank, world_size, device)   # verdict agreed inside
         if ok:
             comm.selftest_us = us
             if world_size > 1 and not _shared_device() and os.environ.get("SLU_COMM_RACE", "1") != "0":
                 # one GPU per rank: RCCL is available too — time both planes on the step's payload and keep the faster
                 # (the kernel has only ever run on ranks SHARING a GPU in this repository's test environment; on real links
-                # it must earn its place against the library)
-                rccl = None
-                try:
-                    rccl = DirectComm(rank, world_size, device)
-                    t_ipc, t_rccl = _time_plane(comm, device), _time_plane(rccl, device)
-                    both = torch.tensor([t_ipc, t_rccl], dtype=torch.float64)
-                    dist.all_reduce(both, op=dist.ReduceOp.MAX)          # the slowest rank's view, the same on every rank
-                    comm.race_us = {"ipc": round(both[0].item(), 2), "rccl": round(both[1].item(), 2)}
-                    if both[1].item() < both[0].item():
-                        rccl.race_us = comm.race_us
-                        comm.close()
-                        return rccl
-                    rccl.close()
-                except Exception as e:                           # noqa: BLE001 - RCCL unavailable: the proven kernel stays
-                    print("data parallel: no RCCL communicator to race against (%s)" % str(e)[:200])
+                # it must earn its place against the library).  Every step that can fail on one rank is AGREED before the
+                # next control-plane collective: the ranks keep the IPC plane together or switch together.
+                return _race(comm, rank, world_size, device)
             return comm
         if rank == 0:
             print("data parallel: the hand-written IPC all-reduce failed its self-test; falling back to RCCL")
@@ -397,11 +450,63 @@ def make_comm(rank, world_size, device):
             comm.close(collective=False)                     # the verdict was agreed above: every rank is here, nothing in flight
         except Exception:                                    # noqa: BLE001
             pass
-        if world_size > 1:
-            dist.barrier()                                   # nobody unmaps a window a slower peer is still verifying against
+    if world_size > 1:
+        dist.barrier()                                       # nobody unmaps a window a slower peer is still verifying against
     if _shared_device():
         return None                                          # RCCL refuses duplicate devices: gloo carries the buckets
-    return DirectComm(rank, world_size, device)
+    try:
+        return DirectComm(rank, world_size, device)          # (agreed inside: raises on every rank or on none)
+    except Exception as e:                                   # noqa: BLE001 - last resort: torch.distributed's own collective
+        if rank == 0:
+            print("data parallel: no RCCL communicator either (%s); the buckets go through torch.distributed" % str(e)[:200])
+        return None
+
+
+def _race(comm, rank, world_size, device, payloads=(302616,)):
+    """The start-up race of make_comm: `comm` (the proven IPC plane) against RCCL on the step's payload(s).  Returns the
+    plane that carries the gradients; the other one is closed.  No rank can leave this function on a different path than its
+    peers: DirectComm's construction is collective-consistent, the timing's success and its figures are agreed (MIN / MAX)."""
+    rccl = None
+    try:
+        rccl = DirectComm(rank, world_size, device)
+    except Exception as e:                                   # noqa: BLE001 - RCCL unavailable (on every rank): the proven kernel stays
+        if rank == 0:
+            print("data parallel: no RCCL communicator to race against (%s)" % str(e)[:200])
+        comm.race_us = {"ipc": None, "rccl": None, "reason": "rccl unavailable"}
+        return comm
+    keep_ipc = True
+    try:
+        t = [float("inf"), float("inf")]
+        fine = True
+        for k, plane in enumerate((comm, rccl)):
+            # agreed PER PLANE: a rank that failed in the first timing must not leave its peers inside the second plane's
+            # collective (RCCL waits without a bound)
+            try:
+                t[k] = sum(_time_plane(plane, device, n, world_size=world_size) for n in payloads)
+            except Exception as e:                           # noqa: BLE001
+                print("data parallel: timing the %s plane failed on rank %d (%s)" % (plane.kind, rank, str(e)[:200]))
+                fine = False
+            fine = _agree(fine)
+            if not fine:
+                break
+        if fine:
+            both = torch.tensor(t, dtype=torch.float64)
+            dist.all_reduce(both, op=dist.ReduceOp.MAX)      # the slowest rank's view, the same on every rank
+            comm.race_us = {"ipc": round(both[0].item(), 2), "rccl": round(both[1].item(), 2)}
+            keep_ipc = not (both[1].item() < both[0].item())
+        else:
+            comm.race_us = {"ipc": None, "rccl": None, "reason": "timing failed on some rank"}
+    finally:
+        if keep_ipc:
+            try:
+                rccl.close()
+            except Exception:                                # noqa: BLE001
+                pass
+    if keep_ipc:
+        return comm
+    rccl.race_us = comm.race_us
+    comm.close()                                             # collective (a barrier): every rank took this branch
+    return rccl
 
 
 class GradBucket:

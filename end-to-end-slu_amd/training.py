@@ -146,6 +146,11 @@ class Trainer:
     def save_checkpoint(self):
         if self.rank != 0:
             return
+        if getattr(self, "poisoned", False):
+            # a bounded wait of the gradient all-reduce expired during the last epoch (_run raised on every rank): the
+            # parameters have absorbed unreduced gradients since — never overwrite a good checkpoint with them
+            print("Could not save model (the data-parallel replicas went out of step)")
+            return
         try:
             torch.save(self.model.state_dict(), os.path.join(self.checkpoint_path, "model_state.pth"))
         except Exception:
@@ -671,10 +676,17 @@ class Trainer:
                     self._say("truth: " + truth[0])
         comm = self.bucket.comm if self.bucket is not None else None
         if train and comm is not None and hasattr(comm, "status"):
-            st = comm.status()                 # the epoch statistics are read here anyway: the device is idle
-            if st != 0:
-                raise RuntimeError("data parallel: rank %d gave up waiting for rank %d inside the gradient all-reduce (bounded "
-                                   "wait, slu_comm_allreduce_ipc): the replicas are out of step" % (self.rank, st - 1))
+            # the epoch statistics are read here anyway: the device is idle.  The verdict is AGREED over the control plane
+            # (MAX): a rank whose wait timed out must not raise alone — its peers saw its flags, finished with status 0 and
+            # would sit in the next collective (_epoch_means) until the control plane's own timeout
+            st = comm.status()
+            worst = dp.agreed_status(st)
+            if worst != 0:
+                self.poisoned = True           # every step since the timeout applied unreduced gradients: no checkpoint
+                raise RuntimeError("data parallel: %s gave up waiting for rank %d inside the gradient all-reduce (bounded "
+                                   "wait, slu_comm_allreduce_ipc): the replicas are out of step — every rank stops here"
+                                   % ("rank %d" % self.rank if st != 0 else "a peer of rank %d" % self.rank,
+                                      (st if st != 0 else worst) - 1))
         means = self._epoch_means(self.epoch_sums[:len(names)].tolist() + [string_acc], num_examples, dev)
         if not all(math.isfinite(float(m)) for m in means[:len(names)]):
             import models

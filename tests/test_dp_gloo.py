@@ -154,3 +154,178 @@ def test_grad_bucket_and_metric_reduction(tmp_path):
     port = 30000 + os.getpid() % 1000
     mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "ok0").read() == "True" and open(tmp_path / "ok1").read() == "True"
+
+
+# ---- forced failures of the data plane's set-up: every rank must leave on the SAME path (round-5 advisor findings) ----------
+class _FakeLib:
+    """Stands in for libslu_hip.so's slu_comm_* entry points on a CPU box: each call can be made to fail on chosen ranks."""
+
+    def __init__(self, rank, fail):
+        self.rank, self.fail, self.destroyed = rank, fail, 0
+
+    def _rc(self, name):
+        return -3 if self.rank in self.fail.get(name, ()) else 0
+
+    def slu_comm_unique_id(self, buf):
+        return self._rc("unique_id")
+
+    def slu_comm_init(self, handle_ref, buf, world, rank):
+        return self._rc("init")
+
+    def slu_comm_destroy(self, handle):
+        self.destroyed += 1
+        return 0
+
+    def slu_last_error(self):
+        return b"forced failure"
+
+
+class _FakePlane:
+    """A data plane for _race: all-reduce over gloo on host tensors; can be told to fail while it is being timed."""
+    kind = "ipc"
+
+    def __init__(self, fail_timing=False):
+        self.fail_timing, self.closed = fail_timing, False
+
+    def allreduce(self, flat):
+        torch.distributed.all_reduce(flat)
+        if self.fail_timing:
+            flat.add_(1.0)            # wrong sums on this rank only: _time_plane's verification raises after the last call
+
+    def close(self, collective=True):
+        if collective:
+            torch.distributed.barrier()
+        self.closed = True
+
+
+def _fallback_worker(rank, world, port, out):
+    import contextlib
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from slu_hip import dp, lib
+    dp.init_from_env(backend="gloo")
+    cpu = torch.device("cpu")
+    torch.cuda.device = lambda d: contextlib.nullcontext()            # DirectComm selects its device; none here
+    torch.cuda.synchronize = lambda *a, **k: None
+    log = []
+
+    def direct(fail):
+        fake = _FakeLib(rank, fail)
+        lib.load = lambda: fake
+        try:
+            c = dp.DirectComm(rank, world, cpu)
+            return "built", fake, c
+        except lib.SluHipError as e:
+            return "raised: " + str(e)[:60], fake, None
+
+    # 1. rank 0 cannot draw a unique id: BOTH ranks raise (rank 1 used to wait in the broadcast)
+    r, fake, _ = direct({"unique_id": (0,)})
+    log.append(("unique_id@0", r.startswith("raised")))
+    torch.distributed.barrier()
+    # 2. slu_comm_init fails on rank 1 only: both raise, rank 0 destroys the communicator it had built
+    r, fake, _ = direct({"init": (1,)})
+    log.append(("init@1", r.startswith("raised") and fake.destroyed == (1 if rank == 0 else 0)))
+    torch.distributed.barrier()
+    # 3. nothing fails: both build
+    r, fake, c = direct({})
+    log.append(("clean", r == "built" and c is not None))
+    c._handle = None                                                  # (nothing to destroy behind the fake)
+    torch.distributed.barrier()
+
+    # 4. the start-up race: timing fails on rank 1 only -> both ranks keep the IPC plane, the RCCL one is closed
+    class FakeDirect(_FakePlane):
+        kind = "rccl"
+
+        def __init__(self, *a):
+            super().__init__(fail_timing=False)
+
+        def close(self):
+            self.closed = True
+    made = []
+    real_direct = dp.DirectComm
+    dp.DirectComm = lambda *a: made.append(FakeDirect()) or made[-1]
+    ipc = _FakePlane(fail_timing=(rank == 1))
+    try:
+        kept = dp._race(ipc, rank, world, cpu, payloads=(1000,))
+    except Exception as e:                                            # noqa: BLE001
+        kept = e
+    log.append(("race, timing fails@1", kept is ipc and made[-1].closed and ipc.race_us["reason"].startswith("timing failed")))
+    torch.distributed.barrier()
+    # 5. the race proper (host tensors over gloo, verified sums): both ranks agree on one plane and close the other
+    ipc = _FakePlane()
+    kept = dp._race(ipc, rank, world, cpu, payloads=(1000,))
+    same = torch.tensor([1.0 if kept is ipc else 0.0])
+    both = [torch.zeros(1), torch.zeros(1)]
+    torch.distributed.all_gather(both, same)
+    log.append(("race agrees", both[0].item() == both[1].item() and (made[-1].closed if kept is ipc else ipc.closed)
+                and isinstance(kept.race_us["ipc"], float)))
+    # 6. RCCL unavailable on every rank (DirectComm raises everywhere): the proven plane stays
+    def no_rccl(*a):
+        raise lib.SluHipError("no RCCL here")
+    dp.DirectComm = no_rccl
+    ipc = _FakePlane()
+    log.append(("race, no rccl", dp._race(ipc, rank, world, cpu) is ipc and ipc.race_us["reason"] == "rccl unavailable"))
+    dp.DirectComm = real_direct
+    # 7. a bounded wait expired on rank 1 only: every rank sees the worst status
+    log.append(("agreed status", dp.agreed_status(3 if rank == 1 else 0) == 3 and dp.agreed_status(0) == 0))
+    open(os.path.join(out, "fb%d" % rank), "w").write(repr(log))
+    torch.distributed.destroy_process_group()
+
+
+def test_data_plane_fallbacks_leave_on_the_same_path(tmp_path):
+    """SURVEY 8(e) readiness: each fallback edge of slu_hip/dp.py with a forced failure on ONE rank (world size 2, gloo) —
+    DirectComm's unique id and init, the start-up race's timing, RCCL missing, a timed-out wait's status: no rank hangs in
+    a control-plane collective its peer never enters, both take the same branch."""
+    port = 31000 + os.getpid() % 1000
+    mp.spawn(_fallback_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        log = eval(open(tmp_path / ("fb%d" % r)).read())
+        assert len(log) == 7 and all(ok for _, ok in log), (r, log)
+
+
+class _StatusComm:
+    """bucket.comm stand-in whose bounded wait 'expired' on rank 1."""
+    kind = "ipc"
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def allreduce_flats(self, flats):
+        for f in flats.values():
+            torch.distributed.all_reduce(f)
+
+    def status(self):
+        return 1 if self.rank == 1 else 0          # rank 1 gave up waiting for rank 0
+
+
+def _poison_worker(rank, world, port, tmp):
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from slu_hip import dp
+    import training
+    dp.init_from_env(backend="gloo")
+    cfg = Cfg()
+    cfg.folder = tmp
+    trainer = training.Trainer(TinySLU(), cfg)
+    trainer.bucket.comm = _StatusComm(rank)
+    shard = [(x[rank::world], y[rank::world]) for x, y in _batches(2, 8)]
+    try:
+        trainer.train(OneShotDataset(shard), print_interval=1000)
+        verdict = "no exception"
+    except RuntimeError as e:
+        verdict = str(e)
+    trainer.save_checkpoint()
+    open(os.path.join(tmp, "poison%d" % rank), "w").write(verdict)
+    torch.distributed.destroy_process_group()
+
+
+def test_timed_out_wait_stops_every_rank_and_blocks_the_checkpoint(tmp_path):
+    """training.Trainer._run: comm.status() != 0 on ONE rank raises on EVERY rank (agreed over the control plane) instead of
+    leaving the healthy rank in the epoch-metric all-reduce, and the poisoned parameters are not written over a checkpoint."""
+    os.makedirs(tmp_path / "training")
+    port = 32000 + os.getpid() % 1000
+    mp.spawn(_poison_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        v = open(tmp_path / ("poison%d" % r)).read()
+        assert "out of step" in v and "rank 0 inside" in v.replace("for rank 0", "rank 0"), v
+    assert not os.path.isfile(tmp_path / "training" / "model_state.pth")

@@ -133,7 +133,7 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
         assert torch.equal(v, sd[k]), k
 
 
-@pytest.mark.parametrize("n_utt,math", [(1024, "f16x2"), (1280, "f16x2"), (768, "bf16x3")])
+@pytest.mark.parametrize("n_utt,math", [(1024, "f16x2"), (1280, "f16x2"), (768, "bf16x3"), (1280, "bf16x3")])
 def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, monkeypatch, n_utt, math):
     """One look-ahead super-batch through the frozen encoder with the oracle's dropout masks, against the CPU oracle's
     encoder (models.py:349-361), features within 1e-4.  1024 = 16 x 64 utterances of 3 s is exactly what bench.py's
@@ -141,7 +141,8 @@ def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, monkeypatch,
     projection, the 96-row panel GEMM (M = 150 x 1024 = 153 600 rows >= 131 072, K = 256), the tiled GEMM for the shorter
     layers and the 16-sequence split-precision (f16x2) recurrence on 64 tiles x 2 directions; 1280 = the 20-batch
     super-batch of the 96 + 160 CU partition (rounds 1-2); 768 = a 12-batch super-batch (all launches below the panel
-    threshold), on the bf16x3 scheme (whose first layer takes the row-panel GEMM for K = 60 + the plain recurrence)."""
+    threshold), on the bf16x3 scheme (whose first layer takes the row-panel GEMM for K = 60 + the plain recurrence); 1280 on
+    bf16x3 = THE DEFAULT arithmetic at the default width (round 6: it had been compared with the oracle at 768 only)."""
     import models
     monkeypatch.setenv("SLU_FROZEN_MATH", math)
     cfg = _full_cfg(tmp_path)
