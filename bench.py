@@ -423,7 +423,7 @@ def kernel_table(model, trainer, batch, samples, width, asr=False):
                 # K <= 64: the row-panel kernel (A resident in LDS, HBM-write bound); else the tiled kernel
                 if kc <= 2:
                     gemm_name = "gemm_bf_panel_kernel<%d,%d>" % (ns, kc)
-                elif kc in (4, 8) and T * B >= 128 * 1024 and os.environ.get("SLU_GEMM_PANEL96", "1") != "0":
+                elif kc in (4, 8) and T * B >= 16 * 1024 and os.environ.get("SLU_GEMM_PANEL96", "1") != "0":
                     gemm_name = "gemm_bf_panel96_kernel<%d,%d>" % (ns, kc)        # 96-row panels, A resident in LDS
                 else:
                     gemm_name = "gemm_bf_kernel<%d>" % ns
@@ -533,14 +533,81 @@ def _cu_split():
     return pipeline.cu_split()
 
 
+def models_nsplit():
+    """Split scheme of the frozen stages in this process (3 = bf16x3, the default; 2 = f16x2; 0 = exact fp32)."""
+    import models
+    return models.guarded_frozen_nsplit() or 3
+
+
 def _n_cus():
     from slu_hip import pipeline
     return pipeline.n_compute_units(torch.cuda.current_device())
 
 
-# Committed evidence for the numbers this process cannot measure itself (it has no profiler): named as `source`, never read.
-PMC_SOURCE = "profiles/r05_z_pmc_gru_bf.txt"                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (HBM bytes per launch)
+# Committed evidence of the same measurements (named as `source`, never read at run time).
+PMC_SOURCE = "profiles/r05_z_pmc_gru_bf.txt"                     # rocprofv3 --pmc passes of the dominant kernel (HBM bytes, SQ activity)
 INLOOP_SOURCE = "profiles/r05_z_default_kernel_stats_by_shape.txt"  # rocprofv3 --kernel-trace of the default command (in-loop durations)
+
+
+def pmc_dominant_kernel(n_seq, nsplit, timeout=150):
+    """HBM traffic and SQ activity of the dominant kernel (the frozen GRU layers' split-precision recurrence, product form,
+    the four layer shapes of one look-ahead super-batch) from rocprofv3 PMC counters, collected LIVE by this run: three
+    separate passes (FETCH_SIZE; WRITE_SIZE; SQ set — the TCC counters do not fit one pass) of tools/run_one.py
+    gru_frozen_layers in child processes, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
+    (FETCH_SIZE counts 64 B per 128-B request: x 2; counter unit KiB).  -> dict, or {"error": ...} when the profiler is not
+    available (the line then carries traffic = null and says why)."""
+    import csv
+    import glob
+    rocprof = shutil.which("rocprofv3")
+    if rocprof is None:
+        return {"error": "rocprofv3 not on PATH"}
+    work = tempfile.mkdtemp(prefix="slu_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("SLU_BENCH_VERBOSE", None)
+    passes = {"fetch": "FETCH_SIZE", "write": "WRITE_SIZE",
+              "sq": "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES"}
+    got, launches, us = {}, 0, []
+    try:
+        for tag, counters in passes.items():
+            cmd = [rocprof, "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, tag),
+                                                           "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", "run_one.py"),
+                                                           "gru_frozen_layers", str(n_seq), str(nsplit)]
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout)
+            f = glob.glob(os.path.join(work, tag, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not f:
+                return {"error": "rocprofv3 pass %s failed (rc %d): %s" % (tag, r.returncode, (r.stderr or r.stdout)[-160:])}
+            acc = {}
+            for row in csv.DictReader(open(f[0])):
+                if "gru_bf_fwd" in row["Kernel_Name"] or "gru_bf2_fwd" in row["Kernel_Name"]:
+                    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if not acc:
+                return {"error": "no gru_bf_fwd dispatch in pass %s" % tag}
+            launches = max(len(v) for v in acc.values())
+            got.update({k: sum(v) for k, v in acc.items()})
+            if tag == "sq":
+                t = glob.glob(os.path.join(work, tag, "**", "*kernel_trace.csv"), recursive=True)
+                us = [(int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3 for row in csv.DictReader(open(t[0]))
+                      if "gru_bf_fwd" in row["Kernel_Name"] or "gru_bf2_fwd" in row["Kernel_Name"]]
+    except Exception as e:                                       # noqa: BLE001 - a side measurement never takes the headline down
+        return {"error": str(e)[:200]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    H, D = 128, 2
+    waves = -(-n_seq // 16) * D * (H // 16)
+    steps = 3 * (300 + 150 + 75 + 38)                           # wave-steps per wave over the 12 launches
+    fetch_b, write_b = 2.0 * got["FETCH_SIZE"] * 1024.0, got["WRITE_SIZE"] * 1024.0
+    q = 4.0 / (waves * steps)                                   # SQ_* cycle counters tick once per four cycles
+    out = {"launches_profiled": launches, "hbm_bytes_per_launch": round((fetch_b + write_b) / launches),
+           "fetch_bytes_per_launch": round(fetch_b / launches), "write_bytes_per_launch": round(write_b / launches),
+           "avg_launch_us_under_profiler": round(sum(us) / max(1, len(us)), 1),
+           "per_wave_step_cycles": {"wave": round(q * got["SQ_WAVE_CYCLES"]), "issuing": round(q * got["SQ_ACTIVE_INST_ANY"]),
+                                    "valu_active": round(q * got["SQ_ACTIVE_INST_VALU"]), "waiting": round(q * got["SQ_WAIT_ANY"]),
+                                    "issue_stalled": round(q * got["SQ_WAIT_INST_ANY"]),
+                                    "mfma_busy": round(got["SQ_VALU_MFMA_BUSY_CYCLES"] / (waves * steps))}}
+    c = out["per_wave_step_cycles"]
+    # two waves share a SIMD: the share of a step in which the SIMD's matrix pipe or VALU works for this kernel's dependent chain
+    out["issue_frac"] = round(2.0 * (c["mfma_busy"] + c["valu_active"]) / max(1, c["wave"]), 4)
+    return out
 
 
 def side_run(extra_args, env_extra=None, timeout=600):
@@ -921,6 +988,7 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true",
                     help="skip the extra large-batch point (B=2048/GPU, forward-dominant kernels throughput-bound)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel roofline measurement")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes of the dominant kernel")
     ap.add_argument("--no-side-runs", action="store_true",
                     help="skip the extra measurements attached to the default line (exact fp32, host inputs, other workloads)")
     ap.add_argument("--sub", action="store_true", help=argparse.SUPPRESS)       # a side run started by another bench.py
@@ -1048,6 +1116,10 @@ def main():
         }
         if steady:
             out["steady_state"] = steady
+            # (also inside `config`, which every consumer of the line keeps)
+            out["config"]["steady_state_utterances_per_s"] = steady["utterances_per_s"]
+            out["config"]["steady_state_ms_per_step"] = steady["ms_per_step"]
+            out["config"]["steady_state_steps"] = steady["steps"]
         if trainer.data_parallel:
             out["rccl"] = comm_info
             if dp_costs:
@@ -1079,7 +1151,7 @@ def main():
                 "frac_hbm": top["hbm_frac"], "frac_mfma_algorithmic": top["mfma_frac"],
                 "mfma_issued_frac": top["mfma_issued_frac"],           # utilisation of the unit by the 16-bit products issued
                 "frac_of_fp32_mfma_peak": top["frac_of_fp32_mfma_peak"],
-                "traffic": None,                                        # PMC counters need the profiler: see traffic_source
+                "traffic": None, "traffic_over_algorithmic": None,      # filled below from live rocprofv3 PMC passes
                 "traffic_source": PMC_SOURCE, "in_loop_source": INLOOP_SOURCE,
                 "algorithmic_bytes_per_launch": alg_per_launch,
                 "algorithmic_gflop_per_launch": round(top["algorithmic_gflop"] / top["launches_per_cycle"], 3),
@@ -1100,6 +1172,26 @@ def main():
                         "stages: %d sequences on CUs [0,%d)) between two HIP events on that stream.  Peaks are whole-chip: fp32 MFMA "
                         "157.3, dense bf16 / fp16 MFMA 2500 TFLOP/s, HBM 8 TB/s."
                         % (width, args.batch * width, _cu_split(), _n_cus(), args.batch, _cu_split())}
+            r_ = out["roofline"]
+            # SURVEY 8(d)'s MINIMUM bytes of the dominant kernel's share (layer input + pooled output only: the fp32 gx it
+            # reads is avoidable in principle): 2 x 4 x 256 x (T + T/2) bytes per sequence and layer
+            if top["kernel"].startswith("gru_bf") and width > 1:
+                min_bytes = sum(4.0 * 256 * (T_ + -(-T_ // 2)) for T_ in (300, 150, 75, 38)) * n_utt
+                r_["frac_8d"] = round(min_bytes / (top["avg_us"] * 1e-6 * top["launches_per_cycle"]) / (PEAK_HBM_TBS * 1e12), 4)
+                if not args.no_pmc:
+                    note("PMC passes of the dominant kernel (rocprofv3)")
+                    pmc = pmc_dominant_kernel(n_utt, models_nsplit())
+                    r_["pmc"] = pmc
+                    if "error" not in pmc:
+                        r_["traffic"] = pmc["hbm_bytes_per_launch"]
+                        r_["traffic_over_algorithmic"] = round(pmc["hbm_bytes_per_launch"] / max(1, alg_per_launch), 3)
+                        # the larger MEASURED limiter names the bound: the kernel's own dependent issue chain when the SIMDs
+                        # spend most of a step on it while neither roofline is near
+                        r_["issue_frac"] = pmc["issue_frac"]
+                        if pmc["issue_frac"] > max(r_["frac_hbm"], r_["frac_mfma_algorithmic"], r_["mfma_issued_frac"]):
+                            r_["bound_measured"] = "issue"
+                        else:
+                            r_["bound_measured"] = r_["bound"]
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
         if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing" and not args.hidden:

@@ -332,7 +332,11 @@ gemm_bf_panel_kernel(const GemmBfParams p) {
 // workgroup per CU, one wave per SIMD, i.e. the whole 512-register file per wave).  2 x 2 waves: 48 rows x 32 columns
 // each.  The panel load is exposed (~20 % of the panel's MFMA time); everything after it is not.
 constexpr int GP_ROWS = 96;
-constexpr int64_t GP_PANEL_MIN_M = 128 * 1024;          // below: the tiled kernel (see slu_gemm_bf16)
+// Below: the tiled kernel.  Round 6, with the loads interleaved between the MFMAs (G9_STEP), 160 CUs, bf16x3, panel | tiled:
+// M = 192 000: 558 | -, 115 200: 359 | 412, 96 000: 311 | 351, 57 600: 190 | 199, 48 640: 172 | 174, 29 184: 98 | 112 us
+// (profiles/r06_b_gemm_panel96.txt; cutting short launches in two along N — twice the workgroups, a shorter tail round, the
+// A panel fetched twice — was slower everywhere: the panel load is the exposed part)
+constexpr int64_t GP_PANEL_MIN_M = 16 * 1024;
 
 template <int NS, int KC>
 __global__ void __launch_bounds__(GB_THREADS, 1)
@@ -394,16 +398,35 @@ gemm_bf_panel96_kernel(const GemmBfParams p) {
     _Pragma("unroll") for (int pl = 0; pl < NS; ++pl) _Pragma("unroll") for (int a = 0; a < 3; ++a)     \
       dst[pl][a] = sA[kc_ * CH_U4 + pl * GP_ROWS * 4 + a_frag[a]];                                      \
   }
+#ifndef SLU_G9_SCHED
+#define SLU_G9_SCHED 1
+#endif
 #define G9_STEP(s_, SET, fcur, fnxt)                                                                    \
   {                                                                                                     \
     G9_FETCH((s_) + 3, (SET + 3) % 4)                                                                   \
     G9_READ_A((s_) + 1, fnxt)                                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if constexpr (SLU_G9_SCHED == 0) __builtin_amdgcn_sched_barrier(0);                                 \
     _Pragma("unroll") for (int q = 0; q < SP::NPAIR; ++q) {                                             \
       _Pragma("unroll") for (int a = 0; a < 3; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)       \
         accs[SP::ACC(q)][a][b] = mfma_split<NS>(fcur[SP::PA(q)][a], wr[SET][SP::PB(q)][b], accs[SP::ACC(q)][a][b]); \
     }                                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if constexpr (SLU_G9_SCHED == 0) {                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    } else {                                                                                            \
+      /* one wave per SIMD issues in order: a load placed BETWEEN two MFMAs costs nothing (the wave would wait for the    \
+         matrix pipe anyway), a block of loads in front of 36 back-to-back MFMAs costs its whole issue time (round 6:   \
+         MFMA-busy 51 % of the wave cycles with the block form).  Pattern: MFMA + W load (x 2 NS), MFMA + A fragment     \
+         read (x 3 NS), the remaining MFMAs */                                                                          \
+      _Pragma("unroll") for (int g_ = 0; g_ < 2 * NS; ++g_) {                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                              \
+      }                                                                                                 \
+      _Pragma("unroll") for (int g_ = 0; g_ < 3 * NS; ++g_) {                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
+      }                                                                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x008, SP::NPAIR * 6 - 5 * NS, 0);                           \
+    }                                                                                                   \
   }
   uint4 fa0[NS][3], fa1[NS][3];
   G9_READ_A(0, fa0)
@@ -662,8 +685,7 @@ extern "C" int slu_gemm_bf16(const void* A_planes, int64_t a_plane_stride, int64
     SLU_CHECK_LAUNCH("gemm_bf_panel_kernel");
     return SLU_OK;
   }
-  // panels pay their A load once per panel and leave a tail of idle CUs in the last round: they win from ~1300 panels
-  // on (M = 192 000 on 160 CUs: 585 vs 624 us; 96 000: 319 vs 319; 48 640: 173 vs 134 — the tiled kernel keeps those)
+  // panels pay their A load once per panel and leave a tail of idle CUs in the last round (GP_PANEL_MIN_M has the figures)
   if ((p.KC == 4 || p.KC == 8) && N >= 2 * GB_BN && M >= GP_PANEL_MIN_M && (bias == nullptr || ((uintptr_t)bias & 15) == 0)
       && !(getenv("SLU_GEMM_PANEL96") && atoi(getenv("SLU_GEMM_PANEL96")) == 0)) {     // SLU_GEMM_PANEL96=0: tiled kernel
     const size_t lds = (size_t)p.KC * nsplit * GP_ROWS * 64 + 4 * 16 * 36 * sizeof(float);

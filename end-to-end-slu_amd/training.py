@@ -65,23 +65,20 @@ def _lookahead_width(depth, batch_size):
     return max(2, min(32, (8 * cus) // max(1, batch_size)))
 
 
-def _ramp_plan(n_run, width, n_slots, first_share=0.7):
+def _ramp_plan(n_run, width, n_slots, first_share=2.0 / 3.0):
     """Sizes of the FIRST super-batches of a run of n_run batches (the rest are `width` batches each), and how many of
-    them are started side by side instead of one behind the other.  Default: ONE capped first super-batch — a run that
-    fits in two super-batches is split first_share : rest — 70 : 30 with the frozen stages on bf16x3 / exact fp32 (20
-    batches: 14 + 6), 60 : 40 on the faster f16x2 (12 + 8; with 14 + 6 its 20-step rate fell from 240 to 214 k utt/s) —: the
-    second one's encoder runs beside the first one's steps and is ready when they end.  Round 5, bf16x3, the driver's 20-step
-    command, profiles/r05_g_first_sb.txt: first 10 / 12 / 14 / 16 / 20 batches -> 188.3 / 194.9 / 201.8 / 189.6 / 176.3 k
-    utt/s; running the first super-batch on an unmasked stream — the training partition is idle until it is through —
-    changed nothing: 190.1 / 196.5 / 187.2 / 180.3 for 12 / 14 / 16 / 20) —, nothing side by side.
-    SLU_RAMP=a,b,c: explicit sizes, one behind the other (SLU_RAMP_SIDE=1 with as many look-ahead slots: side by side).  Round 5
-    measured the obvious refinement and it is SLOWER (profiles/r05_a_sweep.txt, bf16x3 frozen stages, the driver's 20-step
-    command): 3 + 6 + 11 side by side 181.9 k utt/s, 2 + 5 + 13: 184.3 k, 4 + 6 + 10: 186.4 k, against 194.2 k for 12 + 8
-    chained; time to the first step 3.0 - 4.0 ms against 3.3.  The look-ahead streams have no priorities
-    (hipExtStreamCreateWithCUMask takes none), so super-batches side by side share the partition evenly: the small one's
-    latency chain (~560 dependent recurrence steps) waits behind the big ones' convolutions and GEMMs and ALL of them
-    finish late.  A frozen prefix is ~1.4 ms of latency + ~0.12 ms per batch of throughput on 160 CUs in this arithmetic;
-    short runs are bound by that sum, whatever the split."""
+    them are started side by side instead of one behind the other.  Default: ONE capped first super-batch — a run that fits
+    in two super-batches (n_run < 2 width) is split a : n_run - a with a = ceil(2/3 n_run): the second super-batch's encoder
+    runs beside the first one's steps and is ready when they end.  Where 2/3 comes from: a frozen prefix of k batches costs
+    L + r k on the look-ahead partition (L = the latency of ~560 dependent recurrence steps, r = the throughput term), a
+    trainable step costs s; the first super-batch's steps (a s) hide the second's encoder (L + r (n - a)) when
+    a = (L + r n) / (s + r).  With L = 1.0 - 1.4 ms, r = 0.08 - 0.12 ms and s = 0.15 - 0.17 ms (f16x2 ... bf16x3 frozen stages,
+    DESIGN.md section 7) and the driver's n = 20 that is a = 10.6 ... 13.3: one rule, 2/3, for every arithmetic — no constant
+    fitted to a mode (rounds 4-5 carried 0.6 / 0.7 per arithmetic; round 5 measured, bf16x3, the driver's 20-step command,
+    profiles/r05_g_first_sb.txt: first 10 / 12 / 14 / 16 / 20 batches -> 188.3 / 194.9 / 201.8 / 189.6 / 176.3 k utt/s).
+    SLU_RAMP=a,b,c: explicit sizes, one behind the other (SLU_RAMP_SIDE=1 with as many look-ahead slots: side by side — measured
+    slower, profiles/r05_a_sweep.txt: CU-masked streams have no priorities, super-batches side by side share the partition and
+    ALL finish late)."""
     env = os.environ.get("SLU_RAMP", "0")
     if env not in ("auto", "0"):
         sizes = [max(1, int(v)) for v in env.split(",") if v.strip()]
@@ -537,9 +534,7 @@ class Trainer:
                 if bs not in wcache:
                     w = _lookahead_width(depth, bs)
                     if launched == 0:
-                        import models as _models
-                        share = 0.6 if _models.guarded_frozen_nsplit(self.model) == 2 else 0.7
-                        ramp[0], ramp[1] = _ramp_plan(n_run, w, len(self._slots), share)
+                        ramp[0], ramp[1] = _ramp_plan(n_run, w, len(self._slots))
                     wcache[bs] = min(ramp[0][launched], w) if launched < len(ramp[0]) else w
                 return wcache[bs]
             while not group or len(group) < width():

@@ -195,9 +195,10 @@ def test_ramp_plan_of_the_first_super_batches(monkeypatch):
     by side (70 : 30 for a run that fits in two); SLU_RAMP = explicit sizes / auto = the measured-and-slower side-by-side start."""
     import training
     monkeypatch.delenv("SLU_RAMP", raising=False)
-    assert training._ramp_plan(20, 20, 2) == ([14], 0)                  # the driver's 20-step command: 14 + 6
-    assert training._ramp_plan(20, 20, 2, 0.6) == ([12], 0)             # the opt-in f16x2 arithmetic: 12 + 8
+    assert training._ramp_plan(20, 20, 2) == ([14], 0)                  # the driver's 20-step command: 14 + 6 (ceil(2/3 n))
+    assert training._ramp_plan(20, 20, 2, 0.6) == ([12], 0)             # (an explicit share)
     assert training._ramp_plan(5, 20, 2) == ([4], 0) and training._ramp_plan(5, 20, 2, 0.6) == ([3], 0)
+    assert training._ramp_plan(30, 20, 2) == ([20], 0) and training._ramp_plan(39, 40, 2) == ([26], 0)
     assert training._ramp_plan(100, 20, 2) == ([], 0) and training._ramp_plan(100, 20, 3) == ([], 0)
     monkeypatch.setenv("SLU_RAMP", "auto")
     assert training._ramp_plan(20, 20, 3) == ([3, 6, 11], 3)

@@ -51,6 +51,20 @@ elif what in ("gru_bf3_pool_300_t2", "gru_bf3_pool_150_t2"):
     for _ in range(5):
         ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, 3, keep, 0.5, True, seq_tiles=2)
     torch.cuda.synchronize()
+elif what == "gru_frozen_layers":
+    # the dominant kernel of the default loop in its product form, all four frozen layers of a super-batch (bench.py's live
+    # PMC passes): gx in, recurrence + Dropout(0.5) + avg-pool(2) epilogue, planes out (last layer: fp32 out); 3 rounds
+    B, H = (int(sys.argv[2]) if len(sys.argv) > 2 else 1280), 128
+    NS = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    wf, wr = torch.randn(3 * H, H, device="cuda") * 0.08, torch.randn(3 * H, H, device="cuda") * 0.08
+    bf, br = torch.randn(3 * H, device="cuda"), torch.randn(3 * H, device="cuda")
+    layers = []
+    for T, planes in ((300, True), (150, True), (75, True), (38, False)):
+        layers.append((T, planes, torch.randn(T, B, 6 * H, device="cuda"), ops.dropout_bits(T, B, 2 * H, 0.5, 1234, 19, None, 64, "cuda")))
+    for _ in range(3):
+        for T, planes, gx, keep in layers:
+            ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, NS, keep, 0.5, planes)
+    torch.cuda.synchronize()
 elif what in ("gru_bf3_pool_300", "gru_bf3_pool_150"):
     # round 5, the DEFAULT arithmetic (bf16x3): a frozen GRU layer as the look-ahead super-batch launches it — gx in (the
     # projection GEMM wrote it), recurrence + Dropout(0.5) + avg-pool(2) epilogue, three bf16 planes out; T = 300 / 150
@@ -80,14 +94,19 @@ elif what in ("gru_bf_pool_fused", "gru_bf_pool"):
         for _ in range(5):
             ops.gru_seq_fwd_pool_bf16(gx, wf, wr, bf, br, T, B, H, 2, 2, keep, 0.5, True)
     torch.cuda.synchronize()
-elif what in ("wconv_sinc", "wconv_conv1"):
-    # frozen CNN blocks of a 1024-sequence super-batch on the split-precision kernel (f16x2)
+elif what in ("wconv_sinc", "wconv_conv1", "wconv_conv2"):
+    # frozen CNN blocks of a super-batch on the split-precision kernel (RUN_ONE_NSPLIT: 2 = f16x2 (default here), 3 = bf16x3);
+    # conv2 writes its time-major result as planes (what the first frozen GRU layer reads)
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    L, C, Co, k, stride, do_abs, pool = (48000, 1, 80, 401, 80, True, 2) if what == "wconv_sinc" else (300, 80, 60, 5, 1, False, 1)
+    NS = int(os.environ.get("RUN_ONE_NSPLIT", "2"))
+    L, C, Co, k, stride, do_abs, pool = {"wconv_sinc": (48000, 1, 80, 401, 80, True, 2), "wconv_conv1": (300, 80, 60, 5, 1, False, 1),
+                                         "wconv_conv2": (300, 60, 60, 5, 1, False, 1)}[what]
     x = torch.randn(B, L, C, device="cuda") * 0.1
     w = torch.randn(Co, C, k, device="cuda") / (C * k) ** 0.5
+    bias = None if what == "wconv_sinc" else torch.randn(Co, device="cuda") * 0.1
+    tm = what == "wconv_conv2"
     for _ in range(5):
-        ops.wconv_fwd_bf16(x, w, None, B, L, C, stride, do_abs, pool, 0.2, False, 2)
+        ops.wconv_fwd_bf16(x, w, bias, B, L, C, stride, do_abs, pool, 0.2, tm, NS, out_planes=tm)
     torch.cuda.synchronize()
 elif what == "gru_bf_fused":
     # the first frozen GRU layer of a super-batch (K = 60, T = 300): recurrence with the fused input projection
