@@ -893,6 +893,67 @@ def _time_collective(call, stream, reps=50):
     return round(1e3 * e0.elapsed_time(e1) / reps, 2)
 
 
+def scaling_model(model, trainer, width, steady_ms):
+    """What this ONE-GPU process can say about the data-parallel step on N GPUs: the two halves of the pipelined
+    loop timed alone — the trainable suffix (the captured step graph replayed back to back on the training partition) and the
+    frozen prefix (one super-batch graph replayed on the look-ahead partition, per step) — and the step's gradient all-reduce
+    through the hand-written IPC plane with ONE rank (launch + three local passes + its flag protocol; no link traffic).  Under
+    weak scaling every rank runs this same loop plus the collective on the training stream, so
+        step(N) ~ max(prefix, suffix + allreduce(N)),   efficiency(N) ~ step(1) / step(N).
+    allreduce(8) is NOT measurable here: the line carries the one-rank call and the efficiency for an ASSUMED 8-rank call of
+    that + 10 us (two cross-GPU flag hand-offs and two remote 16-byte round trips of ~2.5 us each), so
+    that a SCALE record can be checked against a stated prediction."""
+    from slu_hip import dp
+    out = {}
+    try:
+        sg = next(iter(trainer._step_graphs.values()))
+        main = trainer._train_stream
+        slot = trainer._slots[0]
+        graph, _x, _f = next(v for v in slot.graphs.values() if v is not None)
+    except Exception as e:                                   # noqa: BLE001 - no captured pipeline (eager run): nothing to model
+        return {"error": "no captured pipeline: %s" % str(e)[:100]}
+
+    def wall(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(n)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    def suffix(n):
+        with torch.cuda.stream(main):
+            for i in range(n):
+                sg.run(sg.inputs, 100000 + i)
+
+    def prefix(n):
+        with torch.cuda.stream(slot.stream):
+            for _ in range(n):
+                graph.replay()
+    suffix(16)
+    out["suffix_ms_per_step_alone"] = round(wall(suffix, 256), 4)
+    prefix(2)
+    out["prefix_ms_per_step_alone"] = round(wall(prefix, 16) / width, 4)
+    b = trainer.bucket
+    dev = next(model.parameters()).device
+    try:
+        comm = dp.IpcComm(0, 1, dev)
+        flats = {k: torch.zeros_like(v) for k, v in b.flats.items()}
+        out["allreduce_us_one_rank_ipc"] = _time_collective(lambda: comm.allreduce_flats(flats), main)
+        out["allreduce_bytes"] = b.nbytes()
+        comm.close()
+    except Exception as e:                                   # noqa: BLE001
+        out["allreduce_us_one_rank_ipc"] = None
+        out["allreduce_error"] = str(e)[:120]
+    if out.get("allreduce_us_one_rank_ipc"):
+        ar8 = out["allreduce_us_one_rank_ipc"] + 10.0
+        step8 = max(out["prefix_ms_per_step_alone"], out["suffix_ms_per_step_alone"] + 1e-3 * ar8, steady_ms)
+        out["allreduce_us_assumed_8_ranks"] = round(ar8, 2)
+        out["slack_us_before_the_collective_shows"] = round(1e3 * (max(out["prefix_ms_per_step_alone"], steady_ms) - out["suffix_ms_per_step_alone"]), 2)
+        out["predicted_ms_per_step_8_gpus"] = round(step8, 4)
+        out["predicted_weak_scaling_efficiency_8_gpus"] = round(steady_ms / step8, 4)
+    return out
+
+
 def dp_point(model, trainer, batches, steps, asr, fence):
     """Data parallel runs, EVERY rank (collectives inside): (1) the step's gradient all-reduce alone — the flat bucket(s),
     50 back-to-back calls on the training stream between two HIP events — through the communicator the loop used AND
@@ -1194,6 +1255,14 @@ def main():
                             r_["bound_measured"] = r_["bound"]
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
+        if world == 1 and args.workload == "no_unfreezing" and depth and not args.sub:
+            note("scaling model (suffix / prefix alone, one-rank collective)")
+            try:
+                ss = steady["ms_per_step"] if steady else 1e3 * elapsed / args.steps
+                out["scaling_model"] = scaling_model(model, trainer, width, ss)
+                out["config"]["predicted_weak_scaling_efficiency_8_gpus"] = out["scaling_model"].get("predicted_weak_scaling_efficiency_8_gpus")
+            except Exception as e:                           # noqa: BLE001 - a side measurement never takes the headline down
+                out["scaling_model"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_large_batch and args.workload == "no_unfreezing" and not args.hidden:
             note("large-batch point")
             out["large_batch_point"] = large_batch_point(rank, samples)

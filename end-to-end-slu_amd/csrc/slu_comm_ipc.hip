@@ -34,6 +34,9 @@ constexpr int IPC_WGS = 64;                 // all resident at once on any parti
 // GPU (the test set-up) were seen to be descheduled for more than two seconds now and then (status raised in 1 of ~10
 // four-rank runs with a 2^21 limit; the longest wait of a call is kept in the window, slu_comm_ipc_max_wait).
 constexpr unsigned IPC_SPIN_LIMIT = 1u << 26;
+// ... which is the START-UP limit (a rank whose first matmul initialises rocBLAS arrives seconds late).  Once a job is
+// running the waits are microseconds, and 64 workgroups spinning for a minute on every peer's training partition is a poor
+// way to learn that a rank has died: slu_comm_ipc_set_spin_limit lowers the limit of a window (word 23; 0 = this default).
 
 // window-relative offsets of the control words (each on a 64-byte line of its own)
 //   flag_in[src]  at 64 * src            flag_out[src] at 64 * (8 + src)
@@ -71,9 +74,11 @@ __device__ __forceinline__ void ipc_wait_all(const IpcArgs& a, int line, unsigne
   if ((int)threadIdx.x < a.nranks) {
     unsigned long long* f = ipc_word(own, line + (int)threadIdx.x);
     unsigned spins = 0;
+    const unsigned long long lim_ = __hip_atomic_load(ipc_word(own, 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned limit = lim_ ? (unsigned)lim_ : IPC_SPIN_LIMIT;
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > IPC_SPIN_LIMIT) {
+      if (++spins > limit) {
         __hip_atomic_store(ipc_word(own, 20), 1ull + (unsigned long long)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
@@ -331,6 +336,30 @@ extern "C" int slu_comm_ipc_window_touch(void* const* windows, int64_t rank, int
   a.f32 = nullptr; a.n32 = 0; a.f64 = nullptr; a.n64 = 0;
   hipLaunchKernelGGL(ipc_touch_kernel, dim3(16), dim3(256), 0, (hipStream_t)stream, a, (long long)window_bytes);
   SLU_CHECK_LAUNCH("ipc_touch_kernel");
+  return SLU_OK;
+}
+
+// Bound of every later wait of this rank's launches, in polls of ~1 - 2.5 us (0 = the start-up default, 2^26).  Synchronises
+// the device (no launch may be reading the word while it changes).
+extern "C" int slu_comm_ipc_set_spin_limit(void* own_window, int64_t polls) {
+  SLU_REQUIRE(own_window && polls >= 0 && polls <= 0xffffffffLL, "slu_comm_ipc_set_spin_limit: bad argument");
+  const unsigned long long v = (unsigned long long)polls;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy((unsigned char*)own_window + 64 * 23, &v, 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "slu_comm_ipc_set_spin_limit: %s", hipGetErrorString(e));
+  return SLU_OK;
+}
+
+// How many workgroups of the all-reduce kernel can be RESIDENT at once on `cus` compute units (occupancy of the kernel x
+// cus) against the IPC_WGS = 64 it launches: its workgroups spin on flags that the LAST workgroup of the same launch raises,
+// so all of them must be co-resident — the communicator refuses a partition on which they would not be.
+extern "C" int slu_comm_ipc_resident_workgroups(int64_t cus, int64_t* resident_out, int64_t* launched_out) {
+  SLU_REQUIRE(cus > 0 && resident_out && launched_out, "slu_comm_ipc_resident_workgroups: bad argument");
+  int per_cu = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, allreduce_ipc_kernel, 256, 0);
+  if (e != hipSuccess) SLU_FAIL(SLU_ERR_HIP, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+  *resident_out = (int64_t)per_cu * cus;
+  *launched_out = IPC_WGS;
   return SLU_OK;
 }
 

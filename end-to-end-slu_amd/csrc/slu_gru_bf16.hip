@@ -269,6 +269,11 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   float held[4] = {0.f, 0.f, 0.f, 0.f};
   int pend_t = -1;                     // frame (EPI 0) / pooled frame (EPI > 0) whose rows wait in ost[pend_buf], -1 = none
   int pend_buf = 0;
+  // (Round 6, measured and not kept — profiles/r06_c_gru_deferred_epilogue.txt: running the Dropout + pooling + split epilogue
+  // of step s - 1 INSIDE step s, branch-free, so that its ~60 VALU instructions could sit between the step's MFMAs.  The
+  // scheduler places them in FRONT of the MFMAs whatever sched_group_barrier pattern asks for (their operands are ready, the
+  // MFMAs wait for their LDS fragments), a non-emitting step then also pays the plane split, and the launch got 4 % SLOWER:
+  // T = 300, 1280 sequences 636 -> 663 us.)
   // the previous step's output: staging tile -> global memory, whole rows
   auto flush = [&]() {
     if (pend_t < 0) return;

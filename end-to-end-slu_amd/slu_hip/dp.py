@@ -202,6 +202,20 @@ class IpcComm:
         err = None
         try:
             with torch.cuda.device(device):
+                # the kernel's publish / consume ordering (relaxed atomics + s_waitcnt vmcnt(0) + sc0 sc1 write-through) is
+                # gfx942 / gfx950 behaviour: refuse any other device
+                _lib.check(self._L.slu_device_check(), "slu_device_check")
+                # its 64 workgroups spin on flags that the launch's own LAST workgroup raises: they must be co-resident on
+                # the CUs the training stream is confined to
+                from . import pipeline as _pl
+                cus = _pl.cu_split(device) or _pl.n_compute_units(device)
+                res, launched = ctypes.c_int64(0), ctypes.c_int64(0)
+                _lib.check(self._L.slu_comm_ipc_resident_workgroups(cus, ctypes.byref(res), ctypes.byref(launched)),
+                           "slu_comm_ipc_resident_workgroups")
+                self.resident_workgroups = (int(res.value), int(launched.value), int(cus))
+                if res.value < launched.value:
+                    raise _lib.SluHipError("the all-reduce kernel launches %d workgroups that must be resident together; "
+                                           "only %d fit the %d CUs of the training partition" % (launched.value, res.value, cus))
                 _lib.check(self._L.slu_comm_ipc_window_create(self.window_bytes, fine, ctypes.byref(own), handle),
                            "slu_comm_ipc_window_create")
             self._own = own
@@ -305,6 +319,17 @@ class IpcComm:
             self._lib.check(self._L.slu_comm_ipc_status(self._own, ctypes.byref(v)), "slu_comm_ipc_status")
         return int(v.value)
 
+    def set_wait_limit(self, polls=None):
+        """Bound of every later wait (polls of ~1 - 2.5 us).  Start-up keeps the library's 2^26 (a rank whose first matmul
+        initialises rocBLAS arrives seconds late); make_comm lowers it once the planes have proven themselves — steady-state
+        waits are microseconds, a dead peer should stop the job in seconds, not park 64 spinning workgroups on every
+        rank's training partition for minutes.  SLU_IPC_WAIT_POLLS (default 2^22, ~10 s; 0 = keep the start-up bound)."""
+        if polls is None:
+            polls = int(os.environ.get("SLU_IPC_WAIT_POLLS", str(1 << 22)))
+        with torch.cuda.device(self.device):
+            self._lib.check(self._L.slu_comm_ipc_set_spin_limit(self._own, int(polls)), "slu_comm_ipc_set_spin_limit")
+        self.wait_limit_polls = int(polls)
+
     def max_wait_polls(self):
         """The longest flag wait of any call so far, in polls of ~1 us (diagnostics; synchronises the device)."""
         import ctypes
@@ -331,10 +356,11 @@ class IpcComm:
             pass
 
 
-def _selftest(comm, rank, world_size, device, rounds=12, n=70001):
+def _selftest(comm, rank, world_size, device, rounds=12, n=1380001):
     """A communicator must PROVE itself before it carries gradients: `rounds` all-reduces of rank- and round-dependent
-    fp32 + float64 patterns (odd length: exercises the padded tail and the typed float64 segment), every word compared
-    with the known sum; the ranks agree on the verdict over the control plane.  -> (ok, microseconds per call)."""
+    fp32 + float64 patterns — 1 380 001 + 161 elements: the LARGEST payload a step of the reference architecture carries
+    (everything trainable, 5.52 MB), odd lengths (the padded tail, the typed float64 segment) —, every word compared with
+    the known sum; the ranks agree on the verdict over the control plane.  -> (ok, microseconds per call)."""
     ok = 1.0
     us = 0.0
     try:
@@ -425,7 +451,14 @@ def make_comm(rank, world_size, device):
     if mode == "rccl":
         return DirectComm(rank, world_size, device)
     if mode == "ipc":
-        return IpcComm(rank, world_size, device)
+        comm = IpcComm(rank, world_size, device)
+        ok, us = _selftest(comm, rank, world_size, device)   # forced, but never unproven: the verdict is agreed
+        if not ok:
+            comm.close(collective=False)
+            raise RuntimeError("SLU_COMM=ipc: the IPC all-reduce failed its start-up self-test")
+        comm.selftest_us = us
+        comm.set_wait_limit()
+        return comm
     comm = None
     try:
         comm = IpcComm(rank, world_size, device)             # (its own set-up failures are agreed: all ranks raise together)
@@ -441,7 +474,9 @@ def make_comm(rank, world_size, device):
                 # (the kernel has only ever run on ranks SHARING a GPU in this repository's test environment; on real links
                 # it must earn its place against the library).  Every step that can fail on one rank is AGREED before the
                 # next control-plane collective: the ranks keep the IPC plane together or switch together.
-                return _race(comm, rank, world_size, device)
+                comm = _race(comm, rank, world_size, device)
+            if hasattr(comm, "set_wait_limit"):
+                comm.set_wait_limit()                        # start-up is over: seconds, not minutes, for a dead peer
             return comm
         if rank == 0:
             print("data parallel: the hand-written IPC all-reduce failed its self-test; falling back to RCCL")

@@ -89,6 +89,8 @@ SIGNATURES = {
     "slu_comm_ipc_window_destroy": (c_int, [vp]),
     "slu_comm_allreduce_ipc": (c_int, [vp, c_i64, c_i64, c_i64, vp, c_i64, vp, c_i64, vp]),
     "slu_comm_ipc_status": (c_int, [vp, vp]),
+    "slu_comm_ipc_set_spin_limit": (c_int, [vp, c_i64]),
+    "slu_comm_ipc_resident_workgroups": (c_int, [c_i64, vp, vp]),
     "slu_comm_ipc_max_wait": (c_int, [vp, vp]),
     "slu_comm_ipc_window_touch": (c_int, [vp, c_i64, c_i64, c_i64, vp]),
     "slu_gru_proj_supported": (c_int, [c_i64, c_i64, c_i64, c_i64, c_i64]),

@@ -518,6 +518,13 @@ int slu_comm_ipc_window_destroy(void* own_window);
 int slu_comm_allreduce_ipc(void* const* windows, int64_t rank, int64_t nranks, int64_t window_bytes,
                            float* f32, int64_t n32, double* f64, int64_t n64, void* stream);
 int slu_comm_ipc_status(void* own_window, int64_t* status_out);
+/* Bound of every later wait of this rank's all-reduce launches, in polls (0 = the start-up default, 2^26 ~ minutes): set
+ * after start-up, when waits are microseconds and a dead peer should be noticed in seconds (ABI 9).  Synchronises.      */
+int slu_comm_ipc_set_spin_limit(void* own_window, int64_t polls);
+/* Workgroups of the all-reduce kernel that can be resident together on `cus` compute units, and the number one call
+ * launches (64): they spin on flags raised by the launch's own last workgroup, so launched <= resident is REQUIRED on the
+ * partition the training stream is confined to (checked by the Python communicator at start-up; ABI 9).                 */
+int slu_comm_ipc_resident_workgroups(int64_t cus, int64_t* resident_out, int64_t* launched_out);
 int slu_comm_ipc_max_wait(void* own_window, int64_t* polls_out);   /* longest wait so far in ~1 us polls (diagnostics)   */
 /* One load per 4 KiB page of every window, no flags, no waits: peer windows are mapped lazily, and a first touch inside
  * the all-reduce can stall a rank past its peers' bounded waits.  Call once after every window is open (then synchronise
