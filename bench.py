@@ -895,11 +895,13 @@ def _time_collective(call, stream, reps=50):
 
 def scaling_model(model, trainer, width, steady_ms):
     """What this ONE-GPU process can say about the data-parallel step on N GPUs: the two halves of the pipelined
-    loop timed alone — the trainable suffix (the captured step graph replayed back to back on the training partition) and the
-    frozen prefix (one super-batch graph replayed on the look-ahead partition, per step) — and the step's gradient all-reduce
-    through the hand-written IPC plane with ONE rank (launch + three local passes + its flag protocol; no link traffic).  Under
-    weak scaling every rank runs this same loop plus the collective on the training stream, so
-        step(N) ~ max(prefix, suffix + allreduce(N)),   efficiency(N) ~ step(1) / step(N).
+    loop — the trainable suffix (the captured step graph on the training partition) and the frozen prefix (one super-batch
+    graph on the look-ahead partition) — replayed ALONE and SIDE BY SIDE without dependencies (each stream between its own
+    pair of HIP events: what the partitions cost each other), and the step's gradient all-reduce through the hand-written IPC
+    plane with ONE rank (launch + three local passes + its flag protocol; no link traffic).  Under weak scaling every rank
+    runs this same loop plus the collective on the training stream, so
+        step(N) ~ step(1) + max(0, suffix + allreduce(N) - prefix)      (both side-by-side figures),
+        efficiency(N) ~ step(1) / step(N).
     allreduce(8) is NOT measurable here: the line carries the one-rank call and the efficiency for an ASSUMED 8-rank call of
     that + 10 us (two cross-GPU flag hand-offs and two remote 16-byte round trips of ~2.5 us each), so
     that a SCALE record can be checked against a stated prediction."""
@@ -913,26 +915,29 @@ def scaling_model(model, trainer, width, steady_ms):
     except Exception as e:                                   # noqa: BLE001 - no captured pipeline (eager run): nothing to model
         return {"error": "no captured pipeline: %s" % str(e)[:100]}
 
-    def wall(fn, n):
+    def run(n_prefix, n_suffix):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fn(n)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        if n_prefix:
+            with torch.cuda.stream(slot.stream):
+                ev[0].record(slot.stream)
+                for _ in range(n_prefix):
+                    graph.replay()
+                ev[1].record(slot.stream)
+        if n_suffix:
+            with torch.cuda.stream(main):
+                ev[2].record(main)
+                for i in range(n_suffix):
+                    sg.run(sg.inputs, 100000 + i)
+                ev[3].record(main)
         torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / n
+        return (ev[0].elapsed_time(ev[1]) / n_prefix / width if n_prefix else 0.0, ev[2].elapsed_time(ev[3]) / n_suffix if n_suffix else 0.0)
 
-    def suffix(n):
-        with torch.cuda.stream(main):
-            for i in range(n):
-                sg.run(sg.inputs, 100000 + i)
-
-    def prefix(n):
-        with torch.cuda.stream(slot.stream):
-            for _ in range(n):
-                graph.replay()
-    suffix(16)
-    out["suffix_ms_per_step_alone"] = round(wall(suffix, 256), 4)
-    prefix(2)
-    out["prefix_ms_per_step_alone"] = round(wall(prefix, 16) / width, 4)
+    run(2, 2 * width)
+    out["prefix_ms_per_step_alone"] = round(run(24, 0)[0], 4)
+    out["suffix_ms_per_step_alone"] = round(run(0, 24 * width)[1], 4)
+    pb, sb = run(24, 24 * width)
+    out["prefix_ms_per_step_side_by_side"], out["suffix_ms_per_step_side_by_side"] = round(pb, 4), round(sb, 4)
     b = trainer.bucket
     dev = next(model.parameters()).device
     try:
@@ -946,9 +951,10 @@ def scaling_model(model, trainer, width, steady_ms):
         out["allreduce_error"] = str(e)[:120]
     if out.get("allreduce_us_one_rank_ipc"):
         ar8 = out["allreduce_us_one_rank_ipc"] + 10.0
-        step8 = max(out["prefix_ms_per_step_alone"], out["suffix_ms_per_step_alone"] + 1e-3 * ar8, steady_ms)
+        slack = 1e3 * (pb - sb)                              # what the suffix may grow by before it becomes the longer half
+        step8 = steady_ms + max(0.0, 1e-3 * (ar8 - slack))
         out["allreduce_us_assumed_8_ranks"] = round(ar8, 2)
-        out["slack_us_before_the_collective_shows"] = round(1e3 * (max(out["prefix_ms_per_step_alone"], steady_ms) - out["suffix_ms_per_step_alone"]), 2)
+        out["slack_us_before_the_collective_shows"] = round(slack, 2)
         out["predicted_ms_per_step_8_gpus"] = round(step8, 4)
         out["predicted_weak_scaling_efficiency_8_gpus"] = round(steady_ms / step8, 4)
     return out

@@ -184,13 +184,21 @@ class _FakePlane:
     """A data plane for _race: all-reduce over gloo on host tensors; can be told to fail while it is being timed."""
     kind = "ipc"
 
-    def __init__(self, fail_timing=False):
-        self.fail_timing, self.closed = fail_timing, False
+    def __init__(self, fail_timing=False, delay=None):
+        self.fail_timing, self.closed, self.delay, self.calls = fail_timing, False, delay, 0
 
     def allreduce(self, flat):
+        import time
         torch.distributed.all_reduce(flat)
+        self.calls += 1
+        if self.delay is not None:
+            time.sleep(self.delay(flat.numel()))
         if self.fail_timing:
             flat.add_(1.0)            # wrong sums on this rank only: _time_plane's verification raises after the last call
+
+    def allreduce_flats(self, flats):
+        for f in flats.values():
+            self.allreduce(f)
 
     def close(self, collective=True):
         if collective:
@@ -265,6 +273,21 @@ def _fallback_worker(rank, world, port, out):
     dp.DirectComm = no_rccl
     ipc = _FakePlane()
     log.append(("race, no rccl", dp._race(ipc, rank, world, cpu) is ipc and ipc.race_us["reason"] == "rccl unavailable"))
+    # 6b. each plane faster for one payload: BOTH stay, a RacedComm picks per payload (the same choice on every rank)
+    class SlowSmall(FakeDirect):
+        def __init__(self, *a):
+            _FakePlane.__init__(self, delay=lambda n: 0.004 if n < 10000 else 0.0)
+    dp.DirectComm = lambda *a: made.append(SlowSmall()) or made[-1]
+    ipc = _FakePlane(delay=lambda n: 0.0 if n < 10000 else 0.004)
+    kept = dp._race(ipc, rank, world, cpu, payloads=(1000, 100000))
+    ok = isinstance(kept, dp.RacedComm) and kept._pick(4 * 1000)[0] == "ipc" and kept._pick(4 * 100000)[0] == "rccl" \
+        and kept._pick(4 * 50000)[0] == "rccl" and not ipc.closed and not made[-1].closed
+    before = (ipc.calls, made[-1].calls)
+    kept.allreduce_flats({torch.float32: torch.ones(1000)})
+    kept.allreduce_flats({torch.float32: torch.ones(100000)})
+    ok = ok and (ipc.calls, made[-1].calls) == (before[0] + 1, before[1] + 1) and kept.kind == "rccl"
+    kept.close()
+    log.append(("race, mixed winners", ok and ipc.closed and made[-1].closed))
     dp.DirectComm = real_direct
     # 7. a bounded wait expired on rank 1 only: every rank sees the worst status
     log.append(("agreed status", dp.agreed_status(3 if rank == 1 else 0) == 3 and dp.agreed_status(0) == 0))
@@ -280,7 +303,7 @@ def test_data_plane_fallbacks_leave_on_the_same_path(tmp_path):
     mp.spawn(_fallback_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in (0, 1):
         log = eval(open(tmp_path / ("fb%d" % r)).read())
-        assert len(log) == 7 and all(ok for _, ok in log), (r, log)
+        assert len(log) == 8 and all(ok for _, ok in log), (r, log)
 
 
 class _StatusComm:
