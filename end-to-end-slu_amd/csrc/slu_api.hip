@@ -94,14 +94,14 @@ stage_inputs_kernel(const StageArgs a) {
 // no staging buffer whose lifetime the caller would have to track) — the row-pointer table and the dropout-stream
 // offset of a captured look-ahead super-batch ----
 namespace slu {
-struct StoreArgs { unsigned long long v[32]; unsigned long long* dst; int n; };
+struct StoreArgs { unsigned long long v[64]; unsigned long long* dst; int n; };
 __global__ void store_u64_kernel(const StoreArgs a) {
   if ((int)threadIdx.x < a.n) a.dst[threadIdx.x] = a.v[threadIdx.x];
 }
 }  // namespace slu
 
 extern "C" int slu_store_u64(uint64_t* dst, const uint64_t* values, int64_t count, void* stream) {
-  SLU_REQUIRE(dst && values && count >= 1 && count <= 32, "slu_store_u64: 1..32 values");
+  SLU_REQUIRE(dst && values && count >= 1 && count <= 64, "slu_store_u64: 1..64 values");
   slu::StoreArgs a;
   for (int k = 0; k < (int)count; ++k) a.v[k] = values[k];
   a.dst = (unsigned long long*)dst; a.n = (int)count;

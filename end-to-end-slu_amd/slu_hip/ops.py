@@ -514,7 +514,7 @@ def store_u64(dst, values):
     import ctypes
     L = _lib.load()
     n = len(values)
-    assert 1 <= n <= 32 and dst.dtype == torch.int64 and dst.numel() >= n and dst.is_contiguous()
+    assert 1 <= n <= 64 and dst.dtype == torch.int64 and dst.numel() >= n and dst.is_contiguous()
     arr = (ctypes.c_uint64 * n)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in values])
     _lib.check(L.slu_store_u64(dst.data_ptr(), arr, n, _stream()), "slu_store_u64")
 

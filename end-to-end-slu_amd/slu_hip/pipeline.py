@@ -109,7 +109,10 @@ class PrefixSlot:
     kernels then launch #batches times as many workgroups (one per CU and direction) and every other kernel sees a
     proportionally larger problem, at (nearly) the latency of a single batch."""
     MAX_GRAPHS = 4          # distinct (super-batch shape, prefix length, mode) keys kept per slot
-    MAX_TABLE = 31          # batches a super-batch may read through the row-pointer table (slu_store_u64: 32 words)
+    # batches a super-batch may read through the row-pointer table; wider super-batches copy their batches into one input
+    # (slu_store_u64 carries 64 words since ABI 9, but the pipelined loop with 40-entry tables faulted on MI355X in round 6 —
+    # profiles/r06_a_gru_two_tiles.txt — while the same graphs replayed alone did not: 31 stays the tested envelope)
+    MAX_TABLE = 31
 
     def __init__(self, device):
         self.device = device

@@ -51,7 +51,7 @@ const char* slu_device_arch(void);        /* gcnArchName of the current device (
  * contiguous range is spread over all XCDs); look-ahead pipeline of training.Trainer. Never freed. */
 int slu_stream_create_cu_range(int64_t first_cu, int64_t n_cus, void** stream_out);
 
-/* dst[0..count) = values[0..count) (count <= 32; `values` is a HOST array travelling in the kernel arguments): the
+/* dst[0..count) = values[0..count) (count <= 64 (ABI 9; 32 before); `values` is a HOST array travelling in the kernel arguments): the
  * row-pointer table (slu_wconv_fwd_bf16 in_table) and the dropout-stream offset of a captured super-batch.          */
 int slu_store_u64(uint64_t* dst, const uint64_t* values, int64_t count, void* stream);
 /* One launch for the per-step input refresh of a captured step: up to 4 strided 2-D copies (rows x row_bytes
