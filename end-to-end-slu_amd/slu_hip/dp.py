@@ -445,6 +445,15 @@ def make_comm(rank, world_size, device):
     mode = os.environ.get("SLU_COMM", "auto")
     if mode not in ("auto", "ipc", "rccl", "torch"):
         raise ValueError("SLU_COMM=%r: expected auto, ipc, rccl or torch" % mode)
+    if dist.is_initialized() and world_size > 1 and device.type == "cuda":
+        # settings that fix summation orders / arithmetic must agree, or the replicas drift apart bit by bit
+        from . import ops as _ops
+        mine = _ops.wgrad_signature()
+        sigs = [None] * world_size
+        dist.all_gather_object(sigs, mine)
+        if len(set(sigs)) != 1:
+            raise RuntimeError("data parallel: the ranks disagree on arithmetic / weight-gradient settings (SLU_WGRAD_BRANCH, "
+                               "SLU_WGRAD_WGS, SLU_TRAIN_MATH, SLU_FROZEN_MATH, SLU_DTYPE): %s" % sigs)
     if mode == "torch" or device.type != "cuda" or not dist.is_initialized():
         return None
     if mode == "auto" and dist.get_backend() == "nccl":

@@ -849,10 +849,32 @@ def wgrad_branch():
     weight gradients are free as long as they do not take every CU; beside the BPTT they still lengthen its dependent steps
     by more than they save, budget or not — and not by sharing its CUs: with BPTT workgroups that own their CU (a probe
     build claiming all 512 registers per lane) the open form measured 2.686 against 2.683 ms."""
+    if _WGRAD[0] is None:
+        resolve_wgrad()
+    return _WGRAD[0]
+
+
+_WGRAD = [None]
+
+
+def resolve_wgrad():
+    """Read SLU_WGRAD_BRANCH / SLU_WGRAD_WGS ONCE — training.Trainer calls this when it is built — instead of on every
+    backward call: the budget sets the split-K factor, i.e. the summation order; an environment change in mid-run would
+    silently lose bit-identity between steps (and between a run and its resumption).  dp.make_comm compares
+    wgrad_signature() across the ranks."""
     mode = os.environ.get("SLU_WGRAD_BRANCH", "layer")
     if mode not in ("layer", "pass", "0"):
         raise ValueError("SLU_WGRAD_BRANCH=%r: expected layer, pass or 0" % mode)
-    return mode, (0 if mode == "0" else int(os.environ.get("SLU_WGRAD_WGS", "216")))
+    _WGRAD[0] = (mode, 0 if mode == "0" else int(os.environ.get("SLU_WGRAD_WGS", "216")))
+    return _WGRAD[0]
+
+
+def wgrad_signature():
+    """What must be EQUAL on every data-parallel rank for the replicas to stay bit-identical: the weight-gradient launch's
+    (mode, workgroup budget) and the arithmetic modes."""
+    mode, budget = wgrad_branch()
+    return "%s/%d/%s/%s/%s" % (mode, budget, os.environ.get("SLU_TRAIN_MATH", "fp32"), os.environ.get("SLU_FROZEN_MATH", "bf16x3"),
+                               os.environ.get("SLU_DTYPE", "f32"))
 
 
 def gemm_tn_splitk_ok(operands):

@@ -106,6 +106,8 @@ class Trainer:
         # launch per dtype on the HIP kernel (slu_hip/optim.py: same rule and per-parameter step counts)
         on_gpu = all(p.is_cuda for p in model.parameters())
         if on_gpu:
+            from slu_hip import ops as _ops
+            self.wgrad = _ops.resolve_wgrad()      # (mode, workgroup budget) of the weight-gradient launches, fixed for this trainer
             from slu_hip.optim import HipAdam
             self.optimizer = HipAdam(model.parameters(), lr=self.lr)
         else:
