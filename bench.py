@@ -910,10 +910,13 @@ def scaling_model(model, trainer, width, steady_ms):
     try:
         sg = next(iter(trainer._step_graphs.values()))
         main = trainer._train_stream
-        slot = trainer._slots[0]
-        graph, _x, _f = next(v for v in slot.graphs.values() if v is not None)
+        # the WIDEST captured super-batch of any slot (a short run has captured its ramp sizes only)
+        key, (graph, _x, _f), slot = max(((k, v, sl) for sl in trainer._slots for k, v in sl.graphs.items() if v is not None),
+                                         key=lambda kv: kv[0][0])
+        width = int(key[0])
     except Exception as e:                                   # noqa: BLE001 - no captured pipeline (eager run): nothing to model
         return {"error": "no captured pipeline: %s" % str(e)[:100]}
+    out["super_batch_width"] = width
 
     def run(n_prefix, n_suffix):
         torch.cuda.synchronize()
@@ -1261,7 +1264,7 @@ def main():
                             r_["bound_measured"] = r_["bound"]
         # The side measurements run on rank 0 at N = 1 only: under data parallelism a Trainer built by
         # one rank alone would issue gradient all-reduces the other ranks never join.
-        if world == 1 and args.workload == "no_unfreezing" and depth and not args.sub:
+        if world == 1 and args.workload == "no_unfreezing" and depth and not args.sub and not args.no_kernel_table:
             note("scaling model (suffix / prefix alone, one-rank collective)")
             try:
                 ss = steady["ms_per_step"] if steady else 1e3 * elapsed / args.steps
