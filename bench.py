@@ -893,7 +893,7 @@ def _time_collective(call, stream, reps=50):
     return round(1e3 * e0.elapsed_time(e1) / reps, 2)
 
 
-def scaling_model(model, trainer, width, steady_ms):
+def scaling_model(model, trainer, width, steady_ms, batches=None):
     """What this ONE-GPU process can say about the data-parallel step on N GPUs: the two halves of the pipelined
     loop — the trainable suffix (the captured step graph on the training partition) and the frozen prefix (one super-batch
     graph on the look-ahead partition) — replayed ALONE and SIDE BY SIDE without dependencies (each stream between its own
@@ -914,6 +914,12 @@ def scaling_model(model, trainer, width, steady_ms):
         key, (graph, _x, _f), slot = max(((k, v, sl) for sl in trainer._slots for k, v in sl.graphs.items() if v is not None),
                                          key=lambda kv: kv[0][0])
         width = int(key[0])
+        from slu_hip import ops as _ops
+        if isinstance(_x, _ops.RowTable):
+            # the graph reads its batches through the slot's row-pointer table: point ALL of its entries at live batches (the
+            # table still holds whatever the slot's last super-batch — possibly a narrower one — wrote)
+            xs = [batches[i % len(batches)][0] for i in range(width)]
+            _ops.store_u64(slot.words, [x.data_ptr() for x in xs] + [0] * (slot.MAX_TABLE - width) + [16])
     except Exception as e:                                   # noqa: BLE001 - no captured pipeline (eager run): nothing to model
         return {"error": "no captured pipeline: %s" % str(e)[:100]}
     out["super_batch_width"] = width
@@ -1268,7 +1274,7 @@ def main():
             note("scaling model (suffix / prefix alone, one-rank collective)")
             try:
                 ss = steady["ms_per_step"] if steady else 1e3 * elapsed / args.steps
-                out["scaling_model"] = scaling_model(model, trainer, width, ss)
+                out["scaling_model"] = scaling_model(model, trainer, width, ss, batches)
                 out["config"]["predicted_weak_scaling_efficiency_8_gpus"] = out["scaling_model"].get("predicted_weak_scaling_efficiency_8_gpus")
             except Exception as e:                           # noqa: BLE001 - a side measurement never takes the headline down
                 out["scaling_model"] = {"error": str(e)[:200]}

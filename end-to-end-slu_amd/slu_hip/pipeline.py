@@ -109,10 +109,11 @@ class PrefixSlot:
     kernels then launch #batches times as many workgroups (one per CU and direction) and every other kernel sees a
     proportionally larger problem, at (nearly) the latency of a single batch."""
     MAX_GRAPHS = 4          # distinct (super-batch shape, prefix length, mode) keys kept per slot
-    # batches a super-batch may read through the row-pointer table; wider super-batches copy their batches into one input
-    # (slu_store_u64 carries 64 words since ABI 9, but the pipelined loop with 40-entry tables faulted on MI355X in round 6 —
-    # profiles/r06_a_gru_two_tiles.txt — while the same graphs replayed alone did not: 31 stays the tested envelope)
-    MAX_TABLE = 31
+    # batches a super-batch may read through the row-pointer table (slu_store_u64 carries 64 words since ABI 9); wider
+    # super-batches copy their batches into one input.  SLU_MAX_TABLE=63 admits 32 - 63 batches (measured in round 6 with
+    # the two-tile recurrence: 40-batch super-batches 347 - 349 k utt/s against 347 - 356 k for the default 20 — no gain, so
+    # the default width, and with it the tested envelope of the table, stay where they were)
+    MAX_TABLE = max(1, min(63, int(os.environ.get("SLU_MAX_TABLE", "31"))))
 
     def __init__(self, device):
         self.device = device
