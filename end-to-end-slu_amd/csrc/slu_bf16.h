@@ -82,6 +82,23 @@ __device__ __forceinline__ void split_f16x2(float x, unsigned short (&h)[2]) {
   h[1] = __builtin_bit_cast(unsigned short, (_Float16)((x - hi) * F16X2_LO_SCALE));     // x - hi is exact
 }
 
+// Two values -> the three bf16 planes' words, each word = term of a | term of b << 16 (what the plane layouts store for two
+// consecutive elements): the same roundings and exact residuals as split_bf16<3> on a and b separately, on the PACKED
+// conversion (one v_cvt_pk_bf16_f32 per level) — 11 VALU instructions per pair instead of ~20 with per-element conversions
+// and 16-bit packing.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2s{a, b}, bf16x2v));
+}
+__device__ __forceinline__ void split_bf16x3_pair(float a, float b, unsigned (&w)[3]) {
+  w[0] = cvt_pk_bf16(a, b);
+  const float ra = a - __uint_as_float(w[0] << 16), rb = b - __uint_as_float(w[0] & 0xffff0000u);          // exact
+  w[1] = cvt_pk_bf16(ra, rb);
+  const float sa = ra - __uint_as_float(w[1] << 16), sb = rb - __uint_as_float(w[1] & 0xffff0000u);        // exact
+  w[2] = cvt_pk_bf16(sa, sb);
+}
+
 // The same pair under the rule v_cvt_pk_f16_f32 follows when MODE.FP_DENORM[7:6] = 0 (fp16 denormal results flushed).
 // Measured exhaustively over all 2^32 inputs (tools/probes/f16_flush_probe.cpp): tininess is detected AFTER rounding to 11
 // bits with an unbounded exponent — |x| >= 2^-14 - 2^-26 (bit pattern 0x387FF000) rounds up to the smallest normal and is
