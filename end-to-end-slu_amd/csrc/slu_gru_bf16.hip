@@ -699,6 +699,12 @@ gru_bf2_fwd_kernel(const GruBfParams p) {
         split_f16x2_pair_flush(hn[2], hn[3], hi23, lo23);                                                              \
         *reinterpret_cast<uint2*>(hx + h_off) = make_uint2(hi01, hi23);                                                \
         *reinterpret_cast<uint2*>(hx + 16 * ROWB + h_off) = make_uint2(lo01, lo23);                                    \
+      } else if constexpr (NS == 3) {                                                                                  \
+        unsigned w01[3], w23[3];                                                                                       \
+        split_bf16x3_pair(hn[0], hn[1], w01);                                                                          \
+        split_bf16x3_pair(hn[2], hn[3], w23);                                                                          \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                               \
+          *reinterpret_cast<uint2*>(hx + pl * (16 * ROWB) + h_off) = make_uint2(w01[pl], w23[pl]);                     \
       } else {                                                                                                         \
         unsigned short sp[4][NS];                                                                                      \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) split_terms<NS>(hn[r], sp[r]);                                   \
@@ -742,6 +748,12 @@ gru_bf2_fwd_kernel(const GruBfParams p) {
           split_f16x2_pair_flush(v[2], v[3], hi23, lo23);                                                              \
           *reinterpret_cast<uint2*>(ox__ + ps_off) = make_uint2(hi01, hi23);                                           \
           *reinterpret_cast<uint2*>(ox__ + 16 * PROWB + ps_off) = make_uint2(lo01, lo23);                              \
+        } else if constexpr (NS == 3) {                                                                                \
+          unsigned w01[3], w23[3];                                                                                     \
+          split_bf16x3_pair(v[0], v[1], w01);                                                                          \
+          split_bf16x3_pair(v[2], v[3], w23);                                                                          \
+          _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                             \
+            *reinterpret_cast<uint2*>(ox__ + (pl * 16) * PROWB + ps_off) = make_uint2(w01[pl], w23[pl]);               \
         } else {                                                                                                       \
           unsigned short sp[4][NS];                                                                                    \
           _Pragma("unroll") for (int r = 0; r < 4; ++r) split_terms<NS>(v[r], sp[r]);                                  \

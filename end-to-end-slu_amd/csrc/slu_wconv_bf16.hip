@@ -211,6 +211,11 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
             split_f16x2_pair_flush(a0, a1, hi, lo);
             *reinterpret_cast<unsigned*>(dst) = hi;
             *reinterpret_cast<unsigned*>(dst + plane) = lo;
+          } else if constexpr (NS == 3) {
+            unsigned w[3];               // (round 6: the packed pair split — one v_cvt_pk_bf16_f32 per level)
+            split_bf16x3_pair(a0, a1, w);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<unsigned*>(dst + pl * plane) = w[pl];
           } else {
             unsigned short a[NS], c[NS];
             split_terms<NS>(a0, a);
@@ -276,6 +281,12 @@ wconv_bf_fwd_kernel(const WconvBfParams p) {
             split_f16x2_pair_flush(a[2], a[3], hi.y, lo.y);
             *reinterpret_cast<uint2*>(dst) = hi;
             *reinterpret_cast<uint2*>(dst + plane) = lo;
+          } else if constexpr (NS == 3) {
+            unsigned w01[3], w23[3];
+            split_bf16x3_pair(a[0], a[1], w01);
+            split_bf16x3_pair(a[2], a[3], w23);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint2*>(dst + pl * plane) = make_uint2(w01[pl], w23[pl]);
           } else {
             unsigned short t[4][NS];
 #pragma unroll

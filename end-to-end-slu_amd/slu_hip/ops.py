@@ -1459,7 +1459,9 @@ class GRULayerFn(torch.autograd.Function):
                 with fork:
                     gemm_tn_batched_splitk(probs, None, max_wg=budget)
                 if branch and fork.active:
-                    for t in (d_gx, d_gh, x, raw):
+                    # operands AND results: the results are written on the branch's stream (in "pass" mode long after this
+                    # function has returned), the allocator must not recycle them for the main stream before that
+                    for t in (d_gx, d_gh, x, raw, *dWs, *outs):
                         t.record_stream(fork.side)
                     if mode == "layer":
                         join_here = True                 # after the data-gradient GEMM below
