@@ -545,8 +545,8 @@ def _n_cus():
 
 
 # Committed evidence of the same measurements (named as `source`, never read at run time).
-PMC_SOURCE = "profiles/r05_z_pmc_gru_bf.txt"                     # rocprofv3 --pmc passes of the dominant kernel (HBM bytes, SQ activity)
-INLOOP_SOURCE = "profiles/r05_z_default_kernel_stats_by_shape.txt"  # rocprofv3 --kernel-trace of the default command (in-loop durations)
+PMC_SOURCE = "profiles/r06_z_pmc_gru_bf.txt"                     # rocprofv3 --pmc passes of the dominant kernel (HBM bytes, SQ activity)
+INLOOP_SOURCE = "profiles/r06_z_default_kernel_stats_by_shape.txt"  # rocprofv3 --kernel-trace of the default command (in-loop durations)
 
 
 def pmc_dominant_kernel(n_seq, nsplit, timeout=150):
