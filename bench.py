@@ -911,7 +911,7 @@ def scaling_model(model, trainer, width, steady_ms, batches=None):
         sg = next(iter(trainer._step_graphs.values()))
         main = trainer._train_stream
         # the WIDEST captured super-batch of any slot (a short run has captured its ramp sizes only)
-        key, (graph, _x, _f), slot = max(((k, v, sl) for sl in trainer._slots for k, v in sl.graphs.items() if v is not None),
+        key, (graph, _x, _f), slot = max(((k, v, sl) for sl in trainer._slots for k, v in sl.graphs.items() if v is not None and not k[-1]),     # (k[-1]: whole-chip variant)
                                          key=lambda kv: kv[0][0])
         width = int(key[0])
         from slu_hip import ops as _ops
@@ -1157,7 +1157,7 @@ def main():
     # steady state of the same loop (long run), reported beside `value` when K is short: the first
     # super-batch of a run has to be computed before its first step can start (pipeline fill)
     steady = None
-    if args.steps < 256 and world == 1:
+    if args.steps < 256 and world == 1 and os.environ.get("SLU_BENCH_NO_STEADY", "0") != "1":      # (the env: timeline traces of the K-step region)
         n_long = 512
         run_steps(model, trainer, batches, n_long, asr)
         run_steps(model, trainer, batches, n_long, asr)

@@ -956,11 +956,21 @@ class PretrainedModel(torch.nn.Module):
                 h = st.run(h, self.training, planes)
         return h
 
+    def stage_parameters(self):
+        """[[parameters of stage 0], [of stage 1], ...] — the stages and their parameter OBJECTS are fixed after
+        construction (requires_grad / versions are read live by the callers), so the module-tree walk is done once: the
+        trainer asks at the start of every run, in front of the first launch."""
+        cached = getattr(self, "_stage_params", None)
+        stages = self._stages()
+        if cached is None or len(cached) != len(stages):
+            cached = self._stage_params = [list(st.parameters()) for st in stages]
+        return cached
+
     def frozen_prefix_len(self):
         """Number of leading stages none of whose parameters is trainable."""
         n = 0
-        for st in self._stages():
-            if any(p.requires_grad for p in st.parameters()):
+        for ps in self.stage_parameters():
+            if any(p.requires_grad for p in ps):
                 break
             n += 1
         return n

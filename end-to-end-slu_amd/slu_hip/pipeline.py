@@ -120,6 +120,9 @@ class PrefixSlot:
         n = cu_split()
         self.stream = (cu_range_stream(device, n, n_compute_units(device) - n) if n > 0
                        else torch.cuda.Stream(device))
+        # unmasked: the FIRST super-batch of a run is replayed here (SLU_RAMP_WHOLE_CHIP, _run) — the training partition
+        # has nothing to do until that super-batch is through
+        self.whole = torch.cuda.Stream(device) if n > 0 else None
         # [row-pointer table of a super-batch (MAX_TABLE entries) | step0*16, read by the dropout kernels]
         self.words = torch.zeros(self.MAX_TABLE + 1, dtype=torch.int64, device=device)
         self.rng = self.words[self.MAX_TABLE:]
@@ -154,44 +157,54 @@ class PrefixSlot:
         self.graphs = {}
         self.seen = {}
 
-    def run(self, model, xs, n_prefix, step0, use_graph, after=None, guarded=True):
+    def run(self, model, xs, n_prefix, step0, use_graph, after=None, guarded=True, whole_chip=False):
         """-> (features, done event, guard or None).  guarded=False: the re-run of a super-batch whose range words
-        reported a violation — no guard scope, so the default arithmetic resolves to bf16x3."""
+        reported a violation — no guard scope, so the default arithmetic resolves to bf16x3.  whole_chip: the caller
+        knows the training partition to be idle until this super-batch is through (the first one of a run)."""
         import models as _models
         pm = getattr(model, "pretrained_model", model)
         guard = self.guard if (guarded and hasattr(pm, "f16x2_allowed") and pm.f16x2_allowed()) else None
         with _models.frozen_math_scope(guard):
-            feats, done = self._run(model, xs, n_prefix, step0, use_graph, after, guard)
+            feats, done = self._run(model, xs, n_prefix, step0, use_graph, after, guard, whole_chip)
         return feats, done, guard
 
-    def _run(self, model, xs, n_prefix, step0, use_graph, after, guard):
+    def _run(self, model, xs, n_prefix, step0, use_graph, after, guard, whole_chip=False):
         """Enqueue stages [0, n_prefix) for the batches `xs` (equal shapes; consecutive dropout steps
         step0, step0+1, ...) on this slot's stream, after the event `after` (the previous super-batch:
         two super-batches side by side would only delay the one the training step is waiting for).
-        (Replaying the FIRST super-batch of a run on an unmasked stream, while the training partition is still idle,
-        was tried twice: round 2 — 2.85 ms either way; round 3, f16x2 kernels, 12 batches on 256 instead of 128 CUs —
-        2.27 vs 2.48 ms for the super-batch, no change of the 20-step throughput (199.1 k utt/s both): its kernels are
-        latency-bound at that size.)
+        whole_chip: replay an ALREADY CAPTURED super-batch on the unmasked stream (device-resident batches only).  Rounds
+        2 and 3 tried this and saw nothing (round 3, f16x2, 12 batches on 256 instead of 128 CUs: 2.27 vs 2.48 ms for
+        the super-batch, 199.1 k utt/s either way — inside the run-to-run spread of the 20-step figure); round 6 measured
+        the bf16x3 timeline of the driver's command (profiles/r06_y_timeline_k20.txt): 14 batches spend 1.55 of 2.79 ms in
+        throughput-bound convolution / projection kernels on 160 CUs while 96 CUs idle.
         Returns (features of the concatenated batch, event recorded when they are complete)."""
         B, T = xs[0].shape
         host = not all(x.is_cuda for x in xs)
-        with torch.cuda.stream(self.stream):
+        whole = (whole_chip and self.whole is not None and not host and use_graph
+                 and os.environ.get("SLU_RAMP_WHOLE_CHIP", "1") != "0")
+        stream = self.stream
+        if whole:
+            stream = self.whole
+            stream.wait_stream(self.stream)         # this slot's earlier work (normally long finished)
+        with torch.cuda.stream(stream):
             if self.consumed is not None:
-                self.stream.wait_event(self.consumed)
+                stream.wait_event(self.consumed)
             if after is not None and not host:
-                self.stream.wait_event(after)
+                stream.wait_event(after)
             feats = None
             if use_graph:
                 import models as _models
+                # (a graph is captured PER STREAM: replaying one on another stream than the last time costs ~12 ms on
+                # ROCm 7 — measured, profiles/r06_y_timeline_k20.txt — so the whole-chip replay has a graph of its own)
                 key = (len(xs), B, T, n_prefix, bool(model.training), _models.contraction_nsplit(True),
-                       self._table_ok(model, xs), xs[0].dtype)
+                       self._table_ok(model, xs), xs[0].dtype, whole)
                 entry = self.graphs.get(key)
                 # capture a shape on its second appearance in this slot: a one-off shape (the ragged last
                 # group of an epoch, a short run) is cheaper launched eagerly than captured (~10 ms)
                 self.seen[key] = self.seen.get(key, 0) + 1
                 if (entry is None and key not in self.graphs and self.seen[key] >= 2
                         and len(self.graphs) < self.MAX_GRAPHS):
-                    entry = self._capture(model, xs, n_prefix, step0, key, guard)
+                    entry = self._capture(model, xs, n_prefix, step0, key, guard, stream)
                 if entry is not None:
                     graph, x_static, feats = entry
                     if isinstance(x_static, ops.RowTable):
@@ -211,8 +224,10 @@ class PrefixSlot:
                 if guard is not None:
                     guard.collect()
             done = torch.cuda.Event()
-            done.record(self.stream)
+            done.record(stream)
             self.last_done = done
+        if stream is not self.stream:
+            self.stream.wait_event(done)            # the slot's own stream stays ordered behind what ran elsewhere
         return feats, done
 
     def _copy_in(self, dst, xs, host, after):
@@ -256,10 +271,11 @@ class PrefixSlot:
                 and all(x.is_cuda and x.device == self.device and x.dtype == xs[0].dtype and x.is_contiguous()
                         and x.data_ptr() % 16 == 0 for x in xs))
 
-    def _capture(self, model, xs, n_prefix, step0, key, guard=None):
+    def _capture(self, model, xs, n_prefix, step0, key, guard=None, stream=None):
+        stream = self.stream if stream is None else stream
         B, T = xs[0].shape
         sub = B if len(xs) > 1 else 0
-        if key[-2]:
+        if key[6]:
             x_static = ops.RowTable(self.words[:len(xs)], B, T, xs[0].dtype)
             ops.store_u64(self.words, [x.data_ptr() for x in xs] + [0] * (self.MAX_TABLE - len(xs)) + [step0 * 16])
         else:
@@ -267,12 +283,12 @@ class PrefixSlot:
             self._fill(x_static, xs)
             self.rng.fill_(step0 * 16)
         model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)      # warm-up (lazy initialisation)
-        self.stream.synchronize()
+        stream.synchronize()
         graph = torch.cuda.CUDAGraph()
         try:
             # thread-local capture mode: other threads (e.g. the RCCL watchdog) may keep calling the
             # runtime while this thread captures
-            with capture(graph, self.stream):
+            with capture(graph, stream):
                 if guard is not None:
                     guard.arm()                     # memset node
                 feats = model.prefix_features(x_static, n_prefix, self.rng, sub_batch=sub)

@@ -216,6 +216,13 @@ class Trainer:
             intent_loss, intent_acc = self.model(x, y_intent, rng_step=rng_step)
         return [intent_loss, intent_acc], intent_loss
 
+    def _parameters(self):
+        """The model's parameter objects (the set is fixed; device / requires_grad / version are read live): walked once
+        instead of at the start of every run."""
+        if getattr(self, "_plist", None) is None or self._plist[0] is not self.model:
+            self._plist = (self.model, list(self.model.parameters()))
+        return self._plist[1]
+
     def lookahead_depth(self, train, asr):
         """How many batches ahead the FROZEN prefix of the encoder is evaluated on side HIP streams
         (0 = plain sequential steps).  Only SLU training with a frozen prefix qualifies: a frozen
@@ -227,7 +234,7 @@ class Trainer:
         depth = _lookahead_env()
         if not train or asr or depth in (0, 1) or not hasattr(self.model, "prefix_features"):
             return 0, 0
-        if not all(p.is_cuda for p in self.model.parameters()) or models_masks_injected():
+        if not all(p.is_cuda for p in self._parameters()) or models_masks_injected():
             return 0, 0
         n = self.model.frozen_prefix_len()
         # a CNN-block dropout inside the frozen prefix has no per-sub-batch stream (all shipped cfgs have
@@ -497,18 +504,16 @@ class Trainer:
         pm = self.model.pretrained_model
         with torch.cuda.stream(main):
             pm.warm_weight_caches()
-        frozen = [p for st in pm._stages()[:n_prefix] for p in st.parameters()]
-        signature = tuple(p._version for p in frozen)
+        signature = tuple(p._version for ps in pm.stage_parameters()[:n_prefix] for p in ps)
         for slot in self._slots:
             if slot.signature != signature:          # frozen weights were reloaded: re-capture
                 slot.invalidate()
                 slot.signature = signature
             slot.stream.wait_stream(main)
         use_graph = pipeline.graphs_enabled()
-        step_graphs = use_graph and self._graphable()
-        fused = step_graphs and self._fused_sums()
-        forward = self._slu_forward(n_prefix, sums if fused else None)
-        trainable = _param_signature(self.model)
+        # (what the optimisation steps need — step graphs, the forward closure, the parameter signature — is set up AFTER
+        # the first super-batches are on their way, below: the device is idle until the first of them is enqueued, and
+        # ~0.15 ms of host work in front of it was ~2 % of a 20-step run)
         # the first super-batches of a run are sized and started by _ramp_plan (pipeline fill)
         try:
             n_run = len(loader)
@@ -554,10 +559,16 @@ class Trainer:
             slot = self._slots[launched % len(self._slots)]
             launched += 1
             steps = [next_rng_step() for _ in group]                        # consecutive by construction
+            # whole_chip: the capped first super-batch of a SHORT run (one that _ramp_plan splits: fewer than two full
+            # super-batches, e.g. the driver's 20 steps) is replayed on the whole chip — the training partition has
+            # nothing to do until it is through, and in a short run that wait is a large share of the run (14 batches:
+            # 2.6 -> 2.3 ms).  Decided by the run's length alone, not by stream.query(): which captured graph a run uses
+            # must not be a race.  Long runs keep every super-batch on the look-ahead partition (one key per slot).
             # the first ramp[1] super-batches of the run start side by side; from then on each waits for its predecessor
             # (two full-width super-batches side by side would only delay the one the training stream is waiting for)
             feats, done, guard = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
-                                          after=None if (launched <= ramp[1] or not chain) else last_done[0])
+                                          after=None if (launched <= ramp[1] or not chain) else last_done[0],
+                                          whole_chip=(launched == 1 and bool(ramp[0]) and ramp[1] == 0))
             last_done[0] = done
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on
@@ -570,10 +581,25 @@ class Trainer:
         # synchronisation with blocking streams (the CU-masked ones) would serialise the pipeline.
         try:
             with torch.cuda.stream(main):
-                for _ in self._slots:
+                launch_next()
+                step_graphs = use_graph and self._graphable()
+                fused = step_graphs and self._fused_sums()
+                forward = self._slu_forward(n_prefix, sums if fused else None)
+                trainable = _param_signature(self.model)
+                for _ in self._slots[1:]:
                     launch_next()
+                first_group = os.environ.get("SLU_RAMP_HOST_WAIT", "1") != "0"
                 while pending:
                     group, feats_cat, done, steps, slot, versions, guard = pending.popleft()
+                    if first_group:
+                        # The host WAITS for the run's first super-batch before it enqueues that group's steps: nothing
+                        # can run before it anyway, and step graphs queued on the (high-priority) training stream behind
+                        # its event slow the running super-batch down — measured, tools/diag_whole_chip.py,
+                        # profiles/r06_y_first_super_batch.txt: 2.62 - 2.89 ms with the steps queued, 2.34 - 2.36 ms with
+                        # the host waiting (14 batches on the whole chip).  Later groups are enqueued while an earlier
+                        # group's steps still run: the host never waits again.
+                        done.synchronize()
+                        first_group = False
                     for b, v in zip(group, versions):
                         if v is not None and b[0]._version != v:
                             raise RuntimeError(

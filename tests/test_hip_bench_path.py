@@ -133,6 +133,51 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
         assert torch.equal(v, sd[k]), k
 
 
+def test_first_super_batch_on_the_whole_chip_replayed_over_repeated_runs_is_bit_identical(tmp_path, monkeypatch):
+    """bench.py's K = 20 command, repeated: every run's FIRST super-batch (14 batches) goes to the unmasked stream, is
+    captured there on the second run and replayed from the third on, and the host waits for it before it enqueues the
+    steps (training._iterate).  Five runs of 20 steps on one trainer against the same 100 steps of the sequential eager
+    loop: per-step losses and final parameters bit-equal."""
+    import contextlib
+    import data
+    import models
+    import training
+    cfg = _full_cfg(tmp_path)
+    torch.manual_seed(1)
+    torch.save(O.init_pretrained_state_dict(cfg), tmp_path / "pretraining" / "model_state.pth")
+    ds = data.SyntheticSLUDataset(4, 64, 48000, cfg.values_per_slot, seed=1234)
+    dev_batches = [tuple(t.cuda() for t in b) for b in ds.batches]
+    runs, per_run = 5, 20
+
+    def go(lookahead, graphs):
+        monkeypatch.setenv("SLU_LOOKAHEAD", lookahead)
+        monkeypatch.setenv("SLU_GRAPHS", graphs)
+        monkeypatch.delenv("SLU_FROZEN_MATH", raising=False)
+        torch.manual_seed(2)
+        model = models.Model(cfg)
+        models.set_dropout_seed(1234)
+        trainer = training.Trainer(model, cfg)
+        model.train()
+        losses = []
+        for r in range(runs):
+            loader = [dev_batches[(r * per_run + i) % 4] for i in range(per_run)]
+            with contextlib.closing(trainer._iterate(loader, True, False, accumulate=True)) as it:
+                for v, _ in it:
+                    losses.append(v.clone() if torch.is_tensor(v) else torch.stack([v[0].detach(), v[1].detach()]))
+            torch.cuda.synchronize()
+        return trainer, [float(v[0]) for v in losses], {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    _, ref_losses, ref_sd = go("0", "0")
+    tr, losses, sd = go("auto", "1")
+    whole = [(k, v) for k, v in tr._slots[0].graphs.items() if k[-1]]
+    assert whole and all(v is not None for _, v in whole), "the whole-chip variant of the first super-batch was not captured"
+    assert max(tr._slots[0].seen[k] for k, _ in whole) == runs          # captured on run 2, replayed on runs 3 - 5
+    assert whole[0][0][0] == 14                                         # ceil(2/3 * 20) batches (training._ramp_plan)
+    assert losses == ref_losses
+    for k, v in ref_sd.items():
+        assert torch.equal(v, sd[k]), k
+
+
 @pytest.mark.parametrize("n_utt,math", [(1024, "f16x2"), (1280, "f16x2"), (768, "bf16x3"), (1280, "bf16x3")])
 def test_super_batch_prefix_vs_oracle_with_injected_masks(tmp_path, monkeypatch, n_utt, math):
     """One look-ahead super-batch through the frozen encoder with the oracle's dropout masks, against the CPU oracle's
