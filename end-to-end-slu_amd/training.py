@@ -65,17 +65,21 @@ def _lookahead_width(depth, batch_size):
     return max(2, min(32, (8 * cus) // max(1, batch_size)))
 
 
-def _ramp_plan(n_run, width, n_slots, first_share=2.0 / 3.0):
+def _ramp_plan(n_run, width, n_slots, latency_steps=5.0, slope=0.4):
     """Sizes of the FIRST super-batches of a run of n_run batches (the rest are `width` batches each), and how many of
     them are started side by side instead of one behind the other.  Default: ONE capped first super-batch — a run that fits
-    in two super-batches (n_run < 2 width) is split a : n_run - a with a = ceil(2/3 n_run): the second super-batch's encoder
-    runs beside the first one's steps and is ready when they end.  Where 2/3 comes from: a frozen prefix of k batches costs
-    L + r k on the look-ahead partition (L = the latency of ~560 dependent recurrence steps, r = the throughput term), a
-    trainable step costs s; the first super-batch's steps (a s) hide the second's encoder (L + r (n - a)) when
-    a = (L + r n) / (s + r).  With L = 1.0 - 1.4 ms, r = 0.08 - 0.12 ms and s = 0.15 - 0.17 ms (f16x2 ... bf16x3 frozen stages,
-    DESIGN.md section 7) and the driver's n = 20 that is a = 10.6 ... 13.3: one rule, 2/3, for every arithmetic — no constant
-    fitted to a mode (rounds 4-5 carried 0.6 / 0.7 per arithmetic; round 5 measured, bf16x3, the driver's 20-step command,
-    profiles/r05_g_first_sb.txt: first 10 / 12 / 14 / 16 / 20 batches -> 188.3 / 194.9 / 201.8 / 189.6 / 176.3 k utt/s).
+    in two super-batches (n_run < 2 width) is split a : n_run - a so that the second super-batch's encoder, which runs
+    beside the first one's steps, is ready when they end.  A frozen prefix of k batches costs L + r k on the look-ahead
+    partition (L = the latency of ~560 dependent recurrence steps, r = the throughput term), a trainable step costs s; the
+    first super-batch's steps (a s) hide the second's encoder (L + r (n - a)) when
+        a >= L / (s + r) + n r / (s + r).
+    With L = 1.0 - 1.4 ms, r = 0.08 - 0.12 ms, s = 0.15 - 0.17 ms (f16x2 ... exact fp32 frozen stages) the
+    two terms are 4.3 - 4.8 batches and 0.35 - 0.41 n: ONE rule for every arithmetic, a = ceil(5 + 0.4 n), capped by the
+    width and the run — no constant fitted to a mode.  One batch too few stalls the steps for s + r = 0.27 ms, one too many
+    costs 0.085 ms.  (Rounds 4 - 6 used a share of n — 0.6 / 0.7 per arithmetic, then 2/3 — which is this line at n = 20 only.
+    Measured, bf16x3, first super-batch on the whole chip, k utt/s, 3 runs each, profiles/r06_y_ramp_sweep.txt:
+    n = 12: 8+4 175, 9+3 187, 10+2 190;  n = 20: 12+8 221, 13+7 222, 14+6 220;  n = 30: 16+14 242, 17+13 246, 20+10 238.)
+    A run shorter than the rule's a is ONE super-batch.
     SLU_RAMP=a,b,c: explicit sizes, one behind the other (SLU_RAMP_SIDE=1 with as many look-ahead slots: side by side — measured
     slower, profiles/r05_a_sweep.txt: CU-masked streams have no priorities, super-batches side by side share the partition and
     ALL finish late)."""
@@ -86,7 +90,9 @@ def _ramp_plan(n_run, width, n_slots, first_share=2.0 / 3.0):
         return sizes, (len(sizes) if side else 0)
     T = min(n_run, width)
     if env == "0" or n_slots < 3 or T < 9:
-        return ([max(2, int(math.ceil(first_share * n_run - 1e-9)))] if n_run < 2 * width else []), 0
+        if n_run >= 2 * width:
+            return [], 0
+        return [max(1, min(T, int(math.ceil(latency_steps + slope * n_run - 1e-9))))], 0
     a = max(2, int(T / 7.0 + 0.5))
     b = max(a, int(2 * T / 7.0 + 0.5))
     return [a, b, T - a - b], 3

@@ -134,7 +134,7 @@ def test_benchmarked_pipeline_equals_sequential_eager_at_full_size(tmp_path, mon
 
 
 def test_first_super_batch_on_the_whole_chip_replayed_over_repeated_runs_is_bit_identical(tmp_path, monkeypatch):
-    """bench.py's K = 20 command, repeated: every run's FIRST super-batch (14 batches) goes to the unmasked stream, is
+    """bench.py's K = 20 command, repeated: every run's FIRST super-batch (13 batches) goes to the unmasked stream, is
     captured there on the second run and replayed from the third on, and the host waits for it before it enqueues the
     steps (training._iterate).  Five runs of 20 steps on one trainer against the same 100 steps of the sequential eager
     loop: per-step losses and final parameters bit-equal."""
@@ -172,7 +172,7 @@ def test_first_super_batch_on_the_whole_chip_replayed_over_repeated_runs_is_bit_
     whole = [(k, v) for k, v in tr._slots[0].graphs.items() if k[-1]]
     assert whole and all(v is not None for _, v in whole), "the whole-chip variant of the first super-batch was not captured"
     assert max(tr._slots[0].seen[k] for k, _ in whole) == runs          # captured on run 2, replayed on runs 3 - 5
-    assert whole[0][0][0] == 14                                         # ceil(2/3 * 20) batches (training._ramp_plan)
+    assert whole[0][0][0] == training._ramp_plan(per_run, 20, 2)[0][0] == 13          # ceil(5 + 0.4 * 20) batches
     assert losses == ref_losses
     for k, v in ref_sd.items():
         assert torch.equal(v, sd[k]), k

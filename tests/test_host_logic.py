@@ -191,21 +191,25 @@ def test_bench_stdout_carries_the_json_line_only(tmp_path):
 
 
 def test_ramp_plan_of_the_first_super_batches(monkeypatch):
-    """training._ramp_plan: by default one capped first super-batch (a run that fits in two is split 60 : 40), nothing side
-    by side (70 : 30 for a run that fits in two); SLU_RAMP = explicit sizes / auto = the measured-and-slower side-by-side start."""
+    """training._ramp_plan: by default ONE capped first super-batch of ceil(5 + 0.4 n) batches for a run that fits in two
+    super-batches (the prefix latency in units of step + per-batch prefix cost, plus the share of the run whose steps hide
+    the second super-batch's encoder), nothing side by side; SLU_RAMP = explicit sizes / auto = the measured-and-slower
+    side-by-side start."""
     import training
     monkeypatch.delenv("SLU_RAMP", raising=False)
-    assert training._ramp_plan(20, 20, 2) == ([14], 0)                  # the driver's 20-step command: 14 + 6 (ceil(2/3 n))
-    assert training._ramp_plan(20, 20, 2, 0.6) == ([12], 0)             # (an explicit share)
-    assert training._ramp_plan(5, 20, 2) == ([4], 0) and training._ramp_plan(5, 20, 2, 0.6) == ([3], 0)
-    assert training._ramp_plan(30, 20, 2) == ([20], 0) and training._ramp_plan(39, 40, 2) == ([26], 0)
+    assert training._ramp_plan(20, 20, 2) == ([13], 0)                  # the driver's 20-step command: 13 + 7
+    assert training._ramp_plan(12, 20, 2) == ([10], 0) and training._ramp_plan(30, 20, 2) == ([17], 0)
+    assert training._ramp_plan(20, 20, 2, 4.0, 0.5) == ([14], 0)        # (explicit model terms)
+    assert training._ramp_plan(5, 20, 2) == ([5], 0) and training._ramp_plan(8, 20, 2) == ([8], 0)     # short run: one super-batch
+    assert training._ramp_plan(9, 20, 2) == ([9], 0) and training._ramp_plan(10, 20, 2) == ([9], 0)
+    assert training._ramp_plan(39, 20, 2) == ([20], 0) and training._ramp_plan(39, 40, 2) == ([21], 0)  # capped by the width
     assert training._ramp_plan(100, 20, 2) == ([], 0) and training._ramp_plan(100, 20, 3) == ([], 0)
     monkeypatch.setenv("SLU_RAMP", "auto")
     assert training._ramp_plan(20, 20, 3) == ([3, 6, 11], 3)
     assert training._ramp_plan(512, 24, 3) == ([3, 7, 14], 3)
     sizes, side = training._ramp_plan(12, 20, 3)
     assert sum(sizes) == 12 and side == 3 and sizes[0] <= sizes[1] <= sizes[2]
-    assert training._ramp_plan(5, 20, 3) == ([4], 0) and training._ramp_plan(20, 20, 2) == ([14], 0)
+    assert training._ramp_plan(5, 20, 3) == ([5], 0) and training._ramp_plan(20, 20, 2) == ([13], 0)
     monkeypatch.setenv("SLU_RAMP", "2,4,8")
     assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 0)             # explicit sizes: one behind the other ...
     monkeypatch.setenv("SLU_RAMP_SIDE", "1")

@@ -1,4 +1,4 @@
-"""Start-up of a short run of the look-ahead loop (the driver's `bench.py --steps 20`): where the first super-batch (14
+"""Start-up of a short run of the look-ahead loop (the driver's `bench.py --steps 20`): where the first super-batch (13
 batches) runs and what the host does meanwhile.  No profiler: HIP events on the replaying streams.
   1. whole 20-step runs under the four combinations of SLU_RAMP_WHOLE_CHIP (first super-batch on the unmasked stream) and
      SLU_RAMP_HOST_WAIT (the host waits for it before enqueuing the steps), with device-side marks around the first replays
@@ -51,15 +51,17 @@ torch.cuda.CUDAGraph.replay = _replay
 os.environ.pop("SLU_RAMP_WHOLE_CHIP", None); os.environ.pop("SLU_RAMP_HOST_WAIT", None)
 
 from slu_hip import ops as _ops
+import training as _training
+A = _training._ramp_plan(n, 20, 2)[0][0]                 # batches of the first super-batch
 sl = trainer._slots[0]
-firsts = sorted(((k, v) for k, v in sl.graphs.items() if v is not None and k[0] == 14), key=lambda kv: kv[0][-1])
-xs = [batches[i % len(batches)][0] for i in range(14)]
-_ops.store_u64(sl.words, [t.data_ptr() for t in xs] + [0] * (sl.MAX_TABLE - 14) + [16])
+firsts = sorted(((k, v) for k, v in sl.graphs.items() if v is not None and k[0] == A), key=lambda kv: kv[0][-1])
+xs = [batches[i % len(batches)][0] for i in range(A)]
+_ops.store_u64(sl.words, [t.data_ptr() for t in xs] + [0] * (sl.MAX_TABLE - A) + [16])
 torch.cuda.synchronize()
 sg = next(iter(trainer._step_graphs.values()))
 main = trainer._train_stream
 other = trainer._slots[1]
-g2 = [v for k, v in other.graphs.items() if v is not None and k[0] == 6][0][0]
+g2 = [v for k, v in other.graphs.items() if v is not None and k[0] == n - A][0][0]
 
 def timed(graph, st, pend="nothing", gap=0.0, reps=5):
     ts = []
@@ -75,10 +77,10 @@ def timed(graph, st, pend="nothing", gap=0.0, reps=5):
             with torch.cuda.stream(other.stream):
                 other.stream.wait_event(e1)
                 g2.replay()
-        if pend in ("14 optimisation steps", "both"):
+        if pend in ("the group's optimisation steps", "both"):
             with torch.cuda.stream(main):
                 main.wait_event(e1)
-                for i in range(14):
+                for i in range(A):
                     sg.run(sg.inputs, 200000 + i)
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
@@ -87,8 +89,8 @@ def timed(graph, st, pend="nothing", gap=0.0, reps=5):
 for key, (graph, x, f) in firsts:
     st = sl.whole if key[-1] else sl.stream
     where = "whole chip (256 CUs)" if key[-1] else "look-ahead partition (160 CUs)"
-    print("2. first super-batch (14 batches) on the %s, replayed alone: %s ms" % (where, timed(graph, st)))
-    for pend in ("the second super-batch", "14 optimisation steps", "both"):
+    print("2. first super-batch (%d batches) on the %s, replayed alone: %s ms" % (A, where, timed(graph, st)))
+    for pend in ("the second super-batch", "the group's optimisation steps", "both"):
         print("3.    with %s queued behind it on the other stream(s): %s ms" % (pend, timed(graph, st, pend)))
     for gap in (0.0003, 0.001, 0.005, 0.05):
         print("4.    after %.1f ms of idle device: %s ms" % (1e3 * gap, timed(graph, st, gap=gap, reps=4)))
