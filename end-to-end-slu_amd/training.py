@@ -86,8 +86,9 @@ def _ramp_plan(n_run, width, n_slots, latency_steps=5.0, slope=0.4):
     env = os.environ.get("SLU_RAMP", "0")
     if env not in ("auto", "0"):
         sizes = [max(1, int(v)) for v in env.split(",") if v.strip()]
-        side = os.environ.get("SLU_RAMP_SIDE", "0") == "1" and n_slots >= len(sizes)
-        return sizes, (len(sizes) if side else 0)
+        k = int(os.environ.get("SLU_RAMP_SIDE", "0"))           # 1: all of them side by side; k >= 2: the first k
+        side = min(len(sizes), n_slots) if k == 1 and n_slots >= len(sizes) else (min(k, len(sizes), n_slots) if k >= 2 else 0)
+        return sizes, side
     T = min(n_run, width)
     if env == "0" or n_slots < 3 or T < 9:
         if n_run >= 2 * width:
@@ -574,7 +575,7 @@ class Trainer:
             # (two full-width super-batches side by side would only delay the one the training stream is waiting for)
             feats, done, guard = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
                                           after=None if (launched <= ramp[1] or not chain) else last_done[0],
-                                          whole_chip=(launched == 1 and bool(ramp[0]) and ramp[1] == 0))
+                                          whole_chip=(bool(ramp[0]) and launched <= (1 if ramp[1] == 0 else int(os.environ.get("SLU_RAMP_WHOLE_N", "0")))))
             last_done[0] = done
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on
@@ -594,24 +595,27 @@ class Trainer:
                 trainable = _param_signature(self.model)
                 for _ in self._slots[1:]:
                     launch_next()
-                first_group = os.environ.get("SLU_RAMP_HOST_WAIT", "1") != "0"
+                host_wait = os.environ.get("SLU_HOST_WAIT", "all")          # "all" | "first" | "0"
                 while pending:
                     group, feats_cat, done, steps, slot, versions, guard = pending.popleft()
-                    if first_group:
-                        # The host WAITS for the run's first super-batch before it enqueues that group's steps: nothing
-                        # can run before it anyway, and step graphs queued on the (high-priority) training stream behind
-                        # its event slow the running super-batch down — measured, tools/diag_whole_chip.py,
-                        # profiles/r06_y_first_super_batch.txt: 2.62 - 2.89 ms with the steps queued, 2.34 - 2.36 ms with
-                        # the host waiting (14 batches on the whole chip).  Later groups are enqueued while an earlier
-                        # group's steps still run: the host never waits again.
-                        done.synchronize()
-                        first_group = False
                     for b, v in zip(group, versions):
                         if v is not None and b[0]._version != v:
                             raise RuntimeError(
                                 "a device-resident input batch was modified in place while its look-ahead super-batch was "
                                 "still reading it (the loader recycles device buffers): hand over fresh tensors per batch or "
                                 "host batches, or set SLU_LOOKAHEAD=0")
+                    if host_wait != "0":
+                        # The host WAITS for a super-batch before it enqueues that group's steps.  For the run's first one
+                        # nothing can run before it anyway, and step graphs queued on the (high-priority) training stream
+                        # behind its event slow the running super-batch down — measured, tools/diag_whole_chip.py,
+                        # profiles/r06_y_first_super_batch.txt: 13 batches on the whole chip 2.7 - 3.0 ms with the steps
+                        # queued, 2.3 ms with the host waiting.  In steady state the super-batch is normally through when the
+                        # previous group's steps are (the prefix bounds the loop), so the wait is short; it keeps the host
+                        # at most one group ahead and is worth 0.5 % there (363.2 - 365.0 -> 365.8 - 367.2 k utt/s,
+                        # profiles/r06_y_host_wait_all.txt).  "first": only the run's first super-batch.
+                        done.synchronize()
+                        if host_wait == "first":
+                            host_wait = "0"
                     if guard is not None:
                         # f16x2 ran under the slot's range guard: read its words BEFORE the features are used (the
                         # super-batch normally finished while the previous group's steps were running: the wait is short

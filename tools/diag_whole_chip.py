@@ -1,7 +1,7 @@
 """Start-up of a short run of the look-ahead loop (the driver's `bench.py --steps 20`): where the first super-batch (13
 batches) runs and what the host does meanwhile.  No profiler: HIP events on the replaying streams.
   1. whole 20-step runs under the four combinations of SLU_RAMP_WHOLE_CHIP (first super-batch on the unmasked stream) and
-     SLU_RAMP_HOST_WAIT (the host waits for it before enqueuing the steps), with device-side marks around the first replays
+     SLU_HOST_WAIT (the host waits for it before enqueuing the steps), with device-side marks around the first replays
   2. the captured first-super-batch graphs replayed alone on their streams
   3. the same with dependent work queued behind them on the other streams
   4. the same after an idle gap (clock ramp)
@@ -20,7 +20,7 @@ model.train()
 COMBOS = (("0", "0", "round 5: look-ahead partition, steps queued at once"), ("0", "1", "look-ahead partition, host waits"),
           ("1", "0", "whole chip, steps queued at once"), ("1", "1", "DEFAULT: whole chip, host waits"))
 for w, h, _ in COMBOS:
-    os.environ["SLU_RAMP_WHOLE_CHIP"], os.environ["SLU_RAMP_HOST_WAIT"] = w, h
+    os.environ["SLU_RAMP_WHOLE_CHIP"], os.environ["SLU_HOST_WAIT"] = w, ("all" if h == "1" else "0")
     for _ in range(4):
         bench.run_steps(model, trainer, batches, n)
         torch.cuda.synchronize()
@@ -35,7 +35,7 @@ def replay(self):
 torch.cuda.CUDAGraph.replay = replay
 print("1. 20-step runs (ms after the run was entered; s0 = first super-batch, s1 = second, s2 = optimisation steps)")
 for w, h, label in COMBOS:
-    os.environ["SLU_RAMP_WHOLE_CHIP"], os.environ["SLU_RAMP_HOST_WAIT"] = w, h
+    os.environ["SLU_RAMP_WHOLE_CHIP"], os.environ["SLU_HOST_WAIT"] = w, ("all" if h == "1" else "0")
     for rep in range(3):
         del marks[:]
         ev0, ev2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,7 +48,7 @@ for w, h, label in COMBOS:
         print("   %-52s all 20 steps %.3f ms | %s" % (label, ev0.elapsed_time(ev2), "  ".join(
             "s%d %.3f-%.3f" % (names.setdefault(sid, len(names)), ev0.elapsed_time(a), ev0.elapsed_time(b)) for a, b, sid in marks[:4])))
 torch.cuda.CUDAGraph.replay = _replay
-os.environ.pop("SLU_RAMP_WHOLE_CHIP", None); os.environ.pop("SLU_RAMP_HOST_WAIT", None)
+os.environ.pop("SLU_RAMP_WHOLE_CHIP", None); os.environ.pop("SLU_HOST_WAIT", None)
 
 from slu_hip import ops as _ops
 import training as _training
