@@ -612,7 +612,9 @@ class Trainer:
                         # queued, 2.3 ms with the host waiting.  In steady state the super-batch is normally through when the
                         # previous group's steps are (the prefix bounds the loop), so the wait is short; it keeps the host
                         # at most one group ahead and is worth 0.5 % there (363.2 - 365.0 -> 365.8 - 367.2 k utt/s,
-                        # profiles/r06_y_host_wait_all.txt).  "first": only the run's first super-batch.
+                        # profiles/r06_y_host_wait_all.txt).  "first": only the run's first super-batch.  (Queuing the
+                        # group's first 1 / 2 / 4 steps BEFORE the wait, to hide the host's wake-up: 227 / 228 / 226 k
+                        # against 230 k utt/s for the 20-step command — not kept.)
                         done.synchronize()
                         if host_wait == "first":
                             host_wait = "0"
