@@ -35,6 +35,12 @@ print("gemm_tn_batched (3 weight gradients): %.1f us" % (1e3 * _timed_graph(lamb
 db = torch.empty(dbp.shape[1:], device=dev)
 print("gemm_tn_batched (3 weight gradients + bias-gradient row sums): %.1f us"
       % (1e3 * _timed_graph(lambda: ops.gemm_tn_batched(probs, (dbp, db)), st)))
+for wg in (0, 96, 144, 192, 216, 288):
+    with torch.cuda.stream(st):
+        ops.gemm_tn_batched_splitk(probs, (dbp, db), max_wg=wg)     # (ticket words of this stream)
+    torch.cuda.synchronize()
+    print("gemm_tn_batched_splitk (3 weight gradients + bias row sums), workgroup budget %d: %.1f us"
+          % (wg, 1e3 * _timed_graph(lambda: ops.gemm_tn_batched_splitk(probs, (dbp, db), max_wg=wg), st)))
 def old():
     ops.gemm(g2.t(), x, out=dW); ops.gemm(probs[1][0].t(), probs[1][1], out=dWf); ops.gemm(probs[2][0].t(), probs[2][1], out=dWr)
 print("three split-K gemms + reduces (round-1 path): %.1f us" % (1e3 * _timed_graph(old, st)))
