@@ -534,6 +534,9 @@ class Trainer:
         ramp = [[], 0]                                # [sizes of the first super-batches, how many start side by side]
         # SLU_PREFIX_CHAIN=0 (experiment): super-batches of different slots never wait for each other
         chain = os.environ.get("SLU_PREFIX_CHAIN", "1") != "0"
+        # several ranks on ONE GPU (the --share-gpu / SLU_LOCAL_DEVICE test set-up): a whole-chip super-batch of one process
+        # would run over the other processes' training partitions (measured: 4 ranks 185 -> 83 k utt/s)
+        own_gpu = not dp._shared_device()
 
         def launch_next():
             """Read up to `depth` equally-shaped batches and start their frozen prefix as one super-batch."""
@@ -575,7 +578,8 @@ class Trainer:
             # (two full-width super-batches side by side would only delay the one the training stream is waiting for)
             feats, done, guard = slot.run(self.model, [b[0] for b in group], n_prefix, steps[0], use_graph,
                                           after=None if (launched <= ramp[1] or not chain) else last_done[0],
-                                          whole_chip=(bool(ramp[0]) and launched <= (1 if ramp[1] == 0 else int(os.environ.get("SLU_RAMP_WHOLE_N", "0")))))
+                                          whole_chip=(own_gpu and bool(ramp[0])
+                                                      and launched <= (1 if ramp[1] == 0 else int(os.environ.get("SLU_RAMP_WHOLE_N", "0")))))
             last_done[0] = done
             # device-resident batches are read IN PLACE by the (asynchronous) super-batch: remember their tensor
             # versions, so that a loader that recycles its device buffers is caught instead of silently training on
