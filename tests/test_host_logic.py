@@ -215,6 +215,8 @@ def test_ramp_plan_of_the_first_super_batches(monkeypatch):
     monkeypatch.setenv("SLU_RAMP_SIDE", "1")
     assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 3)             # ... side by side on request,
     assert training._ramp_plan(20, 20, 2) == ([2, 4, 8], 0)             # if there are enough slots
+    monkeypatch.setenv("SLU_RAMP_SIDE", "2")
+    assert training._ramp_plan(20, 20, 3) == ([2, 4, 8], 2)             # ... or only the first k of them
 
 
 def test_data_plane_selection_without_a_gpu(monkeypatch):
