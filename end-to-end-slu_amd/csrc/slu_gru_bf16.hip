@@ -23,6 +23,7 @@
 // The keep bits come from slu_dropout_bits (one bit per element, drawn with the element -> counter map of
 // dropout_pool_fwd4_kernel: the fused and the two-launch paths produce identical bits).
 #include "slu_bf16.h"
+#include <type_traits>
 
 namespace slu {
 
@@ -94,9 +95,11 @@ struct GruLds {
   static constexpr int BYTES = HBUF + BIAS + GXS + OST;
 };
 
-template <int H, int NS, int KI, int EPI>
-__global__ void __launch_bounds__(H * 4)
-gru_bf_fwd_kernel(const GruBfParams p) {
+// REV (round 6): the direction is a template parameter of the body — blockIdx.y picks the instantiation —, so that the ~20
+// selects per step on the (workgroup-uniform) direction in the Dropout + pooling epilogue and the time arithmetic are
+// resolved at compile time: the loop is bound by instruction issue, every VALU slot counts (same arithmetic, same bits).
+template <int H, int NS, int KI, int EPI, bool REV>
+__device__ __forceinline__ void gru_bf_fwd_body(const GruBfParams& p) {
   constexpr int NW = H / 16;          // waves
   constexpr int KC = H / 32;          // 32-wide k-chunks
   constexpr int SLOTS = H / 8;        // 16-byte slots per h row
@@ -112,7 +115,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, kg = lane >> 4;      // compute layout: i = sequence of the tile (MFMA column), kg = unit quad
-  const int dir = blockIdx.y;
+  constexpr int dir = REV ? 1 : 0;
   const int b0 = blockIdx.x * 16;
   const int u0 = w * 16 + kg * 4;               // first of this lane's four hidden units
   const int T = p.T, B = p.B, D = p.D;
@@ -303,9 +306,12 @@ gru_bf_fwd_kernel(const GruBfParams p) {
   // it would otherwise place INSIDE the loop for the entry path would execute on every iteration.
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
 
-  for (int s = 0; s < T; ++s) {
+  // The loop is unrolled by two with the buffer index `cur` = s & 1 a compile-time constant of each half (round 6: staging
+  // tile / h buffer addresses fold into the LDS instructions' immediate offsets, and in the forward direction the frame
+  // parity of the pooling epilogue is static).
+  auto step = [&](auto cur_c, const int s) {
+    constexpr int cur = decltype(cur_c)::value;
     const int t = dir ? T - 1 - s : s;
-    const int cur = s & 1;
     const int tn = (s + 1 < T) ? (dir ? t - 1 : t + 1) : t;      // last step: re-reads its own row (unused)
 
     // ---- A: seed the accumulator chains with gx + b_hh (r, z) and b_hh (n) ----
@@ -410,7 +416,7 @@ gru_bf_fwd_kernel(const GruBfParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         m[r] = drop ? __fmul_rn(hn[r], ((kbits >> r) & 1u) ? p.keep_scale : 0.0f) : hn[r];
-      const bool even = (t & 1) == 0;
+      const bool even = dir ? (t & 1) == 0 : cur == 0;     // forward: t = s, its parity is the half's
       const bool single = even && t == T - 1;
       const bool emit = dir ? even : (!even || single);
       pend_t = -1;
@@ -423,7 +429,12 @@ gru_bf_fwd_kernel(const GruBfParams p) {
         for (int r = 0; r < 4; ++r) {
           const float first = dir ? __fadd_rn(0.0f, m[r]) : held[r];      // 0 + v(2 to)
           const float second = dir ? held[r] : m[r];                       // v(2 to + 1)
-          v[r] = single ? __fadd_rn(0.0f, m[r]) : __fmul_rn(__fadd_rn(first, second), 0.5f);
+          v[r] = __fmul_rn(__fadd_rn(first, second), 0.5f);
+        }
+        if (single) {                     // the partial last window (T odd): one step of the T — a branch, not four selects
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(0.0f, m[r]);
         }
         pend_t = t >> 1; pend_buf = cur;
         if constexpr (EPI == 2) {
@@ -469,10 +480,25 @@ gru_bf_fwd_kernel(const GruBfParams p) {
     for (int r = 0; r < 4; ++r) hprev[r] = hn[r];
     kcur = knext;
     lds_barrier();
+  };
+  {
+    int s = 0;
+    for (; s + 1 < T; s += 2) {
+      step(std::integral_constant<int, 0>{}, s);
+      step(std::integral_constant<int, 1>{}, s + 1);
+    }
+    if (s < T) step(std::integral_constant<int, 0>{}, s);
   }
   flush();
 #undef SLU_GX_REQUEST
 #undef SLU_GX_STAGE
+}
+
+template <int H, int NS, int KI, int EPI>
+__global__ void __launch_bounds__(H * 4)
+gru_bf_fwd_kernel(const GruBfParams p) {
+  if (blockIdx.y) gru_bf_fwd_body<H, NS, KI, EPI, true>(p);
+  else gru_bf_fwd_body<H, NS, KI, EPI, false>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
