@@ -374,6 +374,9 @@ gemm_bf_panel96_kernel(const GemmBfParams p) {
   const int col4 = (lane & 7) * 4;
   float* const sC = reinterpret_cast<float*>(dsmem + (size_t)KC * CH_U4 * 16) + wave * (16 * 36);
 
+  // (Round 6, measured and not kept: the W fragments through a buffer descriptor — base + constant VGPR offset + uniform SGPR
+  // offset, no per-lane 64-bit address per load: VALU instructions per 288 MFMAs 106 -> 34, and the launches got 1.5 % SLOWER,
+  // 521 / 281 / 154 -> 529 / 288 / 156 us: with one wave per SIMD those additions sat in the MFMAs' shadow already.)
   uint4 wr[4][NS][2];                  // ring of W fragment sets: chunk c of a tile lives in set c % 4 (KC % 4 == 0 or
                                        // the ring position is carried: see SETOF)
   // flattened (tile, chunk) sequence: step s = j * KC + kc; its set is s % 4
