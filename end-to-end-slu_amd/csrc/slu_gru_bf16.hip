@@ -39,6 +39,20 @@ __device__ __forceinline__ float bf_tanh(float x) {
 // i.e. for the write acknowledgement of the stores issued a few instructions earlier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Separately ROUNDED product / sum: the operations carry no `contract` flag, so the backend cannot fuse them into an fma
+// (HIP compiles with -ffp-contract=fast, and __fmul_rn / __fadd_rn are plain x * y / x + y of a header compiled under it:
+// whether "h * scale" and the pooling window's addition fused depended on the surrounding code — round 6 saw the forward
+// direction fuse them after an unrelated change to the mask arithmetic: 1-ulp differences from the two-launch path for
+// every dropout scale that is not a power of two, caught by test_gru_dropout_pool_epilogue_equals_the_two_launch_path).
+__device__ __forceinline__ float mul_rnd(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_rnd(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+
 struct GruBfParams {
   const float* gx;        // (T, B, D*3H); unused by the fused-input kernels
   // fused input projection (KI > 0: K <= 32 KI input channels): x as NS planes of (T*B) x (32 KI) 16-bit terms
@@ -415,26 +429,26 @@ __device__ __forceinline__ void gru_bf_fwd_body(const GruBfParams& p) {
       float m[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        m[r] = drop ? __fmul_rn(hn[r], ((kbits >> r) & 1u) ? p.keep_scale : 0.0f) : hn[r];
+        m[r] = drop ? mul_rnd(hn[r], ((kbits >> r) & 1u) ? p.keep_scale : 0.0f) : hn[r];
       const bool even = dir ? (t & 1) == 0 : cur == 0;     // forward: t = s, its parity is the half's
       const bool single = even && t == T - 1;
       const bool emit = dir ? even : (!even || single);
       pend_t = -1;
       if (!emit) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) held[r] = dir ? m[r] : __fadd_rn(0.0f, m[r]);
+        for (int r = 0; r < 4; ++r) held[r] = dir ? m[r] : add_rnd(0.0f, m[r]);
       } else {
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float first = dir ? __fadd_rn(0.0f, m[r]) : held[r];      // 0 + v(2 to)
+          const float first = dir ? add_rnd(0.0f, m[r]) : held[r];      // 0 + v(2 to)
           const float second = dir ? held[r] : m[r];                       // v(2 to + 1)
-          v[r] = __fmul_rn(__fadd_rn(first, second), 0.5f);
+          v[r] = mul_rnd(add_rnd(first, second), 0.5f);
         }
         if (single) {                     // the partial last window (T odd): one step of the T — a branch, not four selects
           asm volatile("" ::: "memory");
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = __fadd_rn(0.0f, m[r]);
+          for (int r = 0; r < 4; ++r) v[r] = add_rnd(0.0f, m[r]);
         }
         pend_t = t >> 1; pend_buf = cur;
         if constexpr (EPI == 2) {
