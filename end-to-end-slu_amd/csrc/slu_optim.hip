@@ -41,8 +41,6 @@ adam_multi_kernel(const AdamList L, long long* step_dev, const double lr,
   int k = 0;
   while (k + 1 < L.count && (int)blockIdx.x >= L.chunk_end[k]) ++k;
   const int chunk = blockIdx.x - (k ? L.chunk_end[k - 1] : 0);
-  __syncthreads();
-  const float step_size = s_coef[0], bc2_sqrt = s_coef[1];
   const float fb1 = (float)b1, fb2 = (float)b2, feps = (float)eps, fdiv = (float)grad_div;
   T* __restrict__ p = reinterpret_cast<T*>(L.p[k]);
   const T* __restrict__ g = reinterpret_cast<const T*>(L.g[k]);
@@ -50,28 +48,41 @@ adam_multi_kernel(const AdamList L, long long* step_dev, const double lr,
   T* __restrict__ v = reinterpret_cast<T*>(L.v[k]);
   const long long n = L.n[k];
   const long long base = (long long)chunk * ADAM_CHUNK;
+  // the operands are requested BEFORE the barrier: their round trip passes while thread 0 evaluates the two double-precision
+  // pow() of the bias corrections (round 6: the launch is a chain of latencies — counter, pow, operands, ticket — on the
+  // latency-bound training stream; this takes one of them out)
+  constexpr int U = ADAM_CHUNK / 256;
+  T pg[U], pm[U], pv[U], pp[U];
 #pragma unroll
-  for (int u = 0; u < ADAM_CHUNK / 256; ++u) {
+  for (int u = 0; u < U; ++u) {
+    const long long e = base + u * 256 + threadIdx.x;
+    const long long ec = e < n ? e : n - 1;          // clamped: loaded unconditionally, used only when e < n
+    pg[u] = g[ec]; pm[u] = m[ec]; pv[u] = v[ec]; pp[u] = p[ec];
+  }
+  __syncthreads();
+  const float step_size = s_coef[0], bc2_sqrt = s_coef[1];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
     const long long e = base + u * 256 + threadIdx.x;
     if (e >= n) continue;
     if (sizeof(T) == 4) {
-      float gg = (float)g[e];
+      float gg = (float)pg[u];
       if (fdiv != 1.0f) gg = gg / fdiv;            // data-parallel mean of the all-reduced sum
-      float mm = (float)m[e], vv = (float)v[e];
+      float mm = (float)pm[u], vv = (float)pv[u];
       mm = mm + (gg - mm) * (1.0f - fb1);
       vv = fb2 * vv + (1.0f - fb2) * gg * gg;
       const float denom = sqrtf(vv) / bc2_sqrt + feps;
-      p[e] = (T)((float)p[e] - step_size * (mm / denom));
+      p[e] = (T)((float)pp[u] - step_size * (mm / denom));
       m[e] = (T)mm; v[e] = (T)vv;
     } else {                       // float64 parameters (the Sinc band edges): double arithmetic
-      double gg = (double)g[e];
+      double gg = (double)pg[u];
       if (grad_div != 1.0) gg = gg / grad_div;
-      double mm = (double)m[e], vv = (double)v[e];
+      double mm = (double)pm[u], vv = (double)pv[u];
       mm = mm + (gg - mm) * (1.0 - b1);
       vv = b2 * vv + (1.0 - b2) * gg * gg;
       const double t = (double)(step_now + 1);
       const double denom = sqrt(vv) / sqrt(1.0 - pow(b2, t)) + eps;
-      p[e] = (T)((double)p[e] - (lr / (1.0 - pow(b1, t))) * (mm / denom));
+      p[e] = (T)((double)pp[u] - (lr / (1.0 - pow(b1, t))) * (mm / denom));
       m[e] = (T)mm; v[e] = (T)vv;
     }
   }
